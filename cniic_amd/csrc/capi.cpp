@@ -1,0 +1,597 @@
+// capi.cpp -- the extern "C" surface declared in include/cniic_hip.h.
+// Every entry point: lock the context, bind host-or-device buffers, run the HIP path, report an
+// error code.  Nothing here computes on the CPU what the reference computes per pixel.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "codec.hpp"
+#include "common.hpp"
+#include "huff_host.hpp"
+
+using namespace cniic;
+
+struct cniic_ctx : public Ctx {};
+
+struct cniic_km {
+    Ctx *c = nullptr;
+    KmRgbwState *st = nullptr;
+    In<uint32_t> keys, weight;
+    uint64_t lo = 0, hi = 0;
+    uint32_t K = 0;
+};
+
+#define LOCK(ctx)                          \
+    if (!(ctx)) return CNIIC_ERR_BAD_ARG;  \
+    std::lock_guard<std::mutex> _lk((ctx)->mu); \
+    (ctx)->err.clear();                    \
+    do { hipError_t _e = hipSetDevice((ctx)->device); if (_e != hipSuccess) return (ctx)->fail(CNIIC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(_e)); } while (0)
+
+// results computed into host vectors -> caller buffer (host or device)
+static int to_caller(Ctx *c, void *dst, const void *src_host, uint64_t bytes) {
+    if (!bytes || !dst) return CNIIC_OK;
+    if (is_device_ptr(dst)) CNIIC_HIP_TRY(c, hipMemcpy(dst, src_host, bytes, hipMemcpyHostToDevice));
+    else memcpy(dst, src_host, bytes);
+    return CNIIC_OK;
+}
+// small caller arrays (host or device) -> host vector
+static int from_caller(Ctx *c, void *dst_host, const void *src, uint64_t bytes) {
+    if (!bytes) return CNIIC_OK;
+    if (is_device_ptr(src)) CNIIC_HIP_TRY(c, hipMemcpy(dst_host, src, bytes, hipMemcpyDeviceToHost));
+    else memcpy(dst_host, src, bytes);
+    return CNIIC_OK;
+}
+
+extern "C" {
+
+int32_t cniic_version(void) { return 100; }
+
+int32_t cniic_ctx_create(int32_t device, void *stream, cniic_ctx **out) {
+    if (!out) return CNIIC_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CNIIC_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return CNIIC_ERR_HIP;
+    auto *c = new cniic_ctx();
+    c->device = device;
+    if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CNIIC_ERR_HIP; }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return CNIIC_ERR_HIP; }
+    *out = c;
+    return CNIIC_OK;
+}
+
+void cniic_ctx_destroy(cniic_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->dense.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *cniic_last_error(const cniic_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int32_t cniic_sync(cniic_ctx *c) {
+    LOCK(c);
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_dev_alloc(cniic_ctx *c, uint64_t bytes, void **dptr) {
+    LOCK(c);
+    if (!dptr) return c->fail(CNIIC_ERR_BAD_ARG, "dev_alloc: null out pointer");
+    CNIIC_HIP_TRY(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return CNIIC_OK;
+}
+
+int32_t cniic_dev_free(cniic_ctx *c, void *dptr) {
+    LOCK(c);
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_HIP_TRY(c, hipFree(dptr));
+    return CNIIC_OK;
+}
+
+int32_t cniic_memcpy(cniic_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    LOCK(c);
+    if (!bytes) return CNIIC_OK;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_last_kernel_time(cniic_ctx *c, const char *which, double *ms, uint64_t *launches) {
+    if (!c || !which) return CNIIC_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->ktimes.find(which);
+    if (it == c->ktimes.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return CNIIC_ERR_BAD_ARG; }
+    if (ms) *ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ H1
+static int hist_common(Ctx *c, uint32_t bits, uint32_t *table, uint32_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n_unique) {
+    CompactPlan plan;
+    CNIIC_TRY(hist_compact_count(c, table, bits, &plan));
+    if (n_unique) *n_unique = plan.n_unique;
+    if (!keys && !counts) return CNIIC_OK;
+    if (plan.n_unique > cap)
+        return c->fail(CNIIC_ERR_CAPACITY, "histogram has %llu distinct symbols, capacity %llu", (unsigned long long)plan.n_unique,
+                       (unsigned long long)cap);
+    Out<uint32_t> ko;
+    Out<uint64_t> co;
+    CNIIC_TRY(ko.bind(c, keys, plan.n_unique));
+    CNIIC_TRY(co.bind(c, counts, plan.n_unique));
+    CNIIC_TRY(hist_compact_write(c, table, &plan, ko.d, co.d, nullptr));
+    CNIIC_TRY(ko.finish(c));
+    CNIIC_TRY(co.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_hist_rgb24(cniic_ctx *c, const uint8_t *rgb, uint64_t npx, uint32_t *keys, uint64_t *counts, uint64_t cap,
+                         uint64_t *n_unique) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (npx && !rgb) return c->fail(CNIIC_ERR_BAD_ARG, "hist_rgb24: null image");
+    if (npx >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "hist_rgb24: too many pixels");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, npx * 3));
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 24, &table));
+    {
+        ScopedKernelTimer t(c, "hist_rgb");
+        CNIIC_TRY(hist_rgb_dense(c, in.d, npx, table));
+        t.stop(1);
+    }
+    return hist_common(c, 24, table, keys, counts, cap, n_unique);
+}
+
+int32_t cniic_hist_syms(cniic_ctx *c, int32_t sym_kind, const uint32_t *syms, uint64_t n, uint32_t *keys, uint64_t *counts,
+                        uint64_t cap, uint64_t *n_unique) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (sym_kind != CNIIC_SYM_RGB && sym_kind != CNIIC_SYM_SIGNED) return c->fail(CNIIC_ERR_BAD_ARG, "hist_syms: bad symbol kind");
+    if (n && !syms) return c->fail(CNIIC_ERR_BAD_ARG, "hist_syms: null stream");
+    if (n >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "hist_syms: too many symbols");
+    const uint32_t bits = sym_kind == CNIIC_SYM_RGB ? 24 : 27;
+    In<uint32_t> in;
+    CNIIC_TRY(in.bind(c, syms, n));
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, bits, &table));
+    CNIIC_TRY(hist_syms_dense(c, in.d, n, table, bits));
+    return hist_common(c, bits, table, keys, counts, cap, n_unique);
+}
+
+// ------------------------------------------------------------------ K-means
+int32_t cniic_kmeans_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint32_t K,
+                          const cniic_kmeans_opts *opts, uint8_t *centroids, uint32_t *labels, uint64_t *members,
+                          cniic_kmeans_stats *stats) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!keys || !weight || !centroids) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: null argument");
+    In<uint32_t> k, w;
+    CNIIC_TRY(k.bind(c, keys, U));
+    CNIIC_TRY(w.bind(c, weight, U));
+    KmRgbwState *km = nullptr;
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, opts, nullptr, &km));
+    std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
+    CNIIC_TRY(km_rgbw_run(km));
+    Out<uint32_t> lo;
+    CNIIC_TRY(lo.bind(c, labels, U));
+    cniic_kmeans_stats st{};
+    std::vector<uint8_t> cent(3 * (size_t)K);
+    std::vector<uint64_t> mem(K);
+    CNIIC_TRY(km_rgbw_result(km, cent.data(), lo.d, mem.data(), nullptr, &st));
+    CNIIC_TRY(lo.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_TRY(to_caller(c, centroids, cent.data(), cent.size()));
+    CNIIC_TRY(to_caller(c, members, mem.data(), mem.size() * 8));
+    if (stats) *stats = st;
+    uint64_t min_cc = (uint64_t)(0.99 * (double)K);  // check_enough_active_clusters kmeans.rs:41-57
+    if (U < min_cc) min_cc = U;
+    if (st.active < min_cc)
+        return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
+                       (unsigned long long)st.active, (unsigned long long)min_cc);
+    return CNIIC_OK;
+}
+
+int32_t cniic_kmeans_step_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint32_t K,
+                               const uint8_t *centroids, uint32_t *labels, uint64_t *sums, uint64_t *wsum, uint64_t *members,
+                               uint64_t *changed) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!keys || !weight || !centroids || !labels) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_step_rgbw: null argument");
+    In<uint32_t> k, w, lin;
+    CNIIC_TRY(k.bind(c, keys, U));
+    CNIIC_TRY(w.bind(c, weight, U));
+    CNIIC_TRY(lin.bind(c, labels, U));
+    std::vector<uint8_t> cent(3 * (size_t)K);
+    CNIIC_TRY(from_caller(c, cent.data(), centroids, cent.size()));
+    KmRgbwState *km = nullptr;
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, nullptr, nullptr, &km));
+    std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
+    CNIIC_TRY(km_rgbw_set_state(km, cent.data(), lin.d));
+    CNIIC_TRY(km_rgbw_assign(km));
+    std::vector<uint64_t> s(3 * (size_t)K), ws(K), mem(K);
+    uint64_t ch = 0;
+    CNIIC_TRY(km_rgbw_partials(km, s.data(), ws.data(), mem.data(), &ch));
+    Out<uint32_t> lo;
+    CNIIC_TRY(lo.bind(c, labels, U));
+    CNIIC_TRY(km_rgbw_result(km, nullptr, lo.d, nullptr, nullptr, nullptr));
+    CNIIC_TRY(lo.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_TRY(to_caller(c, sums, s.data(), s.size() * 8));
+    CNIIC_TRY(to_caller(c, wsum, ws.data(), ws.size() * 8));
+    CNIIC_TRY(to_caller(c, members, mem.data(), mem.size() * 8));
+    if (changed) *changed = ch;
+    return CNIIC_OK;
+}
+
+int32_t cniic_kmeans_xyrgb(cniic_ctx *c, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t K, const cniic_kmeans_opts *opts,
+                           cniic_colorpos *centroids, uint32_t *labels, uint64_t *members, cniic_kmeans_stats *stats) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!rgb || !centroids) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_xyrgb: null argument");
+    const uint64_t N = (uint64_t)w * h;
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, N * 3));
+    Out<uint32_t> lo;
+    CNIIC_TRY(lo.bind(c, labels, N));
+    std::vector<cniic_colorpos> cent(K ? K : 1);
+    std::vector<uint64_t> mem(K ? K : 1);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_xyrgb_run(c, in.d, w, h, K, opts, cent.data(), lo.d, mem.data(), &st));
+    CNIIC_TRY(lo.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_TRY(to_caller(c, centroids, cent.data(), (size_t)K * sizeof(cniic_colorpos)));
+    CNIIC_TRY(to_caller(c, members, mem.data(), (size_t)K * 8));
+    if (stats) *stats = st;
+    uint64_t min_cc = (uint64_t)(0.99 * (double)K);
+    if (N < min_cc) min_cc = N;
+    if (st.active < min_cc)
+        return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
+                       (unsigned long long)st.active, (unsigned long long)min_cc);
+    return CNIIC_OK;
+}
+
+int32_t cniic_kmeans_step_xyrgb(cniic_ctx *c, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t K,
+                                const cniic_colorpos *centroids, uint32_t *labels, uint64_t *sums, uint64_t *wsum,
+                                uint64_t *members, uint64_t *changed) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!rgb || !centroids || !labels) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_step_xyrgb: null argument");
+    const uint64_t N = (uint64_t)w * h;
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, N * 3));
+    // labels are in/out: stage a device copy when the caller's buffer is host memory
+    DevBuf lab_own;
+    uint32_t *lab_d = labels;
+    const bool lab_dev = is_device_ptr(labels);
+    if (!lab_dev) {
+        CNIIC_HIP_TRY(c, lab_own.alloc(N * 4));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(lab_own.p, labels, N * 4, hipMemcpyHostToDevice, c->stream));
+        lab_d = lab_own.as<uint32_t>();
+    }
+    std::vector<cniic_colorpos> cent(K ? K : 1);
+    CNIIC_TRY(from_caller(c, cent.data(), centroids, (size_t)K * sizeof(cniic_colorpos)));
+    std::vector<uint64_t> s(5 * (size_t)K + 1), ws(K + 1), mem(K + 1);
+    uint64_t ch = 0;
+    CNIIC_TRY(km_xyrgb_step(c, in.d, w, h, K, cent.data(), lab_d, s.data(), ws.data(), mem.data(), &ch, nullptr));
+    if (!lab_dev) CNIIC_HIP_TRY(c, hipMemcpy(labels, lab_d, N * 4, hipMemcpyDeviceToHost));
+    CNIIC_TRY(to_caller(c, sums, s.data(), 5 * (size_t)K * 8));
+    CNIIC_TRY(to_caller(c, wsum, ws.data(), (size_t)K * 8));
+    CNIIC_TRY(to_caller(c, members, mem.data(), (size_t)K * 8));
+    if (changed) *changed = ch;
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ sharded session
+uint64_t cniic_km_partial_words(uint32_t K, uint32_t D) { return (uint64_t)K * D + 2ull * K + 1; }
+
+int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint64_t lo, uint64_t hi,
+                             uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev, cniic_km **out) {
+    LOCK(c);
+    if (!out || !keys || !weight) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: null argument");
+    if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: partials must be device memory");
+    auto km = std::make_unique<cniic_km>();
+    km->c = c; km->lo = lo; km->hi = hi; km->K = K;
+    CNIIC_TRY(km->keys.bind(c, keys, U));
+    CNIIC_TRY(km->weight.bind(c, weight, U));
+    CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, lo, hi, K, opts, partials_dev, &km->st));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out = km.release();
+    return CNIIC_OK;
+}
+
+int32_t cniic_km_partials(cniic_km *km, void **dev_ptr) {
+    if (!km || !dev_ptr) return CNIIC_ERR_BAD_ARG;
+    *dev_ptr = km_rgbw_partials_dev(km->st);
+    return CNIIC_OK;
+}
+
+int32_t cniic_km_assign(cniic_km *km) {
+    if (!km) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
+    LOCK(c);
+    return km_rgbw_assign(km->st);
+}
+
+int32_t cniic_km_update(cniic_km *km, uint64_t *changed) {
+    if (!km) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
+    LOCK(c);
+    CNIIC_TRY(km_rgbw_update(km->st));
+    uint64_t ch = 0;
+    CNIIC_TRY(km_rgbw_poll_changed(km->st, &ch));
+    if (changed) *changed = ch;
+    return CNIIC_OK;
+}
+
+int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels_slice, uint64_t *members, cniic_kmeans_stats *stats) {
+    if (!km) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
+    LOCK(c);
+    Out<uint32_t> lo;
+    CNIIC_TRY(lo.bind(c, labels_slice, km->hi - km->lo));
+    std::vector<uint8_t> cent(3 * (size_t)km->K);
+    std::vector<uint64_t> mem(km->K);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_rgbw_result(km->st, cent.data(), lo.d, mem.data(), nullptr, &st));
+    CNIIC_TRY(lo.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_TRY(to_caller(c, centroids, cent.data(), cent.size()));
+    CNIIC_TRY(to_caller(c, members, mem.data(), mem.size() * 8));
+    if (stats) *stats = st;
+    return CNIIC_OK;
+}
+
+int32_t cniic_km_time_assign(cniic_km *km, int32_t reps, double *ms_per_launch) {
+    if (!km || !ms_per_launch || reps <= 0) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
+    LOCK(c);
+    return km_rgbw_time_assign(km->st, reps, ms_per_launch);
+}
+
+void cniic_km_destroy(cniic_km *km) {
+    if (!km) return;
+    {
+        std::lock_guard<std::mutex> lk(km->c->mu);
+        (void)hipSetDevice(km->c->device);
+        (void)hipStreamSynchronize(km->c->stream);
+        km_rgbw_destroy(km->st);
+    }
+    delete km;
+}
+
+// ------------------------------------------------------------------ remap
+int32_t cniic_remap_rgb(cniic_ctx *c, const uint8_t *rgb, uint64_t npx, const uint32_t *keys, const uint32_t *labels, uint64_t U,
+                        const uint8_t *centroids, uint32_t K, uint8_t *out_rgb) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!npx) return CNIIC_OK;
+    if (!rgb || !keys || !labels || !centroids || !out_rgb) return c->fail(CNIIC_ERR_BAD_ARG, "remap_rgb: null argument");
+    In<uint8_t> in;
+    In<uint32_t> k, l;
+    CNIIC_TRY(in.bind(c, rgb, npx * 3));
+    CNIIC_TRY(k.bind(c, keys, U));
+    CNIIC_TRY(l.bind(c, labels, U));
+    std::vector<uint8_t> cent(3 * (size_t)K);
+    CNIIC_TRY(from_caller(c, cent.data(), centroids, cent.size()));
+    std::vector<uint32_t> ck(K);
+    for (uint32_t i = 0; i < K; i++) ck[i] = ((uint32_t)cent[3 * i] << 16) | ((uint32_t)cent[3 * i + 1] << 8) | cent[3 * i + 2];
+    DevBuf ck_d, lut_d;
+    CNIIC_HIP_TRY(c, ck_d.alloc((uint64_t)K * 4));
+    CNIIC_HIP_TRY(c, lut_d.alloc(U * 4));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(ck_d.p, ck.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 24, &table));
+    CNIIC_TRY(rank_from_keys(c, k.d, U, table));
+    CNIIC_TRY(label_lut(c, l.d, U, ck_d.as<uint32_t>(), lut_d.as<uint32_t>()));
+    Out<uint8_t> o;
+    CNIIC_TRY(o.bind(c, out_rgb, npx * 3));
+    {
+        ScopedKernelTimer t(c, "remap_rgb");
+        CNIIC_TRY(remap_rgb(c, in.d, npx, table, lut_d.as<uint32_t>(), o.d));
+        t.stop(1);
+    }
+    CNIIC_TRY(o.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ Hilbert + delta
+int32_t cniic_hilbert_xy(cniic_ctx *c, uint32_t w, uint32_t h, uint32_t *xy) {
+    LOCK(c);
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return CNIIC_OK;
+    if (!xy) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert_xy: null output");
+    Out<uint32_t> o;
+    CNIIC_TRY(o.bind(c, xy, 2 * n));
+    CNIIC_TRY(hilbert_xy(c, w, h, o.d));
+    CNIIC_TRY(o.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_hilbert_linearize(cniic_ctx *c, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *out_rgb) {
+    LOCK(c);
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return CNIIC_OK;
+    if (!rgb || !out_rgb) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert_linearize: null argument");
+    In<uint8_t> in;
+    Out<uint8_t> o;
+    CNIIC_TRY(in.bind(c, rgb, 3 * n));
+    CNIIC_TRY(o.bind(c, out_rgb, 3 * n));
+    CNIIC_TRY(hilbert_linearize(c, in.d, w, h, o.d));
+    CNIIC_TRY(o.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_hilbert_delta(cniic_ctx *c, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t *syms) {
+    LOCK(c);
+    c->ktimes.clear();
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return CNIIC_OK;
+    if (!rgb || !syms) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert_delta: null argument");
+    In<uint8_t> in;
+    Out<uint32_t> o;
+    CNIIC_TRY(in.bind(c, rgb, 3 * n));
+    CNIIC_TRY(o.bind(c, syms, n));
+    CNIIC_TRY(hilbert_delta(c, in.d, w, h, o.d, nullptr));
+    CNIIC_TRY(o.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_hilbert_delta_hist(cniic_ctx *c, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t *keys, uint64_t *counts,
+                                 uint64_t cap, uint64_t *n_unique, uint32_t *syms) {
+    LOCK(c);
+    c->ktimes.clear();
+    const uint64_t n = (uint64_t)w * h;
+    if (n_unique) *n_unique = 0;
+    if (!n) return CNIIC_OK;
+    if (!rgb) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert_delta_hist: null image");
+    In<uint8_t> in;
+    Out<uint32_t> so;
+    CNIIC_TRY(in.bind(c, rgb, 3 * n));
+    CNIIC_TRY(so.bind(c, syms, n));
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 27, &table));
+    CNIIC_TRY(hilbert_delta(c, in.d, w, h, so.d, table));
+    CNIIC_TRY(so.finish(c));
+    return hist_common(c, 27, table, keys, counts, cap, n_unique);
+}
+
+// ------------------------------------------------------------------ H2
+int32_t cniic_huf_encode_all(cniic_ctx *c, int32_t sym_kind, const uint32_t *syms, uint64_t n, uint8_t *out, uint64_t cap,
+                             uint64_t *len) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (sym_kind != CNIIC_SYM_RGB && sym_kind != CNIIC_SYM_SIGNED) return c->fail(CNIIC_ERR_BAD_ARG, "huf_encode_all: bad symbol kind");
+    if (!syms || !len) return c->fail(CNIIC_ERR_BAD_ARG, "huf_encode_all: null argument");
+    if (n >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "huf_encode_all: too many symbols");
+    In<uint32_t> in;
+    CNIIC_TRY(in.bind(c, syms, n));
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, sym_kind == CNIIC_SYM_RGB ? 24 : 27, &table));
+    std::vector<uint8_t> header;
+    DevBuf payload;
+    uint64_t pbytes = 0;
+    CNIIC_TRY(huf_encode_all_dev(c, sym_kind, nullptr, in.d, n, table, false, header, payload, &pbytes));
+    *len = header.size() + pbytes;
+    if (*len > cap) return c->fail(CNIIC_ERR_CAPACITY, "huf_encode_all: stream is %llu bytes, capacity %llu",
+                                   (unsigned long long)*len, (unsigned long long)cap);
+    const bool dev = is_device_ptr(out);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(out, header.data(), header.size(), dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
+    if (pbytes)
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(out + header.size(), payload.p, pbytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int32_t cniic_huf_size(int32_t sym_kind, const uint64_t *counts, uint64_t n, uint64_t *nbytes) {
+    if (!counts || !nbytes || n == 0 || huff_symbol_size(sym_kind) < 0) return CNIIC_ERR_BAD_ARG;
+    HuffTree t;
+    std::vector<uint8_t> len;
+    std::vector<uint64_t> code;
+    if (!huff_build_tree(counts, n, t) || !huff_codes(t, len, code)) return CNIIC_ERR_BAD_ARG;
+    *nbytes = huff_stream_size(sym_kind, counts, len.data(), n);
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ Codec trait
+int32_t cniic_codec_parse(const char *expr, int32_t *kind, uint32_t *arg) {
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return CNIIC_ERR_BAD_ARG;
+    if (kind) *kind = d.kind;
+    if (arg) *arg = d.arg;
+    return CNIIC_OK;
+}
+
+int32_t cniic_codec_name(const char *expr, char *buf, uint64_t cap) {
+    CodecDesc d;
+    if (!parse_codec(expr, &d) || !buf) return CNIIC_ERR_BAD_ARG;
+    std::string s = codec_name(d);
+    if (s.size() + 1 > cap) return CNIIC_ERR_CAPACITY;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return CNIIC_OK;
+}
+
+int32_t cniic_codec_is_lossless(const char *expr) {
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return CNIIC_ERR_BAD_ARG;
+    return codec_is_lossless(d) ? 1 : 0;
+}
+
+int32_t cniic_codec_encode(cniic_ctx *c, const char *expr, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap,
+                           uint64_t *len, cniic_kmeans_stats *stats) {
+    LOCK(c);
+    c->ktimes.clear();
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return c->fail(CNIIC_ERR_BAD_ARG, "Malformed codec argument: %s", expr ? expr : "(null)");
+    if (!len || (!rgb && (uint64_t)w * h) || !out) return c->fail(CNIIC_ERR_BAD_ARG, "codec_encode: null argument");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3));
+    return codec_encode(c, d, in.d, w, h, nullptr, out, cap, len, stats);
+}
+
+int32_t cniic_codec_encode_opts(cniic_ctx *c, const char *expr, const cniic_kmeans_opts *opts, const uint8_t *rgb, uint32_t w,
+                                uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
+    LOCK(c);
+    c->ktimes.clear();
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return c->fail(CNIIC_ERR_BAD_ARG, "Malformed codec argument: %s", expr ? expr : "(null)");
+    if (!len || (!rgb && (uint64_t)w * h) || !out) return c->fail(CNIIC_ERR_BAD_ARG, "codec_encode: null argument");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3));
+    return codec_encode(c, d, in.d, w, h, opts, out, cap, len, stats);
+}
+
+int32_t cniic_codec_decode(cniic_ctx *c, const char *expr, const uint8_t *bytes, uint64_t n, uint8_t *rgb, uint64_t cap, uint32_t *w,
+                           uint32_t *h) {
+    LOCK(c);
+    c->ktimes.clear();
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return c->fail(CNIIC_ERR_BAD_ARG, "Malformed codec argument: %s", expr ? expr : "(null)");
+    if (!bytes || !w || !h) return c->fail(CNIIC_ERR_BAD_ARG, "codec_decode: null argument");
+    std::vector<uint8_t> host;
+    const uint8_t *b = bytes;
+    if (is_device_ptr(bytes)) {
+        host.resize(n);
+        CNIIC_HIP_TRY(c, hipMemcpy(host.data(), bytes, n, hipMemcpyDeviceToHost));
+        b = host.data();
+    }
+    return codec_decode(c, d, b, n, rgb, cap, w, h);
+}
+
+int32_t cniic_mse(cniic_ctx *c, const uint8_t *a, const uint8_t *b, uint64_t npx, double *mse) {
+    LOCK(c);
+    if (!mse || ((!a || !b) && npx)) return c->fail(CNIIC_ERR_BAD_ARG, "mse: null argument");
+    In<uint8_t> ia, ib;
+    CNIIC_TRY(ia.bind(c, a, npx * 3));
+    CNIIC_TRY(ib.bind(c, b, npx * 3));
+    return mse_rgb(c, ia.d, ib.d, npx, mse);
+}
+
+int32_t cniic_synth_image(cniic_ctx *c, int32_t kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *rgb) {
+    LOCK(c);
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return CNIIC_OK;
+    if (!rgb) return c->fail(CNIIC_ERR_BAD_ARG, "synth_image: null output");
+    Out<uint8_t> o;
+    CNIIC_TRY(o.bind(c, rgb, 3 * n));
+    CNIIC_TRY(synth_image(c, kind, seed, w, h, o.d));
+    CNIIC_TRY(o.finish(c));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+}  // extern "C"

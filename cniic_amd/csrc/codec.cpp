@@ -1,0 +1,399 @@
+// codec.cpp -- host-side mirror of the reference's Codec trait (src/codec.rs:14-19) for the four
+// codecs on the hot path, driving the HIP kernels.  Same names (Codec::name), same lossless flags,
+// same --codec= expressions (FromStr impls), same wire format, same failure points.
+//
+//   Hufman          src/codec/hufc.rs        dims + huf::encode_all over row-major pixels
+//   ClusterColors   src/codec/clusterc.rs:17 dedup -> K-means -> remap -> Hufman
+//   VoronoiCluster  src/codec/clusterc.rs:147 5-D K-means, centroids only; Voronoi repaint on decode
+//   Delta           src/codec/hilbertc.rs:404 Hilbert gather -> neighbour delta -> huf::encode_all
+#include "codec.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <map>
+
+#include "huff_host.hpp"
+
+namespace cniic {
+
+// ------------------------------------------------------------------ FromStr (codec.rs:41-59)
+static bool match_fun_u32(const std::string &s, const char *const *names, uint32_t *arg) {
+    // Regex::captures is an unanchored search (clusterc.rs:125-127, 281-283)
+    for (size_t p = 0; p < s.size(); p++)
+        for (int i = 0; names[i]; i++) {
+            const size_t l = strlen(names[i]);
+            if (s.compare(p, l, names[i]) != 0 || p + l >= s.size() || s[p + l] != '(') continue;
+            size_t q = p + l + 1;
+            if (q >= s.size() || !isdigit((unsigned char)s[q])) continue;
+            unsigned long long v = 0;
+            bool ok = true;
+            while (q < s.size() && isdigit((unsigned char)s[q])) {
+                v = v * 10 + (unsigned)(s[q] - '0');
+                if (v > 0xffffffffull) { ok = false; break; }
+                q++;
+            }
+            if (!ok || q >= s.size() || s[q] != ')') continue;
+            *arg = (uint32_t)v;
+            return true;
+        }
+    return false;
+}
+
+bool parse_codec(const char *expr, CodecDesc *out) {
+    if (!expr) return false;
+    const std::string s(expr);
+    // alternatives in the order of gen_all! (codec.rs:120-127); Hilbert and Zip are out of scope
+    static const char *const cc[] = {"cluster-colors", "cluster-col", "clustercolors", "clustercol",
+                                     "c-colors", "c-col", "ccolors", "ccol", nullptr};  // c(?:luster)?-?col(?:ors)?
+    static const char *const vo[] = {"voronoi", nullptr};
+    uint32_t k = 0;
+    if (match_fun_u32(s, cc, &k)) { *out = {CODEC_CLUSTER_COLORS, k}; return true; }
+    if (match_fun_u32(s, vo, &k)) { *out = {CODEC_VORONOI, k}; return true; }
+    if (s == "delta") { *out = {CODEC_DELTA, 0}; return true; }  // prs::expect_name: ^delta$
+    if (s.size() == 6) {                                         // hufc.rs:54-59 eq_ignore_ascii_case
+        std::string t = s;
+        std::transform(t.begin(), t.end(), t.begin(), [](unsigned char ch) { return (char)tolower(ch); });
+        if (t == "hufman") { *out = {CODEC_HUFMAN, 0}; return true; }
+    }
+    return false;
+}
+
+std::string codec_name(const CodecDesc &d) {
+    switch (d.kind) {
+    case CODEC_HUFMAN: return "Hufman";                                   // hufc.rs:42-44
+    case CODEC_CLUSTER_COLORS: return "cluster-colors_" + std::to_string(d.arg);  // clusterc.rs:59-61
+    case CODEC_VORONOI: return "voronoi_" + std::to_string(d.arg);        // clusterc.rs:191-193
+    case CODEC_DELTA: return "delta";                                     // hilbertc.rs:433-435
+    }
+    return "";
+}
+
+bool codec_is_lossless(const CodecDesc &d) { return d.kind == CODEC_HUFMAN || d.kind == CODEC_DELTA; }
+
+// ------------------------------------------------------------------ output assembly
+// header (host bytes) followed by a device payload -> caller buffer (host or device)
+static int emit(Ctx *c, const std::vector<uint8_t> &header, const uint8_t *payload_d, uint64_t payload_bytes,
+                uint8_t *out, uint64_t cap, uint64_t *len) {
+    *len = header.size() + payload_bytes;
+    if (*len > cap) return c->fail(CNIIC_ERR_CAPACITY, "encode: stream is %llu bytes, capacity %llu",
+                                   (unsigned long long)*len, (unsigned long long)cap);
+    const bool dev = is_device_ptr(out);
+    if (!header.empty())
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(out, header.data(), header.size(), dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
+    if (payload_bytes)
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(out + header.size(), payload_d, payload_bytes,
+                                        dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ huf::encode_all (huf.rs:22-43)
+// Symbols come either as pixels (rgb_d) or as packed keys (syms_d).  table_d holds the dense
+// histogram on entry when have_hist, otherwise it is built here.
+int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n,
+                       uint32_t *table_d, bool have_hist, std::vector<uint8_t> &header, DevBuf &payload,
+                       uint64_t *payload_bytes) {
+    if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "huf::encode_all on an empty stream (src/huf.rs:99 asserts)");
+    const uint32_t bits = sym_kind == CNIIC_SYM_RGB ? 24 : 27;
+    // 1. utils::count_freqs (huf.rs:30)
+    if (!have_hist) {
+        if (rgb_d) CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table_d));
+        else CNIIC_TRY(hist_syms_dense(c, syms_d, n, table_d, bits));
+    }
+    CompactPlan plan;
+    CNIIC_TRY(hist_compact_count(c, table_d, bits, &plan));
+    const uint64_t U = plan.n_unique;
+    DevBuf keys_d, counts_d;
+    CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
+    CNIIC_HIP_TRY(c, counts_d.alloc(U * 8));
+    CNIIC_TRY(hist_compact_write(c, table_d, &plan, keys_d.as<uint32_t>(), counts_d.as<uint64_t>(), nullptr));
+    std::vector<uint32_t> keys(U);
+    std::vector<uint64_t> counts(U);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
+    HuffTree tree;
+    std::vector<uint8_t> len;
+    std::vector<uint64_t> code;
+    if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, len, code))
+        return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+    huff_serialize_tree(tree, sym_kind, keys.data(), header);
+    // 3. payload (huf.rs:37-41)
+    uint64_t nbits = 0;
+    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * len[i];
+    *payload_bytes = (nbits + 7) / 8;
+    DevBuf len_d, code_d;
+    CNIIC_HIP_TRY(c, len_d.alloc(U));
+    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, len.data(), U, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t cap = ceil_div(nbits, 32) * 4 + 16;
+    CNIIC_HIP_TRY(c, payload.alloc(cap));
+    uint64_t packed_bits = 0;
+    ScopedKernelTimer timer(c, "huff_pack");
+    CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(),
+                             payload.as<uint8_t>(), cap, &packed_bits));
+    timer.stop(1);
+    if (packed_bits != nbits)
+        return c->fail(CNIIC_ERR_HIP, "huffman: packed %llu bits, histogram predicts %llu", (unsigned long long)packed_bits,
+                       (unsigned long long)nbits);
+    return CNIIC_OK;
+}
+
+// ------------------------------------------------------------------ Hufman::encode (hufc.rs:12-17)
+static int encode_hufman(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len) {
+    const uint64_t n = (uint64_t)w * h;
+    std::vector<uint8_t> header;
+    put_u32(header, w);  // img.dimensions().serialize (hufc.rs:13)
+    put_u32(header, h);
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 24, &table));
+    DevBuf payload;
+    uint64_t pbytes = 0;
+    CNIIC_TRY(huf_encode_all_dev(c, CNIIC_SYM_RGB, rgb_d, nullptr, n, table, false, header, payload, &pbytes));
+    return emit(c, header, payload.as<uint8_t>(), pbytes, out, cap, len);
+}
+
+// ------------------------------------------------------------------ ClusterColors::encode (clusterc.rs:18-53)
+static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
+                                 const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
+                                 cniic_kmeans_stats *stats) {
+    const uint64_t n = (uint64_t)w * h;
+    if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
+    // count_freqs over the pixels (clusterc.rs:21): distinct colours, ascending key = point order
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 24, &table));
+    {
+        ScopedKernelTimer t(c, "hist_rgb");
+        CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table));
+        t.stop(1);
+    }
+    CompactPlan plan;
+    CNIIC_TRY(hist_compact_count(c, table, 24, &plan));
+    const uint64_t U = plan.n_unique;
+    if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)",
+                                   (unsigned long long)U, K);
+    DevBuf keys_d, weight_d;
+    CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
+    CNIIC_HIP_TRY(c, weight_d.alloc(U * 4));
+    CNIIC_TRY(hist_compact_write(c, table, &plan, keys_d.as<uint32_t>(), nullptr, weight_d.as<uint32_t>()));
+    // kmeans::cluster (clusterc.rs:28)
+    KmRgbwState *km = nullptr;
+    CNIIC_TRY(km_rgbw_create(c, keys_d.as<uint32_t>(), weight_d.as<uint32_t>(), U, 0, U, K, opts, nullptr, &km));
+    struct Guard { KmRgbwState *k; ~Guard() { km_rgbw_destroy(k); } } guard{km};
+    CNIIC_TRY(km_rgbw_run(km));
+    std::vector<uint8_t> cent(3 * (size_t)K);
+    std::vector<uint64_t> members(K), wsum(K);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_rgbw_result(km, cent.data(), nullptr, members.data(), wsum.data(), &st));
+    if (stats) *stats = st;
+    // check_enough_active_clusters (kmeans.rs:41-57)
+    uint64_t min_cc = (uint64_t)(0.99 * (double)K);
+    if (U < min_cc) min_cc = U;
+    if (st.active < min_cc)
+        return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
+                       (unsigned long long)st.active, (unsigned long long)min_cc);
+    // Histogram of the colour-reduced image = per-centroid-colour sum of member weights
+    // (what count_freqs inside Hufman.encode would find, clusterc.rs:52 -> huf.rs:30).
+    std::map<uint32_t, uint64_t> hist;
+    for (uint32_t k = 0; k < K; k++)
+        if (members[k]) hist[((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2]] += wsum[k];
+    std::vector<uint32_t> skeys;
+    std::vector<uint64_t> scounts;
+    for (auto &kv : hist) { skeys.push_back(kv.first); scounts.push_back(kv.second); }
+    HuffTree tree;
+    std::vector<uint8_t> slen;
+    std::vector<uint64_t> scode;
+    if (!huff_build_tree(scounts.data(), scounts.size(), tree) || !huff_codes(tree, slen, scode))
+        return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code");
+    std::vector<uint8_t> header;
+    put_u32(header, w);
+    put_u32(header, h);
+    huff_serialize_tree(tree, CNIIC_SYM_RGB, skeys.data(), header);
+    uint64_t nbits = 0;
+    for (size_t i = 0; i < scounts.size(); i++) nbits += scounts[i] * slen[i];
+    // per-cluster code, expanded on the device to one (len, code) per distinct input colour:
+    // reduced_colors.get(original_colour) (clusterc.rs:43-47) fused with Enc::encode (huf.rs:137-148)
+    std::vector<uint8_t> clen(K, 0);
+    std::vector<uint64_t> ccode(K, 0);
+    for (uint32_t k = 0; k < K; k++) {
+        if (!members[k]) continue;
+        uint32_t key = ((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2];
+        size_t si = std::lower_bound(skeys.begin(), skeys.end(), key) - skeys.begin();
+        clen[k] = slen[si];
+        ccode[k] = scode[si];
+    }
+    DevBuf clen_d, ccode_d, len_d, code_d, payload;
+    CNIIC_HIP_TRY(c, clen_d.alloc(K));
+    CNIIC_HIP_TRY(c, ccode_d.alloc((uint64_t)K * 8));
+    CNIIC_HIP_TRY(c, len_d.alloc(U));
+    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), K, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    CNIIC_TRY(expand_codes_by_label(c, km_rgbw_labels8_dev(km), km_rgbw_labels16_dev(km), U, clen_d.as<uint8_t>(),
+                                    ccode_d.as<uint64_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>()));
+    const uint64_t pcap = ceil_div(nbits, 32) * 4 + 16;
+    CNIIC_HIP_TRY(c, payload.alloc(pcap));
+    uint64_t packed_bits = 0;
+    {
+        ScopedKernelTimer t(c, "huff_pack");
+        CNIIC_TRY(huff_pack_keys(c, nullptr, rgb_d, n, table, len_d.as<uint8_t>(), code_d.as<uint64_t>(), payload.as<uint8_t>(),
+                                 pcap, &packed_bits));
+        t.stop(1);
+    }
+    if (packed_bits != nbits)
+        return c->fail(CNIIC_ERR_HIP, "cluster-colors: packed %llu bits, histogram predicts %llu",
+                       (unsigned long long)packed_bits, (unsigned long long)nbits);
+    return emit(c, header, payload.as<uint8_t>(), (nbits + 7) / 8, out, cap, len);
+}
+
+// ------------------------------------------------------------------ VoronoiCluster::encode (clusterc.rs:148-166)
+static int encode_voronoi(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K, const cniic_kmeans_opts *opts,
+                          uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
+    if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "voronoi(0)");
+    std::vector<cniic_colorpos> cent(K);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_xyrgb_run(c, rgb_d, w, h, K, opts, cent.data(), nullptr, nullptr, &st));
+    if (stats) *stats = st;
+    const uint64_t N = (uint64_t)w * h;
+    uint64_t min_cc = (uint64_t)(0.99 * (double)K);
+    if (N < min_cc) min_cc = N;
+    if (st.active < min_cc)
+        return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
+                       (unsigned long long)st.active, (unsigned long long)min_cc);
+    std::vector<uint8_t> header;
+    put_u32(header, w);            // clusterc.rs:156-158
+    put_u32(header, h);
+    put_u64(header, K);            // clusterc.rs:161 (usize -> u64)
+    for (uint32_t k = 0; k < K; k++) {  // ColorPos::serialize clusterc.rs:250-257
+        put_u32(header, cent[k].x);
+        put_u32(header, cent[k].y);
+        put_u64(header, 3);        // Rgb<u8> as a length-prefixed slice (ser.rs:210-214)
+        header.push_back(cent[k].rgb[0]); header.push_back(cent[k].rgb[1]); header.push_back(cent[k].rgb[2]);
+    }
+    return emit(c, header, nullptr, 0, out, cap, len);
+}
+
+// ------------------------------------------------------------------ Delta::encode (hilbertc.rs:405-415)
+static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len) {
+    const uint64_t n = (uint64_t)w * h;
+    std::vector<uint8_t> header;
+    put_u32(header, w);
+    put_u32(header, h);
+    if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "delta: empty image (src/huf.rs:99 asserts)");
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 27, &table));
+    DevBuf syms;
+    CNIIC_HIP_TRY(c, syms.alloc(n * 4));
+    // one fused pass: Hilbert gather + DiffStream + count_freqs; the symbol stream is kept for the
+    // second (bit-pack) pass instead of recomputing the scan as the reference does (huf.rs:30,38)
+    CNIIC_TRY(hilbert_delta(c, rgb_d, w, h, syms.as<uint32_t>(), table));
+    DevBuf payload;
+    uint64_t pbytes = 0;
+    CNIIC_TRY(huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), n, table, true, header, payload, &pbytes));
+    return emit(c, header, payload.as<uint8_t>(), pbytes, out, cap, len);
+}
+
+int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, uint32_t h, const cniic_kmeans_opts *opts,
+                 uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if ((uint64_t)w * h >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "image too large");
+    switch (d.kind) {
+    case CODEC_HUFMAN: return encode_hufman(c, rgb_d, w, h, out, cap, len);
+    case CODEC_CLUSTER_COLORS: return encode_cluster_colors(c, rgb_d, w, h, d.arg, opts, out, cap, len, stats);
+    case CODEC_VORONOI: return encode_voronoi(c, rgb_d, w, h, d.arg, opts, out, cap, len, stats);
+    case CODEC_DELTA: return encode_delta(c, rgb_d, w, h, out, cap, len);
+    }
+    return c->fail(CNIIC_ERR_BAD_ARG, "unknown codec");
+}
+
+// ------------------------------------------------------------------ decode
+static int put_image(Ctx *c, const uint8_t *src, bool src_dev, uint64_t bytes, uint8_t *dst) {
+    if (!bytes) return CNIIC_OK;
+    const bool dst_dev = is_device_ptr(dst);
+    hipMemcpyKind kind = src_dev ? (dst_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost)
+                                 : (dst_dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, kind, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
+                 uint32_t *w, uint32_t *h) {
+    uint64_t pos = 0;
+    if (!get_u32(bytes, nbytes, pos, *w) || !get_u32(bytes, nbytes, pos, *h))  // create_image_buffer_standard codec.rs:22-26
+        return c->fail(CNIIC_ERR_DECODE, "decode: truncated dimensions");
+    const uint64_t n = (uint64_t)*w * *h;
+    if (n >= (1ull << 32)) return c->fail(CNIIC_ERR_DECODE, "decode: image too large");
+    if (n * 3 > cap) return c->fail(CNIIC_ERR_CAPACITY, "decode: image needs %llu bytes, capacity %llu",
+                                    (unsigned long long)(n * 3), (unsigned long long)cap);
+    switch (d.kind) {
+    case CODEC_HUFMAN:
+    case CODEC_CLUSTER_COLORS: {  // clusterc.rs:55-57 delegates to Hufman.decode (hufc.rs:19-40)
+        std::vector<uint32_t> keys(n);
+        if (!huff_decode_symbols(CNIIC_SYM_RGB, bytes, nbytes, pos, n, keys.data()))
+            return c->fail(CNIIC_ERR_DECODE, "Failed to decode symbol");
+        std::vector<uint8_t> img(n * 3);
+        for (uint64_t i = 0; i < n; i++) { img[3 * i] = (uint8_t)(keys[i] >> 16); img[3 * i + 1] = (uint8_t)(keys[i] >> 8); img[3 * i + 2] = (uint8_t)keys[i]; }
+        return put_image(c, img.data(), false, n * 3, rgb_out);
+    }
+    case CODEC_DELTA: {  // hilbertc.rs:417-431
+        std::vector<uint32_t> keys(n);
+        if (!huff_decode_symbols(CNIIC_SYM_SIGNED, bytes, nbytes, pos, n, keys.data()))
+            return c->fail(CNIIC_ERR_DECODE, "delta: cannot decode the difference stream");
+        std::vector<uint8_t> lin(n * 3);
+        int last[3] = {0, 0, 0};  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508)
+        for (uint64_t i = 0; i < n; i++)
+            for (int ch = 0; ch < 3; ch++) {
+                int v = last[ch] + (int)((keys[i] >> (18 - 9 * ch)) & 511) - 255;
+                if (v < 0 || v > 255) return c->fail(CNIIC_ERR_DECODE, "delta: colour out of range (hilbertc.rs:505)");
+                last[ch] = v;
+                lin[3 * i + ch] = (uint8_t)v;
+            }
+        if (!n) return CNIIC_OK;
+        DevBuf lin_d, img_d;
+        CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(lin_d.p, lin.data(), n * 3, hipMemcpyHostToDevice, c->stream));
+        uint8_t *dst = rgb_out;
+        const bool dst_dev = is_device_ptr(rgb_out);
+        if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+        CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
+        return CNIIC_OK;
+    }
+    case CODEC_VORONOI: {  // clusterc.rs:168-189
+        uint64_t K;
+        if (!get_u64(bytes, nbytes, pos, K)) return c->fail(CNIIC_ERR_DECODE, "voronoi: truncated");
+        if (K > (nbytes - pos) / 19) return c->fail(CNIIC_ERR_DECODE, "voronoi: truncated centroid list");
+        std::vector<cniic_colorpos> cent(K);
+        for (uint64_t k = 0; k < K; k++) {
+            uint64_t l;
+            if (!get_u32(bytes, nbytes, pos, cent[k].x) || !get_u32(bytes, nbytes, pos, cent[k].y) ||
+                !get_u64(bytes, nbytes, pos, l) || l != 3 || pos + 3 > nbytes)
+                return c->fail(CNIIC_ERR_DECODE, "voronoi: bad centroid");
+            memcpy(cent[k].rgb, bytes + pos, 3);
+            cent[k].pad = 0;
+            pos += 3;
+        }
+        if (!n) return CNIIC_OK;
+        if (K == 0) return c->fail(CNIIC_ERR_DECODE, "voronoi: no centroids (min_by_key().unwrap(), clusterc.rs:184)");
+        if (K > 0xffffffffull) return c->fail(CNIIC_ERR_DECODE, "voronoi: too many centroids");
+        DevBuf cent_d, img_d;
+        CNIIC_HIP_TRY(c, cent_d.alloc(K * sizeof(cniic_colorpos)));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(cent_d.p, cent.data(), K * sizeof(cniic_colorpos), hipMemcpyHostToDevice, c->stream));
+        uint8_t *dst = rgb_out;
+        const bool dst_dev = is_device_ptr(rgb_out);
+        if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+        CNIIC_TRY(voronoi_paint(c, cent_d.as<cniic_colorpos>(), (uint32_t)K, *w, *h, dst));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
+        return CNIIC_OK;
+    }
+    }
+    return c->fail(CNIIC_ERR_BAD_ARG, "unknown codec");
+}
+
+}  // namespace cniic

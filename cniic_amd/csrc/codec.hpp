@@ -1,0 +1,31 @@
+// codec.hpp -- the reference's Codec surface (src/codec.rs:14-19) for the hot-path codecs.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace cniic {
+
+enum CodecKind { CODEC_HUFMAN = 1, CODEC_CLUSTER_COLORS = 2, CODEC_VORONOI = 3, CODEC_DELTA = 4 };
+
+struct CodecDesc {
+    int      kind;
+    uint32_t arg;  // K for cluster-colors / voronoi
+};
+
+bool        parse_codec(const char *expr, CodecDesc *out);  // AnyCodec::from_str (codec.rs:41-59)
+std::string codec_name(const CodecDesc &d);                 // Codec::name
+bool        codec_is_lossless(const CodecDesc &d);          // Codec::is_lossless
+
+// rgb_d is device memory; out / rgb_out may be host or device.
+int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, uint32_t h, const cniic_kmeans_opts *opts,
+                 uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+// bytes is HOST memory.
+int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
+                 uint32_t *w, uint32_t *h);
+
+int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n, uint32_t *table_d,
+                       bool have_hist, std::vector<uint8_t> &header, DevBuf &payload, uint64_t *payload_bytes);
+
+}  // namespace cniic

@@ -1,0 +1,251 @@
+// common.hpp -- shared host-side plumbing of libcniic_hip.so (context, scratch HBM, error
+// handling).  gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/cniic_hip.h"
+
+namespace cniic {
+
+constexpr uint64_t kDefaultSeed = 0x636E696963ULL;
+
+struct KernelTime {
+    double   ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct Ctx;
+
+// RAII device allocation on the context's device.
+struct DevBuf {
+    void    *p = nullptr;
+    uint64_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    hipError_t alloc(uint64_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = false;
+    std::mutex  mu;
+    std::string err;
+    std::map<std::string, KernelTime> ktimes;  // per-call dominant-kernel timings (HIP events)
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
+    DevBuf dense;           // u32[2^24] or u32[2^27]
+    void  *pinned = nullptr; // 4 KiB of mapped host memory for lagged flag polling
+    uint64_t pinned_bytes = 0;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define CNIIC_HIP_TRY(ctx, expr)                                                          \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return (ctx)->fail(CNIIC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
+                               hipGetErrorString(_e));                                    \
+    } while (0)
+
+#define CNIIC_TRY(expr)              \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != CNIIC_OK) return _rc; \
+    } while (0)
+
+// Is p device-accessible memory (hipMalloc / torch allocation)?  Host pointers unknown to HIP
+// report hipErrorInvalidValue, which is cleared.
+inline bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// Input view: device pointer used as is, host pointer staged into an owned HBM buffer.
+template <class T> struct In {
+    const T *d = nullptr;
+    DevBuf   own;
+    int bind(Ctx *c, const T *p, uint64_t n) {
+        if (n == 0 || !p) { d = nullptr; return CNIIC_OK; }
+        if (is_device_ptr(p)) { d = p; return CNIIC_OK; }
+        CNIIC_HIP_TRY(c, own.alloc(n * sizeof(T)));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(own.p, p, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        d = own.as<T>();
+        return CNIIC_OK;
+    }
+};
+
+// Output view: device pointer written in place, host pointer filled by a D2H copy in finish().
+template <class T> struct Out {
+    T       *d = nullptr;
+    T       *host = nullptr;
+    uint64_t n = 0;
+    DevBuf   own;
+    int bind(Ctx *c, T *p, uint64_t count) {
+        n = count;
+        if (!p || count == 0) { d = nullptr; host = nullptr; return CNIIC_OK; }
+        if (is_device_ptr(p)) { d = p; host = nullptr; return CNIIC_OK; }
+        CNIIC_HIP_TRY(c, own.alloc(count * sizeof(T)));
+        d = own.as<T>();
+        host = p;
+        return CNIIC_OK;
+    }
+    // copy the first `count` elements back (async; caller syncs the stream)
+    int finish(Ctx *c, uint64_t count) {
+        if (host && count) CNIIC_HIP_TRY(c, hipMemcpyAsync(host, d, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        return CNIIC_OK;
+    }
+    int finish(Ctx *c) { return finish(c, n); }
+};
+
+inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// Device-resident state of a K-means loop (kmeans.rs:21-39): lets iterations be enqueued back to
+// back; kernels of iterations past convergence exit on `done`.
+constexpr uint32_t kHistRing = 64;
+struct KmDevState {
+    uint64_t iter;         // iterations completed
+    uint32_t done;         // 1 once an iteration moved nothing (kmeans.rs:26) or max_iters was hit
+    uint32_t pad;
+    uint64_t moved_last;
+    uint64_t reseeds;
+    uint64_t active;
+    uint64_t pair_evals;
+    uint64_t changed_ring[kHistRing];
+};
+
+// ---- kernel timing of the dominant kernels (HIP events on the ctx stream) ----
+struct ScopedKernelTimer {
+    Ctx        *c;
+    const char *name;
+    bool        on;
+    ScopedKernelTimer(Ctx *ctx, const char *nm, bool enable = true) : c(ctx), name(nm), on(enable) {
+        if (on) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    // must be called after the launch; synchronises on the stop event
+    void stop(uint64_t launches = 1) {
+        if (!on) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        KernelTime &kt = c->ktimes[name];
+        kt.ms += ms;
+        kt.launches += launches;
+        on = false;
+    }
+};
+
+// =========================================================================== device entry points
+// (host launchers implemented in the .hip files)
+
+// ---- k_hist.hip ----
+// Dense-table histogram of packed keys.  table: u32[1<<bits], must be zero on entry.
+int hist_rgb_dense(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *table_d);
+int hist_syms_dense(Ctx *c, const uint32_t *syms_d, uint64_t n, uint32_t *table_d, uint32_t bits);
+// Compaction of a dense count table into ascending (key,count) pairs (3-phase scan).
+struct CompactPlan {
+    DevBuf   blockoff;
+    uint64_t n_unique = 0;
+    uint32_t bits = 0;
+};
+int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan);
+// After this call the table holds, for every occupied bin, its RANK (index into the compacted
+// list) + 1; empty bins stay 0.  Outputs are optional device arrays of plan->n_unique entries.
+int hist_compact_write(Ctx *c, uint32_t *table_d, const CompactPlan *plan, uint32_t *keys_d, uint64_t *counts_d,
+                       uint32_t *weights_d);
+int dense_table(Ctx *c, uint32_t bits, uint32_t **table_d);  // zeroed scratch table of the ctx
+
+// ---- k_kmeans_rgbw.hip ----
+struct KmRgbwState;  // opaque device state of one rgbw K-means problem
+int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint64_t lo,
+                   uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
+                   KmRgbwState **out);
+void km_rgbw_destroy(KmRgbwState *s);
+int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
+int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials
+int km_rgbw_update(KmRgbwState *s);                       // async: centroids from partials
+int km_rgbw_run(KmRgbwState *s);                          // full loop to convergence (single GPU)
+int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
+int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
+                   uint64_t *wsum_h, cniic_kmeans_stats *stats);
+int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch);
+int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h);
+void *km_rgbw_partials_dev(KmRgbwState *s);
+const uint8_t *km_rgbw_labels8_dev(KmRgbwState *s);       // device labels (u8 when K<=256 else null)
+const uint16_t *km_rgbw_labels16_dev(KmRgbwState *s);
+
+// ---- k_kmeans_xyrgb.hip ----
+int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
+                 const cniic_kmeans_opts *opts, cniic_colorpos *centroids_h, uint32_t *labels_d_u32,
+                 uint64_t *members_h, cniic_kmeans_stats *stats);
+int km_xyrgb_step(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
+                  const cniic_colorpos *centroids_h, uint32_t *labels_d_u32, uint64_t *sums_h,
+                  uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h, const cniic_kmeans_opts *opts);
+
+// ---- k_misc.hip ----
+// per-pixel colour -> centroid colour through the rank table left by hist_compact
+int remap_rgb(Ctx *c, const uint8_t *rgb_d, uint64_t npx, const uint32_t *rank_table_d,
+              const uint32_t *lut_rgb_d /* packed centroid colour per unique colour rank */, uint8_t *out_d);
+int expand_codes_by_label(Ctx *c, const uint8_t *labels8_d, const uint16_t *labels16_d, uint64_t U, const uint8_t *clen_d,
+                          const uint64_t *ccode_d, uint8_t *len_d, uint64_t *code_d);
+int label_lut(Ctx *c, const uint32_t *labels_d, uint64_t U, const uint32_t *cent_d, uint32_t *lut_d);
+int rank_from_keys(Ctx *c, const uint32_t *keys_d, uint64_t U, uint32_t *table_d);
+int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d);
+int mse_rgb(Ctx *c, const uint8_t *a_d, const uint8_t *b_d, uint64_t npx, double *mse_h);
+int synth_image(Ctx *c, int kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *out_d);
+int rgb_to_keys(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *keys_d);
+
+// ---- k_hilbert.hip ----
+int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d);
+int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out_d);
+// gather + delta; syms_d (packed SIGNED keys, may be null) and/or histogram into table_d (u32[2^27], may be null)
+int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t *syms_d, uint32_t *table_d);
+int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d);
+
+// ---- k_huff.hip ----
+// MSB-first bit-pack of n symbols.  sym index per element comes from a rank table lookup
+// (key -> rank+1) or directly (16-bit symbol ids).  len_d/code_d are per-rank code tables.
+int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
+                   const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d,
+                   uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h);
+int huff_pack_sym16(Ctx *c, const uint16_t *sym_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d,
+                    uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h);
+
+}  // namespace cniic

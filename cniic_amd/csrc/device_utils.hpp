@@ -1,0 +1,109 @@
+// device_utils.hpp -- small device-side helpers shared by the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace cniic {
+
+__device__ __forceinline__ uint32_t rgb_key(const uint8_t *p) {
+    return ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
+}
+
+// v holds r in byte 0, g in byte 1, b in byte 2 (byte 3 ignored) -> r<<16|g<<8|b
+__device__ __forceinline__ uint32_t key_from_le24(uint32_t v) { return __builtin_bswap32(v) >> 8; }
+
+// 16 interleaved RGB pixels (48 B, 16-B aligned) -> 16 packed keys
+__device__ __forceinline__ void load16px_keys(const uint4 *p, uint32_t key[16]) {
+    uint4 q0 = p[0], q1 = p[1], q2 = p[2];
+    uint32_t w[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+    for (int g = 0; g < 4; g++) {  // 4 pixels per 3 dwords
+        uint32_t a = w[3 * g], b = w[3 * g + 1], c = w[3 * g + 2];
+        key[4 * g + 0] = key_from_le24(a);
+        key[4 * g + 1] = key_from_le24((a >> 24) | (b << 8));
+        key[4 * g + 2] = key_from_le24((b >> 16) | (c << 16));
+        key[4 * g + 3] = key_from_le24(c >> 8);
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ uint64_t wave_reduce_sum64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_down(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_down(v, off, 64));
+    return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// block-wide sum; result valid in thread 0 (and broadcast to all through LDS)
+template <int THREADS> __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v) {
+    __shared__ uint32_t sh[THREADS / 64];
+    v = wave_reduce_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+// block-wide exclusive scan in thread order; wsum = LDS scratch of THREADS/64 words
+template <int THREADS> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum) {
+    uint32_t inc = wave_inclusive_scan(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++)
+        if (i < wid) off += wsum[i];
+    __syncthreads();
+    return off + inc - v;
+}
+
+__host__ __device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// index of the point stolen for empty cluster c at iteration iter: the deterministic stand-in
+// for rand::thread_rng in the reference's empty-cluster branch (src/kmeans.rs:123-133)
+__host__ __device__ __forceinline__ uint64_t reseed_index(uint64_t seed, uint64_t iter, uint32_t c, uint64_t n) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL * (iter * 65536ULL + (uint64_t)c + 1ULL);
+    return splitmix_mix(z) % n;
+}
+
+// kmeans.rs:61-78 init_assignment expressed per point index
+__host__ __device__ __forceinline__ uint32_t init_label(uint64_t i, uint64_t n, uint32_t K) {
+    uint64_t ppc = n / K;
+    uint64_t c = (n - 1 - i) / ppc;
+    return (uint32_t)(c > (uint64_t)K - 1 ? (uint64_t)K - 1 : c);
+}
+
+}  // namespace cniic

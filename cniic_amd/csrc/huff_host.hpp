@@ -1,0 +1,41 @@
+// huff_host.hpp -- host side of huf::encode_all / decode_all (reference src/huf.rs): code
+// construction from a histogram, decoder (trie) serialisation, and stream decoding.  The
+// per-symbol work (histogram, bit-pack) runs on the GPU; what is here is O(alphabet), not O(pixels),
+// except decode_symbols, which walks the bit stream (Huffman decoding is serial in the stream).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace cniic {
+
+struct HuffTree {
+    // nodes 0..n-1 are leaves (leaf i = i-th symbol of the ascending-key histogram);
+    // nodes n..2n-2 are branches (huf.rs:167-171 BinTrie)
+    uint64_t nleaf = 0;
+    std::vector<uint32_t> left, right;  // per branch
+    uint32_t root = 0;
+};
+
+// huf.rs:58-117 build(): min-heap merge.  Heap = Rust std BinaryHeap semantics, item order = the
+// given (ascending key) order.
+bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t);
+// Enc::from(&Dec) (huf.rs:125-135): code length and code bits (MSB-first in the low bits) per leaf.
+bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code);
+// BinTrie::serialize (huf.rs:305-321), pre-order: 0+symbol for a leaf, 1+left+right for a branch.
+void huff_serialize_tree(const HuffTree &t, int sym_kind, const uint32_t *keys, std::vector<uint8_t> &out);
+int  huff_symbol_size(int sym_kind);
+// total stream size of encode_all for this histogram
+uint64_t huff_stream_size(int sym_kind, const uint64_t *counts, const uint8_t *len, uint64_t n);
+
+// Dec::deserialize + DecStream (huf.rs:323-348, 187-206, 366-374): read the trie at bytes[pos..],
+// then decode nsyms symbols into keys_out.  Returns false where the reference yields None.
+bool huff_decode_symbols(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, uint64_t nsyms,
+                         uint32_t *keys_out);
+
+// little-endian writers (src/ser.rs)
+void put_u32(std::vector<uint8_t> &o, uint32_t v);
+void put_u64(std::vector<uint8_t> &o, uint64_t v);
+bool get_u32(const uint8_t *b, uint64_t n, uint64_t &pos, uint32_t &v);
+bool get_u64(const uint8_t *b, uint64_t n, uint64_t &pos, uint64_t &v);
+
+}  // namespace cniic

@@ -1,0 +1,196 @@
+// k_huff.hip -- second pass of huf::encode_all (reference src/huf.rs:36-41): every symbol's code
+// is appended MSB-first to a bit stream that is zero-padded to a byte (src/bit.rs:209-254).
+//
+// The reference pushes bits one symbol at a time through IoBitWriter.  Here the stream position of
+// every symbol is a prefix sum of code lengths, so the pack is three launches:
+//   1. per-chunk bit totals (4096 symbols per 256-thread block)
+//   2. single-block exclusive scan of the chunk totals (u64 offsets)
+//   3. per-chunk pack: block scan of the per-thread bit counts, codes OR-ed into an LDS image of
+//      the chunk aligned to the 32-bit word grid of the output, whole words stored big-endian;
+//      the (at most two) words shared with neighbouring chunks go out with global atomicOr.
+// Symbols reach their code through the rank table left behind by the histogram compaction
+// (key -> rank+1), then len[rank] / code[rank].
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace cniic {
+
+constexpr int kPackThreads = 256;
+constexpr int kPackPer = 16;
+constexpr int kPackChunk = kPackThreads * kPackPer;  // symbols per block
+constexpr int kPackWords = kPackChunk * 2 + 2;       // LDS words: 64 bits per symbol worst case
+
+enum { SRC_RGB = 0, SRC_KEYS = 1, SRC_SYM16 = 2 };
+
+// fetch the ranks of this thread's 16 consecutive symbols (0xffffffff past the end)
+template <int SRC>
+__device__ __forceinline__ void fetch_ranks(const void *__restrict__ src, uint64_t n, uint64_t first,
+                                            const uint32_t *__restrict__ rank_table, uint32_t rank[kPackPer]) {
+    if (SRC == SRC_RGB) {
+        const uint8_t *rgb = reinterpret_cast<const uint8_t *>(src);
+        if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(rgb) & 15) == 0)) {
+            uint32_t key[16];
+            load16px_keys(reinterpret_cast<const uint4 *>(rgb + 3 * first), key);
+#pragma unroll
+            for (int i = 0; i < kPackPer; i++) rank[i] = rank_table[key[i]] - 1;
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPackPer; i++)
+                rank[i] = (first + i < n) ? rank_table[rgb_key(rgb + 3 * (first + i))] - 1 : 0xffffffffu;
+        }
+    } else if (SRC == SRC_KEYS) {
+        const uint32_t *keys = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+        for (int i = 0; i < kPackPer; i++) rank[i] = (first + i < n) ? rank_table[keys[first + i]] - 1 : 0xffffffffu;
+    } else {
+        const uint16_t *sym = reinterpret_cast<const uint16_t *>(src);
+#pragma unroll
+        for (int i = 0; i < kPackPer; i++) rank[i] = (first + i < n) ? (uint32_t)sym[first + i] : 0xffffffffu;
+    }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kPackThreads) void k_pack_count(const void *__restrict__ src, uint64_t n,
+                                                             const uint32_t *__restrict__ rank_table,
+                                                             const uint8_t *__restrict__ len,
+                                                             uint32_t *__restrict__ chunk_bits) {
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t rank[kPackPer];
+    fetch_ranks<SRC>(src, n, first, rank_table, rank);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++)
+        if (rank[i] != 0xffffffffu) bits += len[rank[i]];
+    bits = block_reduce_sum<kPackThreads>(bits);
+    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
+}
+
+// single block: chunk_off[i] = exclusive prefix (u64) of chunk_bits; total -> *total_bits
+__global__ __launch_bounds__(1024) void k_pack_scan(const uint32_t *__restrict__ chunk_bits, uint32_t nchunks,
+                                                    uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ total_bits) {
+    __shared__ unsigned long long sh[1024];
+    const uint32_t per = (nchunks + 1023) / 1024;
+    const uint32_t lo = min(threadIdx.x * per, nchunks), hi = min(lo + per, nchunks);
+    unsigned long long s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += chunk_bits[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        unsigned long long add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = sh[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i++) { chunk_off[i] = run; run += chunk_bits[i]; }
+    if (threadIdx.x == 1023) *total_bits = sh[1023];
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restrict__ src, uint64_t n,
+                                                             const uint32_t *__restrict__ rank_table,
+                                                             const uint8_t *__restrict__ len,
+                                                             const uint64_t *__restrict__ code,
+                                                             const uint64_t *__restrict__ chunk_off,
+                                                             uint32_t *__restrict__ out_words) {
+    __shared__ uint32_t img[kPackWords];
+    __shared__ uint32_t wsum[kPackThreads / 64];
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t rank[kPackPer];
+    fetch_ranks<SRC>(src, n, first, rank_table, rank);
+    uint32_t l[kPackPer];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        l[i] = rank[i] != 0xffffffffu ? len[rank[i]] : 0;
+        bits += l[i];
+    }
+    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
+    uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);  // contains a __syncthreads after img clear
+    const uint64_t g0 = chunk_off[blockIdx.x];          // global bit offset of the chunk
+    const uint32_t skew = (uint32_t)(g0 & 31);          // chunk image is aligned to the output word grid
+    uint32_t pos = skew + excl;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        uint32_t L = l[i];
+        if (L == 0) continue;                           // zero-length code (single-symbol alphabet, huf.rs:140-142)
+        uint64_t cd = code[rank[i]];                    // L significant bits, first stream bit = bit L-1
+        // place bits [pos, pos+L) MSB-first: word w bit (31 - b)
+        uint32_t w = pos >> 5, b = pos & 31;
+        uint32_t room = 32 - b;                          // bits left in word w
+        if (L <= room) {
+            atomicOr(&img[w], (uint32_t)(cd << (room - L)));
+        } else {
+            uint32_t rem = L - room;                     // bits after the first word
+            atomicOr(&img[w], (uint32_t)(cd >> rem));
+            if (rem <= 32) {
+                atomicOr(&img[w + 1], (uint32_t)(cd << (32 - rem)));
+            } else {
+                atomicOr(&img[w + 1], (uint32_t)(cd >> (rem - 32)));
+                atomicOr(&img[w + 2], (uint32_t)(cd << (64 - rem)));
+            }
+        }
+        pos += L;
+    }
+    __syncthreads();
+    __shared__ uint32_t s_total;
+    if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total == 0) return;
+    const uint32_t nwords = (skew + total + 31) >> 5;
+    const uint64_t w0 = g0 >> 5;
+    for (uint32_t i = threadIdx.x; i < nwords; i += kPackThreads) {
+        uint32_t v = __builtin_bswap32(img[i]);          // MSB-first bit order -> big-endian bytes
+        if (v == 0) continue;
+        if (i == 0 || i == nwords - 1) atomicOr(&out_words[w0 + i], v);   // shared with a neighbour chunk
+        else out_words[w0 + i] = v;
+    }
+}
+
+// interior words of a chunk that are all-zero must still be written: the output is pre-zeroed.
+
+template <int SRC>
+static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank_table_d, const uint8_t *len_d,
+                     const uint64_t *code_d, uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h) {
+    *nbits_h = 0;
+    if (n == 0) return CNIIC_OK;
+    if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
+    const uint64_t nchunks64 = ceil_div(n, kPackChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: too many symbols");
+    const uint32_t nchunks = (uint32_t)nchunks64;
+    DevBuf cb, co, tot;
+    CNIIC_HIP_TRY(c, cb.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    hipLaunchKernelGGL(k_pack_count<SRC>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, src_d, n, rank_table_d, len_d, cb.as<uint32_t>());
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *nbits_h = total;
+    const uint64_t need = ceil_div(total, 32) * 4;
+    if (need > out_cap_bytes) return c->fail(CNIIC_ERR_CAPACITY, "huff_pack: payload needs %llu bytes, capacity %llu",
+                                             (unsigned long long)need, (unsigned long long)out_cap_bytes);
+    CNIIC_HIP_TRY(c, hipMemsetAsync(out_d, 0, need, c->stream));
+    hipLaunchKernelGGL(k_pack_write<SRC>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, src_d, n, rank_table_d, len_d, code_d,
+                       co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // cb/co/tot are released on return
+    return CNIIC_OK;
+}
+
+int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
+                   const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
+                   uint64_t out_cap_bytes, uint64_t *nbits_h) {
+    if (rgb_or_null_d) return pack_impl<SRC_RGB>(c, rgb_or_null_d, n, rank_table_d, len_d, code_d, out_d, out_cap_bytes, nbits_h);
+    return pack_impl<SRC_KEYS>(c, keys_or_null_d, n, rank_table_d, len_d, code_d, out_d, out_cap_bytes, nbits_h);
+}
+
+int huff_pack_sym16(Ctx *c, const uint16_t *sym_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d,
+                    uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h) {
+    return pack_impl<SRC_SYM16>(c, sym_d, n, nullptr, len_d, code_d, out_d, out_cap_bytes, nbits_h);
+}
+
+}  // namespace cniic

@@ -1,0 +1,204 @@
+/*
+ * cniic_hip.h -- C ABI of the MI355X-native (gfx950) implementation of cniic's per-pixel
+ * compression hot path.  This is the drop-in boundary: the entry points are the cut points a
+ * Rust `impl Codec` in the reference would bind over FFI (see INTEGRATION.md for the stub).
+ * The reference has no FFI of its own (it is a single Rust crate), so each entry point cites the
+ * reference function it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - Every function returns int32_t: 0 = OK, negative = error (table below).  Nothing throws or
+ *     aborts across the ABI.  cniic_last_error(ctx) returns a message for the last failure.
+ *   - The caller owns every buffer.  Unless stated otherwise a data pointer may be HOST memory
+ *     or DEVICE (HBM) memory of the context's GPU; the library detects which
+ *     (hipPointerGetAttributes) and stages host buffers over PCIe.  Scalar out-params (`uint64_t
+ *     *n_unique`, stats structs, ...) are always host memory.
+ *   - A cniic_ctx owns one HIP stream plus scratch HBM.  Calls on one ctx are serialised by an
+ *     internal mutex; use one ctx per calling thread for concurrency (the reference calls
+ *     encode/decode from rayon workers, src/bench.rs:24-28).  No process-global mutable state.
+ *   - Functions return after their results are complete (stream synchronised) unless the name
+ *     ends in _async.
+ *   - Images are RGB8, row-major, interleaved (image::DynamicImage::to_rgb, row-major pixels()).
+ *   - The library fails (CNIIC_ERR_HIP) when no gfx950 device is usable; there is no CPU fallback.
+ */
+#ifndef CNIIC_HIP_H
+#define CNIIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNIIC_OK                   0
+#define CNIIC_ERR_BAD_ARG         -1
+#define CNIIC_ERR_TOO_FEW_POINTS  -2  /* src/kmeans.rs:67-68   assert!(points_per_cluster > 0)     */
+#define CNIIC_ERR_FEW_ACTIVE      -3  /* src/kmeans.rs:41-57   "Not enough active clusters"        */
+#define CNIIC_ERR_HIP             -4  /* HIP runtime / no device                                    */
+#define CNIIC_ERR_RCCL            -5
+#define CNIIC_ERR_DECODE          -6  /* Option::None from a decode path                            */
+#define CNIIC_ERR_NOMEM           -7
+#define CNIIC_ERR_CAPACITY        -8  /* caller's output buffer too small (needed size is returned) */
+#define CNIIC_ERR_UNSUPPORTED     -9
+
+typedef struct cniic_ctx cniic_ctx;
+
+/* ------------------------------------------------------------------ context */
+/* device: HIP device ordinal.  stream: an existing hipStream_t to enqueue on (e.g. the caller's
+ * torch stream), or NULL to let the context create its own non-blocking stream. */
+int32_t     cniic_ctx_create(int32_t device, void *stream, cniic_ctx **out);
+void        cniic_ctx_destroy(cniic_ctx *ctx);
+const char *cniic_last_error(const cniic_ctx *ctx);
+int32_t     cniic_version(void);
+int32_t     cniic_sync(cniic_ctx *ctx);
+/* optional helpers so callers without a HIP binding can keep images resident in HBM */
+int32_t     cniic_dev_alloc(cniic_ctx *ctx, uint64_t bytes, void **dptr);
+int32_t     cniic_dev_free(cniic_ctx *ctx, void *dptr);
+int32_t     cniic_memcpy(cniic_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* dominant-kernel timing of the most recent call on this ctx, measured with HIP events on the
+ * ctx stream: *ms = summed duration, *launches = number of launches of that kernel. */
+int32_t     cniic_last_kernel_time(cniic_ctx *ctx, const char *which, double *ms, uint64_t *launches);
+
+/* ------------------------------------------------------------------ H1: utils::count_freqs */
+/* Symbol kinds fix the 32-bit key packing and the wire size of a symbol. */
+#define CNIIC_SYM_RGB    1  /* Rgb<u8>: key = r<<16|g<<8|b; 11 bytes on the wire (src/ser.rs:210-214)   */
+#define CNIIC_SYM_SIGNED 2  /* SignedColor([i16;3]) (src/codec/hilbertc.rs:513-516):                    */
+                            /* key = (dr+255)<<18|(dg+255)<<9|(db+255); 6 bytes (src/ser.rs:188-195)    */
+
+/* utils::count_freqs over the pixels of an image (src/utils.rs:4-16; call sites src/huf.rs:30,
+ * src/codec/clusterc.rs:21).  Output: distinct colours as packed keys in ASCENDING key order and
+ * their occurrence counts.  keys/counts may be NULL to query *n_unique only. */
+int32_t cniic_hist_rgb24(cniic_ctx *ctx, const uint8_t *rgb, uint64_t npx,
+                         uint32_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n_unique);
+/* count_freqs over a stream of packed symbol keys of the given kind. */
+int32_t cniic_hist_syms(cniic_ctx *ctx, int32_t sym_kind, const uint32_t *syms, uint64_t n,
+                        uint32_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n_unique);
+
+/* ------------------------------------------------------------------ K-means: kmeans::cluster */
+typedef struct {
+    uint64_t seed;       /* seeds the deterministic empty-cluster reseed (replaces thread_rng,   */
+                         /* src/kmeans.rs:123-133); 0 = library default                            */
+    uint64_t max_iters;  /* 0 = run until no point moves (the reference has no cap, kmeans.rs:26) */
+    uint32_t flags;      /* CNIIC_KM_* */
+    uint32_t reserved;
+} cniic_kmeans_opts;
+#define CNIIC_KM_BRUTE_FORCE 1u  /* disable bound-based pruning (debug / A-B measurement) */
+
+typedef struct {
+    uint64_t iterations;     /* src/kmeans.rs:33 "#iterations"                         */
+    uint64_t moved_last;     /* points that changed cluster in the last iteration      */
+    uint64_t empty_reseeds;  /* src/kmeans.rs:117-134 occurrences                      */
+    uint64_t active;         /* clusters with >= 1 member (src/kmeans.rs:49-52)        */
+    uint64_t pair_evals;     /* point-centroid distance evaluations (mirrors the       */
+                             /* "tested neighbours" counters of src/kmeans.rs:401-413) */
+} cniic_kmeans_stats;
+
+typedef struct {  /* ColorPos, src/codec/clusterc.rs:200-204 */
+    uint32_t x, y;
+    uint8_t  rgb[3];
+    uint8_t  pad;
+} cniic_colorpos;
+
+/* kmeans::cluster::<ColorCount> (src/kmeans.rs:21-39 with src/codec/clusterc.rs:68-114):
+ * U distinct colours (packed keys, any order; the order IS the point order of the reference's
+ * Vec<ColorCount>) with pixel-count weights.  Out: K centroid colours (K x 3 bytes, r,g,b),
+ * final cluster of every input colour (labels[U]), members[K] = colours per cluster. */
+int32_t cniic_kmeans_rgbw(cniic_ctx *ctx, const uint32_t *keys, const uint32_t *weight, uint64_t U,
+                          uint32_t K, const cniic_kmeans_opts *opts,
+                          uint8_t *centroids, uint32_t *labels, uint64_t *members,
+                          cniic_kmeans_stats *stats);
+/* kmeans::cluster::<ColorPos> over all pixels of an image, row-major point order
+ * (src/codec/clusterc.rs:150-153).  labels (N u32) and members may be NULL. */
+int32_t cniic_kmeans_xyrgb(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h,
+                           uint32_t K, const cniic_kmeans_opts *opts,
+                           cniic_colorpos *centroids, uint32_t *labels, uint64_t *members,
+                           cniic_kmeans_stats *stats);
+
+/* One assign step from given centroids and labels (src/kmeans.rs:330-416 + the sums consumed by
+ * Point::mean): labels updated in place; sums[K x D] (D = 3 / 5), wsum[K] (sum of weights, or
+ * member count), members[K], *changed.  Centroids are not updated.  For parity tests and for
+ * callers that own the reduction (multi-GPU). */
+int32_t cniic_kmeans_step_rgbw(cniic_ctx *ctx, const uint32_t *keys, const uint32_t *weight,
+                               uint64_t U, uint32_t K, const uint8_t *centroids, uint32_t *labels,
+                               uint64_t *sums, uint64_t *wsum, uint64_t *members, uint64_t *changed);
+int32_t cniic_kmeans_step_xyrgb(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h,
+                                uint32_t K, const cniic_colorpos *centroids, uint32_t *labels,
+                                uint64_t *sums, uint64_t *wsum, uint64_t *members, uint64_t *changed);
+
+/* Sharded K-means session (pixels / colours sharded over GPUs, one process per GPU): the library
+ * owns assign + partial sums + centroid update on its shard; the CALLER all-reduces the partials
+ * buffer (RCCL sum over int64 words) between cniic_km_assign and cniic_km_update.
+ * All ranks pass the full point list (U colours) and their own [lo,hi) slice of it. */
+typedef struct cniic_km cniic_km;
+int32_t cniic_km_create_rgbw(cniic_ctx *ctx, const uint32_t *keys, const uint32_t *weight, uint64_t U,
+                             uint64_t lo, uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts,
+                             void *partials_dev /* device buffer of cniic_km_partial_words(K,3) u64, or NULL */,
+                             cniic_km **out);
+uint64_t cniic_km_partial_words(uint32_t K, uint32_t D);   /* K*D sums + K wsum + K members + 1 changed */
+int32_t cniic_km_partials(cniic_km *km, void **dev_ptr);
+int32_t cniic_km_assign(cniic_km *km);                      /* async on the ctx stream */
+int32_t cniic_km_update(cniic_km *km, uint64_t *changed);   /* syncs; *changed = global moved count */
+int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels_slice, uint64_t *members,
+                        cniic_kmeans_stats *stats);
+/* average duration (ms) of the assign kernel alone over `reps` back-to-back launches, measured
+ * with HIP events on the ctx stream (bench.py's roofline figure) */
+int32_t cniic_km_time_assign(cniic_km *km, int32_t reps, double *ms_per_launch);
+void    cniic_km_destroy(cniic_km *km);
+
+/* ------------------------------------------------------------------ cluster-colors remap */
+/* src/codec/clusterc.rs:31-47: every pixel's colour -> the centroid colour of its cluster.
+ * keys[U] ascending (as returned by cniic_hist_rgb24), labels[U], centroids[K x 3]. */
+int32_t cniic_remap_rgb(cniic_ctx *ctx, const uint8_t *rgb, uint64_t npx, const uint32_t *keys,
+                        const uint32_t *labels, uint64_t U, const uint8_t *centroids, uint32_t K,
+                        uint8_t *out_rgb);
+
+/* ------------------------------------------------------------------ Hilbert scan + delta */
+/* hilbert::iter(w,h) (src/hilbert.rs:40-43): xy[2*d], xy[2*d+1] for d in 0..w*h.
+ * The scan is the one frozen by this build (see DESIGN.md "Hilbert scan: parity unpinned"). */
+int32_t cniic_hilbert_xy(cniic_ctx *ctx, uint32_t w, uint32_t h, uint32_t *xy);
+/* hilbert::linearize (src/hilbert.rs:10-12): pixels gathered in scan order. */
+int32_t cniic_hilbert_linearize(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *out_rgb);
+/* DiffStream over the Hilbert-ordered pixels (src/codec/hilbertc.rs:449-477): N packed
+ * CNIIC_SYM_SIGNED keys. */
+int32_t cniic_hilbert_delta(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t *syms);
+/* Fused gather + delta + count_freqs (the first pass of huf::encode_all inside Delta::encode,
+ * src/codec/hilbertc.rs:405-415 -> src/huf.rs:30).  syms may be NULL. */
+int32_t cniic_hilbert_delta_hist(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h,
+                                 uint32_t *keys, uint64_t *counts, uint64_t cap, uint64_t *n_unique,
+                                 uint32_t *syms);
+
+/* ------------------------------------------------------------------ H2: huf::encode_all */
+/* src/huf.rs:22-43: histogram -> tree -> serialised decoder -> MSB-first bit-packed payload.
+ * Returns CNIIC_ERR_CAPACITY with *len = needed bytes when cap is too small. */
+int32_t cniic_huf_encode_all(cniic_ctx *ctx, int32_t sym_kind, const uint32_t *syms, uint64_t n,
+                             uint8_t *out, uint64_t cap, uint64_t *len);
+/* size of that stream as a pure function of the histogram. */
+int32_t cniic_huf_size(int32_t sym_kind, const uint64_t *counts, uint64_t n, uint64_t *nbytes);
+
+/* ------------------------------------------------------------------ Codec trait (src/codec.rs:14-19) */
+/* expr is the reference's --codec= expression: "hufman", "cluster-colors(256)" / "ccol(256)",
+ * "voronoi(2048)", "delta" (src/codec.rs:41-59, FromStr impls of each codec). */
+int32_t cniic_codec_parse(const char *expr, int32_t *kind, uint32_t *arg);
+int32_t cniic_codec_name(const char *expr, char *buf, uint64_t cap);   /* Codec::name()        */
+int32_t cniic_codec_is_lossless(const char *expr);                     /* 1 / 0 / negative err */
+/* Codec::encode: appends nothing, writes the whole stream to out[0..*len). */
+int32_t cniic_codec_encode(cniic_ctx *ctx, const char *expr, const uint8_t *rgb, uint32_t w, uint32_t h,
+                           uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+/* same, with explicit K-means options (seed, iteration cap) */
+int32_t cniic_codec_encode_opts(cniic_ctx *ctx, const char *expr, const cniic_kmeans_opts *opts, const uint8_t *rgb,
+                                uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len,
+                                cniic_kmeans_stats *stats);
+/* Codec::decode: CNIIC_ERR_DECODE where the reference returns None / panics. */
+int32_t cniic_codec_decode(cniic_ctx *ctx, const char *expr, const uint8_t *bytes, uint64_t n,
+                           uint8_t *rgb, uint64_t cap, uint32_t *w, uint32_t *h);
+/* bench::compute_error (src/bench.rs:95-104): MSE between two RGB8 images. */
+int32_t cniic_mse(cniic_ctx *ctx, const uint8_t *a, const uint8_t *b, uint64_t npx, double *mse);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
+#define CNIIC_SYNTH_UNIFORM 0  /* "U": splitmix64 byte stream                               */
+#define CNIIC_SYNTH_PHOTO   1  /* "P": bilinear 64-px lattice + noise, photo-like statistics */
+int32_t cniic_synth_image(cniic_ctx *ctx, int32_t kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,258 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same inputs.
+Bit-exact for every integer / byte / index result."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from cniic_amd import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def synth_img(h, w, seed=0, levels=256, noise=2):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, levels, (h // 4 + 1, w // 4 + 1, 3))
+    img = np.kron(base, np.ones((4, 4, 1), np.int64))[:h, :w]
+    img = img + rng.integers(-noise, noise + 1, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def keys_of(img):
+    p = img.reshape(-1, 3).astype(np.uint32)
+    return (p[:, 0] << 16) | (p[:, 1] << 8) | p[:, 2]
+
+
+def pts_of_keys(keys):
+    return np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], axis=1).astype(np.int32)
+
+
+# ------------------------------------------------------------------ synthetic inputs
+@pytest.mark.parametrize("kind", [0, 1])
+def test_synth_matches_numpy(ctx, kind):
+    from cniic_amd import synth
+    w, h = 200, 131
+    got = ctx.synth_image(kind, 0x636E696963 + 2, w, h)
+    exp = (synth.uniform if kind == 0 else synth.photo)(w, h, 0x636E696963 + 2)
+    assert np.array_equal(got, exp)
+
+
+# ------------------------------------------------------------------ H1 count_freqs
+@pytest.mark.parametrize("shape", [(1, 1), (1, 15), (3, 17), (64, 64), (97, 131), (256, 256)])
+def test_hist_rgb24(ctx, shape):
+    img = synth_img(*shape, seed=shape[0])
+    keys, counts = ctx.hist_rgb24(img)
+    ek, ec = O.count_freqs(keys_of(img))
+    assert np.array_equal(keys, ek) and np.array_equal(counts, ec)
+    assert counts.sum() == shape[0] * shape[1]
+
+
+def test_hist_rgb24_single_colour_and_extremes(ctx):
+    img = np.zeros((40, 40, 3), np.uint8)
+    img[20:] = 255
+    keys, counts = ctx.hist_rgb24(img)
+    assert keys.tolist() == [0, 0xFFFFFF] and counts.tolist() == [800, 800]
+
+
+def test_hist_syms_signed(ctx):
+    rng = np.random.default_rng(3)
+    syms = rng.integers(0, 1 << 27, 5000).astype(np.uint32)
+    syms[:2000] = syms[0]
+    keys, counts = ctx.hist_syms(2, syms)
+    ek, ec = O.count_freqs(syms)
+    assert np.array_equal(keys, ek) and np.array_equal(counts, ec)
+
+
+# ------------------------------------------------------------------ K-means, colour form
+@pytest.mark.parametrize("K", [1, 5, 64, 256, 300])
+def test_kmeans_step_rgbw(ctx, K):
+    rng = np.random.default_rng(K)
+    img = synth_img(96, 96, seed=K)
+    keys, counts = O.count_freqs(keys_of(img))
+    w = counts.astype(np.uint32)
+    cent = rng.integers(0, 256, (K, 3)).astype(np.uint8)
+    cent[K // 2] = cent[0]                       # duplicate centroid: tie -> lowest id
+    labels = rng.integers(0, K, keys.size).astype(np.uint32)
+    got = ctx.kmeans_step_rgbw(keys, w, K, cent, labels)
+    exp = O.kmeans_step(O.PT_RGBW, pts_of_keys(keys), w, K, cent.astype(np.int32), labels)
+    for f in ("labels", "sums", "wsum", "members"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert got["changed"] == exp["changed"]
+
+
+def test_kmeans_step_rgbw_ties_stay(ctx):
+    """kmeans.rs:375 strict '<': a point equidistant from its own and another centroid stays."""
+    keys = np.array([0x000000, 0x020000, 0x010000], np.uint32)   # r = 0, 2, 1
+    w = np.ones(3, np.uint32)
+    cent = np.array([[0, 0, 0], [2, 0, 0]], np.uint8)
+    for lab in (0, 1):
+        labels = np.array([0, 1, lab], np.uint32)
+        got = ctx.kmeans_step_rgbw(keys, w, 2, cent, labels)
+        assert got["labels"].tolist() == [0, 1, lab] and got["changed"] == 0
+
+
+@pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (300, (128, 160))])
+def test_kmeans_rgbw_run(ctx, K, shape):
+    img = synth_img(*shape, seed=7 + K)
+    keys, counts = O.count_freqs(keys_of(img))
+    w = counts.astype(np.uint32)
+    rc, got = ctx.kmeans_rgbw(keys, w, K)
+    rco, exp = O.kmeans(O.PT_RGBW, O.MODE_L, pts_of_keys(keys), w, K)
+    assert rc == rco == 0
+    assert got["stats"]["iterations"] == exp["stats"]["iterations"]
+    assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
+    assert np.array_equal(got["labels"], exp["labels"])
+    assert np.array_equal(got["members"], exp["members"])
+
+
+def test_kmeans_rgbw_errors(ctx):
+    from cniic_amd import _lib
+    keys = np.arange(5, dtype=np.uint32)
+    rc, _ = ctx.kmeans_rgbw(keys, np.ones(5, np.uint32), 8, allow=(_lib.TOO_FEW_POINTS,))
+    assert rc == _lib.TOO_FEW_POINTS                         # kmeans.rs:68
+
+
+def test_remap_rgb(ctx):
+    img = synth_img(50, 70, seed=5)
+    keys, counts = O.count_freqs(keys_of(img))
+    rng = np.random.default_rng(0)
+    K = 9
+    labels = rng.integers(0, K, keys.size).astype(np.uint32)
+    cent = rng.integers(0, 256, (K, 3)).astype(np.uint8)
+    out = ctx.remap_rgb(img, keys, labels, cent)
+    lut = dict(zip(keys.tolist(), labels.tolist()))
+    exp = np.array([cent[lut[k]] for k in keys_of(img).tolist()], np.uint8).reshape(img.shape)
+    assert np.array_equal(out, exp)
+
+
+# ------------------------------------------------------------------ K-means, pixel (x,y,r,g,b) form
+def xy_pts(img):
+    h, w = img.shape[:2]
+    y, x = np.mgrid[0:h, 0:w]
+    return np.concatenate([x.reshape(-1, 1), y.reshape(-1, 1), img.reshape(-1, 3)], axis=1).astype(np.int32)
+
+
+@pytest.mark.parametrize("K,shape", [(1, (8, 8)), (7, (40, 56)), (64, (70, 130)), (300, (64, 64))])
+def test_kmeans_step_xyrgb(ctx, K, shape):
+    from cniic_amd._lib import COLORPOS
+    rng = np.random.default_rng(K)
+    img = synth_img(*shape, seed=K)
+    h, w = shape
+    cent = np.zeros(K, COLORPOS)
+    cent["x"] = rng.integers(0, w, K); cent["y"] = rng.integers(0, h, K)
+    cent["rgb"] = rng.integers(0, 256, (K, 3))
+    labels = rng.integers(0, K, h * w).astype(np.uint32)
+    got = ctx.kmeans_step_xyrgb(img, K, cent, labels)
+    c5 = np.concatenate([cent["x"][:, None], cent["y"][:, None], cent["rgb"]], axis=1).astype(np.int32)
+    exp = O.kmeans_step(O.PT_XYRGB, xy_pts(img), None, K, c5, labels)
+    for f in ("labels", "sums", "members"):
+        assert np.array_equal(got[f], exp[f]), f
+    assert got["changed"] == exp["changed"]
+
+
+@pytest.mark.parametrize("K,shape,flags", [(4, (24, 32), 0), (16, (48, 80), 0), (16, (48, 80), 1), (50, (100, 70), 0)])
+def test_kmeans_xyrgb_run(ctx, K, shape, flags):
+    img = synth_img(*shape, seed=K + 1)
+    rc, got = ctx.kmeans_xyrgb(img, K, flags=flags)
+    rco, exp = O.kmeans(O.PT_XYRGB, O.MODE_L, xy_pts(img), None, K)
+    assert rc == rco == 0
+    assert got["stats"]["iterations"] == exp["stats"]["iterations"]
+    c5 = np.concatenate([got["centroids"]["x"][:, None], got["centroids"]["y"][:, None], got["centroids"]["rgb"]], axis=1)
+    assert np.array_equal(c5.astype(np.int32), exp["centroids"])
+    assert np.array_equal(got["labels"], exp["labels"])
+    assert np.array_equal(got["members"], exp["members"])
+
+
+# ------------------------------------------------------------------ Hilbert + delta
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (4, 4), (16, 16), (5, 3), (13, 8), (31, 10), (64, 48), (100, 37), (128, 128)])
+def test_hilbert_xy(ctx, w, h):
+    assert np.array_equal(ctx.hilbert_xy(w, h), O.hilbert_iter(w, h))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 5), (16, 16), (33, 20), (64, 64), (75, 130)])
+def test_hilbert_linearize_and_delta(ctx, shape):
+    img = synth_img(*shape, seed=11)
+    lin = ctx.hilbert_linearize(img)
+    elin = O.hilbert_linearize(img)
+    assert np.array_equal(lin, elin)
+    syms = ctx.hilbert_delta(img)
+    esyms = O.delta_diff(elin)
+    assert np.array_equal(syms, esyms)
+    keys, counts, syms2 = ctx.hilbert_delta_hist(img, want_syms=True)
+    ek, ec = O.count_freqs(esyms)
+    assert np.array_equal(keys, ek) and np.array_equal(counts, ec) and np.array_equal(syms2, esyms)
+
+
+# ------------------------------------------------------------------ huf::encode_all
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 50000])
+def test_huf_encode_all_rgb(ctx, n):
+    rng = np.random.default_rng(n)
+    syms = (rng.integers(0, 40, n) ** 2 * 1031 % (1 << 24)).astype(np.uint32)
+    got = ctx.huf_encode_all(1, syms)
+    assert got == O.huf_encode_all(O.SYM_RGB, syms)
+
+
+def test_huf_encode_all_long_codes(ctx):
+    """Fibonacci-like counts give code lengths > 32 bits: exercises the 3-word straddle path."""
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    fib = [min(f, 3000) if i > 20 else f for i, f in enumerate(fib)]
+    syms = np.concatenate([np.full(f, i * 7 + 1, np.uint32) for i, f in enumerate(fib)])
+    np.random.default_rng(0).shuffle(syms)
+    assert ctx.huf_encode_all(2, syms) == O.huf_encode_all(O.SYM_SIGNED, syms)
+
+
+# ------------------------------------------------------------------ codecs end to end
+@pytest.mark.parametrize("expr", ["hufman", "delta", "cluster-colors(8)", "ccol(256)", "voronoi(6)", "voronoi(40)"])
+@pytest.mark.parametrize("shape", [(48, 40), (64, 64), (100, 75)])
+def test_codec_bytes_equal_oracle(ctx, expr, shape):
+    img = synth_img(*shape, seed=21, levels=64)
+    rc, data, st = ctx.encode(expr, img)
+    rco, edata, est = O.encode(expr, img, mode=O.MODE_L)
+    assert rc == rco == 0
+    assert data == edata
+    if "col" in expr or "voronoi" in expr:
+        assert st["iterations"] == est["iterations"]
+    rc, back = ctx.decode(expr, data)
+    rco, eback = O.decode(expr, edata)
+    assert rc == rco == 0 and np.array_equal(back, eback)
+    if expr in ("hufman", "delta"):
+        assert np.array_equal(back, img)
+        assert ctx.mse(img, back) == 0.0
+    else:
+        assert abs(ctx.mse(img, back) - O.mse(img, back)) <= 1e-9 * max(1.0, O.mse(img, back))
+
+
+def test_codec_edge_cases(ctx):
+    from cniic_amd import _lib
+    one = np.full((1, 1, 3), 9, np.uint8)
+    for expr in ("hufman", "delta"):
+        rc, data, _ = ctx.encode(expr, one)
+        assert rc == 0 and data == O.encode(expr, one)[1]
+        rc, back = ctx.decode(expr, data)
+        assert rc == 0 and np.array_equal(back, one)
+    flat = np.zeros((8, 8, 3), np.uint8)
+    rc, _, _ = ctx.encode("cluster-colors(4)", flat, allow=(_lib.TOO_FEW_POINTS,))
+    assert rc == _lib.TOO_FEW_POINTS
+    rc, _ = ctx.decode("hufman", b"\x02\x00\x00\x00\x02\x00\x00\x00\x07", allow=(_lib.DECODE,))
+    assert rc == _lib.DECODE
+
+
+def test_codec_trait_surface(ctx):
+    from cniic_amd import AnyCodec
+    c = AnyCodec.from_str("cluster-colors(16)", ctx)
+    assert c.name() == "cluster-colors_16" and not c.is_lossless()
+    d = AnyCodec.from_str("delta", ctx)
+    assert d.name() == "delta" and d.is_lossless()
+    img = synth_img(32, 32, seed=2)
+    assert np.array_equal(d.decode(d.encode(img)), img)
+    assert d.decode(b"\x01\x00\x00\x00\x01\x00\x00\x00") is None
+    with pytest.raises(ValueError):
+        AnyCodec.from_str("hilbert-rle")
