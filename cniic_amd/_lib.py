@@ -22,7 +22,8 @@ SYMBOLS = [
     "cniic_ctx_create", "cniic_ctx_destroy", "cniic_last_error", "cniic_version", "cniic_sync", "cniic_dev_alloc",
     "cniic_dev_free", "cniic_memcpy", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
     "cniic_kmeans_rgbw", "cniic_kmeans_xyrgb", "cniic_kmeans_step_rgbw", "cniic_kmeans_step_xyrgb",
-    "cniic_km_create_rgbw", "cniic_km_partial_words", "cniic_km_partials", "cniic_km_assign", "cniic_km_update",
+    "cniic_km_create_rgbw", "cniic_km_partial_words", "cniic_km_partials", "cniic_km_begin",
+    "cniic_km_labels_internal", "cniic_km_assign", "cniic_km_update",
     "cniic_km_result", "cniic_km_time_assign", "cniic_km_destroy", "cniic_remap_rgb", "cniic_hilbert_xy",
     "cniic_hilbert_linearize", "cniic_hilbert_delta", "cniic_hilbert_delta_hist", "cniic_huf_encode_all",
     "cniic_huf_size", "cniic_codec_parse", "cniic_codec_name", "cniic_codec_is_lossless", "cniic_codec_encode",
@@ -161,7 +162,7 @@ class Context:
     def _opts(seed=0, max_iters=0, flags=0):
         return KmOpts(seed, max_iters, flags, 0)
 
-    def kmeans_rgbw(self, keys, weight, K, seed=0, max_iters=0, allow=()):
+    def kmeans_rgbw(self, keys, weight, K, seed=0, max_iters=0, flags=0, allow=()):
         keys = np.ascontiguousarray(keys, np.uint32)
         weight = np.ascontiguousarray(weight, np.uint32)
         U = keys.size
@@ -169,7 +170,7 @@ class Context:
         labels = np.zeros(U, np.uint32)
         members = np.zeros(K, np.uint64)
         st = KmStats()
-        o = self._opts(seed, max_iters)
+        o = self._opts(seed, max_iters, flags)
         rc = self._check(self._L.cniic_kmeans_rgbw(self.h, _ptr(keys), _ptr(weight), C.c_uint64(U), C.c_uint32(K), C.byref(o),
                                                    _ptr(cent), _ptr(labels), _ptr(members), C.byref(st)), allow)
         return rc, dict(centroids=cent, labels=labels, members=members, stats=st.as_dict())

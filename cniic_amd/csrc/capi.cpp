@@ -17,7 +17,7 @@ struct cniic_km {
     Ctx *c = nullptr;
     KmRgbwState *st = nullptr;
     In<uint32_t> keys, weight;
-    uint64_t lo = 0, hi = 0;
+    uint64_t lo = 0, hi = 0, U = 0;
     uint32_t K = 0;
 };
 
@@ -215,7 +215,8 @@ int32_t cniic_kmeans_step_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_
     std::vector<uint8_t> cent(3 * (size_t)K);
     CNIIC_TRY(from_caller(c, cent.data(), centroids, cent.size()));
     KmRgbwState *km = nullptr;
-    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, nullptr, nullptr, &km));
+    cniic_kmeans_opts step_opts{0, 0, CNIIC_KM_BRUTE_FORCE, 0};  // explicit centroids + labels: full-sum kernel
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, &step_opts, nullptr, &km));
     std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
     CNIIC_TRY(km_rgbw_set_state(km, cent.data(), lin.d));
     CNIIC_TRY(km_rgbw_assign(km));
@@ -293,7 +294,7 @@ int32_t cniic_kmeans_step_xyrgb(cniic_ctx *c, const uint8_t *rgb, uint32_t w, ui
 }
 
 // ------------------------------------------------------------------ sharded session
-uint64_t cniic_km_partial_words(uint32_t K, uint32_t D) { return (uint64_t)K * D + 2ull * K + 1; }
+uint64_t cniic_km_partial_words(uint32_t K, uint32_t D) { return (uint64_t)K * D + 2ull * K + 2; }
 
 int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint64_t lo, uint64_t hi,
                              uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev, cniic_km **out) {
@@ -301,7 +302,7 @@ int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t 
     if (!out || !keys || !weight) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: null argument");
     if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: partials must be device memory");
     auto km = std::make_unique<cniic_km>();
-    km->c = c; km->lo = lo; km->hi = hi; km->K = K;
+    km->c = c; km->lo = lo; km->hi = hi; km->K = K; km->U = U;
     CNIIC_TRY(km->keys.bind(c, keys, U));
     CNIIC_TRY(km->weight.bind(c, weight, U));
     CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, lo, hi, K, opts, partials_dev, &km->st));
@@ -313,6 +314,19 @@ int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t 
 int32_t cniic_km_partials(cniic_km *km, void **dev_ptr) {
     if (!km || !dev_ptr) return CNIIC_ERR_BAD_ARG;
     *dev_ptr = km_rgbw_partials_dev(km->st);
+    return CNIIC_OK;
+}
+
+int32_t cniic_km_begin(cniic_km *km) {
+    if (!km) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
+    LOCK(c);
+    return km_rgbw_fold_initial(km->st);
+}
+
+int32_t cniic_km_labels_internal(cniic_km *km, void **dev_ptr, uint64_t *elem_bytes) {
+    if (!km || !dev_ptr) return CNIIC_ERR_BAD_ARG;
+    *dev_ptr = km_rgbw_labels_internal(km->st, elem_bytes);
     return CNIIC_OK;
 }
 
@@ -339,7 +353,7 @@ int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels_slice
     cniic_ctx *c = static_cast<cniic_ctx *>(km->c);
     LOCK(c);
     Out<uint32_t> lo;
-    CNIIC_TRY(lo.bind(c, labels_slice, km->hi - km->lo));
+    CNIIC_TRY(lo.bind(c, labels_slice, km->U));
     std::vector<uint8_t> cent(3 * (size_t)km->K);
     std::vector<uint64_t> mem(km->K);
     cniic_kmeans_stats st{};

@@ -232,8 +232,12 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), K, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    CNIIC_TRY(expand_codes_by_label(c, km_rgbw_labels8_dev(km), km_rgbw_labels16_dev(km), U, clen_d.as<uint8_t>(),
-                                    ccode_d.as<uint64_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>()));
+    DevBuf lab_d;
+    const bool wide = km_rgbw_is_wide(km);
+    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
+    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
+    CNIIC_TRY(expand_codes_by_label(c, wide ? nullptr : lab_d.as<uint8_t>(), wide ? lab_d.as<uint16_t>() : nullptr, U,
+                                    clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>()));
     const uint64_t pcap = ceil_div(nbits, 32) * 4 + 16;
     CNIIC_HIP_TRY(c, payload.alloc(pcap));
     uint64_t packed_bits = 0;

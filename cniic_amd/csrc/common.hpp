@@ -208,8 +208,10 @@ int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32,
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch);
 int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h);
 void *km_rgbw_partials_dev(KmRgbwState *s);
-const uint8_t *km_rgbw_labels8_dev(KmRgbwState *s);       // device labels (u8 when K<=256 else null)
-const uint16_t *km_rgbw_labels16_dev(KmRgbwState *s);
+bool km_rgbw_is_wide(KmRgbwState *s);                     // u16 labels (K > 256) instead of u8
+int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d); // u8/u16 labels of all points, canonical order
+void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes);
+int km_rgbw_fold_initial(KmRgbwState *s);
 
 // ---- k_kmeans_xyrgb.hip ----
 int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,

@@ -7,47 +7,59 @@
 // colour per iteration ("dedup form").
 //
 // Assign is exact Lloyd under the reference's rules (stay unless another centroid is STRICTLY
-// closer, kmeans.rs:350-378; lowest id among equidistant minima).  Because every comparison is
-// between distances from the SAME point, |p|^2 cancels and the kernel maximises
+// closer, kmeans.rs:350-378; lowest id among equidistant minima).  Every comparison is between
+// distances from the SAME point, so |p|^2 cancels and the kernels maximise
 //     g_k = 2 p.c_k - |c_k|^2          (p.c_k = one v_dot4_u32_u8)
-// packed with the cluster id into one u32 so that arg-max + lowest-id tie-break is a single
-// v_max_u32:  key_k = ((g_k + BIAS) << IDBITS) | (IDMASK - k)  =  (dot << (IDBITS+1)) + const_k.
-// Three VALU instructions per (colour, centroid): dot4, lshl_add, max.  Centroid constants are
-// wave-uniform and come in through scalar loads.  MFMA is deliberately unused: the inner
-// dimension is 3 and the arg-max dominates.
+// packed with the cluster id into one u32, so arg-max + lowest-id tie-break is one v_max_u32:
+//     key_k = ((g_k + BIAS) << IDBITS) | (IDMASK - k)  =  (dot << (IDBITS+1)) + const_k.
+// MFMA is deliberately unused: the inner dimension is 3 and the arg-max dominates.
 //
-// Centroid update is exact u64 integer arithmetic (clusterc.rs:92-105): per-block LDS
-// accumulators (ds_add_u64) -> per-block slab in HBM -> parallel slab reduction -> K-thread
-// finalize (truncating division, empty-cluster reseed).  Integer sums make the result
-// independent of block count, launch order and GPU count.
+// Two assign kernels, identical results:
+//   * k_rgbw_assign        brute force over all K centroids (3 VALU per pair; constants arrive by
+//                          scalar loads).  VALU-bound.  Used by the single-step ABI and for A/B.
+//   * k_rgbw_assign_cells  colour space is cut into 8x8x8 cells and the points are kept in
+//                          cell-major order.  Per cell and iteration the block bounds every
+//                          centroid's squared distance to the cell's cube (lb_k, ub_k) and keeps
+//                          only {k : lb_k <= min_j ub_j}: no other centroid can be nearest - or
+//                          tied - for any colour of the cell.  This is the reference's
+//                          triangle-inequality pruning (kmeans.rs:355-370) applied to a box of
+//                          points instead of one point against a neighbour list; it is exact at
+//                          every iteration (the reference's truncated lists are not).
+//
+// Centroid update is exact u64 integer arithmetic (clusterc.rs:92-105).  The cells path keeps
+// RUNNING per-cluster sums and feeds them signed deltas from the points that moved (integer adds
+// commute, so the result equals a full re-accumulation); per-block LDS accumulators (ds_add_u64),
+// non-zero entries flushed with global u64 atomics.  Sums are independent of block count, launch
+// order and GPU count.
 #include "common.hpp"
 #include "device_utils.hpp"
 
 namespace cniic {
 
 constexpr uint32_t kBias = 1u << 18;  // > max |c|^2 = 195075
-constexpr int kPPT = 8;               // colours per thread per sweep
+constexpr int kPPT = 8;               // colours per thread per sweep (brute kernel)
 constexpr int kAssignThreads = 256;
 constexpr uint32_t kMaxBlocks = 512;
+constexpr int kCellShift = 3;                                  // 8x8x8 colours per cell
+constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
+constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
+constexpr uint32_t kCellBlocks = 1024;
 
 struct KmRgbwState {
     Ctx *c = nullptr;
     uint64_t U = 0, lo = 0, hi = 0, seed = 0, max_iters = 0;
     uint32_t K = 0, Kpad = 0, idbits = 8, nblocks = 1;
-    bool wide = false;  // u16 labels
-    const uint32_t *keys = nullptr, *weight = nullptr;  // device, full list [0,U)
-    DevBuf labels, cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
-    uint64_t *partials = nullptr;  // device: 5K+1 words
-    bool sharded = false;
+    bool wide = false;   // u16 labels
+    bool cells = true;   // cell-pruned assign (default) vs brute force
+    const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
+    DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
+    DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
+    DevBuf ckeys, cweight, crank, cell_start, running;
+    uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
 
 __device__ __forceinline__ uint32_t dot4u8(uint32_t a, uint32_t b, uint32_t acc) {
-#if __has_builtin(__builtin_amdgcn_udot4)
     return __builtin_amdgcn_udot4(a, b, acc, false);
-#else
-    return acc + (a & 255) * (b & 255) + ((a >> 8) & 255) * ((b >> 8) & 255) + ((a >> 16) & 255) * ((b >> 16) & 255) +
-           (a >> 24) * (b >> 24);
-#endif
 }
 
 // (packed centroid key, const term) for cluster k
@@ -57,31 +69,39 @@ __device__ __forceinline__ uint2 make_cconst(uint32_t ckey, uint32_t k, uint32_t
     return make_uint2(ckey, ((kBias - h) << idbits) | (idmask - k));
 }
 
-template <typename LabelT>
-__global__ void k_rgbw_init(const uint32_t *__restrict__ keys, uint64_t U, uint64_t lo, uint64_t hi, uint32_t K,
-                            uint32_t Kpad, uint32_t idbits, LabelT *__restrict__ labels,
-                            uint2 *__restrict__ cconst, uint32_t *__restrict__ cent) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint64_t i = lo + tid; i < hi; i += stride) labels[i - lo] = (LabelT)init_label(i, U, K);  // kmeans.rs:61-78
-    if (tid < Kpad) {
-        uint32_t k = (uint32_t)tid;
-        if (k < K) {
-            // init_centroids (kmeans.rs:101-108): first element of chunk k
-            uint64_t ppc = U / K;
-            uint64_t first = (k < K - 1) ? U - ((uint64_t)k + 1) * ppc : 0;
-            uint32_t ck = keys[first];
-            cent[k] = ck;
-            cconst[k] = make_cconst(ck, k, idbits);
-        } else {
-            cconst[k] = make_uint2(0u, 0u);  // padding: key 0 never wins
-        }
+__device__ __forceinline__ uint32_t cell_of(uint32_t key) {
+    return (((key >> 16) & 255) >> kCellShift) * kCellsPerDim * kCellsPerDim + (((key >> 8) & 255) >> kCellShift) * kCellsPerDim +
+           ((key & 255) >> kCellShift);
+}
+
+// ---------------------------------------------------------------- init (kmeans.rs:61-108)
+__global__ void k_rgbw_init_cent(const uint32_t *__restrict__ keys, uint64_t U, uint32_t K, uint32_t Kpad, uint32_t idbits,
+                                 uint2 *__restrict__ cconst, uint32_t *__restrict__ cent) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) {
+        // init_centroids (kmeans.rs:101-108): first element of chunk k
+        uint64_t ppc = U / K;
+        uint64_t first = (k < K - 1) ? U - ((uint64_t)k + 1) * ppc : 0;
+        uint32_t ck = keys[first];
+        cent[k] = ck;
+        cconst[k] = make_cconst(ck, k, idbits);
+    } else if (k < Kpad) {
+        cconst[k] = make_uint2(0u, 0u);  // padding: key 0 never wins
     }
 }
 
-// ---------------------------------------------------------------- assign + partial sums
+// labels[i - lo] = init label of canonical index rank[i] (or i itself when rank == nullptr)
+template <typename LabelT>
+__global__ void k_rgbw_init_labels(const uint32_t *__restrict__ rank, uint64_t U, uint64_t lo, uint64_t hi, uint32_t K,
+                                   LabelT *__restrict__ labels) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride)
+        labels[i - lo] = (LabelT)init_label(rank ? rank[i] : i, U, K);  // kmeans.rs:61-78
+}
+
+// ---------------------------------------------------------------- brute-force assign + full sums
 // slab row layout (u64 words): [3k+d] sum of channel d * weight, [3K+k] sum of weights,
-// [4K+k] member count, [5K] moved count.
+// [4K+k] member count, [5K] moved count, [5K+1] pair evaluations.
 template <typename LabelT, int IDBITS>
 __global__ __launch_bounds__(kAssignThreads) void k_rgbw_assign(
     const uint32_t *__restrict__ keys, const uint32_t *__restrict__ weight, uint64_t lo, uint64_t hi,
@@ -143,12 +163,17 @@ __global__ __launch_bounds__(kAssignThreads) void k_rgbw_assign(
     }
     moved = block_reduce_sum<kAssignThreads>(moved);
     __syncthreads();
-    uint64_t *row = slabs + (size_t)blockIdx.x * (5 * (size_t)K + 1);
+    uint64_t *row = slabs + (size_t)blockIdx.x * (5 * (size_t)K + 2);
     for (uint32_t i = threadIdx.x; i < 5 * K; i += kAssignThreads) row[i] = acc[i];
-    if (threadIdx.x == 0) row[5 * (size_t)K] = moved;
+    if (threadIdx.x == 0) {
+        row[5 * (size_t)K] = moved;
+        uint64_t per_block = 0;  // points this block visited x K
+        for (uint64_t base = (uint64_t)blockIdx.x * kAssignThreads * kPPT; base < n; base += sweep)
+            per_block += min((uint64_t)kAssignThreads * kPPT, n - base);
+        row[5 * (size_t)K + 1] = per_block * K;
+    }
 }
 
-// ---------------------------------------------------------------- slab reduction
 // grid (ceil(W/64), R): each block sums a stripe of rows for 64 columns, then one atomic per column.
 __global__ __launch_bounds__(256) void k_slab_reduce(const uint64_t *__restrict__ slabs, uint32_t nrows, uint32_t W,
                                                      uint64_t *__restrict__ partials,
@@ -168,32 +193,258 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const uint64_t *__restrict_
     }
 }
 
+// ---------------------------------------------------------------- cell-major point order
+// wave-aggregated histogram of cell ids (sorted input -> one or two atomics per wave)
+__global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__ keys, uint64_t U,
+                                                    uint32_t *__restrict__ cell_count) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < U; base += stride) {
+        const uint64_t i = base + threadIdx.x;
+        bool active = i < U;
+        const uint32_t cell = active ? cell_of(keys[i]) : 0;
+        for (;;) {
+            unsigned long long m = __ballot(active);
+            if (!m) break;
+            const int leader = __ffsll((long long)m) - 1;
+            const uint32_t lc = __shfl(cell, leader, 64);
+            const bool same = active && cell == lc;
+            const unsigned long long ms = __ballot(same);
+            if (lane == leader) atomicAdd(&cell_count[lc], (uint32_t)__popcll(ms));
+            active = active && !same;
+        }
+    }
+}
+
+// single block: exclusive scan of the cell counts -> cell_start[kNumCells + 1], cursor = copy
+__global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__ cell_count, uint32_t *__restrict__ cell_start,
+                                                    uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t sh[1024];
+    constexpr uint32_t per = kNumCells / 1024;
+    const uint32_t lo = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < per; i++) s += cell_count[lo + i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;
+    for (uint32_t i = 0; i < per; i++) {
+        uint32_t v = cell_count[lo + i];
+        cell_start[lo + i] = run;
+        cursor[lo + i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023) cell_start[kNumCells] = sh[1023];
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ weight,
+                                                      uint64_t U, uint32_t *__restrict__ cursor,
+                                                      uint32_t *__restrict__ ckeys, uint32_t *__restrict__ cweight,
+                                                      uint32_t *__restrict__ crank) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < U; base += stride) {
+        const uint64_t i = base + threadIdx.x;
+        bool active = i < U;
+        const uint32_t key = active ? keys[i] : 0;
+        const uint32_t cell = cell_of(key);
+        uint32_t pos = 0;
+        for (;;) {
+            unsigned long long m = __ballot(active);
+            if (!m) break;
+            const int leader = __ffsll((long long)m) - 1;
+            const uint32_t lc = __shfl(cell, leader, 64);
+            const bool same = active && cell == lc;
+            const unsigned long long ms = __ballot(same);
+            uint32_t b = 0;
+            if (lane == leader) b = atomicAdd(&cursor[lc], (uint32_t)__popcll(ms));
+            b = __shfl(b, leader, 64);
+            if (same) pos = b + (uint32_t)__popcll(ms & ((1ull << lane) - 1));
+            active = active && !same;
+        }
+        if (i < U) {
+            ckeys[pos] = key;
+            cweight[pos] = weight[i];
+            crank[pos] = (uint32_t)i;
+        }
+    }
+}
+
+// full accumulation of the current assignment into `partials` (used once, after init)
+template <typename LabelT>
+__global__ __launch_bounds__(256) void k_rgbw_accum_all(const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight,
+                                                        uint64_t lo, uint64_t hi, uint32_t K,
+                                                        const LabelT *__restrict__ labels,
+                                                        unsigned long long *__restrict__ partials) {
+    extern __shared__ __align__(16) unsigned long long acc[];  // [5K]
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += 256) acc[i] = 0ull;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < hi; q += stride) {
+        const uint32_t p = ckeys[q], l = labels[q];
+        const uint64_t w = cweight[q];
+        atomicAdd(&acc[3 * l + 0], (unsigned long long)(((p >> 16) & 255) * w));
+        atomicAdd(&acc[3 * l + 1], (unsigned long long)(((p >> 8) & 255) * w));
+        atomicAdd(&acc[3 * l + 2], (unsigned long long)((p & 255) * w));
+        atomicAdd(&acc[3 * K + l], (unsigned long long)w);
+        atomicAdd(&acc[4 * K + l], 1ull);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += 256)
+        if (acc[i]) atomicAdd(&partials[i], acc[i]);
+}
+
+// ---------------------------------------------------------------- cell-pruned assign, delta sums
+// Block b owns the cell-major positions [lo + n b/G, lo + n (b+1)/G) and walks the cells that
+// overlap them.  partials receives SIGNED deltas (two's complement u64) of the moved points.
+template <typename LabelT, int IDBITS>
+__global__ __launch_bounds__(kAssignThreads) void k_rgbw_assign_cells(
+    const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ cell_start,
+    uint64_t lo, uint64_t hi, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st) {
+    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | uint2 cand[K]
+    __shared__ uint32_t s_minub, s_ncand, s_c0;
+    __shared__ uint32_t s_moved;
+    if (st->done) return;
+    unsigned long long *acc = lds;
+    uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
+    uint2 *cand = tab + K;
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += kAssignThreads) acc[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < K; i += kAssignThreads) tab[i] = cconst[i];
+    const uint64_t n = hi - lo;
+    const uint32_t q_lo = (uint32_t)(lo + n * blockIdx.x / gridDim.x);
+    const uint32_t q_hi = (uint32_t)(lo + n * (blockIdx.x + 1) / gridDim.x);
+    if (threadIdx.x == 0) {
+        // last cell whose start is <= q_lo (binary search over the prefix sums)
+        uint32_t a = 0, b = kNumCells;  // invariant: cell_start[a] <= q_lo, (b == kNumCells or cell_start[b] > q_lo)
+        while (b - a > 1) {
+            uint32_t m = (a + b) >> 1;
+            if (cell_start[m] <= q_lo) a = m; else b = m;
+        }
+        s_c0 = a;
+        s_moved = 0;
+    }
+    __syncthreads();
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    const int lane = threadIdx.x & 63;
+    uint32_t moved = 0;
+    unsigned long long evals = 0;
+    if (q_lo < q_hi) {
+        for (uint32_t c = s_c0; c < kNumCells; c++) {
+            const uint32_t cs = cell_start[c], ce = cell_start[c + 1];
+            if (cs >= q_hi) break;
+            const uint32_t s = max(cs, q_lo), e = min(ce, q_hi);
+            if (s >= e) continue;
+            // ---- candidate centroids of this cell
+            if (threadIdx.x == 0) { s_minub = 0xffffffffu; s_ncand = 0; }
+            __syncthreads();
+            const int32_t r0 = (int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift);
+            const int32_t g0 = (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift);
+            const int32_t b0 = (int32_t)((c % kCellsPerDim) << kCellShift);
+            constexpr int32_t ext = (1 << kCellShift) - 1;
+            uint32_t mub = 0xffffffffu;
+            for (uint32_t k = threadIdx.x; k < K; k += kAssignThreads) {
+                const uint32_t ck = tab[k].x;
+                const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
+                const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
+                mub = min(mub, (uint32_t)(hr * hr + hg * hg + hb * hb));
+            }
+            mub = wave_reduce_min(mub);
+            if (lane == 0) atomicMin(&s_minub, mub);
+            __syncthreads();
+            const uint32_t T = s_minub;
+            for (uint32_t k = threadIdx.x; k < K; k += kAssignThreads) {
+                const uint2 t = tab[k];
+                const int32_t dr0 = (int32_t)((t.x >> 16) & 255) - r0, dg0 = (int32_t)((t.x >> 8) & 255) - g0, db0 = (int32_t)(t.x & 255) - b0;
+                const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
+                if ((uint32_t)(lr * lr + lg * lg + lb * lb) <= T) cand[atomicAdd(&s_ncand, 1u)] = t;
+            }
+            __syncthreads();
+            const uint32_t ncand = s_ncand;
+            // ---- points of the cell owned by this block
+            for (uint32_t q = s + threadIdx.x; q < e; q += kAssignThreads) {
+                const uint32_t p = ckeys[q];
+                uint32_t best = 0;
+                for (uint32_t j = 0; j < ncand; j++) {
+                    const uint2 cc = cand[j];  // LDS broadcast
+                    best = max(best, (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y);
+                }
+                const uint32_t cur = labels[q];
+                const uint2 cc = tab[cur];
+                const uint32_t kcur = (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y;
+                if ((best >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
+                    const uint32_t nl = IDMASK - (best & IDMASK);
+                    labels[q] = (LabelT)nl;
+                    moved++;
+                    const uint64_t w = cweight[q];
+                    const unsigned long long rw = ((p >> 16) & 255) * w, gw = ((p >> 8) & 255) * w, bw = (p & 255) * w;
+                    atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * cur + 0], 0ull - rw);
+                    atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * cur + 1], 0ull - gw);
+                    atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * cur + 2], 0ull - bw);
+                    atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + cur], 0ull - (unsigned long long)w);
+                    atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + cur], 0ull - 1ull);
+                }
+            }
+            if (threadIdx.x == 0) evals += (unsigned long long)(e - s) * (ncand + 1);
+            __syncthreads();  // cand / s_ncand are rewritten for the next cell
+        }
+    }
+    moved = wave_reduce_sum(moved);
+    if (lane == 0 && moved) atomicAdd(&s_moved, moved);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += kAssignThreads)
+        if (acc[i]) atomicAdd(&partials[i], acc[i]);
+    if (threadIdx.x == 0) {
+        if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
+        if (evals) atomicAdd(&partials[5 * (size_t)K + 1], evals);
+    }
+}
+
 // ---------------------------------------------------------------- centroid update
 // Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137).
-__global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ partials, const uint32_t *__restrict__ keys,
+// mode 0: partials hold the full sums of this iteration (brute path)
+// mode 1: partials hold deltas; running += partials first (cells path)
+// mode 2: running += partials only (folds the initial assignment in; no centroid update)
+__global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ partials, uint64_t *__restrict__ running,
+                                                     int mode, const uint32_t *__restrict__ keys,
                                                      uint64_t U, uint32_t K, uint32_t idbits, uint64_t seed,
                                                      uint64_t max_iters, uint2 *__restrict__ cconst,
                                                      uint32_t *__restrict__ cent, uint64_t *__restrict__ members_out,
                                                      uint64_t *__restrict__ wsum_out,
                                                      KmDevState *__restrict__ st) {
     if (st->done) return;
+    if (mode == 2) {
+        for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += blockDim.x) {
+            if (i < 5 * K) running[i] += partials[i];
+            partials[i] = 0;
+        }
+        return;
+    }
     __shared__ uint32_t s_reseed, s_active;
     if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; }
+    if (mode == 1)
+        for (uint32_t i = threadIdx.x; i < 5 * K; i += blockDim.x) running[i] += partials[i];
     __syncthreads();
+    const uint64_t *src = mode == 1 ? running : partials;
     const uint64_t iter = st->iter;
     for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-        uint64_t members = partials[4 * (size_t)K + k];
+        uint64_t members = src[4 * (size_t)K + k];
         members_out[k] = members;
-        wsum_out[k] = partials[3 * (size_t)K + k];
+        wsum_out[k] = src[3 * (size_t)K + k];
         uint32_t ck;
         if (members == 0) {
             ck = keys[reseed_index(seed, iter, k, U)];  // fake_clone of the stolen point
             atomicAdd(&s_reseed, 1u);
         } else {
-            uint64_t w = partials[3 * (size_t)K + k];
-            uint32_t r = (uint32_t)(partials[3 * (size_t)k + 0] / w) & 255;
-            uint32_t g = (uint32_t)(partials[3 * (size_t)k + 1] / w) & 255;
-            uint32_t b = (uint32_t)(partials[3 * (size_t)k + 2] / w) & 255;
+            uint64_t w = src[3 * (size_t)K + k];
+            uint32_t r = (uint32_t)(src[3 * (size_t)k + 0] / w) & 255;
+            uint32_t g = (uint32_t)(src[3 * (size_t)k + 1] / w) & 255;
+            uint32_t b = (uint32_t)(src[3 * (size_t)k + 2] / w) & 255;
             ck = (r << 16) | (g << 8) | b;
             atomicAdd(&s_active, 1u);
         }
@@ -202,27 +453,40 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
     }
     __syncthreads();
     const uint64_t changed = partials[5 * (size_t)K];
+    const uint64_t evals = partials[5 * (size_t)K + 1];
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 5 * K + 1; i += blockDim.x) partials[i] = 0;  // ready for the next reduce
+    for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += blockDim.x) partials[i] = 0;  // ready for the next iteration
     if (threadIdx.x == 0) {
         st->changed_ring[iter % kHistRing] = changed;
         st->moved_last = changed;
         st->reseeds += s_reseed;
         st->active = s_active;
+        st->pair_evals += evals;
         st->iter = iter + 1;
         if (changed == 0 || (max_iters && iter + 1 >= max_iters)) st->done = 1;
     }
 }
 
 template <typename LabelT>
-__global__ void k_widen_labels(const LabelT *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+__global__ void k_widen_labels(const LabelT *__restrict__ in, const uint32_t *__restrict__ rank, uint32_t *__restrict__ out,
+                               uint64_t lo, uint64_t hi) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+    for (uint64_t i = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += stride) {
+        if (rank) out[rank[i]] = in[i];   // cell-major -> canonical order
+        else out[i - lo] = in[i - lo];
+    }
 }
 template <typename LabelT>
 __global__ void k_narrow_labels(const uint32_t *__restrict__ in, LabelT *__restrict__ out, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (LabelT)in[i];
+}
+// canonical-order u8/u16 labels from cell-major ones (for the remap / bit-pack stages)
+template <typename LabelT>
+__global__ void k_labels_to_canonical(const LabelT *__restrict__ in, const uint32_t *__restrict__ rank, LabelT *__restrict__ out,
+                                      uint64_t U) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride) out[rank[i]] = in[i];
 }
 __global__ void k_set_cconst(const uint32_t *__restrict__ cent, uint32_t K, uint32_t Kpad, uint32_t idbits,
                              uint2 *__restrict__ cconst) {
@@ -235,6 +499,13 @@ __global__ void k_set_cconst(const uint32_t *__restrict__ cent, uint32_t K, uint
 static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, 256), 1), cap);
 }
+
+#define KM_ALLOC(buf, bytes)                                                                       \
+    do {                                                                                           \
+        hipError_t _e = (buf).alloc(bytes);                                                        \
+        if (_e != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw: hipMalloc(%llu) failed: %s", \
+                                                        (unsigned long long)(bytes), hipGetErrorString(_e)); } \
+    } while (0)
 
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint64_t lo,
                    uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
@@ -251,45 +522,97 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->idbits = s->wide ? 12 : 8;
     s->seed = (opts && opts->seed) ? opts->seed : kDefaultSeed;
     s->max_iters = opts ? opts->max_iters : 0;
+    s->cells = !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE));
     s->keys = keys_d; s->weight = weight_d;
-    s->sharded = !(lo == 0 && hi == U);
     const uint64_t n = hi - lo;
-    s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, (uint64_t)kAssignThreads * kPPT), 1), kMaxBlocks);
-    const uint64_t W = 5 * (uint64_t)K + 1;
-    hipError_t e = hipSuccess;
-    if ((e = s->labels.alloc(std::max<uint64_t>(n, 1) * (s->wide ? 2 : 1))) != hipSuccess ||
-        (e = s->cconst.alloc((uint64_t)s->Kpad * 8)) != hipSuccess ||
-        (e = s->cent.alloc((uint64_t)K * 4)) != hipSuccess ||
-        (e = s->members_last.alloc((uint64_t)K * 8)) != hipSuccess ||
-        (e = s->wsum_last.alloc((uint64_t)K * 8)) != hipSuccess ||
-        (e = s->slabs.alloc((uint64_t)s->nblocks * W * 8)) != hipSuccess ||
-        (e = s->dstate.alloc(sizeof(KmDevState))) != hipSuccess) {
-        delete s;
-        return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw: hipMalloc failed: %s", hipGetErrorString(e));
-    }
+    const uint64_t W = 5 * (uint64_t)K + 2;
+    const uint64_t lab_bytes = s->wide ? 2 : 1;
+    KM_ALLOC(s->cconst, (uint64_t)s->Kpad * 8);
+    KM_ALLOC(s->cent, (uint64_t)K * 4);
+    KM_ALLOC(s->members_last, (uint64_t)K * 8);
+    KM_ALLOC(s->wsum_last, (uint64_t)K * 8);
+    KM_ALLOC(s->dstate, sizeof(KmDevState));
     if (partials_dev) s->partials = reinterpret_cast<uint64_t *>(partials_dev);
-    else {
-        if ((e = s->partials_own.alloc(W * 8)) != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
-        s->partials = s->partials_own.as<uint64_t>();
-    }
+    else { KM_ALLOC(s->partials_own, W * 8); s->partials = s->partials_own.as<uint64_t>(); }
     (void)hipMemsetAsync(s->partials, 0, W * 8, c->stream);
     (void)hipMemsetAsync(s->dstate.p, 0, sizeof(KmDevState), c->stream);
-    uint32_t g = grid_1d(std::max<uint64_t>(n, s->Kpad));
-    if (s->wide)
-        hipLaunchKernelGGL(k_rgbw_init<uint16_t>, dim3(g), dim3(256), 0, c->stream, keys_d, U, lo, hi, K, s->Kpad,
-                           s->idbits, s->labels.as<uint16_t>(), s->cconst.as<uint2>(), s->cent.as<uint32_t>());
-    else
-        hipLaunchKernelGGL(k_rgbw_init<uint8_t>, dim3(g), dim3(256), 0, c->stream, keys_d, U, lo, hi, K, s->Kpad,
-                           s->idbits, s->labels.as<uint8_t>(), s->cconst.as<uint2>(), s->cent.as<uint32_t>());
-    if ((e = hipGetLastError()) != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "init launch: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_rgbw_init_cent, dim3(ceil_div(s->Kpad, 256)), dim3(256), 0, c->stream, keys_d, U, K, s->Kpad, s->idbits,
+                       s->cconst.as<uint2>(), s->cent.as<uint32_t>());
+    if (s->cells) {
+        // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
+        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, 1024), 1), kCellBlocks);
+        KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
+        KM_ALLOC(s->ckeys, U * 4);
+        KM_ALLOC(s->cweight, U * 4);
+        KM_ALLOC(s->crank, U * 4);
+        KM_ALLOC(s->cell_start, ((uint64_t)kNumCells + 1) * 4);
+        KM_ALLOC(s->running, W * 8);
+        DevBuf count, cursor;
+        KM_ALLOC(count, (uint64_t)kNumCells * 4);
+        KM_ALLOC(cursor, (uint64_t)kNumCells * 4);
+        (void)hipMemsetAsync(count.p, 0, (uint64_t)kNumCells * 4, c->stream);
+        (void)hipMemsetAsync(s->running.p, 0, W * 8, c->stream);
+        const uint32_t g = grid_1d(U);
+        hipLaunchKernelGGL(k_cell_count, dim3(g), dim3(256), 0, c->stream, keys_d, U, count.as<uint32_t>());
+        hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
+                           cursor.as<uint32_t>());
+        hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
+                           s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
+        // init_assignment (kmeans.rs:61-78) by canonical rank, then its sums folded into `running`
+        if (s->wide) {
+            hipLaunchKernelGGL(k_rgbw_init_labels<uint16_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
+                               (uint64_t)0, U, K, s->labels.as<uint16_t>());
+            hipLaunchKernelGGL(k_rgbw_accum_all<uint16_t>, dim3(grid_1d(n, 512)), dim3(256), (size_t)K * 40, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), lo, hi, K, s->labels.as<uint16_t>(),
+                               reinterpret_cast<unsigned long long *>(s->partials));
+        } else {
+            hipLaunchKernelGGL(k_rgbw_init_labels<uint8_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
+                               (uint64_t)0, U, K, s->labels.as<uint8_t>());
+            hipLaunchKernelGGL(k_rgbw_accum_all<uint8_t>, dim3(grid_1d(n, 512)), dim3(256), (size_t)K * 40, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), lo, hi, K, s->labels.as<uint8_t>(),
+                               reinterpret_cast<unsigned long long *>(s->partials));
+        }
+        hipError_t e = hipStreamSynchronize(c->stream);  // count / cursor are released on scope exit
+        if (e != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw setup: %s", hipGetErrorString(e)); }
+    } else {
+        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, (uint64_t)kAssignThreads * kPPT), 1), kMaxBlocks);
+        KM_ALLOC(s->labels, std::max<uint64_t>(n, 1) * lab_bytes);
+        KM_ALLOC(s->slabs, (uint64_t)s->nblocks * W * 8);
+        if (s->wide)
+            hipLaunchKernelGGL(k_rgbw_init_labels<uint16_t>, dim3(grid_1d(n)), dim3(256), 0, c->stream, (const uint32_t *)nullptr, U, lo,
+                               hi, K, s->labels.as<uint16_t>());
+        else
+            hipLaunchKernelGGL(k_rgbw_init_labels<uint8_t>, dim3(grid_1d(n)), dim3(256), 0, c->stream, (const uint32_t *)nullptr, U, lo,
+                               hi, K, s->labels.as<uint8_t>());
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw init launch: %s", hipGetErrorString(e)); }
     *out = s;
     return CNIIC_OK;
 }
 
 void km_rgbw_destroy(KmRgbwState *s) { delete s; }
 
+static int launch_update(KmRgbwState *s, int mode) {
+    Ctx *c = s->c;
+    hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->running.as<uint64_t>(), mode, s->keys, s->U,
+                       s->K, s->idbits, s->seed, s->max_iters, s->cconst.as<uint2>(), s->cent.as<uint32_t>(),
+                       s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(), s->dstate.as<KmDevState>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// Cells path, after create (and after the caller's all-reduce of the initial sums when sharded):
+// fold the initial assignment into the running sums.
+int km_rgbw_fold_initial(KmRgbwState *s) {
+    if (!s->cells) return CNIIC_OK;
+    return launch_update(s, 2);
+}
+
+// Brute path only: explicit centroids + labels (single-step ABI).
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32) {
     Ctx *c = s->c;
+    if (s->cells) return c->fail(CNIIC_ERR_BAD_ARG, "km_rgbw_set_state needs the brute-force state");
     std::vector<uint32_t> ck(s->K);
     for (uint32_t k = 0; k < s->K; k++)
         ck[k] = ((uint32_t)centroids_h[3 * k] << 16) | ((uint32_t)centroids_h[3 * k + 1] << 8) | centroids_h[3 * k + 2];
@@ -308,10 +631,23 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
     return CNIIC_OK;
 }
 
-static int launch_assign(KmRgbwState *s) {
+static void launch_assign(KmRgbwState *s) {
     Ctx *c = s->c;
-    const size_t lds = (size_t)s->K * (5 * 8 + 8);
     const KmDevState *st = s->dstate.as<KmDevState>();
+    if (s->cells) {
+        const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
+        auto *part = reinterpret_cast<unsigned long long *>(s->partials);
+        if (s->wide)
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->cell_start.as<uint32_t>(), s->lo, s->hi, s->K,
+                               s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st);
+        else
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->cell_start.as<uint32_t>(), s->lo, s->hi, s->K,
+                               s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st);
+        return;
+    }
+    const size_t lds = (size_t)s->K * (5 * 8 + 8);
     if (s->wide)
         hipLaunchKernelGGL((k_rgbw_assign<uint16_t, 12>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream, s->keys,
                            s->weight, s->lo, s->hi, s->K, s->Kpad, s->cconst.as<uint2>(), s->labels.as<uint16_t>(),
@@ -320,28 +656,22 @@ static int launch_assign(KmRgbwState *s) {
         hipLaunchKernelGGL((k_rgbw_assign<uint8_t, 8>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream, s->keys,
                            s->weight, s->lo, s->hi, s->K, s->Kpad, s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
                            s->slabs.as<uint64_t>(), st);
-    return CNIIC_OK;
 }
 
 int km_rgbw_assign(KmRgbwState *s) {
     Ctx *c = s->c;
     launch_assign(s);
-    const uint32_t W = 5 * s->K + 1;
-    const uint32_t ry = std::max(1u, std::min(16u, s->nblocks / 4));
-    hipLaunchKernelGGL(k_slab_reduce, dim3(ceil_div(W, 64), ry), dim3(256), 0, c->stream, s->slabs.as<uint64_t>(),
-                       s->nblocks, W, s->partials, s->dstate.as<KmDevState>());
+    if (!s->cells) {
+        const uint32_t W = 5 * s->K + 2;
+        const uint32_t ry = std::max(1u, std::min(16u, s->nblocks / 4));
+        hipLaunchKernelGGL(k_slab_reduce, dim3(ceil_div(W, 64), ry), dim3(256), 0, c->stream, s->slabs.as<uint64_t>(),
+                           s->nblocks, W, s->partials, s->dstate.as<KmDevState>());
+    }
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
 
-int km_rgbw_update(KmRgbwState *s) {
-    Ctx *c = s->c;
-    hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->keys, s->U, s->K, s->idbits,
-                       s->seed, s->max_iters, s->cconst.as<uint2>(), s->cent.as<uint32_t>(), s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(),
-                       s->dstate.as<KmDevState>());
-    CNIIC_HIP_TRY(c, hipGetLastError());
-    return CNIIC_OK;
-}
+int km_rgbw_update(KmRgbwState *s) { return launch_update(s, s->cells ? 1 : 0); }
 
 static int read_state(KmRgbwState *s, KmDevState *h) {
     Ctx *c = s->c;
@@ -364,6 +694,7 @@ int km_rgbw_run(KmRgbwState *s) {
     Ctx *c = s->c;
     const int batch = 8;
     KmDevState h;
+    CNIIC_TRY(km_rgbw_fold_initial(s));
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter");
     for (;;) {
         for (int b = 0; b < batch; b++) {
@@ -378,8 +709,8 @@ int km_rgbw_run(KmRgbwState *s) {
 }
 
 // Average duration of the assign kernel alone (HIP events on the ctx stream around `reps`
-// back-to-back launches on the current state).  The slab outputs are overwritten; labels may move
-// towards the fixed point of the current centroids (idempotent afterwards).
+// back-to-back launches on the current state).  Labels may move towards the fixed point of the
+// current centroids; the partial sums are left inconsistent, so the state must be discarded.
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch) {
     Ctx *c = s->c;
     launch_assign(s);  // warm-up
@@ -397,7 +728,7 @@ int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch) {
 int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h) {
     Ctx *c = s->c;
     const size_t K = s->K;
-    std::vector<uint64_t> p(5 * K + 1);
+    std::vector<uint64_t> p(5 * K + 2);
     CNIIC_HIP_TRY(c, hipMemcpyAsync(p.data(), s->partials, p.size() * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (sums_h) memcpy(sums_h, p.data(), 3 * K * 8);
@@ -408,18 +739,44 @@ int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_
 }
 
 void *km_rgbw_partials_dev(KmRgbwState *s) { return s->partials; }
-const uint8_t *km_rgbw_labels8_dev(KmRgbwState *s) { return s->wide ? nullptr : s->labels.as<uint8_t>(); }
-const uint16_t *km_rgbw_labels16_dev(KmRgbwState *s) { return s->wide ? s->labels.as<uint16_t>() : nullptr; }
+bool km_rgbw_is_wide(KmRgbwState *s) { return s->wide; }
 
+// u8/u16 labels in CANONICAL point order on the device (dst holds U entries)
+int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d) {
+    Ctx *c = s->c;
+    if (s->cells) {
+        if (s->wide)
+            hipLaunchKernelGGL(k_labels_to_canonical<uint16_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(),
+                               s->crank.as<uint32_t>(), reinterpret_cast<uint16_t *>(dst_d), s->U);
+        else
+            hipLaunchKernelGGL(k_labels_to_canonical<uint8_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint8_t>(),
+                               s->crank.as<uint32_t>(), reinterpret_cast<uint8_t *>(dst_d), s->U);
+        CNIIC_HIP_TRY(c, hipGetLastError());
+        return CNIIC_OK;
+    }
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(dst_d, s->labels.p, (s->hi - s->lo) * (s->wide ? 2 : 1), hipMemcpyDeviceToDevice, c->stream));
+    return CNIIC_OK;
+}
+
+// cell-major label array of all U points (cells path): the buffer ranks all-gather over
+void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes) {
+    if (elem_bytes) *elem_bytes = s->wide ? 2 : 1;
+    return s->labels.p;
+}
+
+// labels_d_u32: cells path -> all U labels in canonical order (only [lo,hi) of the internal order
+// are meaningful unless the caller all-gathered the internal array); brute path -> slice [lo,hi).
 int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats) {
     Ctx *c = s->c;
     const uint64_t n = s->hi - s->lo;
     if (labels_d_u32 && n) {
+        const uint32_t *rank = s->cells ? s->crank.as<uint32_t>() : nullptr;
+        const uint64_t a = s->cells ? 0 : s->lo, b = s->cells ? s->U : s->hi;
         if (s->wide)
-            hipLaunchKernelGGL(k_widen_labels<uint16_t>, dim3(grid_1d(n)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(), labels_d_u32, n);
+            hipLaunchKernelGGL(k_widen_labels<uint16_t>, dim3(grid_1d(b - a)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(), rank, labels_d_u32, a, b);
         else
-            hipLaunchKernelGGL(k_widen_labels<uint8_t>, dim3(grid_1d(n)), dim3(256), 0, c->stream, s->labels.as<uint8_t>(), labels_d_u32, n);
+            hipLaunchKernelGGL(k_widen_labels<uint8_t>, dim3(grid_1d(b - a)), dim3(256), 0, c->stream, s->labels.as<uint8_t>(), rank, labels_d_u32, a, b);
         CNIIC_HIP_TRY(c, hipGetLastError());
     }
     std::vector<uint32_t> ck(s->K);
@@ -430,16 +787,14 @@ int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32,
         for (uint32_t k = 0; k < s->K; k++) {
             centroids_h[3 * k] = (uint8_t)(ck[k] >> 16); centroids_h[3 * k + 1] = (uint8_t)(ck[k] >> 8); centroids_h[3 * k + 2] = (uint8_t)ck[k];
         }
-    if (members_h) {  // global member counts of the last completed iteration (after any all-reduce)
-        CNIIC_HIP_TRY(c, hipMemcpy(members_h, s->members_last.p, (size_t)s->K * 8, hipMemcpyDeviceToHost));
-    }
+    if (members_h) CNIIC_HIP_TRY(c, hipMemcpy(members_h, s->members_last.p, (size_t)s->K * 8, hipMemcpyDeviceToHost));
     if (wsum_h) CNIIC_HIP_TRY(c, hipMemcpy(wsum_h, s->wsum_last.p, (size_t)s->K * 8, hipMemcpyDeviceToHost));
     if (stats) {
         stats->iterations = h.iter;
         stats->moved_last = h.moved_last;
         stats->empty_reseeds = h.reseeds;
         stats->active = h.active;
-        stats->pair_evals = h.iter * n * (uint64_t)s->K;
+        stats->pair_evals = h.pair_evals;
     }
     return CNIIC_OK;
 }

@@ -133,11 +133,20 @@ int32_t cniic_km_create_rgbw(cniic_ctx *ctx, const uint32_t *keys, const uint32_
                              uint64_t lo, uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts,
                              void *partials_dev /* device buffer of cniic_km_partial_words(K,3) u64, or NULL */,
                              cniic_km **out);
-uint64_t cniic_km_partial_words(uint32_t K, uint32_t D);   /* K*D sums + K wsum + K members + 1 changed */
+uint64_t cniic_km_partial_words(uint32_t K, uint32_t D);   /* K*D sums + K wsum + K members + moved + evals */
 int32_t cniic_km_partials(cniic_km *km, void **dev_ptr);
+/* After create the partials buffer holds this shard's sums of the INITIAL assignment
+ * (kmeans.rs:61-78); all-reduce it, then call cniic_km_begin once. */
+int32_t cniic_km_begin(cniic_km *km);
+/* Each iteration: cniic_km_assign (async; partials <- signed deltas of the points that moved),
+ * all-reduce the partials, cniic_km_update. */
 int32_t cniic_km_assign(cniic_km *km);                      /* async on the ctx stream */
 int32_t cniic_km_update(cniic_km *km, uint64_t *changed);   /* syncs; *changed = global moved count */
-int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels_slice, uint64_t *members,
+/* The labels live on the device in the library's internal (cell-major) point order, all U of
+ * them, of which this shard owns [lo,hi): all-gather that range before asking for the result. */
+int32_t cniic_km_labels_internal(cniic_km *km, void **dev_ptr, uint64_t *elem_bytes);
+/* labels: all U points, the caller's (canonical) order. */
+int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels, uint64_t *members,
                         cniic_kmeans_stats *stats);
 /* average duration (ms) of the assign kernel alone over `reps` back-to-back launches, measured
  * with HIP events on the ctx stream (bench.py's roofline figure) */

@@ -111,6 +111,35 @@ def test_kmeans_rgbw_run(ctx, K, shape):
     assert np.array_equal(got["members"], exp["members"])
 
 
+@pytest.mark.parametrize("K,flags", [(16, 1), (256, 1), (300, 1), (2048, 0)])
+def test_kmeans_rgbw_brute_and_wide(ctx, K, flags):
+    """brute-force kernel (flag 1) and the cell-pruned kernel give the oracle's run; K > 256 uses u16 labels"""
+    img = synth_img(160, 160, seed=3 * K)
+    keys, counts = O.count_freqs(keys_of(img))
+    w = counts.astype(np.uint32)
+    rc, got = ctx.kmeans_rgbw(keys, w, K, flags=flags)
+    rco, exp = O.kmeans(O.PT_RGBW, O.MODE_L, pts_of_keys(keys), w, K)
+    assert rc == rco == 0
+    assert got["stats"]["iterations"] == exp["stats"]["iterations"]
+    assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
+    assert np.array_equal(got["labels"], exp["labels"])
+    assert np.array_equal(got["members"], exp["members"])
+
+
+def test_kmeans_rgbw_unsorted_input_order(ctx):
+    """the point ORDER is the caller's (the reference clusters a HashMap-ordered Vec, clusterc.rs:21-24):
+    a shuffled list must give the oracle's result for that same order"""
+    img = synth_img(96, 96, seed=77)
+    keys, counts = O.count_freqs(keys_of(img))
+    perm = np.random.default_rng(5).permutation(keys.size)
+    keys, w = keys[perm], counts[perm].astype(np.uint32)
+    rc, got = ctx.kmeans_rgbw(keys, w, 32)
+    rco, exp = O.kmeans(O.PT_RGBW, O.MODE_L, pts_of_keys(keys), w, 32)
+    assert rc == rco == 0
+    assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
+    assert np.array_equal(got["labels"], exp["labels"])
+
+
 def test_kmeans_rgbw_errors(ctx):
     from cniic_amd import _lib
     keys = np.arange(5, dtype=np.uint32)
