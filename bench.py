@@ -117,7 +117,7 @@ def main():
         o = _lib.KmOpts(0, 0, 0, 0)
         L = _lib.lib()
         ctx._check(L.cniic_km_create_rgbw(ctx.h, C.c_void_p(kd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_uint64(U),
-                                          C.c_uint64(0), C.c_uint64(U), C.c_uint32(K), C.byref(o), None, C.byref(km)))
+                                          C.c_uint32(0), C.c_uint32(1), C.c_uint32(K), C.byref(o), None, C.byref(km)))
         ctx._check(L.cniic_km_begin(km))
         # a few real iterations so labels/centroids are in a representative state
         for _ in range(3):
@@ -156,6 +156,7 @@ def main():
             "config": {"workload": "cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
                                    "(seed 0x636E696963+2+rank), to convergence" % (K, W, H),
                        "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
+                       "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2),
                        "bytes_per_px": round(nbytes / (W * H), 4),
                        "parallelism": "1 GPU" if world == 1 else "pixels sharded over %d GPUs, shared palette, RCCL all-reduce "
                                                                    "of histogram + K partial sums per iteration" % world},

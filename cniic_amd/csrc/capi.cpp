@@ -180,7 +180,7 @@ int32_t cniic_kmeans_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *we
     CNIIC_TRY(k.bind(c, keys, U));
     CNIIC_TRY(w.bind(c, weight, U));
     KmRgbwState *km = nullptr;
-    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, opts, nullptr, &km));
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, opts, nullptr, &km));
     std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
     CNIIC_TRY(km_rgbw_run(km));
     Out<uint32_t> lo;
@@ -216,7 +216,7 @@ int32_t cniic_kmeans_step_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_
     CNIIC_TRY(from_caller(c, cent.data(), centroids, cent.size()));
     KmRgbwState *km = nullptr;
     cniic_kmeans_opts step_opts{0, 0, CNIIC_KM_BRUTE_FORCE, 0};  // explicit centroids + labels: full-sum kernel
-    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, U, K, &step_opts, nullptr, &km));
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, &step_opts, nullptr, &km));
     std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
     CNIIC_TRY(km_rgbw_set_state(km, cent.data(), lin.d));
     CNIIC_TRY(km_rgbw_assign(km));
@@ -296,16 +296,16 @@ int32_t cniic_kmeans_step_xyrgb(cniic_ctx *c, const uint8_t *rgb, uint32_t w, ui
 // ------------------------------------------------------------------ sharded session
 uint64_t cniic_km_partial_words(uint32_t K, uint32_t D) { return (uint64_t)K * D + 2ull * K + 2; }
 
-int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint64_t lo, uint64_t hi,
+int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *weight, uint64_t U, uint32_t shard, uint32_t nshards,
                              uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev, cniic_km **out) {
     LOCK(c);
     if (!out || !keys || !weight) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: null argument");
     if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "km_create_rgbw: partials must be device memory");
     auto km = std::make_unique<cniic_km>();
-    km->c = c; km->lo = lo; km->hi = hi; km->K = K; km->U = U;
+    km->c = c; km->K = K; km->U = U;
     CNIIC_TRY(km->keys.bind(c, keys, U));
     CNIIC_TRY(km->weight.bind(c, weight, U));
-    CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, lo, hi, K, opts, partials_dev, &km->st));
+    CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, shard, nshards, K, opts, partials_dev, &km->st));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *out = km.release();
     return CNIIC_OK;

@@ -194,8 +194,8 @@ int dense_table(Ctx *c, uint32_t bits, uint32_t **table_d);  // zeroed scratch t
 
 // ---- k_kmeans_rgbw.hip ----
 struct KmRgbwState;  // opaque device state of one rgbw K-means problem
-int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint64_t lo,
-                   uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
+int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
+                   uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
                    KmRgbwState **out);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);

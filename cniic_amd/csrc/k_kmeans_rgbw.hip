@@ -44,6 +44,7 @@ constexpr int kCellShift = 3;                                  // 8x8x8 colours 
 constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
 constexpr uint32_t kCellBlocks = 1024;
+constexpr uint32_t kCellFixedCost = 64;   // per-cell overhead in point-equivalents (work split between waves)
 
 struct KmRgbwState {
     Ctx *c = nullptr;
@@ -54,7 +55,8 @@ struct KmRgbwState {
     const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
-    DevBuf ckeys, cweight, crank, cell_start, running;
+    DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count;
+    uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
 
@@ -216,30 +218,43 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__
     }
 }
 
-// single block: exclusive scan of the cell counts -> cell_start[kNumCells + 1], cursor = copy
+// single block: exclusive scan of the cell counts -> cell_start[kNumCells + 1] (+ cursor copy), and
+// the compacted list of NON-EMPTY cells: ne_cell[m] = cell id, ne_start[m] = its first position,
+// ne_start[M] = U, *ne_count = M.  Blocks walk the compacted list, never the empty cells.
 __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__ cell_count, uint32_t *__restrict__ cell_start,
-                                                    uint32_t *__restrict__ cursor) {
-    __shared__ uint32_t sh[1024];
+                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ ne_cell,
+                                                    uint32_t *__restrict__ ne_start, uint32_t *__restrict__ ne_cost,
+                                                    uint32_t *__restrict__ ne_count) {
+    __shared__ uint32_t sh[1024], sh2[1024];
     constexpr uint32_t per = kNumCells / 1024;
     const uint32_t lo = threadIdx.x * per;
-    uint32_t s = 0;
-    for (uint32_t i = 0; i < per; i++) s += cell_count[lo + i];
+    uint32_t s = 0, z = 0;
+    for (uint32_t i = 0; i < per; i++) { uint32_t v = cell_count[lo + i]; s += v; z += v != 0; }
     sh[threadIdx.x] = s;
+    sh2[threadIdx.x] = z;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
         uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        uint32_t add2 = threadIdx.x >= off ? sh2[threadIdx.x - off] : 0;
         __syncthreads();
         sh[threadIdx.x] += add;
+        sh2[threadIdx.x] += add2;
         __syncthreads();
     }
-    uint32_t run = sh[threadIdx.x] - s;
+    uint32_t run = sh[threadIdx.x] - s, m = sh2[threadIdx.x] - z;
     for (uint32_t i = 0; i < per; i++) {
         uint32_t v = cell_count[lo + i];
         cell_start[lo + i] = run;
         cursor[lo + i] = run;
+        if (v) { ne_cell[m] = lo + i; ne_start[m] = run; ne_cost[m] = run + m * kCellFixedCost; m++; }
         run += v;
     }
-    if (threadIdx.x == 1023) cell_start[kNumCells] = sh[1023];
+    if (threadIdx.x == 1023) {
+        cell_start[kNumCells] = sh[1023];
+        ne_start[sh2[1023]] = sh[1023];
+        ne_cost[sh2[1023]] = sh[1023] + sh2[1023] * kCellFixedCost;
+        *ne_count = sh2[1023];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ weight,
@@ -300,108 +315,130 @@ __global__ __launch_bounds__(256) void k_rgbw_accum_all(const uint32_t *__restri
 }
 
 // ---------------------------------------------------------------- cell-pruned assign, delta sums
-// Block b owns the cell-major positions [lo + n b/G, lo + n (b+1)/G) and walks the cells that
-// overlap them.  partials receives SIGNED deltas (two's complement u64) of the moved points.
-template <typename LabelT, int IDBITS>
-__global__ __launch_bounds__(kAssignThreads) void k_rgbw_assign_cells(
-    const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ cell_start,
-    uint64_t lo, uint64_t hi, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
+// One WAVE per cell: the 64 lanes bound all K centroids against the cell's cube (K/64 per lane),
+// reduce min ub across the wave, compact the candidate list into the wave's own LDS strip with
+// ballot prefixes, then sweep the cell's points 64 at a time.  No block barrier inside the loop,
+// so sparse and dense cells cost what they contain.  Cells are dealt to waves in contiguous runs
+// of equal COST (cost = kCellFixedCost + points, prefix-summed at setup): wave g of G takes the
+// cells whose cost prefix falls in [total g/G, total (g+1)/G).  With several GPUs the global wave
+// index runs over all shards.  partials receives SIGNED deltas (two's complement u64) of the
+// points that moved.
+template <typename LabelT, int IDBITS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
+    const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
+    const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_count,
+    uint32_t shard, uint32_t nshards, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
     unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st) {
-    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | uint2 cand[K]
-    __shared__ uint32_t s_minub, s_ncand, s_c0;
+    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x uint2 cand[K]
     __shared__ uint32_t s_moved;
+    __shared__ unsigned long long s_evals;
     if (st->done) return;
+    constexpr int THREADS = WAVES * 64;
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
-    uint2 *cand = tab + K;
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += kAssignThreads) acc[i] = 0ull;
-    for (uint32_t i = threadIdx.x; i < K; i += kAssignThreads) tab[i] = cconst[i];
-    const uint64_t n = hi - lo;
-    const uint32_t q_lo = (uint32_t)(lo + n * blockIdx.x / gridDim.x);
-    const uint32_t q_hi = (uint32_t)(lo + n * (blockIdx.x + 1) / gridDim.x);
-    if (threadIdx.x == 0) {
-        // last cell whose start is <= q_lo (binary search over the prefix sums)
-        uint32_t a = 0, b = kNumCells;  // invariant: cell_start[a] <= q_lo, (b == kNumCells or cell_start[b] > q_lo)
-        while (b - a > 1) {
-            uint32_t m = (a + b) >> 1;
-            if (cell_start[m] <= q_lo) a = m; else b = m;
-        }
-        s_c0 = a;
-        s_moved = 0;
-    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint2 *cand = tab + K + (size_t)wid * K;
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
     __syncthreads();
+
+    const uint32_t M = *ne_count;
+    const uint64_t total = ne_cost[M];
+    const uint64_t G = (uint64_t)gridDim.x * WAVES * nshards;
+    const uint64_t g = ((uint64_t)shard * gridDim.x + blockIdx.x) * WAVES + wid;
+    const uint64_t c_lo = total * g / G, c_hi = total * (g + 1) / G;
+    // first cell whose cost prefix is >= c_lo  (prefix strictly increasing; ne_cost[0] = 0)
+    uint32_t m0, m1;
+    {
+        uint32_t a = 0, b = M;
+        while (a < b) { uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_lo) a = mid + 1; else b = mid; }
+        m0 = a;
+        b = M;
+        while (a < b) { uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_hi) a = mid + 1; else b = mid; }
+        m1 = a;
+    }
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
-    const int lane = threadIdx.x & 63;
+    constexpr int32_t ext = (1 << kCellShift) - 1;
+    const uint32_t R = (K + 63) >> 6;  // centroids per lane
+    const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t moved = 0;
     unsigned long long evals = 0;
-    if (q_lo < q_hi) {
-        for (uint32_t c = s_c0; c < kNumCells; c++) {
-            const uint32_t cs = cell_start[c], ce = cell_start[c + 1];
-            if (cs >= q_hi) break;
-            const uint32_t s = max(cs, q_lo), e = min(ce, q_hi);
-            if (s >= e) continue;
-            // ---- candidate centroids of this cell
-            if (threadIdx.x == 0) { s_minub = 0xffffffffu; s_ncand = 0; }
-            __syncthreads();
-            const int32_t r0 = (int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift);
-            const int32_t g0 = (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift);
-            const int32_t b0 = (int32_t)((c % kCellsPerDim) << kCellShift);
-            constexpr int32_t ext = (1 << kCellShift) - 1;
-            uint32_t mub = 0xffffffffu;
-            for (uint32_t k = threadIdx.x; k < K; k += kAssignThreads) {
+    for (uint32_t m = m0; m < m1; m++) {
+        const uint32_t s = ne_start[m], e = ne_start[m + 1];
+        const uint32_t c = ne_cell[m];
+        const int32_t r0 = (int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift);
+        const int32_t g0 = (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift);
+        const int32_t b0 = (int32_t)((c % kCellsPerDim) << kCellShift);
+        // ---- T = min_k ub_k
+        uint32_t mub = 0xffffffffu;
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t k = r * 64 + lane;
+            if (k < K) {
                 const uint32_t ck = tab[k].x;
                 const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
                 const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
                 mub = min(mub, (uint32_t)(hr * hr + hg * hg + hb * hb));
             }
-            mub = wave_reduce_min(mub);
-            if (lane == 0) atomicMin(&s_minub, mub);
-            __syncthreads();
-            const uint32_t T = s_minub;
-            for (uint32_t k = threadIdx.x; k < K; k += kAssignThreads) {
-                const uint2 t = tab[k];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mub = min(mub, (uint32_t)__shfl_xor(mub, off, 64));
+        const uint32_t T = mub;
+        // ---- candidates {k : lb_k <= T}, compacted with ballot prefixes into this wave's strip
+        uint32_t ncand = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            const uint32_t k = r * 64 + lane;
+            bool keep = false;
+            uint2 t = make_uint2(0u, 0u);
+            if (k < K) {
+                t = tab[k];
                 const int32_t dr0 = (int32_t)((t.x >> 16) & 255) - r0, dg0 = (int32_t)((t.x >> 8) & 255) - g0, db0 = (int32_t)(t.x & 255) - b0;
                 const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
-                if ((uint32_t)(lr * lr + lg * lg + lb * lb) <= T) cand[atomicAdd(&s_ncand, 1u)] = t;
+                keep = (uint32_t)(lr * lr + lg * lg + lb * lb) <= T;
             }
-            __syncthreads();
-            const uint32_t ncand = s_ncand;
-            // ---- points of the cell owned by this block
-            for (uint32_t q = s + threadIdx.x; q < e; q += kAssignThreads) {
-                const uint32_t p = ckeys[q];
-                uint32_t best = 0;
-                for (uint32_t j = 0; j < ncand; j++) {
-                    const uint2 cc = cand[j];  // LDS broadcast
-                    best = max(best, (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y);
-                }
-                const uint32_t cur = labels[q];
-                const uint2 cc = tab[cur];
-                const uint32_t kcur = (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y;
-                if ((best >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
-                    const uint32_t nl = IDMASK - (best & IDMASK);
-                    labels[q] = (LabelT)nl;
-                    moved++;
-                    const uint64_t w = cweight[q];
-                    const unsigned long long rw = ((p >> 16) & 255) * w, gw = ((p >> 8) & 255) * w, bw = (p & 255) * w;
-                    atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * cur + 0], 0ull - rw);
-                    atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * cur + 1], 0ull - gw);
-                    atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * cur + 2], 0ull - bw);
-                    atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + cur], 0ull - (unsigned long long)w);
-                    atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + cur], 0ull - 1ull);
-                }
-            }
-            if (threadIdx.x == 0) evals += (unsigned long long)(e - s) * (ncand + 1);
-            __syncthreads();  // cand / s_ncand are rewritten for the next cell
+            const unsigned long long bm = __ballot(keep);
+            if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = t;
+            ncand += (uint32_t)__popcll(bm);
         }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the cell's points, 64 per sweep
+        for (uint32_t q = s + lane; q < e; q += 64) {
+            const uint32_t p = ckeys[q];
+            uint32_t best = 0;
+            for (uint32_t j = 0; j < ncand; j++) {
+                const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
+                best = max(best, (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y);
+            }
+            const uint32_t cur = labels[q];
+            const uint2 cc = tab[cur];
+            const uint32_t kcur = (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y;
+            if ((best >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
+                const uint32_t nl = IDMASK - (best & IDMASK);
+                labels[q] = (LabelT)nl;
+                moved++;
+                const uint64_t w = cweight[q];
+                const unsigned long long rw = ((p >> 16) & 255) * w, gw = ((p >> 8) & 255) * w, bw = (p & 255) * w;
+                atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * cur + 0], 0ull - rw);
+                atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * cur + 1], 0ull - gw);
+                atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * cur + 2], 0ull - bw);
+                atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + cur], 0ull - (unsigned long long)w);
+                atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + cur], 0ull - 1ull);
+            }
+        }
+        evals += (unsigned long long)(e - s) * (ncand + 1);
+        __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
     }
     moved = wave_reduce_sum(moved);
-    if (lane == 0 && moved) atomicAdd(&s_moved, moved);
+    if (lane == 0) {
+        if (moved) atomicAdd(&s_moved, moved);
+        if (evals) atomicAdd(&s_evals, evals);
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += kAssignThreads)
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS)
         if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
-        if (evals) atomicAdd(&partials[5 * (size_t)K + 1], evals);
+        if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
     }
 }
 
@@ -507,16 +544,17 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
                                                         (unsigned long long)(bytes), hipGetErrorString(_e)); } \
     } while (0)
 
-int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint64_t lo,
-                   uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
+int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
+                   uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
                    KmRgbwState **out) {
-    if (K == 0 || U == 0 || lo > hi || hi > U) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
+    if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
+    const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
     if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
                                    (unsigned long long)U, K);
     if (K > 2048) return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 2048 not supported", K);
     if (U >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: too many points");
     auto *s = new KmRgbwState();
-    s->c = c; s->U = U; s->lo = lo; s->hi = hi; s->K = K;
+    s->c = c; s->U = U; s->lo = lo; s->hi = hi; s->K = K; s->shard = shard; s->nshards = nshards;
     s->Kpad = (K + 3) & ~3u;
     s->wide = K > 256;
     s->idbits = s->wide ? 12 : 8;
@@ -540,12 +578,16 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                        s->cconst.as<uint2>(), s->cent.as<uint32_t>());
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
-        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, 1024), 1), kCellBlocks);
+        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, 1024), 1), s->wide ? 2048u : kCellBlocks);
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
         KM_ALLOC(s->crank, U * 4);
         KM_ALLOC(s->cell_start, ((uint64_t)kNumCells + 1) * 4);
+        KM_ALLOC(s->ne_cell, (uint64_t)kNumCells * 4);
+        KM_ALLOC(s->ne_start, ((uint64_t)kNumCells + 1) * 4);
+        KM_ALLOC(s->ne_cost, ((uint64_t)kNumCells + 1) * 4);
+        KM_ALLOC(s->ne_count, 4);
         KM_ALLOC(s->running, W * 8);
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
@@ -555,7 +597,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         const uint32_t g = grid_1d(U);
         hipLaunchKernelGGL(k_cell_count, dim3(g), dim3(256), 0, c->stream, keys_d, U, count.as<uint32_t>());
         hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
-                           cursor.as<uint32_t>());
+                           cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
+                           s->ne_count.as<uint32_t>());
         hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
                            s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
         // init_assignment (kmeans.rs:61-78) by canonical rank, then its sums folded into `running`
@@ -635,16 +678,20 @@ static void launch_assign(KmRgbwState *s) {
     Ctx *c = s->c;
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
-        const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
         auto *part = reinterpret_cast<unsigned long long *>(s->partials);
-        if (s->wide)
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->cell_start.as<uint32_t>(), s->lo, s->hi, s->K,
+        if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
+            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
+                               s->ne_cost.as<uint32_t>(), s->ne_count.as<uint32_t>(), s->shard, s->nshards, s->K,
                                s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st);
-        else
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->cell_start.as<uint32_t>(), s->lo, s->hi, s->K,
+        } else {
+            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 8);
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
+                               s->ne_cost.as<uint32_t>(), s->ne_count.as<uint32_t>(), s->shard, s->nshards, s->K,
                                s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st);
+        }
         return;
     }
     const size_t lds = (size_t)s->K * (5 * 8 + 8);

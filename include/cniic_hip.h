@@ -127,10 +127,11 @@ int32_t cniic_kmeans_step_xyrgb(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, 
 /* Sharded K-means session (pixels / colours sharded over GPUs, one process per GPU): the library
  * owns assign + partial sums + centroid update on its shard; the CALLER all-reduces the partials
  * buffer (RCCL sum over int64 words) between cniic_km_assign and cniic_km_update.
- * All ranks pass the full point list (U colours) and their own [lo,hi) slice of it. */
+ * All ranks pass the full point list (U colours); rank r of n passes shard = r, nshards = n and
+ * works on its share of the colour-space cells. */
 typedef struct cniic_km cniic_km;
 int32_t cniic_km_create_rgbw(cniic_ctx *ctx, const uint32_t *keys, const uint32_t *weight, uint64_t U,
-                             uint64_t lo, uint64_t hi, uint32_t K, const cniic_kmeans_opts *opts,
+                             uint32_t shard, uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts,
                              void *partials_dev /* device buffer of cniic_km_partial_words(K,3) u64, or NULL */,
                              cniic_km **out);
 uint64_t cniic_km_partial_words(uint32_t K, uint32_t D);   /* K*D sums + K wsum + K members + moved + evals */
