@@ -13,6 +13,13 @@ using namespace cniic;
 
 struct cniic_ctx : public Ctx {};
 
+// routes every DevBuf allocated during the call through the context's caching pool
+struct PoolScope {
+    DevPool *prev;
+    explicit PoolScope(DevPool *p) : prev(current_pool()) { current_pool() = p; }
+    ~PoolScope() { current_pool() = prev; }
+};
+
 struct cniic_km {
     Ctx *c = nullptr;
     KmRgbwState *st = nullptr;
@@ -25,6 +32,7 @@ struct cniic_km {
     if (!(ctx)) return CNIIC_ERR_BAD_ARG;  \
     std::lock_guard<std::mutex> _lk((ctx)->mu); \
     (ctx)->err.clear();                    \
+    PoolScope _ps(&(ctx)->pool);           \
     do { hipError_t _e = hipSetDevice((ctx)->device); if (_e != hipSuccess) return (ctx)->fail(CNIIC_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(_e)); } while (0)
 
 // results computed into host vectors -> caller buffer (host or device)
@@ -69,6 +77,7 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->dense.release();
+    c->pool.trim();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -379,7 +388,10 @@ void cniic_km_destroy(cniic_km *km) {
         std::lock_guard<std::mutex> lk(km->c->mu);
         (void)hipSetDevice(km->c->device);
         (void)hipStreamSynchronize(km->c->stream);
+        PoolScope ps(&km->c->pool);
         km_rgbw_destroy(km->st);
+        km->keys.own.release();
+        km->weight.own.release();
     }
     delete km;
 }
@@ -497,18 +509,7 @@ int32_t cniic_huf_encode_all(cniic_ctx *c, int32_t sym_kind, const uint32_t *sym
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, sym_kind == CNIIC_SYM_RGB ? 24 : 27, &table));
     std::vector<uint8_t> header;
-    DevBuf payload;
-    uint64_t pbytes = 0;
-    CNIIC_TRY(huf_encode_all_dev(c, sym_kind, nullptr, in.d, n, table, false, header, payload, &pbytes));
-    *len = header.size() + pbytes;
-    if (*len > cap) return c->fail(CNIIC_ERR_CAPACITY, "huf_encode_all: stream is %llu bytes, capacity %llu",
-                                   (unsigned long long)*len, (unsigned long long)cap);
-    const bool dev = is_device_ptr(out);
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(out, header.data(), header.size(), dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
-    if (pbytes)
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(out + header.size(), payload.p, pbytes, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return CNIIC_OK;
+    return huf_encode_all_dev(c, sym_kind, nullptr, in.d, n, table, false, header, out, cap, len);
 }
 
 int32_t cniic_huf_size(int32_t sym_kind, const uint64_t *counts, uint64_t n, uint64_t *nbytes) {

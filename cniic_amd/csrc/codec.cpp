@@ -72,28 +72,46 @@ std::string codec_name(const CodecDesc &d) {
 bool codec_is_lossless(const CodecDesc &d) { return d.kind == CODEC_HUFMAN || d.kind == CODEC_DELTA; }
 
 // ------------------------------------------------------------------ output assembly
-// header (host bytes) followed by a device payload -> caller buffer (host or device)
-static int emit(Ctx *c, const std::vector<uint8_t> &header, const uint8_t *payload_d, uint64_t payload_bytes,
-                uint8_t *out, uint64_t cap, uint64_t *len) {
-    *len = header.size() + payload_bytes;
-    if (*len > cap) return c->fail(CNIIC_ERR_CAPACITY, "encode: stream is %llu bytes, capacity %llu",
-                                   (unsigned long long)*len, (unsigned long long)cap);
-    const bool dev = is_device_ptr(out);
-    if (!header.empty())
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(out, header.data(), header.size(), dev ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
-    if (payload_bytes)
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(out + header.size(), payload_d, payload_bytes,
-                                        dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return CNIIC_OK;
-}
+// The encoded stream (host-built header + device-packed payload) is assembled in HBM: directly in
+// the caller's buffer when that is 4-byte aligned device memory, otherwise in a staging buffer
+// that is copied out once.
+struct StreamOut {
+    Ctx *c;
+    uint8_t *caller;
+    uint64_t cap;
+    uint64_t *len;
+    bool direct = false;
+    DevBuf staging;
+    uint8_t *dev = nullptr;
+    uint64_t total = 0;
+    StreamOut(Ctx *ctx, uint8_t *out, uint64_t capacity, uint64_t *len_out) : c(ctx), caller(out), cap(capacity), len(len_out) {}
+    int begin(const std::vector<uint8_t> &header, uint64_t payload_bytes) {
+        total = header.size() + payload_bytes;
+        *len = total;
+        if (total > cap) return c->fail(CNIIC_ERR_CAPACITY, "encode: stream is %llu bytes, capacity %llu",
+                                        (unsigned long long)total, (unsigned long long)cap);
+        const uint64_t padded = (total + 3) & ~3ull;
+        direct = is_device_ptr(caller) && (reinterpret_cast<uintptr_t>(caller) & 3) == 0 && padded <= cap;
+        if (direct) dev = caller;
+        else { CNIIC_HIP_TRY(c, staging.alloc(padded + 16)); dev = staging.as<uint8_t>(); }
+        CNIIC_HIP_TRY(c, hipMemsetAsync(dev, 0, padded, c->stream));
+        if (!header.empty()) CNIIC_HIP_TRY(c, hipMemcpyAsync(dev, header.data(), header.size(), hipMemcpyHostToDevice, c->stream));
+        return CNIIC_OK;
+    }
+    int finish() {
+        if (!direct && total)
+            CNIIC_HIP_TRY(c, hipMemcpyAsync(caller, dev, total, is_device_ptr(caller) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return CNIIC_OK;
+    }
+};
 
 // ------------------------------------------------------------------ huf::encode_all (huf.rs:22-43)
 // Symbols come either as pixels (rgb_d) or as packed keys (syms_d).  table_d holds the dense
 // histogram on entry when have_hist, otherwise it is built here.
 int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n,
-                       uint32_t *table_d, bool have_hist, std::vector<uint8_t> &header, DevBuf &payload,
-                       uint64_t *payload_bytes) {
+                       uint32_t *table_d, bool have_hist, std::vector<uint8_t> &header, uint8_t *out, uint64_t cap,
+                       uint64_t *len) {
     if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "huf::encode_all on an empty stream (src/huf.rs:99 asserts)");
     const uint32_t bits = sym_kind == CNIIC_SYM_RGB ? 24 : 27;
     // 1. utils::count_freqs (huf.rs:30)
@@ -115,31 +133,30 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
     HuffTree tree;
-    std::vector<uint8_t> len;
+    std::vector<uint8_t> clen;
     std::vector<uint64_t> code;
-    if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, len, code))
+    if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, clen, code))
         return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
     huff_serialize_tree(tree, sym_kind, keys.data(), header);
-    // 3. payload (huf.rs:37-41)
+    // 3. payload (huf.rs:37-41), packed in place behind the header
     uint64_t nbits = 0;
-    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * len[i];
-    *payload_bytes = (nbits + 7) / 8;
+    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
+    StreamOut so(c, out, cap, len);
+    CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
     DevBuf len_d, code_d;
     CNIIC_HIP_TRY(c, len_d.alloc(U));
     CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, len.data(), U, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen.data(), U, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
-    const uint64_t cap = ceil_div(nbits, 32) * 4 + 16;
-    CNIIC_HIP_TRY(c, payload.alloc(cap));
     uint64_t packed_bits = 0;
     ScopedKernelTimer timer(c, "huff_pack");
-    CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(),
-                             payload.as<uint8_t>(), cap, &packed_bits));
+    CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev,
+                             (uint64_t)header.size() * 8, &packed_bits));
     timer.stop(1);
     if (packed_bits != nbits)
         return c->fail(CNIIC_ERR_HIP, "huffman: packed %llu bits, histogram predicts %llu", (unsigned long long)packed_bits,
                        (unsigned long long)nbits);
-    return CNIIC_OK;
+    return so.finish();
 }
 
 // ------------------------------------------------------------------ Hufman::encode (hufc.rs:12-17)
@@ -150,10 +167,7 @@ static int encode_hufman(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, u
     put_u32(header, h);
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, 24, &table));
-    DevBuf payload;
-    uint64_t pbytes = 0;
-    CNIIC_TRY(huf_encode_all_dev(c, CNIIC_SYM_RGB, rgb_d, nullptr, n, table, false, header, payload, &pbytes));
-    return emit(c, header, payload.as<uint8_t>(), pbytes, out, cap, len);
+    return huf_encode_all_dev(c, CNIIC_SYM_RGB, rgb_d, nullptr, n, table, false, header, out, cap, len);
 }
 
 // ------------------------------------------------------------------ ClusterColors::encode (clusterc.rs:18-53)
@@ -214,7 +228,7 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     huff_serialize_tree(tree, CNIIC_SYM_RGB, skeys.data(), header);
     uint64_t nbits = 0;
     for (size_t i = 0; i < scounts.size(); i++) nbits += scounts[i] * slen[i];
-    // per-cluster code, expanded on the device to one (len, code) per distinct input colour:
+    // per-cluster code; every pixel reaches it through a dense colour -> cluster-label table:
     // reduced_colors.get(original_colour) (clusterc.rs:43-47) fused with Enc::encode (huf.rs:137-148)
     std::vector<uint8_t> clen(K, 0);
     std::vector<uint64_t> ccode(K, 0);
@@ -225,32 +239,29 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
         clen[k] = slen[si];
         ccode[k] = scode[si];
     }
-    DevBuf clen_d, ccode_d, len_d, code_d, payload;
+    StreamOut so(c, out, cap, len);
+    CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
+    const bool wide = km_rgbw_is_wide(km);
+    DevBuf clen_d, ccode_d, lab_d, key2label;
     CNIIC_HIP_TRY(c, clen_d.alloc(K));
     CNIIC_HIP_TRY(c, ccode_d.alloc((uint64_t)K * 8));
-    CNIIC_HIP_TRY(c, len_d.alloc(U));
-    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
+    CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), K, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    DevBuf lab_d;
-    const bool wide = km_rgbw_is_wide(km);
-    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
     CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
-    CNIIC_TRY(expand_codes_by_label(c, wide ? nullptr : lab_d.as<uint8_t>(), wide ? lab_d.as<uint16_t>() : nullptr, U,
-                                    clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>()));
-    const uint64_t pcap = ceil_div(nbits, 32) * 4 + 16;
-    CNIIC_HIP_TRY(c, payload.alloc(pcap));
+    CNIIC_TRY(scatter_labels_by_key(c, keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
     uint64_t packed_bits = 0;
     {
         ScopedKernelTimer t(c, "huff_pack");
-        CNIIC_TRY(huff_pack_keys(c, nullptr, rgb_d, n, table, len_d.as<uint8_t>(), code_d.as<uint64_t>(), payload.as<uint8_t>(),
-                                 pcap, &packed_bits));
+        CNIIC_TRY(huff_pack_labels(c, rgb_d, n, key2label.p, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), so.dev,
+                                   (uint64_t)header.size() * 8, &packed_bits));
         t.stop(1);
     }
     if (packed_bits != nbits)
         return c->fail(CNIIC_ERR_HIP, "cluster-colors: packed %llu bits, histogram predicts %llu",
                        (unsigned long long)packed_bits, (unsigned long long)nbits);
-    return emit(c, header, payload.as<uint8_t>(), (nbits + 7) / 8, out, cap, len);
+    return so.finish();
 }
 
 // ------------------------------------------------------------------ VoronoiCluster::encode (clusterc.rs:148-166)
@@ -277,7 +288,9 @@ static int encode_voronoi(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, 
         put_u64(header, 3);        // Rgb<u8> as a length-prefixed slice (ser.rs:210-214)
         header.push_back(cent[k].rgb[0]); header.push_back(cent[k].rgb[1]); header.push_back(cent[k].rgb[2]);
     }
-    return emit(c, header, nullptr, 0, out, cap, len);
+    StreamOut so(c, out, cap, len);
+    CNIIC_TRY(so.begin(header, 0));
+    return so.finish();
 }
 
 // ------------------------------------------------------------------ Delta::encode (hilbertc.rs:405-415)
@@ -294,10 +307,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     // one fused pass: Hilbert gather + DiffStream + count_freqs; the symbol stream is kept for the
     // second (bit-pack) pass instead of recomputing the scan as the reference does (huf.rs:30,38)
     CNIIC_TRY(hilbert_delta(c, rgb_d, w, h, syms.as<uint32_t>(), table));
-    DevBuf payload;
-    uint64_t pbytes = 0;
-    CNIIC_TRY(huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), n, table, true, header, payload, &pbytes));
-    return emit(c, header, payload.as<uint8_t>(), pbytes, out, cap, len);
+    return huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), n, table, true, header, out, cap, len);
 }
 
 int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, uint32_t h, const cniic_kmeans_opts *opts,

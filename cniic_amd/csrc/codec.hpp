@@ -25,7 +25,9 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
 int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
                  uint32_t *w, uint32_t *h);
 
+// header carries any prefix already serialised (image dimensions); the decoder trie is appended
+// to it and the whole stream lands in out[0..*len)  (out: host or device memory).
 int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n, uint32_t *table_d,
-                       bool have_hist, std::vector<uint8_t> &header, DevBuf &payload, uint64_t *payload_bytes);
+                       bool have_hist, std::vector<uint8_t> &header, uint8_t *out, uint64_t cap, uint64_t *len);
 
 }  // namespace cniic

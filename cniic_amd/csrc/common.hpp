@@ -25,27 +25,82 @@ struct KernelTime {
 
 struct Ctx;
 
-// RAII device allocation on the context's device.
+// Caching HBM allocator: hipMalloc / hipFree cost tens of microseconds and hipFree synchronises
+// the device, so scratch buffers are recycled per context (a codec call allocates ~20 of them).
+struct DevPool {
+    struct Block { void *p; uint64_t cap; };
+    std::vector<Block> free_blocks;
+    uint64_t cached_bytes = 0;
+    hipError_t get(uint64_t bytes, void **p, uint64_t *cap) {
+        // best fit among cached blocks that are not more than 2x too large
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < free_blocks.size(); i++)
+            if (free_blocks[i].cap >= bytes && free_blocks[i].cap <= 2 * bytes + 4096 &&
+                (best == SIZE_MAX || free_blocks[i].cap < free_blocks[best].cap))
+                best = i;
+        if (best != SIZE_MAX) {
+            *p = free_blocks[best].p;
+            *cap = free_blocks[best].cap;
+            cached_bytes -= *cap;
+            free_blocks.erase(free_blocks.begin() + (long)best);
+            return hipSuccess;
+        }
+        const uint64_t rounded = (bytes + 255) & ~255ull;
+        hipError_t e = hipMalloc(p, rounded);
+        if (e != hipSuccess && !free_blocks.empty()) {  // out of memory: drop the cache and retry
+            trim();
+            e = hipMalloc(p, rounded);
+        }
+        *cap = rounded;
+        return e;
+    }
+    void put(void *p, uint64_t cap) {
+        free_blocks.push_back({p, cap});
+        cached_bytes += cap;
+    }
+    void trim() {
+        for (auto &b : free_blocks) (void)hipFree(b.p);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+};
+
+// the pool of the context whose call is running on this thread (set by the ABI entry points)
+inline DevPool *&current_pool() {
+    static thread_local DevPool *p = nullptr;
+    return p;
+}
+
+// RAII device allocation on the context's device (recycled through the context's pool).
 struct DevBuf {
     void    *p = nullptr;
     uint64_t bytes = 0;
+    uint64_t cap = 0;
+    DevPool *pool = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool) { o.p = nullptr; o.bytes = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; o.p = nullptr; o.bytes = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
     hipError_t alloc(uint64_t n) {
         release();
         if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
+        pool = current_pool();
+        hipError_t e;
+        if (pool) e = pool->get(n, &p, &cap);
+        else { e = hipMalloc(&p, n); cap = n; }
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void release() {
+        if (!p) return;
+        if (pool) pool->put(p, cap); else (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -57,6 +112,7 @@ struct Ctx {
     std::string err;
     std::map<std::string, KernelTime> ktimes;  // per-call dominant-kernel timings (HIP events)
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    DevPool pool;           // recycled scratch HBM (all DevBufs created inside an ABI call)
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
     void  *pinned = nullptr; // 4 KiB of mapped host memory for lagged flag polling
@@ -242,12 +298,15 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
 int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d);
 
 // ---- k_huff.hip ----
-// MSB-first bit-pack of n symbols.  sym index per element comes from a rank table lookup
-// (key -> rank+1) or directly (16-bit symbol ids).  len_d/code_d are per-rank code tables.
+// MSB-first bit-pack of n symbols at bit offset bit_base of out_d (4-byte aligned, pre-zeroed,
+// large enough; bytes before bit_base may already hold the stream header).
+// Generic path: symbol -> rank (dense table left by the compaction) -> len_d / code_d per rank.
 int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
                    const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d,
-                   uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h);
-int huff_pack_sym16(Ctx *c, const uint16_t *sym_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d,
-                    uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h);
+                   uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+// cluster-colors path: pixel -> cluster label through a dense colour->label table, codes per cluster
+int huff_pack_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, uint32_t K,
+                     const uint8_t *clen_d, const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U, void *key2label_d);
 
 }  // namespace cniic

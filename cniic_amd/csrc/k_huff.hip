@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restr
                                                              const uint8_t *__restrict__ len,
                                                              const uint64_t *__restrict__ code,
                                                              const uint64_t *__restrict__ chunk_off,
-                                                             uint32_t *__restrict__ out_words) {
+                                                             uint32_t *__restrict__ out_words, uint64_t bit_base) {
     __shared__ uint32_t img[kPackWords];
     __shared__ uint32_t wsum[kPackThreads / 64];
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restr
     }
     for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
     uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);  // contains a __syncthreads after img clear
-    const uint64_t g0 = chunk_off[blockIdx.x];          // global bit offset of the chunk
+    const uint64_t g0 = bit_base + chunk_off[blockIdx.x];  // global bit offset of the chunk
     const uint32_t skew = (uint32_t)(g0 & 31);          // chunk image is aligned to the output word grid
     uint32_t pos = skew + excl;
 #pragma unroll
@@ -148,11 +148,149 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restr
     }
 }
 
+// ---------------------------------------------------------------- cluster-colors fast path
+// Symbols are cluster labels (<= K distinct): pass 1 turns every pixel into its label through a
+// dense colour -> label table (ONE random read per pixel), stores the label stream and sums code
+// lengths from an LDS table; pass 2 streams the labels back and packs from an LDS (len, code) table.
+template <typename LabelT>
+__global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const uint8_t *__restrict__ rgb, uint64_t n,
+                                                                 const LabelT *__restrict__ key2label, uint32_t K,
+                                                                 const uint8_t *__restrict__ clen,
+                                                                 LabelT *__restrict__ pixlab,
+                                                                 uint32_t *__restrict__ chunk_bits) {
+    extern __shared__ uint8_t s_len[];  // [K]
+    for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) s_len[i] = clen[i];
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t bits = 0;
+    if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(rgb) & 15) == 0)) {
+        uint32_t key[16];
+        load16px_keys(reinterpret_cast<const uint4 *>(rgb + 3 * first), key);
+        LabelT lab[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { lab[i] = key2label[key[i]]; bits += s_len[lab[i]]; }
+        if (sizeof(LabelT) == 1) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = (uint32_t)lab[4 * j] | ((uint32_t)lab[4 * j + 1] << 8) | ((uint32_t)lab[4 * j + 2] << 16) | ((uint32_t)lab[4 * j + 3] << 24);
+            *reinterpret_cast<uint4 *>(pixlab + first) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) pixlab[first + i] = lab[i];
+        }
+    } else {
+        for (int i = 0; i < kPackPer; i++)
+            if (first + i < n) {
+                LabelT l = key2label[rgb_key(rgb + 3 * (first + i))];
+                pixlab[first + i] = l;
+                bits += s_len[l];
+            }
+    }
+    bits = block_reduce_sum<kPackThreads>(bits);
+    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
+}
+
+template <typename LabelT>
+__global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *__restrict__ pixlab, uint64_t n, uint32_t K,
+                                                                 const uint8_t *__restrict__ clen,
+                                                                 const uint64_t *__restrict__ ccode,
+                                                                 const uint64_t *__restrict__ chunk_off,
+                                                                 uint32_t *__restrict__ out_words, uint64_t bit_base) {
+    extern __shared__ __align__(8) unsigned long long s_tab[];  // [K] codes, then [K] lens (bytes)
+    __shared__ uint32_t img[kPackWords];
+    __shared__ uint32_t wsum[kPackThreads / 64];
+    __shared__ uint32_t s_total;
+    uint8_t *s_len = reinterpret_cast<uint8_t *>(s_tab + K);
+    for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) { s_tab[i] = ccode[i]; s_len[i] = clen[i]; }
+    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t lab[kPackPer], l[kPackPer];
+    uint32_t bits = 0;
+    if (sizeof(LabelT) == 1 && first + kPackPer <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pixlab + first);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) lab[i] = (w[i >> 2] >> (8 * (i & 3))) & 255;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPackPer; i++) lab[i] = first + i < n ? (uint32_t)pixlab[first + i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) { l[i] = lab[i] != 0xffffffffu ? s_len[lab[i]] : 0; bits += l[i]; }
+    uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);
+    const uint64_t g0 = bit_base + chunk_off[blockIdx.x];
+    const uint32_t skew = (uint32_t)(g0 & 31);
+    uint32_t pos = skew + excl;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        const uint32_t L = l[i];
+        if (L == 0) continue;
+        const uint64_t cd = s_tab[lab[i]];
+        const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;
+        if (L <= room) {
+            atomicOr(&img[w], (uint32_t)(cd << (room - L)));
+        } else {
+            const uint32_t rem = L - room;
+            atomicOr(&img[w], (uint32_t)(cd >> rem));
+            if (rem <= 32) atomicOr(&img[w + 1], (uint32_t)(cd << (32 - rem)));
+            else { atomicOr(&img[w + 1], (uint32_t)(cd >> (rem - 32))); atomicOr(&img[w + 2], (uint32_t)(cd << (64 - rem))); }
+        }
+        pos += L;
+    }
+    if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total == 0) return;
+    const uint32_t nwords = (skew + total + 31) >> 5;
+    const uint64_t w0 = g0 >> 5;
+    for (uint32_t i = threadIdx.x; i < nwords; i += kPackThreads) {
+        const uint32_t v = __builtin_bswap32(img[i]);
+        if (v == 0) continue;
+        if (i == 0 || i == nwords - 1) atomicOr(&out_words[w0 + i], v);
+        else out_words[w0 + i] = v;
+    }
+}
+
+// key2label_d: LabelT[2^24] dense colour -> cluster label.  Packs directly at bit_base of out_d
+// (a 4-byte aligned, pre-zeroed buffer; the bytes before bit_base may already hold the header).
+int huff_pack_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, uint32_t K,
+                     const uint8_t *clen_d, const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h) {
+    *nbits_h = 0;
+    if (n == 0) return CNIIC_OK;
+    if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
+    const uint32_t nchunks = (uint32_t)ceil_div(n, kPackChunk);
+    DevBuf cb, co, tot, pixlab;
+    CNIIC_HIP_TRY(c, cb.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
+    if (wide)
+        hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, rgb_d, n,
+                           reinterpret_cast<const uint16_t *>(key2label_d), K, clen_d, pixlab.as<uint16_t>(), cb.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, rgb_d, n,
+                           reinterpret_cast<const uint8_t *>(key2label_d), K, clen_d, pixlab.as<uint8_t>(), cb.as<uint32_t>());
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    if (wide)
+        hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, pixlab.as<uint16_t>(), n, K,
+                           clen_d, ccode_d, co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
+    else
+        hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, pixlab.as<uint8_t>(), n, K,
+                           clen_d, ccode_d, co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *nbits_h = total;
+    return CNIIC_OK;
+}
+
 // interior words of a chunk that are all-zero must still be written: the output is pre-zeroed.
 
 template <int SRC>
 static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank_table_d, const uint8_t *len_d,
-                     const uint64_t *code_d, uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h) {
+                     const uint64_t *code_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h) {
     *nbits_h = 0;
     if (n == 0) return CNIIC_OK;
     if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
@@ -170,27 +308,20 @@ static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *nbits_h = total;
-    const uint64_t need = ceil_div(total, 32) * 4;
-    if (need > out_cap_bytes) return c->fail(CNIIC_ERR_CAPACITY, "huff_pack: payload needs %llu bytes, capacity %llu",
-                                             (unsigned long long)need, (unsigned long long)out_cap_bytes);
-    CNIIC_HIP_TRY(c, hipMemsetAsync(out_d, 0, need, c->stream));
     hipLaunchKernelGGL(k_pack_write<SRC>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, src_d, n, rank_table_d, len_d, code_d,
-                       co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d));
+                       co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // cb/co/tot are released on return
     return CNIIC_OK;
 }
 
+// Packs at bit_base of out_d: a 4-byte aligned, PRE-ZEROED buffer that is large enough (the caller
+// knows the payload size from the histogram); bytes before bit_base may already hold the header.
 int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
                    const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
-                   uint64_t out_cap_bytes, uint64_t *nbits_h) {
-    if (rgb_or_null_d) return pack_impl<SRC_RGB>(c, rgb_or_null_d, n, rank_table_d, len_d, code_d, out_d, out_cap_bytes, nbits_h);
-    return pack_impl<SRC_KEYS>(c, keys_or_null_d, n, rank_table_d, len_d, code_d, out_d, out_cap_bytes, nbits_h);
-}
-
-int huff_pack_sym16(Ctx *c, const uint16_t *sym_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d,
-                    uint8_t *out_d, uint64_t out_cap_bytes, uint64_t *nbits_h) {
-    return pack_impl<SRC_SYM16>(c, sym_d, n, nullptr, len_d, code_d, out_d, out_cap_bytes, nbits_h);
+                   uint64_t bit_base, uint64_t *nbits_h) {
+    if (rgb_or_null_d) return pack_impl<SRC_RGB>(c, rgb_or_null_d, n, rank_table_d, len_d, code_d, out_d, bit_base, nbits_h);
+    return pack_impl<SRC_KEYS>(c, keys_or_null_d, n, rank_table_d, len_d, code_d, out_d, bit_base, nbits_h);
 }
 
 }  // namespace cniic

@@ -43,7 +43,8 @@ constexpr uint32_t kMaxBlocks = 512;
 constexpr int kCellShift = 3;                                  // 8x8x8 colours per cell
 constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
-constexpr uint32_t kCellBlocks = 1024;
+constexpr uint32_t kCellBlocks = 1536;     // 6 blocks of 4 waves per CU: every wave resident at once
+constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
 constexpr uint32_t kCellFixedCost = 64;   // per-cell overhead in point-equivalents (work split between waves)
 
 struct KmRgbwState {
@@ -55,7 +56,7 @@ struct KmRgbwState {
     const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
-    DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count;
+    DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -317,17 +318,30 @@ __global__ __launch_bounds__(256) void k_rgbw_accum_all(const uint32_t *__restri
 // ---------------------------------------------------------------- cell-pruned assign, delta sums
 // One WAVE per cell: the 64 lanes bound all K centroids against the cell's cube (K/64 per lane),
 // reduce min ub across the wave, compact the candidate list into the wave's own LDS strip with
-// ballot prefixes, then sweep the cell's points 64 at a time.  No block barrier inside the loop,
-// so sparse and dense cells cost what they contain.  Cells are dealt to waves in contiguous runs
-// of equal COST (cost = kCellFixedCost + points, prefix-summed at setup): wave g of G takes the
-// cells whose cost prefix falls in [total g/G, total (g+1)/G).  With several GPUs the global wave
-// index runs over all shards.  partials receives SIGNED deltas (two's complement u64) of the
-// points that moved.
-template <typename LabelT, int IDBITS, int WAVES>
+// ballot prefixes, then sweep the cell's points 64 x kSweep at a time.  No block barrier inside
+// the loop, so sparse and dense cells cost what they contain.  Cells are dealt to waves in
+// contiguous runs of equal COST (cost = kCellFixedCost + points, prefix-summed at setup; the
+// per-wave first cell is precomputed by k_wave_ranges).  With several GPUs the global wave index
+// runs over all shards.  The points of a wave's cells are contiguous in memory, so the loads of
+// the next sweep - of this cell or of the next one - are always in flight while the current sweep
+// computes.  partials receives SIGNED deltas (two's complement u64) of the points that moved.
+__global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_count,
+                                                     uint32_t G, uint32_t *__restrict__ wfirst) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > G) return;
+    const uint32_t M = *ne_count;
+    const uint64_t total = ne_cost[M];
+    const uint64_t c_lo = total * g / G;
+    uint32_t a = 0, b = M;  // first cell whose cost prefix is >= c_lo (prefix strictly increasing, ne_cost[0] = 0)
+    while (a < b) { uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_lo) a = mid + 1; else b = mid; }
+    wfirst[g] = g == G ? M : a;
+}
+
+template <typename LabelT, int IDBITS, int WAVES, int RSTORE>
 __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
-    const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_count,
-    uint32_t shard, uint32_t nshards, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
+    const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
+    uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
     unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x uint2 cand[K]
     __shared__ uint32_t s_moved;
@@ -338,26 +352,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint2 *cand = tab + K + (size_t)wid * K;
+    const uint32_t g = (shard * gridDim.x + blockIdx.x) * WAVES + wid;
+    const uint32_t m0 = wfirst[g], m1 = wfirst[g + 1];
+    // descriptors of the first cell and the loads of its first sweep go out before the LDS set-up
+    uint32_t s = 0, e = 0, c = 0, e_next = 0, c_next = 0;
+    uint32_t p[kSweep], cur[kSweep];
+    if (m0 < m1) {
+        s = ne_start[m0]; e = ne_start[m0 + 1]; c = ne_cell[m0];
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) {
+            const uint32_t q = s + u * 64 + lane;
+            p[u] = q < e ? ckeys[q] : 0u;
+            cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+        }
+    }
     for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
     for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
     if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
     __syncthreads();
 
-    const uint32_t M = *ne_count;
-    const uint64_t total = ne_cost[M];
-    const uint64_t G = (uint64_t)gridDim.x * WAVES * nshards;
-    const uint64_t g = ((uint64_t)shard * gridDim.x + blockIdx.x) * WAVES + wid;
-    const uint64_t c_lo = total * g / G, c_hi = total * (g + 1) / G;
-    // first cell whose cost prefix is >= c_lo  (prefix strictly increasing; ne_cost[0] = 0)
-    uint32_t m0, m1;
-    {
-        uint32_t a = 0, b = M;
-        while (a < b) { uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_lo) a = mid + 1; else b = mid; }
-        m0 = a;
-        b = M;
-        while (a < b) { uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_hi) a = mid + 1; else b = mid; }
-        m1 = a;
-    }
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     constexpr int32_t ext = (1 << kCellShift) - 1;
     const uint32_t R = (K + 63) >> 6;  // centroids per lane
@@ -365,13 +378,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     uint32_t moved = 0;
     unsigned long long evals = 0;
     for (uint32_t m = m0; m < m1; m++) {
-        const uint32_t s = ne_start[m], e = ne_start[m + 1];
-        const uint32_t c = ne_cell[m];
+        const bool has_next = m + 1 < m1;
+        if (has_next) { e_next = ne_start[m + 2]; c_next = ne_cell[m + 1]; }  // consumed at the end of this cell
         const int32_t r0 = (int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift);
         const int32_t g0 = (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift);
         const int32_t b0 = (int32_t)((c % kCellsPerDim) << kCellShift);
-        // ---- T = min_k ub_k
+        // ---- bounds of every centroid against the cell's cube; T = min_k ub_k
         uint32_t mub = 0xffffffffu;
+        uint32_t lbv[RSTORE];
+#pragma unroll
+        for (int r = 0; r < RSTORE; r++) lbv[r] = 0xffffffffu;
         for (uint32_t r = 0; r < R; r++) {
             const uint32_t k = r * 64 + lane;
             if (k < K) {
@@ -379,6 +395,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                 const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
                 const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
                 mub = min(mub, (uint32_t)(hr * hr + hg * hg + hb * hb));
+                if (RSTORE > 1) {
+                    const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
+#pragma unroll
+                    for (int rr = 0; rr < RSTORE; rr++)
+                        if (rr == (int)r) lbv[rr] = (uint32_t)(lr * lr + lg * lg + lb * lb);
+                }
             }
         }
 #pragma unroll
@@ -389,44 +411,67 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         for (uint32_t r = 0; r < R; r++) {
             const uint32_t k = r * 64 + lane;
             bool keep = false;
-            uint2 t = make_uint2(0u, 0u);
-            if (k < K) {
-                t = tab[k];
-                const int32_t dr0 = (int32_t)((t.x >> 16) & 255) - r0, dg0 = (int32_t)((t.x >> 8) & 255) - g0, db0 = (int32_t)(t.x & 255) - b0;
+            if (RSTORE > 1) {
+#pragma unroll
+                for (int rr = 0; rr < RSTORE; rr++)
+                    if (rr == (int)r) keep = lbv[rr] <= T;   // 0xffffffff for k >= K never passes (T < 2^18)
+            } else if (k < K) {
+                const uint32_t ck = tab[k].x;
+                const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
                 const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
                 keep = (uint32_t)(lr * lr + lg * lg + lb * lb) <= T;
             }
             const unsigned long long bm = __ballot(keep);
-            if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = t;
+            if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = tab[k];
             ncand += (uint32_t)__popcll(bm);
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- the cell's points, 64 per sweep
-        for (uint32_t q = s + lane; q < e; q += 64) {
-            const uint32_t p = ckeys[q];
-            uint32_t best = 0;
+        // ---- the cell's points; the next sweep (of this cell or of the next) loads meanwhile
+        for (uint32_t base = s; base < e; base += 64 * kSweep) {
+            const bool more = base + 64 * kSweep < e;
+            const uint32_t nts = more ? base + 64 * kSweep : e;
+            const uint32_t nte = more ? e : (has_next ? e_next : e);
+            uint32_t pn[kSweep], curn[kSweep];
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) {
+                const uint32_t qn = nts + u * 64 + lane;
+                pn[u] = qn < nte ? ckeys[qn] : 0u;
+                curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
+            }
+            uint32_t best[kSweep];
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) best[u] = 0;
             for (uint32_t j = 0; j < ncand; j++) {
                 const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
-                best = max(best, (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y);
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
             }
-            const uint32_t cur = labels[q];
-            const uint2 cc = tab[cur];
-            const uint32_t kcur = (dot4u8(p, cc.x, 0) << (IDBITS + 1)) + cc.y;
-            if ((best >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
-                const uint32_t nl = IDMASK - (best & IDMASK);
-                labels[q] = (LabelT)nl;
-                moved++;
-                const uint64_t w = cweight[q];
-                const unsigned long long rw = ((p >> 16) & 255) * w, gw = ((p >> 8) & 255) * w, bw = (p & 255) * w;
-                atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * cur + 0], 0ull - rw);
-                atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * cur + 1], 0ull - gw);
-                atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * cur + 2], 0ull - bw);
-                atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + cur], 0ull - (unsigned long long)w);
-                atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + cur], 0ull - 1ull);
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) {
+                const uint32_t q = base + u * 64 + lane;
+                if (q < e) {
+                    const uint2 cc = tab[cur[u]];
+                    const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
+                    if ((best[u] >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
+                        const uint32_t nl = IDMASK - (best[u] & IDMASK), ol = cur[u], pp = p[u];
+                        labels[q] = (LabelT)nl;
+                        moved++;
+                        const uint64_t w = cweight[q];
+                        const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
+                        atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * ol + 0], 0ull - rw);
+                        atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * ol + 1], 0ull - gw);
+                        atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * ol + 2], 0ull - bw);
+                        atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
+                        atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
         }
         evals += (unsigned long long)(e - s) * (ncand + 1);
         __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
+        s = e; e = e_next; c = c_next;
     }
     moved = wave_reduce_sum(moved);
     if (lane == 0) {
@@ -578,7 +623,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                        s->cconst.as<uint2>(), s->cent.as<uint32_t>());
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
-        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, 1024), 1), s->wide ? 2048u : kCellBlocks);
+        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, 1024), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
@@ -588,6 +633,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_start, ((uint64_t)kNumCells + 1) * 4);
         KM_ALLOC(s->ne_cost, ((uint64_t)kNumCells + 1) * 4);
         KM_ALLOC(s->ne_count, 4);
+        const uint32_t G = s->nblocks * (s->wide ? 1u : 4u) * nshards;   // waves over all shards
+        KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->running, W * 8);
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
@@ -599,6 +646,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
                            cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
                            s->ne_count.as<uint32_t>());
+        hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)G + 1, 256)), dim3(256), 0, c->stream, s->ne_cost.as<uint32_t>(),
+                           s->ne_count.as<uint32_t>(), G, s->wfirst.as<uint32_t>());
         hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
                            s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
         // init_assignment (kmeans.rs:61-78) by canonical rank, then its sums folded into `running`
@@ -681,16 +730,14 @@ static void launch_assign(KmRgbwState *s) {
         auto *part = reinterpret_cast<unsigned long long *>(s->partials);
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->ne_cost.as<uint32_t>(), s->ne_count.as<uint32_t>(), s->shard, s->nshards, s->K,
-                               s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st);
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 8);
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->ne_cost.as<uint32_t>(), s->ne_count.as<uint32_t>(), s->shard, s->nshards, s->K,
-                               s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st);
         }
         return;
     }

@@ -113,6 +113,25 @@ int expand_codes_by_label(Ctx *c, const uint8_t *labels8_d, const uint16_t *labe
     return CNIIC_OK;
 }
 
+// dense colour -> cluster label table: key2label[keys[i]] = labels[i]  (clusterc.rs:31-40)
+template <typename LabelT>
+__global__ __launch_bounds__(256) void k_scatter_labels(const uint32_t *__restrict__ keys, const LabelT *__restrict__ labels,
+                                                        uint64_t U, LabelT *__restrict__ key2label) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride) key2label[keys[i] & 0xffffff] = labels[i];
+}
+int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U, void *key2label_d) {
+    if (!U) return CNIIC_OK;
+    if (wide)
+        hipLaunchKernelGGL(k_scatter_labels<uint16_t>, dim3(grid_for(U)), dim3(256), 0, c->stream, keys_d,
+                           reinterpret_cast<const uint16_t *>(labels_d), U, reinterpret_cast<uint16_t *>(key2label_d));
+    else
+        hipLaunchKernelGGL(k_scatter_labels<uint8_t>, dim3(grid_for(U)), dim3(256), 0, c->stream, keys_d,
+                           reinterpret_cast<const uint8_t *>(labels_d), U, reinterpret_cast<uint8_t *>(key2label_d));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
 // LUT of packed centroid colours per distinct input colour, for cniic_remap_rgb
 __global__ __launch_bounds__(256) void k_label_lut(const uint32_t *__restrict__ labels, uint64_t U,
                                                    const uint32_t *__restrict__ cent, uint32_t *__restrict__ lut) {
