@@ -189,7 +189,7 @@ int32_t cniic_kmeans_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t *we
     CNIIC_TRY(k.bind(c, keys, U));
     CNIIC_TRY(w.bind(c, weight, U));
     KmRgbwState *km = nullptr;
-    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, opts, nullptr, &km));
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, opts, nullptr, nullptr, &km));
     std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
     CNIIC_TRY(km_rgbw_run(km));
     Out<uint32_t> lo;
@@ -225,7 +225,7 @@ int32_t cniic_kmeans_step_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_
     CNIIC_TRY(from_caller(c, cent.data(), centroids, cent.size()));
     KmRgbwState *km = nullptr;
     cniic_kmeans_opts step_opts{0, 0, CNIIC_KM_BRUTE_FORCE, 0};  // explicit centroids + labels: full-sum kernel
-    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, &step_opts, nullptr, &km));
+    CNIIC_TRY(km_rgbw_create(c, k.d, w.d, U, 0, 1, K, &step_opts, nullptr, nullptr, &km));
     std::unique_ptr<KmRgbwState, void (*)(KmRgbwState *)> guard(km, km_rgbw_destroy);
     CNIIC_TRY(km_rgbw_set_state(km, cent.data(), lin.d));
     CNIIC_TRY(km_rgbw_assign(km));
@@ -314,7 +314,7 @@ int32_t cniic_km_create_rgbw(cniic_ctx *c, const uint32_t *keys, const uint32_t 
     km->c = c; km->K = K; km->U = U;
     CNIIC_TRY(km->keys.bind(c, keys, U));
     CNIIC_TRY(km->weight.bind(c, weight, U));
-    CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, shard, nshards, K, opts, partials_dev, &km->st));
+    CNIIC_TRY(km_rgbw_create(c, km->keys.d, km->weight.d, U, shard, nshards, K, opts, partials_dev, nullptr, &km->st));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *out = km.release();
     return CNIIC_OK;

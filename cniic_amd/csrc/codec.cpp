@@ -195,7 +195,7 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     CNIIC_TRY(hist_compact_write(c, table, &plan, keys_d.as<uint32_t>(), nullptr, weight_d.as<uint32_t>()));
     // kmeans::cluster (clusterc.rs:28)
     KmRgbwState *km = nullptr;
-    CNIIC_TRY(km_rgbw_create(c, keys_d.as<uint32_t>(), weight_d.as<uint32_t>(), U, 0, 1, K, opts, nullptr, &km));
+    CNIIC_TRY(km_rgbw_create(c, keys_d.as<uint32_t>(), weight_d.as<uint32_t>(), U, 0, 1, K, opts, nullptr, table, &km));
     struct Guard { KmRgbwState *k; ~Guard() { km_rgbw_destroy(k); } } guard{km};
     CNIIC_TRY(km_rgbw_run(km));
     std::vector<uint8_t> cent(3 * (size_t)K);

@@ -252,7 +252,7 @@ int dense_table(Ctx *c, uint32_t bits, uint32_t **table_d);  // zeroed scratch t
 struct KmRgbwState;  // opaque device state of one rgbw K-means problem
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
-                   KmRgbwState **out);
+                   const uint32_t *rank_table_d /* dense key -> rank+1 table, or null */, KmRgbwState **out);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
 int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials

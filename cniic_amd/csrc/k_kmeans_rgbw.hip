@@ -31,6 +31,8 @@
 // commute, so the result equals a full re-accumulation); per-block LDS accumulators (ds_add_u64),
 // non-zero entries flushed with global u64 atomics.  Sums are independent of block count, launch
 // order and GPU count.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -45,7 +47,7 @@ constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
 constexpr uint32_t kCellBlocks = 1536;     // 6 blocks of 4 waves per CU: every wave resident at once
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
-constexpr uint32_t kCellFixedCost = 64;   // per-cell overhead in point-equivalents (work split between waves)
+constexpr uint32_t kCellFixedCost = 1024; // per-cell overhead in point-equivalents (work split between waves)
 
 struct KmRgbwState {
     Ctx *c = nullptr;
@@ -225,12 +227,17 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__
 __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__ cell_count, uint32_t *__restrict__ cell_start,
                                                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ ne_cell,
                                                     uint32_t *__restrict__ ne_start, uint32_t *__restrict__ ne_cost,
-                                                    uint32_t *__restrict__ ne_count) {
+                                                    uint32_t *__restrict__ ne_count, uint32_t fixed_cost) {
     __shared__ uint32_t sh[1024], sh2[1024];
-    constexpr uint32_t per = kNumCells / 1024;
+    constexpr uint32_t per = kNumCells / 1024;  // 32 consecutive cells per thread, held in registers
     const uint32_t lo = threadIdx.x * per;
+    uint32_t v[per];
+    const uint4 *src = reinterpret_cast<const uint4 *>(cell_count + lo);
+#pragma unroll
+    for (uint32_t i = 0; i < per / 4; i++) { uint4 q = src[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
     uint32_t s = 0, z = 0;
-    for (uint32_t i = 0; i < per; i++) { uint32_t v = cell_count[lo + i]; s += v; z += v != 0; }
+#pragma unroll
+    for (uint32_t i = 0; i < per; i++) { s += v[i]; z += v[i] != 0; }
     sh[threadIdx.x] = s;
     sh2[threadIdx.x] = z;
     __syncthreads();
@@ -243,18 +250,60 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__
         __syncthreads();
     }
     uint32_t run = sh[threadIdx.x] - s, m = sh2[threadIdx.x] - z;
+    uint32_t st[per];
+#pragma unroll
     for (uint32_t i = 0; i < per; i++) {
-        uint32_t v = cell_count[lo + i];
-        cell_start[lo + i] = run;
-        cursor[lo + i] = run;
-        if (v) { ne_cell[m] = lo + i; ne_start[m] = run; ne_cost[m] = run + m * kCellFixedCost; m++; }
-        run += v;
+        st[i] = run;
+        if (v[i]) { ne_cell[m] = lo + i; ne_start[m] = run; ne_cost[m] = run + m * fixed_cost; m++; }
+        run += v[i];
+    }
+    uint4 *d1 = reinterpret_cast<uint4 *>(cell_start + lo);
+    uint4 *d2 = cursor ? reinterpret_cast<uint4 *>(cursor + lo) : nullptr;
+#pragma unroll
+    for (uint32_t i = 0; i < per / 4; i++) {
+        const uint4 q = make_uint4(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3]);
+        d1[i] = q;
+        if (d2) d2[i] = q;
     }
     if (threadIdx.x == 1023) {
         cell_start[kNumCells] = sh[1023];
         ne_start[sh2[1023]] = sh[1023];
-        ne_cost[sh2[1023]] = sh[1023] + sh2[1023] * kCellFixedCost;
+        ne_cost[sh2[1023]] = sh[1023] + sh2[1023] * fixed_cost;
         *ne_count = sh2[1023];
+    }
+}
+
+// ---- cell-major order straight from the dense colour table (codec path).  After the canonical
+// compaction table[key] = rank + 1 for every colour that occurs.  One 512-thread block per cell:
+// thread t owns colour (r_lo, g_lo, b_lo) = (t >> 6, (t >> 3) & 7, t & 7) of the cell.
+__device__ __forceinline__ uint32_t cell_key(uint32_t cell, uint32_t t) {
+    const uint32_t r = ((cell / (kCellsPerDim * kCellsPerDim)) << kCellShift) | (t >> 6);
+    const uint32_t g = (((cell / kCellsPerDim) % kCellsPerDim) << kCellShift) | ((t >> 3) & 7);
+    const uint32_t b = ((cell % kCellsPerDim) << kCellShift) | (t & 7);
+    return (r << 16) | (g << 8) | b;
+}
+__global__ __launch_bounds__(512) void k_cells_count_tbl(const uint32_t *__restrict__ table, uint32_t *__restrict__ cell_count) {
+    const uint32_t v = table[cell_key(blockIdx.x, threadIdx.x)];
+    const uint32_t n = block_reduce_sum<512>(v != 0);
+    if (threadIdx.x == 0) cell_count[blockIdx.x] = n;
+}
+template <typename LabelT>
+__global__ __launch_bounds__(512) void k_cells_write_tbl(const uint32_t *__restrict__ table, const uint32_t *__restrict__ weight,
+                                                         const uint32_t *__restrict__ cell_start, uint64_t U, uint32_t K,
+                                                         uint32_t *__restrict__ ckeys, uint32_t *__restrict__ cweight,
+                                                         uint32_t *__restrict__ crank, LabelT *__restrict__ labels) {
+    __shared__ uint32_t wsum[512 / 64];
+    const uint32_t s = cell_start[blockIdx.x], e = cell_start[blockIdx.x + 1];
+    if (s == e) return;
+    const uint32_t key = cell_key(blockIdx.x, threadIdx.x);
+    const uint32_t v = table[key];
+    const uint32_t pos = s + block_exclusive_scan<512>(v != 0, wsum);
+    if (v) {
+        const uint32_t rank = v - 1;
+        ckeys[pos] = key;
+        cweight[pos] = weight[rank];
+        crank[pos] = rank;
+        labels[pos] = (LabelT)init_label(rank, U, K);  // init_assignment kmeans.rs:61-78
     }
 }
 
@@ -289,30 +338,6 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t *__restrict
             crank[pos] = (uint32_t)i;
         }
     }
-}
-
-// full accumulation of the current assignment into `partials` (used once, after init)
-template <typename LabelT>
-__global__ __launch_bounds__(256) void k_rgbw_accum_all(const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight,
-                                                        uint64_t lo, uint64_t hi, uint32_t K,
-                                                        const LabelT *__restrict__ labels,
-                                                        unsigned long long *__restrict__ partials) {
-    extern __shared__ __align__(16) unsigned long long acc[];  // [5K]
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += 256) acc[i] = 0ull;
-    __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < hi; q += stride) {
-        const uint32_t p = ckeys[q], l = labels[q];
-        const uint64_t w = cweight[q];
-        atomicAdd(&acc[3 * l + 0], (unsigned long long)(((p >> 16) & 255) * w));
-        atomicAdd(&acc[3 * l + 1], (unsigned long long)(((p >> 8) & 255) * w));
-        atomicAdd(&acc[3 * l + 2], (unsigned long long)((p & 255) * w));
-        atomicAdd(&acc[3 * K + l], (unsigned long long)w);
-        atomicAdd(&acc[4 * K + l], 1ull);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += 256)
-        if (acc[i]) atomicAdd(&partials[i], acc[i]);
 }
 
 // ---------------------------------------------------------------- cell-pruned assign, delta sums
@@ -373,6 +398,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
 
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     constexpr int32_t ext = (1 << kCellShift) - 1;
+    // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
+    // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
+    // iterations add/subtract only the points that moved.
+    const bool first = st->iter == 0;
     const uint32_t R = (K + 63) >> 6;  // centroids per lane
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t moved = 0;
@@ -452,17 +481,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                 if (q < e) {
                     const uint2 cc = tab[cur[u]];
                     const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
-                    if ((best[u] >> IDBITS) > (kcur >> IDBITS)) {  // strictly closer (kmeans.rs:375)
-                        const uint32_t nl = IDMASK - (best[u] & IDMASK), ol = cur[u], pp = p[u];
-                        labels[q] = (LabelT)nl;
-                        moved++;
+                    const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+                    const uint32_t ol = cur[u], pp = p[u];
+                    const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
+                    if (mv) { labels[q] = (LabelT)nl; moved++; }
+                    if (mv || first) {
                         const uint64_t w = cweight[q];
                         const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
-                        atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * ol + 0], 0ull - rw);
-                        atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * ol + 1], 0ull - gw);
-                        atomicAdd(&acc[3 * nl + 2], bw); atomicAdd(&acc[3 * ol + 2], 0ull - bw);
-                        atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
-                        atomicAdd(&acc[4 * K + nl], 1ull); atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
+                        atomicAdd(&acc[3 * nl + 0], rw);
+                        atomicAdd(&acc[3 * nl + 1], gw);
+                        atomicAdd(&acc[3 * nl + 2], bw);
+                        atomicAdd(&acc[3 * K + nl], (unsigned long long)w);
+                        atomicAdd(&acc[4 * K + nl], 1ull);
+                        if (!first) {
+                            atomicAdd(&acc[3 * ol + 0], 0ull - rw);
+                            atomicAdd(&acc[3 * ol + 1], 0ull - gw);
+                            atomicAdd(&acc[3 * ol + 2], 0ull - bw);
+                            atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
+                            atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
+                        }
                     }
                 }
             }
@@ -490,8 +527,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
 // ---------------------------------------------------------------- centroid update
 // Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137).
 // mode 0: partials hold the full sums of this iteration (brute path)
-// mode 1: partials hold deltas; running += partials first (cells path)
-// mode 2: running += partials only (folds the initial assignment in; no centroid update)
+// mode 1: partials hold deltas (full sums at iteration 0); running += partials first (cells path)
 __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ partials, uint64_t *__restrict__ running,
                                                      int mode, const uint32_t *__restrict__ keys,
                                                      uint64_t U, uint32_t K, uint32_t idbits, uint64_t seed,
@@ -500,13 +536,6 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
                                                      uint64_t *__restrict__ wsum_out,
                                                      KmDevState *__restrict__ st) {
     if (st->done) return;
-    if (mode == 2) {
-        for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += blockDim.x) {
-            if (i < 5 * K) running[i] += partials[i];
-            partials[i] = 0;
-        }
-        return;
-    }
     __shared__ uint32_t s_reseed, s_active;
     if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; }
     if (mode == 1)
@@ -591,7 +620,7 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
 
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
-                   KmRgbwState **out) {
+                   const uint32_t *rank_table_d, KmRgbwState **out) {
     if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
     const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
     if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
@@ -638,32 +667,44 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->running, W * 8);
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
-        KM_ALLOC(cursor, (uint64_t)kNumCells * 4);
-        (void)hipMemsetAsync(count.p, 0, (uint64_t)kNumCells * 4, c->stream);
         (void)hipMemsetAsync(s->running.p, 0, W * 8, c->stream);
-        const uint32_t g = grid_1d(U);
-        hipLaunchKernelGGL(k_cell_count, dim3(g), dim3(256), 0, c->stream, keys_d, U, count.as<uint32_t>());
-        hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
-                           cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
-                           s->ne_count.as<uint32_t>());
+        uint32_t fixed_cost = kCellFixedCost;
+        if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knob
+        if (rank_table_d) {
+            // codec path: the dense colour table (key -> canonical rank + 1) is walked cell by cell
+            hipLaunchKernelGGL(k_cells_count_tbl, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, count.as<uint32_t>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
+                               (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
+                               s->ne_count.as<uint32_t>(), fixed_cost);
+            if (s->wide)
+                hipLaunchKernelGGL(k_cells_write_tbl<uint16_t>, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, weight_d,
+                                   s->cell_start.as<uint32_t>(), U, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
+                                   s->crank.as<uint32_t>(), s->labels.as<uint16_t>());
+            else
+                hipLaunchKernelGGL(k_cells_write_tbl<uint8_t>, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, weight_d,
+                                   s->cell_start.as<uint32_t>(), U, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
+                                   s->crank.as<uint32_t>(), s->labels.as<uint8_t>());
+        } else {
+            // generic path (any point order): counting sort of the point list by cell
+            KM_ALLOC(cursor, (uint64_t)kNumCells * 4);
+            (void)hipMemsetAsync(count.p, 0, (uint64_t)kNumCells * 4, c->stream);
+            const uint32_t g = grid_1d(U);
+            hipLaunchKernelGGL(k_cell_count, dim3(g), dim3(256), 0, c->stream, keys_d, U, count.as<uint32_t>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
+                               cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
+                               s->ne_count.as<uint32_t>(), fixed_cost);
+            hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
+                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
+            // init_assignment (kmeans.rs:61-78) by canonical rank
+            if (s->wide)
+                hipLaunchKernelGGL(k_rgbw_init_labels<uint16_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
+                                   (uint64_t)0, U, K, s->labels.as<uint16_t>());
+            else
+                hipLaunchKernelGGL(k_rgbw_init_labels<uint8_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
+                                   (uint64_t)0, U, K, s->labels.as<uint8_t>());
+        }
         hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)G + 1, 256)), dim3(256), 0, c->stream, s->ne_cost.as<uint32_t>(),
                            s->ne_count.as<uint32_t>(), G, s->wfirst.as<uint32_t>());
-        hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
-                           s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
-        // init_assignment (kmeans.rs:61-78) by canonical rank, then its sums folded into `running`
-        if (s->wide) {
-            hipLaunchKernelGGL(k_rgbw_init_labels<uint16_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
-                               (uint64_t)0, U, K, s->labels.as<uint16_t>());
-            hipLaunchKernelGGL(k_rgbw_accum_all<uint16_t>, dim3(grid_1d(n, 512)), dim3(256), (size_t)K * 40, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), lo, hi, K, s->labels.as<uint16_t>(),
-                               reinterpret_cast<unsigned long long *>(s->partials));
-        } else {
-            hipLaunchKernelGGL(k_rgbw_init_labels<uint8_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
-                               (uint64_t)0, U, K, s->labels.as<uint8_t>());
-            hipLaunchKernelGGL(k_rgbw_accum_all<uint8_t>, dim3(grid_1d(n, 512)), dim3(256), (size_t)K * 40, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), lo, hi, K, s->labels.as<uint8_t>(),
-                               reinterpret_cast<unsigned long long *>(s->partials));
-        }
         hipError_t e = hipStreamSynchronize(c->stream);  // count / cursor are released on scope exit
         if (e != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw setup: %s", hipGetErrorString(e)); }
     } else {
@@ -694,12 +735,8 @@ static int launch_update(KmRgbwState *s, int mode) {
     return CNIIC_OK;
 }
 
-// Cells path, after create (and after the caller's all-reduce of the initial sums when sharded):
-// fold the initial assignment into the running sums.
-int km_rgbw_fold_initial(KmRgbwState *s) {
-    if (!s->cells) return CNIIC_OK;
-    return launch_update(s, 2);
-}
+// Kept for ABI stability: the first assign produces full sums, nothing to fold in beforehand.
+int km_rgbw_fold_initial(KmRgbwState *) { return CNIIC_OK; }
 
 // Brute path only: explicit centroids + labels (single-step ABI).
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32) {
