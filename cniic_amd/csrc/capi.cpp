@@ -396,6 +396,105 @@ void cniic_km_destroy(cniic_km *km) {
     delete km;
 }
 
+// ------------------------------------------------------------------ sharded cluster-colors session
+struct cniic_cc {
+    Ctx *c = nullptr;
+    CcSession *s = nullptr;
+};
+
+int32_t cniic_hist_rgb24_dense(cniic_ctx *c, const uint8_t *rgb, uint64_t npx, uint32_t *table_dev) {
+    LOCK(c);
+    c->ktimes.clear();
+    if (!table_dev || !is_device_ptr(table_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "hist_rgb24_dense: table must be device memory (u32[2^24])");
+    if (npx && !rgb) return c->fail(CNIIC_ERR_BAD_ARG, "hist_rgb24_dense: null image");
+    if (npx >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "hist_rgb24_dense: too many pixels");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, npx * 3));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(table_dev, 0, (1ull << 24) * 4, c->stream));
+    ScopedKernelTimer t(c, "hist_rgb");
+    CNIIC_TRY(hist_rgb_dense(c, in.d, npx, table_dev));
+    t.stop(1);
+    return CNIIC_OK;
+}
+
+int32_t cniic_cc_create(cniic_ctx *c, uint32_t *table_dev, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard,
+                        uint32_t nshards, void *partials_dev, cniic_cc **out) {
+    LOCK(c);
+    if (!out || !table_dev || !is_device_ptr(table_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_create: table must be device memory");
+    if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_create: partials must be device memory");
+    CcSession *s = nullptr;
+    CNIIC_TRY(cc_prepare(c, table_dev, K, opts, shard, nshards, partials_dev, &s));
+    auto *cc = new cniic_cc();
+    cc->c = c; cc->s = s;
+    *out = cc;
+    return CNIIC_OK;
+}
+
+uint64_t cniic_cc_unique(cniic_cc *cc) { return cc && cc->s ? cc->s->U : 0; }
+uint32_t cniic_cc_label_bytes(cniic_cc *cc) { return cc && cc->s && km_rgbw_is_wide(cc->s->km) ? 2 : 1; }
+
+int32_t cniic_cc_assign(cniic_cc *cc) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    return km_rgbw_assign(cc->s->km);
+}
+
+int32_t cniic_cc_update(cniic_cc *cc, uint64_t *changed) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    CNIIC_TRY(km_rgbw_update(cc->s->km));
+    uint64_t ch = 0;
+    CNIIC_TRY(km_rgbw_poll_changed(cc->s->km, &ch));
+    if (changed) *changed = ch;
+    return CNIIC_OK;
+}
+
+int32_t cniic_cc_partials(cniic_cc *cc, void **dev_ptr) {
+    if (!cc || !dev_ptr) return CNIIC_ERR_BAD_ARG;
+    *dev_ptr = km_rgbw_partials_dev(cc->s->km);
+    return CNIIC_OK;
+}
+
+int32_t cniic_cc_export_labels(cniic_cc *cc, void *dst_dev) {
+    if (!cc || !dst_dev) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    return km_rgbw_export_labels(cc->s->km, dst_dev);
+}
+
+int32_t cniic_cc_import_labels(cniic_cc *cc, const void *src_dev) {
+    if (!cc || !src_dev) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    return km_rgbw_import_labels(cc->s->km, src_dev);
+}
+
+int32_t cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h, const uint32_t *local_table_dev, uint8_t *out,
+                        uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    if (!rgb || !out || !len) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish: null argument");
+    if (local_table_dev && !is_device_ptr(local_table_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish: local table must be device memory");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3));
+    return cc_finish(cc->s, in.d, w, h, local_table_dev, out, cap, len, stats);
+}
+
+void cniic_cc_destroy(cniic_cc *cc) {
+    if (!cc) return;
+    {
+        std::lock_guard<std::mutex> lk(cc->c->mu);
+        (void)hipSetDevice(cc->c->device);
+        (void)hipStreamSynchronize(cc->c->stream);
+        PoolScope ps(&cc->c->pool);
+        delete cc->s;
+    }
+    delete cc;
+}
+
 // ------------------------------------------------------------------ remap
 int32_t cniic_remap_rgb(cniic_ctx *c, const uint8_t *rgb, uint64_t npx, const uint32_t *keys, const uint32_t *labels, uint64_t U,
                         const uint8_t *centroids, uint32_t K, uint8_t *out_rgb) {

@@ -12,6 +12,7 @@
 #include <cctype>
 #include <cstring>
 #include <map>
+#include <memory>
 
 #include "huff_host.hpp"
 
@@ -171,33 +172,40 @@ static int encode_hufman(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, u
 }
 
 // ------------------------------------------------------------------ ClusterColors::encode (clusterc.rs:18-53)
-static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
-                                 const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
-                                 cniic_kmeans_stats *stats) {
-    const uint64_t n = (uint64_t)w * h;
+// Split in two so that a multi-GPU caller can all-reduce between the pieces:
+//   cc_prepare  dense colour counts -> distinct colours (ascending key = point order, clusterc.rs:21-24)
+//               + K-means state (kmeans::init, kmeans.rs:80-90)
+//   (K-means loop: km_rgbw_run on one GPU, or assign / all-reduce / update driven by the caller)
+//   cc_finish   clusters -> colour lookup -> Hufman.encode of the reduced image (clusterc.rs:31-52)
+CcSession::~CcSession() { if (km) km_rgbw_destroy(km); }
+
+int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard, uint32_t nshards,
+               void *partials_dev, CcSession **out) {
     if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
-    // count_freqs over the pixels (clusterc.rs:21): distinct colours, ascending key = point order
-    uint32_t *table = nullptr;
-    CNIIC_TRY(dense_table(c, 24, &table));
-    {
-        ScopedKernelTimer t(c, "hist_rgb");
-        CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table));
-        t.stop(1);
-    }
+    auto s = std::make_unique<CcSession>();
+    s->c = c; s->K = K; s->table = table_counts_d;
     CompactPlan plan;
-    CNIIC_TRY(hist_compact_count(c, table, 24, &plan));
+    CNIIC_TRY(hist_compact_count(c, table_counts_d, 24, &plan));
     const uint64_t U = plan.n_unique;
+    s->U = U;
     if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)",
                                    (unsigned long long)U, K);
-    DevBuf keys_d, weight_d;
-    CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
-    CNIIC_HIP_TRY(c, weight_d.alloc(U * 4));
-    CNIIC_TRY(hist_compact_write(c, table, &plan, keys_d.as<uint32_t>(), nullptr, weight_d.as<uint32_t>()));
-    // kmeans::cluster (clusterc.rs:28)
-    KmRgbwState *km = nullptr;
-    CNIIC_TRY(km_rgbw_create(c, keys_d.as<uint32_t>(), weight_d.as<uint32_t>(), U, 0, 1, K, opts, nullptr, table, &km));
-    struct Guard { KmRgbwState *k; ~Guard() { km_rgbw_destroy(k); } } guard{km};
-    CNIIC_TRY(km_rgbw_run(km));
+    CNIIC_HIP_TRY(c, s->keys_d.alloc(U * 4));
+    CNIIC_HIP_TRY(c, s->weight_d.alloc(U * 4));
+    CNIIC_TRY(hist_compact_write(c, table_counts_d, &plan, s->keys_d.as<uint32_t>(), nullptr, s->weight_d.as<uint32_t>()));
+    // kmeans::cluster (clusterc.rs:28); the table now maps key -> rank + 1
+    CNIIC_TRY(km_rgbw_create(c, s->keys_d.as<uint32_t>(), s->weight_d.as<uint32_t>(), U, shard, nshards, K, opts, partials_dev,
+                             table_counts_d, &s->km));
+    *out = s.release();
+    return CNIIC_OK;
+}
+
+int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
+              uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
+    Ctx *c = s->c;
+    const uint32_t K = s->K;
+    const uint64_t U = s->U, n = (uint64_t)w * h;
+    KmRgbwState *km = s->km;
     std::vector<uint8_t> cent(3 * (size_t)K);
     std::vector<uint64_t> members(K), wsum(K);
     cniic_kmeans_stats st{};
@@ -209,6 +217,21 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     if (st.active < min_cc)
         return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
                        (unsigned long long)st.active, (unsigned long long)min_cc);
+    const bool wide = km_rgbw_is_wide(km);
+    DevBuf lab_d, key2label;
+    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
+    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
+    if (local_counts_d) {
+        // shared palette over several images: THIS image's pixels per cluster (its reduced image is
+        // what Hufman.encode sees, clusterc.rs:52), from its own colour counts
+        DevBuf lw;
+        CNIIC_HIP_TRY(c, lw.alloc((uint64_t)K * 8));
+        CNIIC_HIP_TRY(c, hipMemsetAsync(lw.p, 0, (uint64_t)K * 8, c->stream));
+        CNIIC_TRY(local_cluster_weights(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, local_counts_d, K, lw.as<uint64_t>()));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(wsum.data(), lw.p, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint32_t k = 0; k < K; k++) members[k] = wsum[k] ? 1 : 0;
+    }
     // Histogram of the colour-reduced image = per-centroid-colour sum of member weights
     // (what count_freqs inside Hufman.encode would find, clusterc.rs:52 -> huf.rs:30).
     std::map<uint32_t, uint64_t> hist;
@@ -241,16 +264,13 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     }
     StreamOut so(c, out, cap, len);
     CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
-    const bool wide = km_rgbw_is_wide(km);
-    DevBuf clen_d, ccode_d, lab_d, key2label;
+    DevBuf clen_d, ccode_d;
     CNIIC_HIP_TRY(c, clen_d.alloc(K));
     CNIIC_HIP_TRY(c, ccode_d.alloc((uint64_t)K * 8));
-    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
     CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), K, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
-    CNIIC_TRY(scatter_labels_by_key(c, keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
+    CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
     uint64_t packed_bits = 0;
     {
         ScopedKernelTimer t(c, "huff_pack");
@@ -262,6 +282,25 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
         return c->fail(CNIIC_ERR_HIP, "cluster-colors: packed %llu bits, histogram predicts %llu",
                        (unsigned long long)packed_bits, (unsigned long long)nbits);
     return so.finish();
+}
+
+static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
+                                 const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
+                                 cniic_kmeans_stats *stats) {
+    const uint64_t n = (uint64_t)w * h;
+    // count_freqs over the pixels (clusterc.rs:21)
+    uint32_t *table = nullptr;
+    CNIIC_TRY(dense_table(c, 24, &table));
+    {
+        ScopedKernelTimer t(c, "hist_rgb");
+        CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table));
+        t.stop(1);
+    }
+    CcSession *raw = nullptr;
+    CNIIC_TRY(cc_prepare(c, table, K, opts, 0, 1, nullptr, &raw));
+    std::unique_ptr<CcSession> s(raw);
+    CNIIC_TRY(km_rgbw_run(s->km));
+    return cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
 }
 
 // ------------------------------------------------------------------ VoronoiCluster::encode (clusterc.rs:148-166)

@@ -25,6 +25,21 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
 int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
                  uint32_t *w, uint32_t *h);
 
+// cluster-colors in pieces (see codec.cpp)
+struct CcSession {
+    Ctx *c = nullptr;
+    uint32_t K = 0;
+    uint32_t *table = nullptr;   // dense colour table: counts on entry of cc_prepare, key -> rank + 1 afterwards
+    uint64_t U = 0;
+    DevBuf keys_d, weight_d;
+    KmRgbwState *km = nullptr;
+    ~CcSession();
+};
+int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard, uint32_t nshards,
+               void *partials_dev, CcSession **out);
+int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
+              uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+
 // header carries any prefix already serialised (image dimensions); the decoder trie is appended
 // to it and the whole stream lands in out[0..*len)  (out: host or device memory).
 int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n, uint32_t *table_d,

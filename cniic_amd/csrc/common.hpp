@@ -268,6 +268,10 @@ bool km_rgbw_is_wide(KmRgbwState *s);                     // u16 labels (K > 256
 int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d); // u8/u16 labels of all points, canonical order
 void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes);
 int km_rgbw_fold_initial(KmRgbwState *s);
+// sharded runs: labels of this shard's cells (zeros elsewhere) out of / merged labels into the state
+int km_rgbw_export_labels(KmRgbwState *s, void *dst_d);
+int km_rgbw_import_labels(KmRgbwState *s, const void *src_d);
+uint64_t km_rgbw_points(KmRgbwState *s);
 
 // ---- k_kmeans_xyrgb.hip ----
 int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
@@ -283,6 +287,8 @@ int remap_rgb(Ctx *c, const uint8_t *rgb_d, uint64_t npx, const uint32_t *rank_t
               const uint32_t *lut_rgb_d /* packed centroid colour per unique colour rank */, uint8_t *out_d);
 int expand_codes_by_label(Ctx *c, const uint8_t *labels8_d, const uint16_t *labels16_d, uint64_t U, const uint8_t *clen_d,
                           const uint64_t *ccode_d, uint8_t *len_d, uint64_t *code_d);
+int local_cluster_weights(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U,
+                          const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d);
 int label_lut(Ctx *c, const uint32_t *labels_d, uint64_t U, const uint32_t *cent_d, uint32_t *lut_d);
 int rank_from_keys(Ctx *c, const uint32_t *keys_d, uint64_t U, uint32_t *table_d);
 int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d);

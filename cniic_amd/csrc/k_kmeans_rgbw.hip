@@ -889,6 +889,41 @@ int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d) {
     return CNIIC_OK;
 }
 
+// Sharded runs: copy this shard's labels (cell-major positions of its waves' cells) into dst,
+// zero elsewhere; the caller sums the exports of all ranks (each position has one owner).
+template <typename LabelT>
+__global__ void k_export_labels(const LabelT *__restrict__ labels, const uint32_t *__restrict__ ne_start,
+                                const uint32_t *__restrict__ wfirst, uint32_t g_lo, uint32_t g_hi, uint64_t U,
+                                LabelT *__restrict__ dst) {
+    const uint32_t q_lo = ne_start[wfirst[g_lo]], q_hi = ne_start[wfirst[g_hi]];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride)
+        dst[i] = (i >= q_lo && i < q_hi) ? labels[i] : (LabelT)0;
+}
+
+int km_rgbw_export_labels(KmRgbwState *s, void *dst_d) {
+    Ctx *c = s->c;
+    if (!s->cells) return c->fail(CNIIC_ERR_BAD_ARG, "export_labels needs the cells path");
+    const uint32_t wpb = s->wide ? 1u : 4u;
+    const uint32_t g_lo = s->shard * s->nblocks * wpb, g_hi = (s->shard + 1) * s->nblocks * wpb;
+    if (s->wide)
+        hipLaunchKernelGGL(k_export_labels<uint16_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(),
+                           s->ne_start.as<uint32_t>(), s->wfirst.as<uint32_t>(), g_lo, g_hi, s->U, reinterpret_cast<uint16_t *>(dst_d));
+    else
+        hipLaunchKernelGGL(k_export_labels<uint8_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint8_t>(),
+                           s->ne_start.as<uint32_t>(), s->wfirst.as<uint32_t>(), g_lo, g_hi, s->U, reinterpret_cast<uint8_t *>(dst_d));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+int km_rgbw_import_labels(KmRgbwState *s, const void *src_d) {
+    Ctx *c = s->c;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(s->labels.p, src_d, s->U * (s->wide ? 2 : 1), hipMemcpyDeviceToDevice, c->stream));
+    return CNIIC_OK;
+}
+
+uint64_t km_rgbw_points(KmRgbwState *s) { return s->U; }
+
 // cell-major label array of all U points (cells path): the buffer ranks all-gather over
 void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes) {
     if (elem_bytes) *elem_bytes = s->wide ? 2 : 1;

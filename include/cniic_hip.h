@@ -154,6 +154,38 @@ int32_t cniic_km_result(cniic_km *km, uint8_t *centroids, uint32_t *labels, uint
 int32_t cniic_km_time_assign(cniic_km *km, int32_t reps, double *ms_per_launch);
 void    cniic_km_destroy(cniic_km *km);
 
+/* ------------------------------------------------------------------ cluster-colors over several GPUs */
+/* One process per GPU, every rank holds its own image(s); the ranks build ONE palette for the
+ * union of their pixels (north_star config 4) and each encodes its own image with it.  The caller
+ * owns the collectives (RCCL through torch.distributed, or ncclAllReduce directly):
+ *
+ *   cniic_hist_rgb24_dense(img)            -> local  u32[2^24] colour counts (device)
+ *   all-reduce(sum) a COPY of it           -> global counts
+ *   cniic_cc_create(global, K, rank, n)    -> distinct colours, K-means state; the global table
+ *                                             is overwritten (key -> rank + 1)
+ *   repeat: cniic_cc_assign; all-reduce(sum) the partials buffer (int64 words); cniic_cc_update
+ *           until *changed == 0
+ *   cniic_cc_export_labels; all-reduce(sum) that buffer; cniic_cc_import_labels
+ *   cniic_cc_finish(img, local counts)     -> this rank's Hufman stream (clusterc.rs:31-52)
+ *
+ * Integer sums make the palette bit-identical for any number of ranks. */
+typedef struct cniic_cc cniic_cc;
+int32_t  cniic_hist_rgb24_dense(cniic_ctx *ctx, const uint8_t *rgb, uint64_t npx, uint32_t *table_dev);
+int32_t  cniic_cc_create(cniic_ctx *ctx, uint32_t *table_dev, uint32_t K, const cniic_kmeans_opts *opts,
+                         uint32_t shard, uint32_t nshards,
+                         void *partials_dev /* device, cniic_km_partial_words(K,3) u64, or NULL */, cniic_cc **out);
+uint64_t cniic_cc_unique(cniic_cc *cc);        /* distinct colours U */
+uint32_t cniic_cc_label_bytes(cniic_cc *cc);   /* 1 (K <= 256) or 2: element size of the label buffers */
+int32_t  cniic_cc_partials(cniic_cc *cc, void **dev_ptr);
+int32_t  cniic_cc_assign(cniic_cc *cc);                        /* async on the ctx stream */
+int32_t  cniic_cc_update(cniic_cc *cc, uint64_t *changed);     /* syncs */
+int32_t  cniic_cc_export_labels(cniic_cc *cc, void *dst_dev);  /* U labels, zero outside this shard */
+int32_t  cniic_cc_import_labels(cniic_cc *cc, const void *src_dev);
+int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h,
+                         const uint32_t *local_table_dev /* this image's own counts, or NULL = single image */,
+                         uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+void     cniic_cc_destroy(cniic_cc *cc);
+
 /* ------------------------------------------------------------------ cluster-colors remap */
 /* src/codec/clusterc.rs:31-47: every pixel's colour -> the centroid colour of its cluster.
  * keys[U] ascending (as returned by cniic_hist_rgb24), labels[U], centroids[K x 3]. */

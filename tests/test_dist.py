@@ -1,0 +1,209 @@
+"""The N>1 path: shared-palette cluster-colors driven by cniic_amd.dist.ShardedClusterColors.
+
+CPU (gloo, world_size 2): the driver's protocol (histogram all-reduce, per-iteration all-reduce of
+the K partial sums as SIGNED DELTAS, label merge, per-rank Huffman of the reduced image) is run
+with the oracle as the compute backend and must equal a single-process computation bit for bit.
+GPU: the same driver on the HIP backend (world_size 1, and 2 ranks sharing the GPU over gloo)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def keys_of(img):
+    p = img.reshape(-1, 3).astype(np.uint32)
+    return (p[:, 0] << 16) | (p[:, 1] << 8) | p[:, 2]
+
+
+def make_img(rank, h=40, w=56):
+    from cniic_amd import synth
+    return synth.photo(w, h, synth.SEED0 + 40 + rank)
+
+
+class OracleBackend:
+    """CPU stand-in for HipBackend (tests only): same interface, compute done by the oracle."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+
+    def hist_dense(self, img, npx):
+        cnt = np.bincount(keys_of(np.asarray(img)), minlength=1 << 24).astype(np.int32)
+        return self.torch.from_numpy(cnt)
+
+    def new_partials(self, K):
+        return self.torch.zeros(5 * K + 2, dtype=self.torch.int64)
+
+    def cc_create(self, table, K, rank, world, partials, max_iters=0, seed=0):
+        import oracle_lib as O
+        cnt = table.numpy()
+        keys = np.nonzero(cnt)[0].astype(np.uint32)
+        U = keys.size
+        st = dict(K=K, keys=keys, w=cnt[keys].astype(np.uint32), U=U, lo=U * rank // world, hi=U * (rank + 1) // world,
+                  pts=np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], 1).astype(np.int32), partials=partials,
+                  labels=O.init_labels(U, K), running=np.zeros(5 * K, np.int64), prev=np.zeros(5 * K, np.int64), it=0,
+                  seed=seed or O.DEFAULT_SEED)
+        ppc = U // K
+        st["cent"] = np.stack([st["pts"][U - (c + 1) * ppc] if c < K - 1 else st["pts"][0] for c in range(K)]).astype(np.int32)
+        return st
+
+    def assign(self, st):
+        import oracle_lib as O
+        lo, hi, K = st["lo"], st["hi"], st["K"]
+        r = O.kmeans_step(O.PT_RGBW, st["pts"][lo:hi], st["w"][lo:hi], K, st["cent"], st["labels"][lo:hi])
+        st["labels"][lo:hi] = r["labels"]
+        full = np.concatenate([r["sums"].reshape(-1), r["wsum"], r["members"]]).astype(np.int64)
+        p = st["partials"].numpy()
+        p[:5 * K] = full - st["prev"]            # signed deltas (full sums at iteration 0)
+        p[5 * K] = r["changed"]
+        p[5 * K + 1] = 0
+        st["prev"] = full
+
+    def update(self, st):
+        import oracle_lib as O
+        K = st["K"]
+        p = st["partials"].numpy()
+        st["running"] += p[:5 * K]
+        run = st["running"].astype(np.uint64)
+        st["cent"], _ = O.kmeans_finalize(O.PT_RGBW, st["pts"], K, st["seed"], st["it"], run[:3 * K].reshape(K, 3), run[3 * K:4 * K],
+                                          run[4 * K:5 * K])
+        st["it"] += 1
+        changed = int(p[5 * K])
+        p[:] = 0
+        return changed
+
+    def export_labels(self, st):
+        out = np.zeros(st["U"], np.uint8)
+        out[st["lo"]:st["hi"]] = st["labels"][st["lo"]:st["hi"]]
+        return self.torch.from_numpy(out)
+
+    def import_labels(self, st, t):
+        st["labels"] = t.numpy().astype(np.uint32)
+
+    def finish(self, st, img, w, h, local_table, out):
+        import oracle_lib as O
+        img = np.asarray(img)
+        lut = dict(zip(st["keys"].tolist(), st["labels"].tolist()))
+        cent = st["cent"].astype(np.uint8)
+        reduced = np.array([cent[lut[k]] for k in keys_of(img).tolist()], np.uint8).reshape(img.shape)
+        rc, data, _ = O.encode("hufman", reduced)      # Hufman.encode(&reduced_img) clusterc.rs:52
+        assert rc == 0
+        out[:len(data)] = self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8)
+        return len(data), dict(iterations=st["it"])
+
+    def destroy(self, st):
+        pass
+
+
+def expected_streams(imgs, K):
+    """single-process: oracle K-means (mode L) over the union histogram, then each image coded alone"""
+    import oracle_lib as O
+    allk = np.concatenate([keys_of(i) for i in imgs])
+    keys, counts = O.count_freqs(allk)
+    pts = np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], 1).astype(np.int32)
+    rc, r = O.kmeans(O.PT_RGBW, O.MODE_L, pts, counts.astype(np.uint32), K)
+    assert rc == 0
+    lut = dict(zip(keys.tolist(), r["labels"].tolist()))
+    cent = r["centroids"].astype(np.uint8)
+    outs = []
+    for img in imgs:
+        reduced = np.array([cent[lut[k]] for k in keys_of(img).tolist()], np.uint8).reshape(img.shape)
+        rc, data, _ = O.encode("hufman", reduced)
+        outs.append(data)
+    return outs, r["stats"]["iterations"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, K, use_hip, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cniic_amd.dist import ShardedClusterColors
+        img = make_img(rank)
+        h, w = img.shape[:2]
+        if use_hip:
+            import cniic_amd
+            dev = torch.device("cuda", 0)
+            torch.cuda.set_device(0)
+            ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+            enc = ShardedClusterColors(ctx, K, dist, dev)
+            timg = torch.from_numpy(img).to(dev)
+            out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8, device=dev)
+        else:
+            enc = ShardedClusterColors(None, K, dist, None, backend=OracleBackend())
+            timg = img
+            out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8)
+        n, st = enc.encode(timg, w, h, out)
+        q.put((rank, bytes(out[:n].cpu().numpy().tobytes()), int(st["iterations"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, K, use_hip):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, use_hip, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, data, it = q.get(timeout=300)
+        res[r] = (data, it)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_driver_gloo_world2_matches_single_process():
+    K = 8
+    res = _run(2, K, use_hip=False)
+    exp, iters = expected_streams([make_img(0), make_img(1)], K)
+    for r in (0, 1):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
+
+
+@pytest.mark.gpu
+def test_sharded_hip_world1_equals_plain_encode():
+    import torch
+
+    import cniic_amd
+    from cniic_amd.dist import ShardedClusterColors
+    img = make_img(3, 96, 128)
+    h, w = img.shape[:2]
+    dev = torch.device("cuda", 0)
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    rc, exp, st = ctx.encode("cluster-colors(16)", img)
+    out = torch.zeros(w * h * 16, dtype=torch.uint8, device=dev)
+    n, st2 = ShardedClusterColors(ctx, 16, None, dev).encode(torch.from_numpy(img).to(dev), w, h, out)
+    assert bytes(out[:n].cpu().numpy().tobytes()) == exp and st2["iterations"] == st["iterations"]
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_sharded_hip_world2_shared_gpu_matches_single_process():
+    """two ranks (sharing the one GPU of the test box; collectives over gloo) = the oracle's union result"""
+    K = 8
+    res = _run(2, K, use_hip=True)
+    exp, iters = expected_streams([make_img(0), make_img(1)], K)
+    for r in (0, 1):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
