@@ -62,7 +62,10 @@ def main():
     K = args.k
     expr = "cluster-colors(%d)" % K
     seed = synth.SEED0 + 2 + rank  # config 2 of SURVEY 8(d); one image per rank
-    stream = torch.cuda.current_stream()
+    # one non-default stream shared by torch (collectives) and the library (kernels): stream order
+    # is the only synchronisation between them
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = cniic_amd.Context(local_rank, stream=stream.cuda_stream)
 
     img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)

@@ -106,6 +106,11 @@ class Context:
     """One cniic_ctx: a HIP stream + scratch HBM on one GPU.  Not shared between threads."""
 
     def __init__(self, device=0, stream=None):
+        """stream: a hipStream_t handle to enqueue on (e.g. torch.cuda.current_stream().cuda_stream of a
+        NON-default torch stream), or None for a private stream.  The NULL/default stream has handle 0
+        and cannot be shared this way: make a torch.cuda.Stream() current first."""
+        if stream is not None and int(stream) == 0:
+            raise ValueError("cannot share the default (NULL) stream: use torch.cuda.set_stream(torch.cuda.Stream()) first")
         self._L = lib()
         h = C.c_void_p()
         rc = self._L.cniic_ctx_create(C.c_int32(device), C.c_void_p(stream or 0), C.byref(h))

@@ -140,6 +140,7 @@ def _worker(rank, world, port, K, use_hip, q):
             import cniic_amd
             dev = torch.device("cuda", 0)
             torch.cuda.set_device(0)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev))
             ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
             enc = ShardedClusterColors(ctx, K, dist, dev)
             timg = torch.from_numpy(img).to(dev)
@@ -164,7 +165,7 @@ def _run(world, K, use_hip):
         p.start()
     res = {}
     for _ in range(world):
-        r, data, it = q.get(timeout=300)
+        r, data, it = q.get(timeout=120)
         res[r] = (data, it)
     for p in procs:
         p.join(60)
@@ -190,6 +191,7 @@ def test_sharded_hip_world1_equals_plain_encode():
     img = make_img(3, 96, 128)
     h, w = img.shape[:2]
     dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     rc, exp, st = ctx.encode("cluster-colors(16)", img)
     out = torch.zeros(w * h * 16, dtype=torch.uint8, device=dev)

@@ -17,6 +17,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 flags = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device("cuda", 0)
+torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev)
 ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
