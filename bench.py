@@ -51,8 +51,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rehearsal knobs for a 1-GPU box: CNIIC_BENCH_BACKEND=gloo CNIIC_BENCH_ONE_GPU=1 put every rank on cuda:0
+        if os.environ.get("CNIIC_BENCH_ONE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CNIIC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
