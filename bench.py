@@ -36,7 +36,6 @@ def main():
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--max-iters", type=int, default=0, help="0 = to convergence, like the reference")
     ap.add_argument("--cpu-sample", type=int, default=1536, help="side of the crop timed on the CPU (0 = skip)")
-    ap.add_argument("--assign-reps", type=int, default=50)
     args = ap.parse_args()
 
     import numpy as np
@@ -120,28 +119,25 @@ def main():
     if rank == 0:
         keys, counts = ctx.hist_rgb24(img, npx=W * H)
         U = int(keys.size)
-        kd = torch.from_numpy(keys.astype(np.uint32).view(np.int32)).to(dev)
-        wd = torch.from_numpy(counts.astype(np.uint32).view(np.int32)).to(dev)
-        import ctypes as C
-        km = C.c_void_p()
-        o = _lib.KmOpts(0, 0, 0, 0)
-        L = _lib.lib()
-        ctx._check(L.cniic_km_create_rgbw(ctx.h, C.c_void_p(kd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_uint64(U),
-                                          C.c_uint32(0), C.c_uint32(1), C.c_uint32(K), C.byref(o), None, C.byref(km)))
-        ctx._check(L.cniic_km_begin(km))
-        # a few real iterations so labels/centroids are in a representative state
-        for _ in range(3):
-            ctx._check(L.cniic_km_assign(km))
-            ctx._check(L.cniic_km_update(km, None))
-        ms = C.c_double(0)
-        ctx._check(L.cniic_km_time_assign(km, C.c_int32(args.assign_reps), C.byref(ms)))
-        L.cniic_km_destroy(km)
+        del keys, counts
+        # one more encode of the same image with a HIP-event pair around every assign launch (on the
+        # stream the kernel runs on): average launch duration over ALL iterations of a real encode
+        rc, ln, stp = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE)
+        ms_sum, launches = ctx.kernel_time("kmeans_rgbw_assign")
+        launch_ms = ms_sum / max(1, launches)
         algo_bytes = 10.0 * U
-        achieved = algo_bytes / (ms.value * 1e-3) / 1e9
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see DESIGN.md 6
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("size") == W and tj.get("K") == K and tj.get("unique_colours") == U:
+                traffic = tj.get("hbm_bytes_per_launch")
         roofline = {"kernel": "k_rgbw_assign_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                    "launch_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": algo_bytes,
-                    "note": "exact cell-pruned assign over %d distinct colours x %d centroids per launch" % (U, K)}
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "launch_ms": round(launch_ms, 5), "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes,
+                    "note": "average over the %d assign launches of one encode; exact cell-pruned assign over %d distinct colours, "
+                            "K=%d; algorithmic bytes = 10 B/colour (SURVEY 8(d) dedup form)" % (launches, U, K)}
 
     # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
     cpu = None

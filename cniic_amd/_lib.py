@@ -15,7 +15,7 @@ ERR = {-1: "BAD_ARG", -2: "TOO_FEW_POINTS", -3: "FEW_ACTIVE", -4: "HIP", -5: "RC
 BAD_ARG, TOO_FEW_POINTS, FEW_ACTIVE, HIP, RCCL, DECODE, NOMEM, CAPACITY, UNSUPPORTED = range(-1, -10, -1)
 SYM_RGB, SYM_SIGNED = 1, 2
 SYNTH_UNIFORM, SYNTH_PHOTO = 0, 1
-KM_BRUTE_FORCE = 1
+KM_BRUTE_FORCE, KM_PROFILE, KM_NO_SKIP = 1, 2, 4
 
 # every symbol include/cniic_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -288,7 +288,7 @@ class Context:
         return nb.value
 
     # ---- codecs
-    def encode(self, expr, img, w=None, h=None, out=None, seed=0, max_iters=0, allow=()):
+    def encode(self, expr, img, w=None, h=None, out=None, seed=0, max_iters=0, flags=0, allow=()):
         """Codec::encode.  img: HxWx3 uint8 numpy array, or a device tensor / address with w,h given."""
         if isinstance(img, np.ndarray):
             img = np.ascontiguousarray(img, np.uint8)
@@ -301,7 +301,7 @@ class Context:
             cap = out.numel() if hasattr(out, "numel") else out.size
         ln = C.c_uint64(0)
         st = KmStats()
-        o = self._opts(seed, max_iters)
+        o = self._opts(seed, max_iters, flags)
         rc = self._check(self._L.cniic_codec_encode_opts(self.h, expr.encode(), C.byref(o), _ptr(img), C.c_uint32(w), C.c_uint32(h),
                                                          _ptr(out), C.c_uint64(cap), C.byref(ln), C.byref(st)), allow)
         if own:

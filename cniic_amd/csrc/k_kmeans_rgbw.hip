@@ -32,6 +32,7 @@
 // non-zero entries flushed with global u64 atomics.  Sums are independent of block count, launch
 // order and GPU count.
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -55,10 +56,13 @@ struct KmRgbwState {
     uint32_t K = 0, Kpad = 0, idbits = 8, nblocks = 1;
     bool wide = false;   // u16 labels
     bool cells = true;   // cell-pruned assign (default) vs brute force
+    bool profile = false; // per-launch event timing of the assign kernel (CNIIC_KM_PROFILE)
+    bool no_skip = false; // CNIIC_KM_NO_SKIP: always run the full schedule (A/B measurement)
     const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
+    DevBuf cell_T, cell_mask, moved_list, queue;  // skip schedule state
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -344,12 +348,21 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t *__restrict
 // One WAVE per cell: the 64 lanes bound all K centroids against the cell's cube (K/64 per lane),
 // reduce min ub across the wave, compact the candidate list into the wave's own LDS strip with
 // ballot prefixes, then sweep the cell's points 64 x kSweep at a time.  No block barrier inside
-// the loop, so sparse and dense cells cost what they contain.  Cells are dealt to waves in
-// contiguous runs of equal COST (cost = kCellFixedCost + points, prefix-summed at setup; the
-// per-wave first cell is precomputed by k_wave_ranges).  With several GPUs the global wave index
-// runs over all shards.  The points of a wave's cells are contiguous in memory, so the loads of
-// the next sweep - of this cell or of the next one - are always in flight while the current sweep
-// computes.  partials receives SIGNED deltas (two's complement u64) of the points that moved.
+// the loop, so sparse and dense cells cost what they contain.  partials receives SIGNED deltas
+// (two's complement u64) of the points that moved (full sums at iteration 0).
+//
+// Two schedules, same per-cell work:
+//  * FULL (many centroids moved): cells are dealt to waves in contiguous runs of equal COST
+//    (cost = kCellFixedCost + points, prefix-summed at setup; per-wave first cell precomputed by
+//    k_wave_ranges).  A wave's points are contiguous in memory, so the loads of the next sweep -
+//    of this cell or of the next one - are always in flight while the current sweep computes.
+//  * SKIP (at most kMaxMovedSkip centroids changed in the last update - the long tail of Lloyd,
+//    centroids are integers and stop moving one by one): every cell remembers T and the bitmask
+//    of its candidate set.  If no moved centroid is in that mask and none of them comes within T
+//    of the cell, then T, the candidate set and every candidate's value are what they were, so
+//    every point of the cell repeats last iteration's decision: the cell is skipped after
+//    |moved| bound evaluations.  Cells are dealt round-robin because the surviving work is
+//    clustered around the centroids that moved.
 __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_count,
                                                      uint32_t G, uint32_t *__restrict__ wfirst) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,12 +375,132 @@ __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict_
     wfirst[g] = g == G ? M : a;
 }
 
+constexpr uint32_t kMaxMovedSkip = 128;  // skip schedule when at most this many centroids moved (2 per lane)
+
+struct CellBox { int32_t r0, g0, b0; };
+__device__ __forceinline__ CellBox cell_box(uint32_t c) {
+    return CellBox{(int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift), (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift),
+                   (int32_t)((c % kCellsPerDim) << kCellShift)};
+}
+// squared distance bounds of centroid colour ck to the cube [r0,r0+7] x [g0,g0+7] x [b0,b0+7]
+__device__ __forceinline__ void cube_bounds(uint32_t ck, const CellBox &bx, uint32_t &lb, uint32_t &ub) {
+    constexpr int32_t ext = (1 << kCellShift) - 1;
+    const int32_t dr0 = (int32_t)((ck >> 16) & 255) - bx.r0, dg0 = (int32_t)((ck >> 8) & 255) - bx.g0, db0 = (int32_t)(ck & 255) - bx.b0;
+    const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
+    const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lbb = db0 < 0 ? -db0 : max(db0 - ext, 0);
+    ub = (uint32_t)(hr * hr + hg * hg + hb * hb);
+    lb = (uint32_t)(lr * lr + lg * lg + lbb * lbb);
+}
+
+// bounds of all K centroids, T = min ub, candidates {k : lb_k <= T} into the wave's strip; the
+// candidate bitmask (bit `lane` of word r <=> centroid r*64+lane) and T are stored for the skip test
+template <int RSTORE>
+__device__ __forceinline__ uint32_t build_candidates(const uint2 *tab, uint32_t K, uint32_t R, uint32_t c, int lane,
+                                                     unsigned long long lt_mask, uint2 *cand, uint32_t *cell_T,
+                                                     unsigned long long *cell_mask, uint32_t m, uint32_t MW) {
+    const CellBox bx = cell_box(c);
+    uint32_t mub = 0xffffffffu;
+    uint32_t lbv[RSTORE];
+#pragma unroll
+    for (int r = 0; r < RSTORE; r++) lbv[r] = 0xffffffffu;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t k = r * 64 + lane;
+        if (k < K) {
+            uint32_t lb, ub;
+            cube_bounds(tab[k].x, bx, lb, ub);
+            mub = min(mub, ub);
+            if (RSTORE > 1) {
+#pragma unroll
+                for (int rr = 0; rr < RSTORE; rr++)
+                    if (rr == (int)r) lbv[rr] = lb;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mub = min(mub, (uint32_t)__shfl_xor(mub, off, 64));
+    const uint32_t T = mub;
+    uint32_t ncand = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        const uint32_t k = r * 64 + lane;
+        bool keep = false;
+        if (RSTORE > 1) {
+#pragma unroll
+            for (int rr = 0; rr < RSTORE; rr++)
+                if (rr == (int)r) keep = lbv[rr] <= T;   // 0xffffffff for k >= K never passes (T < 2^18)
+        } else if (k < K) {
+            uint32_t lb, ub;
+            cube_bounds(tab[k].x, bx, lb, ub);
+            keep = lb <= T;
+        }
+        const unsigned long long bm = __ballot(keep);
+        if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = tab[k];
+        if (lane == 0) cell_mask[(size_t)m * MW + r] = bm;
+        ncand += (uint32_t)__popcll(bm);
+    }
+    if (lane == 0) cell_T[m] = T;
+    __builtin_amdgcn_wave_barrier();
+    return ncand;
+}
+
+// one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip
+template <typename LabelT, int IDBITS>
+__device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], uint32_t base, uint32_t e, int lane,
+                                             const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
+                                             LabelT *__restrict__ labels, const uint32_t *__restrict__ cweight,
+                                             unsigned long long *acc, uint32_t &moved) {
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    uint32_t best[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) best[u] = 0;
+    for (uint32_t j = 0; j < ncand; j++) {
+        const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
+    }
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        const uint32_t q = base + u * 64 + lane;
+        if (q < e) {
+            const uint2 cc = tab[cur[u]];
+            const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
+            const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+            const uint32_t ol = cur[u], pp = p[u];
+            const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
+            if (mv) { labels[q] = (LabelT)nl; moved++; }
+            if (mv || first) {
+                const uint64_t w = cweight[q];
+                const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
+                atomicAdd(&acc[3 * nl + 0], rw);
+                atomicAdd(&acc[3 * nl + 1], gw);
+                atomicAdd(&acc[3 * nl + 2], bw);
+                atomicAdd(&acc[3 * K + nl], (unsigned long long)w);
+                atomicAdd(&acc[4 * K + nl], 1ull);
+                if (!first) {
+                    atomicAdd(&acc[3 * ol + 0], 0ull - rw);
+                    atomicAdd(&acc[3 * ol + 1], 0ull - gw);
+                    atomicAdd(&acc[3 * ol + 2], 0ull - bw);
+                    atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
+                    atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
+                }
+            }
+        }
+    }
+}
+
+struct CellState {          // per non-empty cell, carried between iterations (skip schedule)
+    uint32_t *T;            // [M]
+    unsigned long long *mask;  // [M][MW]
+    const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
+    uint32_t *queue;        // work queue cursor (zeroed by the update kernel)
+    uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
+};
+
 template <typename LabelT, int IDBITS, int WAVES, int RSTORE>
 __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
-    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st) {
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x uint2 cand[K]
     __shared__ uint32_t s_moved;
     __shared__ unsigned long long s_evals;
@@ -377,138 +510,120 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint2 *cand = tab + K + (size_t)wid * K;
-    const uint32_t g = (shard * gridDim.x + blockIdx.x) * WAVES + wid;
-    const uint32_t m0 = wfirst[g], m1 = wfirst[g + 1];
-    // descriptors of the first cell and the loads of its first sweep go out before the LDS set-up
-    uint32_t s = 0, e = 0, c = 0, e_next = 0, c_next = 0;
-    uint32_t p[kSweep], cur[kSweep];
-    if (m0 < m1) {
-        s = ne_start[m0]; e = ne_start[m0 + 1]; c = ne_cell[m0];
-#pragma unroll
-        for (int u = 0; u < kSweep; u++) {
-            const uint32_t q = s + u * 64 + lane;
-            p[u] = q < e ? ckeys[q] : 0u;
-            cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-    for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
-    __syncthreads();
-
-    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
-    constexpr int32_t ext = (1 << kCellShift) - 1;
+    const uint32_t gw0 = shard * gridDim.x * WAVES;          // first wave index of this shard
+    const uint32_t g = gw0 + blockIdx.x * WAVES + wid;
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
     // iterations add/subtract only the points that moved.
     const bool first = st->iter == 0;
+    const uint32_t nS = cs.moved[0];
+    const bool skip_mode = !first && nS <= cs.max_moved;
     const uint32_t R = (K + 63) >> 6;  // centroids per lane
+    const uint32_t MW = R;             // mask words per cell
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t moved = 0;
     unsigned long long evals = 0;
-    for (uint32_t m = m0; m < m1; m++) {
-        const bool has_next = m + 1 < m1;
-        if (has_next) { e_next = ne_start[m + 2]; c_next = ne_cell[m + 1]; }  // consumed at the end of this cell
-        const int32_t r0 = (int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift);
-        const int32_t g0 = (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift);
-        const int32_t b0 = (int32_t)((c % kCellsPerDim) << kCellShift);
-        // ---- bounds of every centroid against the cell's cube; T = min_k ub_k
-        uint32_t mub = 0xffffffffu;
-        uint32_t lbv[RSTORE];
+
+    if (!skip_mode) {
+        // ================================================================= FULL schedule
+        const uint32_t m0 = wfirst[g], m1 = wfirst[g + 1];
+        // descriptors of the first cell and the loads of its first sweep go out before the LDS set-up
+        uint32_t s = 0, e = 0, c = 0, e_next = 0, c_next = 0;
+        uint32_t p[kSweep], cur[kSweep];
+        if (m0 < m1) {
+            s = ne_start[m0]; e = ne_start[m0 + 1]; c = ne_cell[m0];
 #pragma unroll
-        for (int r = 0; r < RSTORE; r++) lbv[r] = 0xffffffffu;
-        for (uint32_t r = 0; r < R; r++) {
-            const uint32_t k = r * 64 + lane;
-            if (k < K) {
-                const uint32_t ck = tab[k].x;
-                const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
-                const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
-                mub = min(mub, (uint32_t)(hr * hr + hg * hg + hb * hb));
-                if (RSTORE > 1) {
-                    const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
+            for (int u = 0; u < kSweep; u++) {
+                const uint32_t q = s + u * 64 + lane;
+                p[u] = q < e ? ckeys[q] : 0u;
+                cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
+        __syncthreads();
+        for (uint32_t m = m0; m < m1; m++) {
+            const bool has_next = m + 1 < m1;
+            if (has_next) { e_next = ne_start[m + 2]; c_next = ne_cell[m + 1]; }  // consumed at the end of this cell
+            const uint32_t ncand = build_candidates<RSTORE>(tab, K, R, c, lane, lt_mask, cand, cs.T, cs.mask, m, MW);
+            // the cell's points; the next sweep (of this cell or of the next) loads meanwhile
+            for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                const bool more = base + 64 * kSweep < e;
+                const uint32_t nts = more ? base + 64 * kSweep : e;
+                const uint32_t nte = more ? e : (has_next ? e_next : e);
+                uint32_t pn[kSweep], curn[kSweep];
 #pragma unroll
-                    for (int rr = 0; rr < RSTORE; rr++)
-                        if (rr == (int)r) lbv[rr] = (uint32_t)(lr * lr + lg * lg + lb * lb);
+                for (int u = 0; u < kSweep; u++) {
+                    const uint32_t qn = nts + u * 64 + lane;
+                    pn[u] = qn < nte ? ckeys[qn] : 0u;
+                    curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
                 }
+                sweep_points<LabelT, IDBITS>(p, cur, base, e, lane, cand, ncand, tab, K, first, labels, cweight, acc, moved);
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
             }
+            evals += (unsigned long long)(e - s) * (ncand + 1);
+            __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
+            s = e; e = e_next; c = c_next;
         }
+    } else {
+        // ================================================================= SKIP schedule
+        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
+        __syncthreads();
+        // this shard's cells: [m_lo, m_hi); the (up to 2 per lane) centroids that moved
+        const uint32_t m_lo = wfirst[gw0], m_hi = wfirst[gw0 + gridDim.x * WAVES];
+        const uint32_t k1 = lane < nS ? cs.moved[1 + lane] : 0xffffffffu;
+        const uint32_t k2 = 64 + lane < nS ? cs.moved[1 + 64 + lane] : 0xffffffffu;
+        const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u, ck2 = k2 != 0xffffffffu ? tab[k2].x : 0u;
+        // cells are dealt round-robin: what survives the skip test is clustered around the centroids that
+        // moved, and striding spreads those clusters over all waves (a shared atomic queue would
+        // saturate: one word serves ~90 dequeues/us)
+        const uint32_t nwaves = gridDim.x * WAVES;
+        {
+            for (uint32_t m = m_lo + blockIdx.x * WAVES + wid; m < m_hi; m += nwaves) {
+                const uint32_t c = ne_cell[m];
+                const uint32_t Tp = cs.T[m];
+                const CellBox bx = cell_box(c);
+                bool dirty = false;
+                if (k1 != 0xffffffffu) {
+                    uint32_t lb, ub;
+                    cube_bounds(ck1, bx, lb, ub);
+                    dirty = lb <= Tp || ((cs.mask[(size_t)m * MW + (k1 >> 6)] >> (k1 & 63)) & 1ull);
+                }
+                if (k2 != 0xffffffffu) {
+                    uint32_t lb, ub;
+                    cube_bounds(ck2, bx, lb, ub);
+                    dirty = dirty || lb <= Tp || ((cs.mask[(size_t)m * MW + (k2 >> 6)] >> (k2 & 63)) & 1ull);
+                }
+                if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
+                const uint32_t s = ne_start[m], e = ne_start[m + 1];
+                uint32_t p[kSweep], cur[kSweep];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mub = min(mub, (uint32_t)__shfl_xor(mub, off, 64));
-        const uint32_t T = mub;
-        // ---- candidates {k : lb_k <= T}, compacted with ballot prefixes into this wave's strip
-        uint32_t ncand = 0;
-        for (uint32_t r = 0; r < R; r++) {
-            const uint32_t k = r * 64 + lane;
-            bool keep = false;
-            if (RSTORE > 1) {
+                for (int u = 0; u < kSweep; u++) {
+                    const uint32_t q = s + u * 64 + lane;
+                    p[u] = q < e ? ckeys[q] : 0u;
+                    cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+                }
+                const uint32_t ncand = build_candidates<RSTORE>(tab, K, R, c, lane, lt_mask, cand, cs.T, cs.mask, m, MW);
+                for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                    uint32_t pn[kSweep], curn[kSweep];
 #pragma unroll
-                for (int rr = 0; rr < RSTORE; rr++)
-                    if (rr == (int)r) keep = lbv[rr] <= T;   // 0xffffffff for k >= K never passes (T < 2^18)
-            } else if (k < K) {
-                const uint32_t ck = tab[k].x;
-                const int32_t dr0 = (int32_t)((ck >> 16) & 255) - r0, dg0 = (int32_t)((ck >> 8) & 255) - g0, db0 = (int32_t)(ck & 255) - b0;
-                const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lb = db0 < 0 ? -db0 : max(db0 - ext, 0);
-                keep = (uint32_t)(lr * lr + lg * lg + lb * lb) <= T;
-            }
-            const unsigned long long bm = __ballot(keep);
-            if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = tab[k];
-            ncand += (uint32_t)__popcll(bm);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- the cell's points; the next sweep (of this cell or of the next) loads meanwhile
-        for (uint32_t base = s; base < e; base += 64 * kSweep) {
-            const bool more = base + 64 * kSweep < e;
-            const uint32_t nts = more ? base + 64 * kSweep : e;
-            const uint32_t nte = more ? e : (has_next ? e_next : e);
-            uint32_t pn[kSweep], curn[kSweep];
-#pragma unroll
-            for (int u = 0; u < kSweep; u++) {
-                const uint32_t qn = nts + u * 64 + lane;
-                pn[u] = qn < nte ? ckeys[qn] : 0u;
-                curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
-            }
-            uint32_t best[kSweep];
-#pragma unroll
-            for (int u = 0; u < kSweep; u++) best[u] = 0;
-            for (uint32_t j = 0; j < ncand; j++) {
-                const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
-            }
-#pragma unroll
-            for (int u = 0; u < kSweep; u++) {
-                const uint32_t q = base + u * 64 + lane;
-                if (q < e) {
-                    const uint2 cc = tab[cur[u]];
-                    const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
-                    const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
-                    const uint32_t ol = cur[u], pp = p[u];
-                    const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
-                    if (mv) { labels[q] = (LabelT)nl; moved++; }
-                    if (mv || first) {
-                        const uint64_t w = cweight[q];
-                        const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
-                        atomicAdd(&acc[3 * nl + 0], rw);
-                        atomicAdd(&acc[3 * nl + 1], gw);
-                        atomicAdd(&acc[3 * nl + 2], bw);
-                        atomicAdd(&acc[3 * K + nl], (unsigned long long)w);
-                        atomicAdd(&acc[4 * K + nl], 1ull);
-                        if (!first) {
-                            atomicAdd(&acc[3 * ol + 0], 0ull - rw);
-                            atomicAdd(&acc[3 * ol + 1], 0ull - gw);
-                            atomicAdd(&acc[3 * ol + 2], 0ull - bw);
-                            atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
-                            atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
-                        }
+                    for (int u = 0; u < kSweep; u++) {
+                        const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
+                        pn[u] = qn < e ? ckeys[qn] : 0u;
+                        curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
                     }
-                }
-            }
+                    sweep_points<LabelT, IDBITS>(p, cur, base, e, lane, cand, ncand, tab, K, false, labels, cweight, acc, moved);
 #pragma unroll
-            for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
+                    for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
+                }
+                evals += (unsigned long long)(e - s) * (ncand + 1);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        evals += (unsigned long long)(e - s) * (ncand + 1);
-        __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
-        s = e; e = e_next; c = c_next;
     }
     moved = wave_reduce_sum(moved);
     if (lane == 0) {
@@ -534,10 +649,11 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
                                                      uint64_t max_iters, uint2 *__restrict__ cconst,
                                                      uint32_t *__restrict__ cent, uint64_t *__restrict__ members_out,
                                                      uint64_t *__restrict__ wsum_out,
+                                                     uint32_t *__restrict__ moved_list, uint32_t *__restrict__ queue,
                                                      KmDevState *__restrict__ st) {
     if (st->done) return;
-    __shared__ uint32_t s_reseed, s_active;
-    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; }
+    __shared__ uint32_t s_reseed, s_active, s_nmoved;
+    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
     if (mode == 1)
         for (uint32_t i = threadIdx.x; i < 5 * K; i += blockDim.x) running[i] += partials[i];
     __syncthreads();
@@ -559,10 +675,12 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
             ck = (r << 16) | (g << 8) | b;
             atomicAdd(&s_active, 1u);
         }
+        if (moved_list && ck != cent[k]) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;  // centroids that changed value
         cent[k] = ck;
         cconst[k] = make_cconst(ck, k, idbits);
     }
     __syncthreads();
+    if (threadIdx.x == 0 && moved_list) { moved_list[0] = s_nmoved; *queue = 0; }
     const uint64_t changed = partials[5 * (size_t)K];
     const uint64_t evals = partials[5 * (size_t)K + 1];
     __syncthreads();
@@ -635,6 +753,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->seed = (opts && opts->seed) ? opts->seed : kDefaultSeed;
     s->max_iters = opts ? opts->max_iters : 0;
     s->cells = !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE));
+    s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
+    s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     s->keys = keys_d; s->weight = weight_d;
     const uint64_t n = hi - lo;
     const uint64_t W = 5 * (uint64_t)K + 2;
@@ -664,6 +784,16 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_count, 4);
         const uint32_t G = s->nblocks * (s->wide ? 1u : 4u) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
+        KM_ALLOC(s->cell_T, (uint64_t)kNumCells * 4);
+        KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
+        KM_ALLOC(s->moved_list, ((uint64_t)K + 1) * 4);
+        KM_ALLOC(s->queue, 16);
+        (void)hipMemsetAsync(s->queue.p, 0, 16, c->stream);
+        {   // before the first update every centroid counts as moved
+            const uint32_t all = K;
+            (void)hipMemcpyAsync(s->moved_list.p, &all, 4, hipMemcpyHostToDevice, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+        }
         KM_ALLOC(s->running, W * 8);
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
@@ -730,7 +860,8 @@ static int launch_update(KmRgbwState *s, int mode) {
     Ctx *c = s->c;
     hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->running.as<uint64_t>(), mode, s->keys, s->U,
                        s->K, s->idbits, s->seed, s->max_iters, s->cconst.as<uint2>(), s->cent.as<uint32_t>(),
-                       s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(), s->dstate.as<KmDevState>());
+                       s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(), s->cells ? s->moved_list.as<uint32_t>() : nullptr,
+                       s->queue.as<uint32_t>(), s->dstate.as<KmDevState>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -765,16 +896,18 @@ static void launch_assign(KmRgbwState *s) {
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = reinterpret_cast<unsigned long long *>(s->partials);
+        CellState cs{s->cell_T.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(), s->queue.as<uint32_t>(),
+                     s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs);
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 8);
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
         }
         return;
     }
@@ -818,41 +951,80 @@ int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed) {
     return CNIIC_OK;
 }
 
+// per-launch HIP event pairs (profiling only): sum of the assign kernel's own durations
+struct LaunchTimer {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    ~LaunchTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+    hipEvent_t next() {
+        if (used == ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
+        return ev[used++];
+    }
+    double total_ms() {
+        double t = 0;
+        for (size_t i = 0; i + 1 < used; i += 2) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); t += ms; }
+        return t;
+    }
+};
+
 // Whole loop on one GPU: iterations are enqueued in batches with no host round trip inside a
 // batch; kernels of iterations past convergence exit on the device-side `done` flag, so the
 // result is exactly that of the reference's `while changed_assignment` loop (kmeans.rs:26-32).
+// With CNIIC_KM_PROFILE every assign launch is bracketed by HIP events on the ctx stream and the
+// summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
 int km_rgbw_run(KmRgbwState *s) {
     Ctx *c = s->c;
     const int batch = 8;
     KmDevState h;
-    CNIIC_TRY(km_rgbw_fold_initial(s));
+    LaunchTimer lt;
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter");
     for (;;) {
         for (int b = 0; b < batch; b++) {
-            CNIIC_TRY(km_rgbw_assign(s));
+            if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
+            launch_assign(s);
+            if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
+            if (!s->cells) {
+                const uint32_t W = 5 * s->K + 2;
+                const uint32_t ry = std::max(1u, std::min(16u, s->nblocks / 4));
+                hipLaunchKernelGGL(k_slab_reduce, dim3(ceil_div(W, 64), ry), dim3(256), 0, c->stream, s->slabs.as<uint64_t>(),
+                                   s->nblocks, W, s->partials, s->dstate.as<KmDevState>());
+            }
             CNIIC_TRY(km_rgbw_update(s));
         }
+        CNIIC_HIP_TRY(c, hipGetLastError());
         CNIIC_TRY(read_state(s, &h));
         if (h.done) break;
     }
     timer.stop(h.iter);
+    if (s->profile) {
+        // launches past convergence are no-ops (a few microseconds each) and are not counted
+        double t = 0;
+        for (size_t i = 0; i + 1 < lt.used && i / 2 < h.iter; i += 2) { float ms = 0.f; (void)hipEventElapsedTime(&ms, lt.ev[i], lt.ev[i + 1]); t += ms; }
+        KernelTime &kt = c->ktimes["kmeans_rgbw_assign"];
+        kt.ms += t;
+        kt.launches += h.iter;
+    }
     return CNIIC_OK;
 }
 
-// Average duration of the assign kernel alone (HIP events on the ctx stream around `reps`
-// back-to-back launches on the current state).  Labels may move towards the fixed point of the
-// current centroids; the partial sums are left inconsistent, so the state must be discarded.
+// Average duration of the assign kernel alone over `reps` launches on the current state (HIP event
+// pair per launch on the ctx stream).  Labels may move towards the fixed point of the current
+// centroids; the partial sums are left inconsistent, so the state must be discarded afterwards.
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch) {
     Ctx *c = s->c;
-    launch_assign(s);  // warm-up
-    CNIIC_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < reps; i++) launch_assign(s);
-    CNIIC_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    CNIIC_HIP_TRY(c, hipEventSynchronize(c->ev1));
+    LaunchTimer lt;
+    for (int i = 0; i <= reps; i++) {  // launch 0 is a warm-up
+        if (s->cells) CNIIC_HIP_TRY(c, hipMemsetAsync(s->queue.p, 0, 4, c->stream));  // skip schedule: rewind the work queue
+        hipEvent_t a = lt.next(), b = lt.next();
+        CNIIC_HIP_TRY(c, hipEventRecord(a, c->stream));
+        launch_assign(s);
+        CNIIC_HIP_TRY(c, hipEventRecord(b, c->stream));
+    }
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     CNIIC_HIP_TRY(c, hipGetLastError());
-    float ms = 0.f;
-    CNIIC_HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    *ms_per_launch = (double)ms / reps;
+    double t = 0;
+    for (size_t i = 2; i + 1 < lt.used; i += 2) { float ms = 0.f; (void)hipEventElapsedTime(&ms, lt.ev[i], lt.ev[i + 1]); t += ms; }
+    *ms_per_launch = t / reps;
     return CNIIC_OK;
 }
 

@@ -82,6 +82,8 @@ typedef struct {
     uint32_t reserved;
 } cniic_kmeans_opts;
 #define CNIIC_KM_BRUTE_FORCE 1u  /* disable bound-based pruning (debug / A-B measurement) */
+#define CNIIC_KM_PROFILE     2u  /* HIP-event pair around every assign launch -> cniic_last_kernel_time("kmeans_rgbw_assign") */
+#define CNIIC_KM_NO_SKIP     4u  /* never use the skip schedule of the pruned assign (A-B measurement) */
 
 typedef struct {
     uint64_t iterations;     /* src/kmeans.rs:33 "#iterations"                         */
