@@ -40,7 +40,8 @@ struct KmXyState {
     uint32_t w = 0, h = 0, K = 0, nblocks = 1, tiles_x = 0, tiles_y = 0, flush_every = 1;
     uint64_t N = 0, seed = 0, max_iters = 0;
     bool brute = false;
-    DevBuf labels, cx, cy, crgb, c2, partials, dstate, members_last;
+    DevBuf labels, cx, cy, crgb, c2, partials, running, dstate, members_last, tile_box, tile_T, tile_mask, moved_list;
+    bool no_skip = false;
     XyCent cent() const { return XyCent{cx.as<int32_t>(), cy.as<int32_t>(), crgb.as<uint32_t>(), c2.as<int32_t>()}; }
 };
 
@@ -84,31 +85,67 @@ __device__ __forceinline__ void cent_bounds(const XyCent &ct, uint32_t k, const 
 }
 
 // partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
-// [6K] moved ; [6K+1] pair evaluations
+// [6K] moved ; [6K+1] pair evaluations.  At iteration 0 the partials are the full sums of the new
+// assignment; afterwards they are SIGNED deltas of the pixels that moved, added to running sums.
+constexpr uint32_t kXMaxMovedSkip = 512;   // tile-skip schedule when at most this many centroids moved
+constexpr int kXMaxR = kXMaxK / kXThreads; // centroids per thread in the candidate pass (16)
+
+struct TileState {              // per tile, carried between iterations
+    uint2 *box;                 // colour extents: x = r0|r1<<8|g0<<16|g1<<24, y = b0|b1<<8   (static)
+    uint32_t *T;                // min_k ub_k of the last candidate build
+    unsigned long long *mask;   // [ntiles][K/64 rounded up] candidate bitmask of the last build
+    const uint32_t *moved;      // [0] = number of centroids changed by the last update, then their ids
+    uint32_t max_moved;         // skip schedule when moved[0] <= max_moved (0 disables it)
+};
+
 __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
                                                          uint32_t tiles_x, uint32_t ntiles, uint32_t K, XyCent ct,
                                                          uint16_t *__restrict__ labels,
                                                          unsigned long long *__restrict__ partials,
                                                          const KmDevState *__restrict__ st, uint32_t flush_every,
-                                                         int brute) {
-    extern __shared__ __align__(16) uint32_t acc[];  // [K][6] per-block partial sums (x,y,r,g,b,count)
+                                                         int brute, TileState ts) {
+    extern __shared__ __align__(16) uint32_t acc[];  // [K][6] per-block partial sums (x,y,r,g,b,count), wrap-around signed
     __shared__ int4 cand[kMaxCand];                   // (cx, cy, crgb, c2) of the tile's candidates
     __shared__ uint16_t cand_k[kMaxCand];
-    __shared__ int32_t red[12];                       // colour bbox reduction + scalars
+    __shared__ unsigned long long s_mask[kXMaxK / 64];
+    __shared__ int32_t red[8];
     __shared__ uint32_t s_minub, s_ncand;
     __shared__ uint32_t wsum[kXThreads / 64];
     if (st->done) return;
     for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) acc[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    const bool first = st->iter == 0;
+    const uint32_t nS = ts.moved[0];
+    const bool skip_mode = !first && !brute && nS <= ts.max_moved;
+    const uint32_t MW = (K + 63) >> 6;
     uint32_t moved = 0;
     unsigned long long evals = 0;
     uint32_t since_flush = 0;
-    const uint32_t R = (K + kXThreads - 1) / kXThreads;  // centroids per thread in the candidate pass
+    const uint32_t R = (K + kXThreads - 1) / kXThreads;  // centroids per thread in the candidate pass (<= kXMaxR)
+    const uint32_t k0 = threadIdx.x * R, k1 = min(k0 + R, K);
 
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t tx0 = (tile % tiles_x) * kTW, ty0 = (tile / tiles_x) * kTH;
         const uint32_t tw = min((uint32_t)kTW, w - tx0), th = min((uint32_t)kTH, h - ty0);
+        TileBox bx{(int32_t)tx0, (int32_t)(tx0 + tw - 1), (int32_t)ty0, (int32_t)(ty0 + th - 1), 0, 0, 0, 0, 0, 0};
+        if (!first) {
+            const uint2 pb = ts.box[tile];
+            bx.r0 = pb.x & 255; bx.r1 = (pb.x >> 8) & 255; bx.g0 = (pb.x >> 16) & 255; bx.g1 = pb.x >> 24;
+            bx.b0 = pb.y & 255; bx.b1 = (pb.y >> 8) & 255;
+        }
+        // ---- skip test: did anything that matters to this tile change?
+        if (skip_mode) {
+            const uint32_t Tp = ts.T[tile];
+            int dirty = 0;
+            for (uint32_t j = threadIdx.x; j < nS; j += kXThreads) {
+                const uint32_t k = ts.moved[1 + j];
+                uint32_t lb, ub;
+                cent_bounds(ct, k, bx, lb, ub);
+                dirty |= lb <= Tp || ((ts.mask[(size_t)tile * MW + (k >> 6)] >> (k & 63)) & 1ull);
+            }
+            if (!__syncthreads_or(dirty)) continue;  // same T, same candidates, same centroid values: every pixel repeats its decision
+        }
         // ---- load this thread's pixels: pixel j of thread t is (t & 63, (t >> 6) + 4 j)
         uint32_t px[kXPPT];
         bool valid[kXPPT];
@@ -124,53 +161,61 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 r0 = min(r0, r); r1 = max(r1, r); g0 = min(g0, g); g1 = max(g1, g); b0 = min(b0, b); b1 = max(b1, b);
             }
         }
-        // ---- tile bounding box (block reduction of the colour extents)
         if (threadIdx.x == 0) {
             red[0] = 255; red[1] = 0; red[2] = 255; red[3] = 0; red[4] = 255; red[5] = 0;
             s_minub = 0xffffffffu; s_ncand = 0;
         }
+        for (uint32_t i = threadIdx.x; i < MW; i += kXThreads) s_mask[i] = 0ull;
         __syncthreads();
+        if (first) {  // tile bounding box (block reduction of the colour extents); static, kept for later iterations
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            r0 = min(r0, __shfl_down(r0, off, 64)); r1 = max(r1, __shfl_down(r1, off, 64));
-            g0 = min(g0, __shfl_down(g0, off, 64)); g1 = max(g1, __shfl_down(g1, off, 64));
-            b0 = min(b0, __shfl_down(b0, off, 64)); b1 = max(b1, __shfl_down(b1, off, 64));
+            for (int off = 32; off > 0; off >>= 1) {
+                r0 = min(r0, __shfl_down(r0, off, 64)); r1 = max(r1, __shfl_down(r1, off, 64));
+                g0 = min(g0, __shfl_down(g0, off, 64)); g1 = max(g1, __shfl_down(g1, off, 64));
+                b0 = min(b0, __shfl_down(b0, off, 64)); b1 = max(b1, __shfl_down(b1, off, 64));
+            }
+            if (lane == 0) {
+                atomicMin(&red[0], r0); atomicMax(&red[1], r1); atomicMin(&red[2], g0);
+                atomicMax(&red[3], g1); atomicMin(&red[4], b0); atomicMax(&red[5], b1);
+            }
+            __syncthreads();
+            bx.r0 = red[0]; bx.r1 = red[1]; bx.g0 = red[2]; bx.g1 = red[3]; bx.b0 = red[4]; bx.b1 = red[5];
+            if (threadIdx.x == 0)
+                ts.box[tile] = make_uint2((uint32_t)bx.r0 | ((uint32_t)bx.r1 << 8) | ((uint32_t)bx.g0 << 16) | ((uint32_t)bx.g1 << 24),
+                                          (uint32_t)bx.b0 | ((uint32_t)bx.b1 << 8));
         }
-        if (lane == 0) {
-            atomicMin(&red[0], r0); atomicMax(&red[1], r1); atomicMin(&red[2], g0);
-            atomicMax(&red[3], g1); atomicMin(&red[4], b0); atomicMax(&red[5], b1);
-        }
-        __syncthreads();
-        TileBox bx{(int32_t)tx0, (int32_t)(tx0 + tw - 1), (int32_t)ty0, (int32_t)(ty0 + th - 1),
-                   red[0], red[1], red[2], red[3], red[4], red[5]};
         // ---- candidate set: thread t owns centroids [t R, (t+1) R) so the list comes out in ascending k
         uint32_t ncand = K;
         bool use_list = !brute;
         if (use_list) {
-            const uint32_t k0 = threadIdx.x * R, k1 = min(k0 + R, K);
+            uint32_t lbv[kXMaxR];
             uint32_t mub = 0xffffffffu;
-            for (uint32_t k = k0; k < k1; k++) {
-                uint32_t lb, ub;
-                cent_bounds(ct, k, bx, lb, ub);
-                mub = min(mub, ub);
+#pragma unroll
+            for (int i = 0; i < kXMaxR; i++) {
+                lbv[i] = 0xffffffffu;
+                const uint32_t k = k0 + i;
+                if ((uint32_t)i < R && k < k1) {
+                    uint32_t ub;
+                    cent_bounds(ct, k, bx, lbv[i], ub);
+                    mub = min(mub, ub);
+                }
             }
             mub = wave_reduce_min(mub);
             if (lane == 0) atomicMin(&s_minub, mub);
             __syncthreads();
             const uint32_t T = s_minub;
             uint32_t mine = 0;
-            for (uint32_t k = k0; k < k1; k++) {
-                uint32_t lb, ub;
-                cent_bounds(ct, k, bx, lb, ub);
-                mine += lb <= T;
-            }
+#pragma unroll
+            for (int i = 0; i < kXMaxR; i++) mine += lbv[i] <= T;
             uint32_t off = block_exclusive_scan<kXThreads>(mine, wsum);
             if (threadIdx.x == kXThreads - 1) s_ncand = off + mine;
-            if (off + mine <= kMaxCand) {
-                for (uint32_t k = k0; k < k1; k++) {
-                    uint32_t lb, ub;
-                    cent_bounds(ct, k, bx, lb, ub);
-                    if (lb <= T) {
+            const bool fits = off + mine <= kMaxCand;
+#pragma unroll
+            for (int i = 0; i < kXMaxR; i++) {
+                if (lbv[i] <= T) {
+                    const uint32_t k = k0 + i;
+                    atomicOr(&s_mask[k >> 6], 1ull << (k & 63));
+                    if (fits) {
                         cand[off] = make_int4(ct.cx[k], ct.cy[k], (int32_t)ct.crgb[k], ct.c2[k]);
                         cand_k[off] = (uint16_t)k;
                         off++;
@@ -181,6 +226,8 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             ncand = s_ncand;
             use_list = ncand <= kMaxCand;
             if (!use_list) ncand = K;
+            if (threadIdx.x == 0) ts.T[tile] = T;
+            for (uint32_t i = threadIdx.x; i < MW; i += kXThreads) ts.mask[(size_t)tile * MW + i] = s_mask[i];
         }
         // ---- assign
 #pragma unroll
@@ -209,31 +256,38 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             }
             const uint32_t cur = labels[idx];
             const int32_t gcur = 2 * (x * ct.cx[cur] + y * ct.cy[cur] + (int32_t)xdot4(px[j], ct.crgb[cur])) - ct.c2[cur];
-            uint32_t nl = cur;
-            if (best > gcur) {  // strictly closer (kmeans.rs:375)
-                nl = bk;
-                labels[idx] = (uint16_t)nl;
-                moved++;
+            const bool mv = best > gcur;  // strictly closer (kmeans.rs:375)
+            const uint32_t nl = mv ? bk : cur;
+            if (mv) { labels[idx] = (uint16_t)nl; moved++; }
+            if (mv || first) {  // vector_add clusterc.rs:221-228, as +new / -old
+                uint32_t *a = acc + 6 * nl;
+                atomicAdd(a + 0, (uint32_t)x);
+                atomicAdd(a + 1, (uint32_t)y);
+                atomicAdd(a + 2, (px[j] >> 16) & 255);
+                atomicAdd(a + 3, (px[j] >> 8) & 255);
+                atomicAdd(a + 4, px[j] & 255);
+                atomicAdd(a + 5, 1u);
+                if (!first) {
+                    uint32_t *o = acc + 6 * cur;
+                    atomicAdd(o + 0, 0u - (uint32_t)x);
+                    atomicAdd(o + 1, 0u - (uint32_t)y);
+                    atomicAdd(o + 2, 0u - ((px[j] >> 16) & 255));
+                    atomicAdd(o + 3, 0u - ((px[j] >> 8) & 255));
+                    atomicAdd(o + 4, 0u - (px[j] & 255));
+                    atomicAdd(o + 5, 0u - 1u);
+                }
             }
-            uint32_t *a = acc + 6 * nl;  // vector_add clusterc.rs:221-228
-            atomicAdd(a + 0, (uint32_t)x);
-            atomicAdd(a + 1, (uint32_t)y);
-            atomicAdd(a + 2, (px[j] >> 16) & 255);
-            atomicAdd(a + 3, (px[j] >> 8) & 255);
-            atomicAdd(a + 4, px[j] & 255);
-            atomicAdd(a + 5, 1u);
             evals += ncand + 1;
         }
-        // ---- flush the LDS partials before a u32 lane can overflow
+        // ---- flush the LDS partials before a signed 32-bit lane can overflow
         if (++since_flush >= flush_every) {
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < K; i += kXThreads) {
-                uint32_t cnt = acc[6 * i + 5];
-                if (cnt) {
-#pragma unroll
-                    for (int d = 0; d < 5; d++) { atomicAdd(&partials[5 * (size_t)i + d], (unsigned long long)acc[6 * i + d]); acc[6 * i + d] = 0; }
-                    atomicAdd(&partials[5 * (size_t)K + i], (unsigned long long)cnt);
-                    acc[6 * i + 5] = 0;
+            for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) {
+                const uint32_t v = acc[i];
+                if (v) {
+                    const uint32_t k = i / 6, d = i % 6;
+                    atomicAdd(&partials[d < 5 ? 5 * (size_t)k + d : 5 * (size_t)K + k], (unsigned long long)(long long)(int32_t)v);
+                    acc[i] = 0;
                 }
             }
             since_flush = 0;
@@ -241,12 +295,11 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         __syncthreads();
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < K; i += kXThreads) {
-        uint32_t cnt = acc[6 * i + 5];
-        if (cnt) {
-#pragma unroll
-            for (int d = 0; d < 5; d++) atomicAdd(&partials[5 * (size_t)i + d], (unsigned long long)acc[6 * i + d]);
-            atomicAdd(&partials[5 * (size_t)K + i], (unsigned long long)cnt);
+    for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) {
+        const uint32_t v = acc[i];
+        if (v) {
+            const uint32_t k = i / 6, d = i % 6;
+            atomicAdd(&partials[d < 5 ? 5 * (size_t)k + d : 5 * (size_t)K + k], (unsigned long long)(long long)(int32_t)v);
         }
     }
     moved = block_reduce_sum<kXThreads>(moved);
@@ -257,16 +310,19 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
 
 // Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137)
 __global__ __launch_bounds__(256) void k_xy_update(unsigned long long *__restrict__ partials,
+                                                   unsigned long long *__restrict__ running,
                                                    const uint8_t *__restrict__ rgb, uint32_t w, uint64_t N,
                                                    uint32_t K, uint64_t seed, uint64_t max_iters, XyCent ct,
-                                                   uint64_t *__restrict__ members_out, KmDevState *__restrict__ st) {
+                                                   uint64_t *__restrict__ members_out, uint32_t *__restrict__ moved_list,
+                                                   KmDevState *__restrict__ st) {
     if (st->done) return;
-    __shared__ uint32_t s_reseed, s_active;
-    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; }
+    __shared__ uint32_t s_reseed, s_active, s_nmoved;
+    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
+    for (uint32_t i = threadIdx.x; i < 6 * K; i += blockDim.x) running[i] += partials[i];
     __syncthreads();
     const uint64_t iter = st->iter;
     for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-        const unsigned long long m = partials[5 * (size_t)K + k];
+        const unsigned long long m = running[5 * (size_t)K + k];
         members_out[k] = m;
         int32_t x, y;
         uint32_t col;
@@ -276,14 +332,15 @@ __global__ __launch_bounds__(256) void k_xy_update(unsigned long long *__restric
             col = rgb_key(rgb + 3 * idx);
             atomicAdd(&s_reseed, 1u);
         } else {
-            x = (int32_t)(uint32_t)(partials[5 * (size_t)k + 0] / m);
-            y = (int32_t)(uint32_t)(partials[5 * (size_t)k + 1] / m);
-            uint32_t r = (uint32_t)(partials[5 * (size_t)k + 2] / m) & 255;
-            uint32_t g = (uint32_t)(partials[5 * (size_t)k + 3] / m) & 255;
-            uint32_t b = (uint32_t)(partials[5 * (size_t)k + 4] / m) & 255;
+            x = (int32_t)(uint32_t)(running[5 * (size_t)k + 0] / m);
+            y = (int32_t)(uint32_t)(running[5 * (size_t)k + 1] / m);
+            uint32_t r = (uint32_t)(running[5 * (size_t)k + 2] / m) & 255;
+            uint32_t g = (uint32_t)(running[5 * (size_t)k + 3] / m) & 255;
+            uint32_t b = (uint32_t)(running[5 * (size_t)k + 4] / m) & 255;
             col = (r << 16) | (g << 8) | b;
             atomicAdd(&s_active, 1u);
         }
+        if (ct.cx[k] != x || ct.cy[k] != y || ct.crgb[k] != col) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
         ct.cx[k] = x; ct.cy[k] = y; ct.crgb[k] = col;
         ct.c2[k] = x * x + y * y + (int32_t)xdot4(col, col);
     }
@@ -293,6 +350,7 @@ __global__ __launch_bounds__(256) void k_xy_update(unsigned long long *__restric
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += blockDim.x) partials[i] = 0;
     if (threadIdx.x == 0) {
+        moved_list[0] = s_nmoved;
         st->changed_ring[iter % kHistRing] = changed;
         st->moved_last = changed;
         st->reseeds += s_reseed;
@@ -329,8 +387,8 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     s.tiles_y = (uint32_t)ceil_div(h, kTH);
     const uint32_t ntiles = s.tiles_x * s.tiles_y;
     s.nblocks = std::min<uint32_t>(ntiles, 512);
-    // u32 LDS partials: (pixels between flushes) * max coordinate < 2^32
-    s.flush_every = std::max<uint32_t>(1, (uint32_t)((1ull << 32) / ((uint64_t)std::max(w, h) * kTW * kTH)) - 1);
+    // signed 32-bit LDS partials: (pixels between flushes) * max coordinate < 2^31
+    s.flush_every = std::max<uint32_t>(1, (uint32_t)((1ull << 31) / ((uint64_t)std::max(w, h) * kTW * kTH)) - 1);
     CNIIC_HIP_TRY(c, s.labels.alloc(N * 2));
     CNIIC_HIP_TRY(c, s.cx.alloc((uint64_t)K * 4));
     CNIIC_HIP_TRY(c, s.cy.alloc((uint64_t)K * 4));
@@ -339,8 +397,18 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, s.partials.alloc((6 * (uint64_t)K + 2) * 8));
     CNIIC_HIP_TRY(c, s.members_last.alloc((uint64_t)K * 8));
     CNIIC_HIP_TRY(c, s.dstate.alloc(sizeof(KmDevState)));
+    CNIIC_HIP_TRY(c, s.running.alloc((6 * (uint64_t)K + 2) * 8));
+    CNIIC_HIP_TRY(c, s.tile_box.alloc((uint64_t)ntiles * 8));
+    CNIIC_HIP_TRY(c, s.tile_T.alloc((uint64_t)ntiles * 4));
+    CNIIC_HIP_TRY(c, s.tile_mask.alloc((uint64_t)ntiles * ((K + 63) / 64) * 8));
+    CNIIC_HIP_TRY(c, s.moved_list.alloc(((uint64_t)K + 1) * 4));
+    s.no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.partials.p, 0, (6 * (uint64_t)K + 2) * 8, c->stream));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(s.running.p, 0, (6 * (uint64_t)K + 2) * 8, c->stream));
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.dstate.p, 0, sizeof(KmDevState), c->stream));
+    const uint32_t all = K;  // before the first update every centroid counts as moved
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.moved_list.p, &all, 4, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
 
@@ -348,15 +416,18 @@ static int xy_assign(KmXyState &s) {
     Ctx *c = s.c;
     hipLaunchKernelGGL(k_xy_assign, dim3(s.nblocks), dim3(kXThreads), (size_t)s.K * 6 * 4, c->stream, s.rgb, s.w, s.h,
                        s.tiles_x, s.tiles_x * s.tiles_y, s.K, s.cent(), s.labels.as<uint16_t>(),
-                       s.partials.as<unsigned long long>(), s.dstate.as<KmDevState>(), s.flush_every, s.brute ? 1 : 0);
+                       s.partials.as<unsigned long long>(), s.dstate.as<KmDevState>(), s.flush_every, s.brute ? 1 : 0,
+                       TileState{s.tile_box.as<uint2>(), s.tile_T.as<uint32_t>(), s.tile_mask.as<unsigned long long>(),
+                                 s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip});
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
 
 static int xy_update(KmXyState &s) {
     Ctx *c = s.c;
-    hipLaunchKernelGGL(k_xy_update, dim3(1), dim3(256), 0, c->stream, s.partials.as<unsigned long long>(), s.rgb, s.w, s.N,
-                       s.K, s.seed, s.max_iters, s.cent(), s.members_last.as<uint64_t>(), s.dstate.as<KmDevState>());
+    hipLaunchKernelGGL(k_xy_update, dim3(1), dim3(256), 0, c->stream, s.partials.as<unsigned long long>(),
+                       s.running.as<unsigned long long>(), s.rgb, s.w, s.N, s.K, s.seed, s.max_iters, s.cent(),
+                       s.members_last.as<uint64_t>(), s.moved_list.as<uint32_t>(), s.dstate.as<KmDevState>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
