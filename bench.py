@@ -136,8 +136,10 @@ def main():
         roofline = {"kernel": "k_rgbw_assign_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "launch_ms": round(launch_ms, 5), "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes,
-                    "note": "average over the %d assign launches of one encode; exact cell-pruned assign over %d distinct colours, "
-                            "K=%d; algorithmic bytes = 10 B/colour (SURVEY 8(d) dedup form)" % (launches, U, K)}
+                    "note": "average over all %d assign launches of one encode (%d iterations + launches that exit on the "
+                            "device-side done flag, as rocprofv3 --stats counts them); exact cell-pruned assign over %d distinct "
+                            "colours, K=%d; algorithmic bytes = 10 B/colour (SURVEY 8(d) dedup form); traffic = PMC "
+                            "2*FETCH_SIZE+WRITE_SIZE of a steady-state launch (profiles/traffic.json)" % (launches, stp["iterations"], U, K)}
 
     # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
     cpu = None

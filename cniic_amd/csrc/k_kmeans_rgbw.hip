@@ -997,12 +997,11 @@ int km_rgbw_run(KmRgbwState *s) {
     }
     timer.stop(h.iter);
     if (s->profile) {
-        // launches past convergence are no-ops (a few microseconds each) and are not counted
-        double t = 0;
-        for (size_t i = 0; i + 1 < lt.used && i / 2 < h.iter; i += 2) { float ms = 0.f; (void)hipEventElapsedTime(&ms, lt.ev[i], lt.ev[i + 1]); t += ms; }
+        // every launch that was issued counts, including the (at most batch-1) launches after
+        // convergence that exit on the device-side flag: the same population rocprofv3 --stats averages
         KernelTime &kt = c->ktimes["kmeans_rgbw_assign"];
-        kt.ms += t;
-        kt.launches += h.iter;
+        kt.ms += lt.total_ms();
+        kt.launches += lt.used / 2;
     }
     return CNIIC_OK;
 }
