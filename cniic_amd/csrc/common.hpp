@@ -115,6 +115,7 @@ struct Ctx {
     DevPool pool;           // recycled scratch HBM (all DevBufs created inside an ABI call)
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
+    DevBuf hilbert_lut;     // state-machine tables of the 2^n Hilbert scan (k_hilbert.hip)
     void  *pinned = nullptr; // 4 KiB of mapped host memory for lagged flag polling
     uint64_t pinned_bytes = 0;
 

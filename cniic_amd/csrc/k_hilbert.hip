@@ -3,15 +3,27 @@
 //  hilbertc.rs:417-431 Delta::decode scatter).
 //
 // The reference walks an iterator (zhang_hilbert::ArbHilbertScan32) one cell at a time.  Here the
-// scan is a pure function d -> (x, y): every thread descends the recursion of the generalised
-// Hilbert curve for its own indices, so the index map, the pixel gather, the delta and the
+// scan is a pure function d -> (x, y), so the index map, the pixel gather, the delta and the
 // histogram are all data-parallel.  The scan definition is the one frozen in DESIGN.md ("Hilbert
-// scan: parity unpinned"): identical to the classic Hilbert curve on 2^n squares.
+// scan: parity unpinned"): the generalised Hilbert curve, identical to the classic Hilbert curve
+// on 2^n squares.
+//   * 2^n x 2^n images (all BASELINE configs): table-driven state machine, 4 levels (8 bits of d)
+//     per LDS look-up: the four orientations of a Hilbert sub-curve form the Klein group
+//     {id, transpose, anti-transpose, rot180}, so a state is 2 bits and composition is XOR.
+//   * any other rectangle: each thread descends the recursion of the generalised curve.
+//
+// Fused delta kernel: the SignedColor histogram (src/utils.rs:4-16 via src/huf.rs:30) is kept in
+// LDS-private bins for the hot cube of deltas in [-16,15]^3 (u32[32768] = 128 KiB per 1024-thread
+// block), flushed once per block with global atomics; symbols outside the cube go straight to the
+// dense 2^27-bin table.  Without this the kernel runs at the global-atomic rate (~27 G/s).
+#include <mutex>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
 namespace cniic {
 
+// ---------------------------------------------------------------- generic rectangles
 __device__ __forceinline__ int32_t sgn32(int32_t v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ int32_t floordiv2(int32_t v) { return v >> 1; }  // arithmetic shift = floor
 
@@ -55,26 +67,132 @@ __device__ __forceinline__ void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t 
     yo = (uint32_t)y;
 }
 
+// ---------------------------------------------------------------- 2^n squares: state machine
+// One level: quadrant q of a sub-curve in state s sits at block (x,y) and continues in state s'.
+// Base state 0 (enter at (0,0), leave at (n-1,0)): q0 -> (0,0) transposed, q1 -> (0,1), q2 -> (1,1),
+// q3 -> (1,0) anti-transposed.  States: 0 id, 1 transpose, 2 anti-transpose, 3 rot180.
+struct HilbertLut {
+    uint16_t l4[4 * 256];  // x:4 | y:4 << 4 | state << 8, four levels per look-up
+    uint8_t  l1[4 * 4];    // x:1 | y:1 << 1 | state << 2, one level
+};
+
+static void lut1_entry(int s, int q, int &x, int &y, int &ns) {
+    static const int bx[4] = {0, 0, 1, 1}, by[4] = {0, 1, 1, 0}, bs[4] = {1, 0, 0, 2};
+    int X = bx[q], Y = by[q];
+    switch (s) {
+    case 1: { int t = X; X = Y; Y = t; break; }               // transpose
+    case 2: { int t = X; X = 1 - Y; Y = 1 - t; break; }       // anti-transpose
+    case 3: X = 1 - X; Y = 1 - Y; break;                       // rot180
+    }
+    x = X; y = Y; ns = s ^ bs[q];
+}
+
+static void host_classic_d2xy(uint32_t n, uint64_t d, uint32_t &x, uint32_t &y) {  // textbook form, for the self-check
+    uint64_t t = d;
+    x = y = 0;
+    for (uint32_t s = 1; s < n; s *= 2) {
+        uint32_t rx = 1 & (uint32_t)(t / 2), ry = 1 & (uint32_t)(t ^ rx);
+        if (ry == 0) {
+            if (rx == 1) { x = s - 1 - x; y = s - 1 - y; }
+            uint32_t tmp = x; x = y; y = tmp;
+        }
+        x += s * rx; y += s * ry;
+        t /= 4;
+    }
+}
+
+static bool build_hilbert_lut(HilbertLut &L) {
+    for (int s = 0; s < 4; s++)
+        for (int q = 0; q < 4; q++) {
+            int x, y, ns;
+            lut1_entry(s, q, x, y, ns);
+            L.l1[s * 4 + q] = (uint8_t)(x | (y << 1) | (ns << 2));
+        }
+    for (int s = 0; s < 4; s++)
+        for (int b = 0; b < 256; b++) {
+            int st = s, X = 0, Y = 0;
+            for (int lv = 3; lv >= 0; lv--) {
+                int x, y, ns;
+                lut1_entry(st, (b >> (2 * lv)) & 3, x, y, ns);
+                X = (X << 1) | x; Y = (Y << 1) | y; st = ns;
+            }
+            L.l4[s * 256 + b] = (uint16_t)(X | (Y << 4) | (st << 8));
+        }
+    // self-check against the textbook algorithm on every order up to 9 (covers l4, l1 and their mix)
+    for (uint32_t order = 1; order <= 9; order++) {
+        const uint32_t n = 1u << order;
+        for (uint64_t d = 0; d < (uint64_t)n * n; d += (order > 6 ? 37 : 1)) {
+            uint32_t st = 0, x = 0, y = 0, rem = order;
+            while (rem >= 4) { uint16_t e = L.l4[st * 256 + ((d >> (2 * (rem - 4))) & 255)]; x = (x << 4) | (e & 15); y = (y << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4; }
+            while (rem >= 1) { uint8_t e = L.l1[st * 4 + ((d >> (2 * (rem - 1))) & 3)]; x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1; }
+            uint32_t cx, cy;
+            host_classic_d2xy(n, d, cx, cy);
+            if (cx != x || cy != y) return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void pow2_d2xy(const uint16_t *l4, const uint8_t *l1, uint32_t order, uint32_t d, uint32_t &xo, uint32_t &yo) {
+    uint32_t st = 0, x = 0, y = 0, rem = order;
+    while (rem >= 4) {
+        const uint32_t e = l4[st * 256 + ((d >> (2 * (rem - 4))) & 255)];
+        x = (x << 4) | (e & 15); y = (y << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4;
+    }
+    while (rem >= 1) {
+        const uint32_t e = l1[st * 4 + ((d >> (2 * (rem - 1))) & 3)];
+        x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
+    }
+    xo = x; yo = y;
+}
+
+// scan position -> pixel; order > 0 selects the table-driven path (w == h == 1 << order)
+struct Scan {
+    uint32_t w, h, order;
+    const uint16_t *l4;
+    const uint8_t *l1;
+    __device__ __forceinline__ void xy(uint64_t d, uint32_t &x, uint32_t &y) const {
+        if (order) pow2_d2xy(l4, l1, order, (uint32_t)d, x, y);
+        else gilbert_d2xy(w, h, d, x, y);
+    }
+};
+
+__device__ __forceinline__ Scan load_scan(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *lut, uint16_t *s_l4, uint8_t *s_l1) {
+    if (order) {
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) s_l4[i] = lut->l4[i];
+        if (threadIdx.x < 16) s_l1[threadIdx.x] = lut->l1[threadIdx.x];
+        __syncthreads();
+    }
+    return Scan{w, h, order, s_l4, s_l1};
+}
+
 // hilbert::iter (hilbert.rs:40-43)
-__global__ __launch_bounds__(256) void k_hilbert_xy(uint32_t w, uint32_t h, uint32_t *__restrict__ xy) {
+__global__ __launch_bounds__(256) void k_hilbert_xy(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *__restrict__ lut,
+                                                    uint32_t *__restrict__ xy) {
+    __shared__ uint16_t s_l4[1024];
+    __shared__ uint8_t s_l1[16];
+    const Scan sc = load_scan(w, h, order, lut, s_l4, s_l1);
     const uint64_t n = (uint64_t)w * h;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += stride) {
         uint32_t x, y;
-        gilbert_d2xy(w, h, d, x, y);
+        sc.xy(d, x, y);
         reinterpret_cast<uint2 *>(xy)[d] = make_uint2(x, y);
     }
 }
 
 // hilbert::linearize (hilbert.rs:10-12, 34-38): out[d] = pixel(scan(d)); SCATTER = inverse
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict__ src, uint32_t w, uint32_t h,
-                                                      uint8_t *__restrict__ dst) {
+__global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict__ src, uint32_t w, uint32_t h, uint32_t order,
+                                                      const HilbertLut *__restrict__ lut, uint8_t *__restrict__ dst) {
+    __shared__ uint16_t s_l4[1024];
+    __shared__ uint8_t s_l1[16];
+    const Scan sc = load_scan(w, h, order, lut, s_l4, s_l1);
     const uint64_t n = (uint64_t)w * h;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += stride) {
         uint32_t x, y;
-        gilbert_d2xy(w, h, d, x, y);
+        sc.xy(d, x, y);
         const uint64_t p = (uint64_t)y * w + x;
         const uint8_t *s = src + 3 * (SCATTER ? d : p);
         uint8_t *o = dst + 3 * (SCATTER ? p : d);
@@ -83,11 +201,24 @@ __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict_
 }
 
 // DiffStream (hilbertc.rs:449-477) over the Hilbert-ordered pixels, START = [0;3] (hilbertc.rs:445).
-// Each thread owns 4 consecutive scan positions (one extra d2xy for the predecessor of the first).
-// The packed SignedColor key goes to syms (16-B store per thread) and/or into the dense histogram.
+// Each thread owns 4 consecutive scan positions (one extra look-up for the predecessor of the
+// first).  The packed SignedColor key goes to syms (16-B store per thread) and, when HIST, into the
+// histogram: LDS bins for the cube [-16,15]^3, the dense table for everything else.
 constexpr int kDeltaRun = 4;
-__global__ __launch_bounds__(256) void k_hilbert_delta(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
-                                                       uint32_t *__restrict__ syms, uint32_t *__restrict__ table) {
+constexpr int kDeltaThreads = 1024;
+constexpr uint32_t kHotBins = 32 * 32 * 32;
+
+template <bool HIST>
+__global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h, uint32_t order,
+                                                                 const HilbertLut *__restrict__ lut, uint32_t *__restrict__ syms,
+                                                                 uint32_t *__restrict__ table) {
+    extern __shared__ uint32_t s_bins[];  // HIST: u32[kHotBins]
+    __shared__ uint16_t s_l4[1024];
+    __shared__ uint8_t s_l1[16];
+    if (HIST)
+        for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) s_bins[i] = 0;
+    const Scan sc = load_scan(w, h, order, lut, s_l4, s_l1);
+    if (HIST && !order) __syncthreads();
     const uint64_t n = (uint64_t)w * h;
     const uint64_t nruns = (n + kDeltaRun - 1) / kDeltaRun;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -96,7 +227,7 @@ __global__ __launch_bounds__(256) void k_hilbert_delta(const uint8_t *__restrict
         int32_t pr = 0, pg = 0, pb = 0;
         if (d0 > 0) {
             uint32_t x, y;
-            gilbert_d2xy(w, h, d0 - 1, x, y);
+            sc.xy(d0 - 1, x, y);
             const uint8_t *p = rgb + 3 * ((uint64_t)y * w + x);
             pr = p[0]; pg = p[1]; pb = p[2];
         }
@@ -106,12 +237,17 @@ __global__ __launch_bounds__(256) void k_hilbert_delta(const uint8_t *__restrict
             key[i] = 0;
             if (d0 + i < n) {
                 uint32_t x, y;
-                gilbert_d2xy(w, h, d0 + i, x, y);
+                sc.xy(d0 + i, x, y);
                 const uint8_t *p = rgb + 3 * ((uint64_t)y * w + x);
                 const int32_t r = p[0], g = p[1], b = p[2];
-                key[i] = ((uint32_t)(r - pr + 255) << 18) | ((uint32_t)(g - pg + 255) << 9) | (uint32_t)(b - pb + 255);
+                const int32_t dr = r - pr, dg = g - pg, db = b - pb;
+                key[i] = ((uint32_t)(dr + 255) << 18) | ((uint32_t)(dg + 255) << 9) | (uint32_t)(db + 255);
                 pr = r; pg = g; pb = b;
-                if (table) atomicAdd(&table[key[i]], 1u);
+                if (HIST) {
+                    const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
+                    if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
+                    else atomicAdd(&table[key[i]], 1u);
+                }
             }
         }
         if (syms) {
@@ -121,8 +257,19 @@ __global__ __launch_bounds__(256) void k_hilbert_delta(const uint8_t *__restrict
                 for (int i = 0; i < kDeltaRun && d0 + i < n; i++) syms[d0 + i] = key[i];
         }
     }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) {
+            const uint32_t cnt = s_bins[i];
+            if (cnt) {
+                const uint32_t dr = (i >> 10) + 255 - 16, dg = ((i >> 5) & 31) + 255 - 16, db = (i & 31) + 255 - 16;
+                atomicAdd(&table[(dr << 18) | (dg << 9) | db], cnt);
+            }
+        }
+    }
 }
 
+// ---------------------------------------------------------------- host
 static inline uint32_t hgrid(uint64_t items) {
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(items, 256), 1), 256 * 16);
 }
@@ -133,11 +280,40 @@ static int check_dims(Ctx *c, uint32_t w, uint32_t h) {
     return CNIIC_OK;
 }
 
+// order of a 2^n square (n >= 1), else 0
+static uint32_t pow2_order(uint32_t w, uint32_t h) {
+    if (w != h || w < 2 || (w & (w - 1))) return 0;
+    uint32_t o = 0;
+    while ((1u << o) < w) o++;
+    return o;
+}
+
+static int get_lut(Ctx *c, const HilbertLut **lut_d) {
+    if (!c->hilbert_lut.p) {
+        static HilbertLut host_lut;
+        static bool ok = false;
+        static std::once_flag once;
+        std::call_once(once, [] { ok = build_hilbert_lut(host_lut); });
+        if (!ok) return c->fail(CNIIC_ERR_HIP, "hilbert: look-up tables failed their self-check");
+        DevPool *saved = current_pool();
+        current_pool() = nullptr;  // lives as long as the context, not recycled
+        hipError_t e = c->hilbert_lut.alloc(sizeof(HilbertLut));
+        current_pool() = saved;
+        if (e != hipSuccess) return c->fail(CNIIC_ERR_HIP, "hilbert: hipMalloc failed");
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(c->hilbert_lut.p, &host_lut, sizeof(HilbertLut), hipMemcpyHostToDevice, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    *lut_d = c->hilbert_lut.as<HilbertLut>();
+    return CNIIC_OK;
+}
+
 int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d) {
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, xy_d);
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(get_lut(c, &lut));
+    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, pow2_order(w, h), lut, xy_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -146,7 +322,9 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, out_d);
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(get_lut(c, &lut));
+    hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, pow2_order(w, h), lut, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -155,7 +333,9 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, rgb_out_d);
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(get_lut(c, &lut));
+    hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -164,8 +344,23 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(get_lut(c, &lut));
+    const uint64_t nruns = ceil_div(n, kDeltaRun);
+    // persistent blocks: one 1024-thread block per CU keeps the LDS bins private for as long as possible
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nruns, kDeltaThreads), 1), 256);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {  // 128 KiB of dynamic LDS per block
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_delta<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(kHotBins * 4));
+    });
     ScopedKernelTimer timer(c, "hilbert_delta");
-    hipLaunchKernelGGL(k_hilbert_delta, dim3(hgrid(ceil_div(n, kDeltaRun))), dim3(256), 0, c->stream, rgb_d, w, h, syms_d, table_d);
+    if (table_d)
+        hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, pow2_order(w, h), lut,
+                           syms_d, table_d);
+    else
+        hipLaunchKernelGGL(k_hilbert_delta<false>, dim3(std::min<uint32_t>(grid * 4, 1024)), dim3(kDeltaThreads), 0, c->stream, rgb_d, w, h,
+                           pow2_order(w, h), lut, syms_d, table_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     timer.stop(1);
     return CNIIC_OK;

@@ -51,7 +51,7 @@ for name, size in (("delta", 4096), ("hufman", 4096), ("delta16k", 16384)):
         continue
     expr = "delta" if name.startswith("delta") else "hufman"
     img = image(size, synth.SEED0 + 5)
-    out = torch.empty(size * size * 6 + (1 << 24), dtype=torch.uint8, device=dev)
+    out = torch.empty(size * size * 12 + (1 << 24), dtype=torch.uint8, device=dev)
     dt, (rc, ln, st) = timed(lambda: ctx.encode(expr, img, w=size, h=size, out=out), reps=2)
     extra = {}
     for k in ("hilbert_delta", "huff_pack", "hist_rgb"):
