@@ -445,9 +445,22 @@ int32_t cniic_cc_update(cniic_cc *cc, uint64_t *changed) {
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
     CNIIC_TRY(km_rgbw_update(cc->s->km));
+    if (!changed) return CNIIC_OK;  // asynchronous: the caller polls later with cniic_cc_poll
     uint64_t ch = 0;
     CNIIC_TRY(km_rgbw_poll_changed(cc->s->km, &ch));
-    if (changed) *changed = ch;
+    *changed = ch;
+    return CNIIC_OK;
+}
+
+int32_t cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    cniic_kmeans_stats st{};
+    uint32_t d = 0;
+    CNIIC_TRY(km_rgbw_poll(cc->s->km, &st, &d));
+    if (iterations) *iterations = st.iterations;
+    if (done) *done = d;
     return CNIIC_OK;
 }
 
@@ -608,7 +621,7 @@ int32_t cniic_huf_encode_all(cniic_ctx *c, int32_t sym_kind, const uint32_t *sym
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, sym_kind == CNIIC_SYM_RGB ? 24 : 27, &table));
     std::vector<uint8_t> header;
-    return huf_encode_all_dev(c, sym_kind, nullptr, in.d, n, table, false, header, out, cap, len);
+    return huf_encode_all_dev(c, sym_kind, nullptr, const_cast<uint32_t *>(in.d), false, n, table, false, header, out, cap, len);
 }
 
 int32_t cniic_huf_size(int32_t sym_kind, const uint64_t *counts, uint64_t n, uint64_t *nbytes) {

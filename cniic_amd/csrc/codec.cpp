@@ -110,7 +110,7 @@ struct StreamOut {
 // ------------------------------------------------------------------ huf::encode_all (huf.rs:22-43)
 // Symbols come either as pixels (rgb_d) or as packed keys (syms_d).  table_d holds the dense
 // histogram on entry when have_hist, otherwise it is built here.
-int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n,
+int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *syms_d, bool syms_scratch, uint64_t n,
                        uint32_t *table_d, bool have_hist, std::vector<uint8_t> &header, uint8_t *out, uint64_t cap,
                        uint64_t *len) {
     if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "huf::encode_all on an empty stream (src/huf.rs:99 asserts)");
@@ -151,8 +151,16 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_
     CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
     uint64_t packed_bits = 0;
     ScopedKernelTimer timer(c, "huff_pack");
-    CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev,
-                             (uint64_t)header.size() * 8, &packed_bits));
+    if (U < (1ull << 26)) {
+        DevBuf packed_own;
+        uint32_t *packed = syms_d;  // in place over our own symbol stream
+        if (!syms_d || !syms_scratch) { CNIIC_HIP_TRY(c, packed_own.alloc(n * 4 + 16)); packed = packed_own.as<uint32_t>(); }
+        CNIIC_TRY(huff_pack_code32(c, syms_d, rgb_d, n, table_d, keys_d.as<uint32_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>(), U,
+                                   packed, so.dev, (uint64_t)header.size() * 8, &packed_bits));
+    } else {
+        CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev,
+                                 (uint64_t)header.size() * 8, &packed_bits));
+    }
     timer.stop(1);
     if (packed_bits != nbits)
         return c->fail(CNIIC_ERR_HIP, "huffman: packed %llu bits, histogram predicts %llu", (unsigned long long)packed_bits,
@@ -168,7 +176,7 @@ static int encode_hufman(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, u
     put_u32(header, h);
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, 24, &table));
-    return huf_encode_all_dev(c, CNIIC_SYM_RGB, rgb_d, nullptr, n, table, false, header, out, cap, len);
+    return huf_encode_all_dev(c, CNIIC_SYM_RGB, rgb_d, nullptr, false, n, table, false, header, out, cap, len);
 }
 
 // ------------------------------------------------------------------ ClusterColors::encode (clusterc.rs:18-53)
@@ -346,7 +354,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     // one fused pass: Hilbert gather + DiffStream + count_freqs; the symbol stream is kept for the
     // second (bit-pack) pass instead of recomputing the scan as the reference does (huf.rs:30,38)
     CNIIC_TRY(hilbert_delta(c, rgb_d, w, h, syms.as<uint32_t>(), table));
-    return huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), n, table, true, header, out, cap, len);
+    return huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), true, n, table, true, header, out, cap, len);
 }
 
 int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, uint32_t h, const cniic_kmeans_opts *opts,

@@ -42,7 +42,8 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
 
 // header carries any prefix already serialised (image dimensions); the decoder trie is appended
 // to it and the whole stream lands in out[0..*len)  (out: host or device memory).
-int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, const uint32_t *syms_d, uint64_t n, uint32_t *table_d,
+// syms_scratch: the symbol stream is ours and may be overwritten.
+int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *syms_d, bool syms_scratch, uint64_t n, uint32_t *table_d,
                        bool have_hist, std::vector<uint8_t> &header, uint8_t *out, uint64_t cap, uint64_t *len);
 
 }  // namespace cniic

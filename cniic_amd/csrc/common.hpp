@@ -260,6 +260,7 @@ int km_rgbw_assign(KmRgbwState *s);                       // async: assign + par
 int km_rgbw_update(KmRgbwState *s);                       // async: centroids from partials
 int km_rgbw_run(KmRgbwState *s);                          // full loop to convergence (single GPU)
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
+int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
 int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats);
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch);
@@ -311,6 +312,11 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
 int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
                    const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d,
                    uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+// same result with one random read per symbol (needs every code length <= 26): the dense table is
+// overwritten with len<<26|code per key; packed_d = n u32 of scratch (may alias syms)
+int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, uint32_t *table_d,
+                     const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint32_t *packed_d,
+                     uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
 // cluster-colors path: pixel -> cluster label through a dense colour->label table, codes per cluster
 int huff_pack_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, uint32_t K,
                      const uint8_t *clen_d, const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);

@@ -315,6 +315,156 @@ static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank
     return CNIIC_OK;
 }
 
+constexpr uint32_t kEscape = 63;  // length field value that redirects to the per-rank tables (U < 2^26)
+
+// ---------------------------------------------------------------- generic fast path (codes <= 26 bits inline)
+// The dense symbol table is overwritten with (len << 26 | code) per symbol key, so a symbol costs
+// ONE random read; pass 1 leaves that word per symbol in a linear array (in place over the symbol
+// stream when it is ours), pass 2 streams it back.
+__global__ __launch_bounds__(256) void k_fill_code32(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ len,
+                                                     const uint64_t *__restrict__ code, uint64_t U, uint32_t *__restrict__ table) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride)
+        table[keys[i]] = len[i] <= 26 ? ((uint32_t)len[i] << 26) | (uint32_t)code[i]
+                                      : (kEscape << 26) | (uint32_t)i;  // long (rare) code: escape to len[rank] / code[rank]
+}
+
+template <int SRC>
+__global__ __launch_bounds__(kPackThreads) void k_pack_count32(const void *__restrict__ src, uint64_t n,
+                                                               const uint32_t *__restrict__ code_table,
+                                                               const uint8_t *__restrict__ len,
+                                                               uint32_t *__restrict__ packed, uint32_t *__restrict__ chunk_bits) {
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t key[kPackPer];
+    bool full = first + kPackPer <= n;
+    if (SRC == SRC_RGB) {
+        const uint8_t *rgb = reinterpret_cast<const uint8_t *>(src);
+        if (full && ((reinterpret_cast<uintptr_t>(rgb) & 15) == 0)) load16px_keys(reinterpret_cast<const uint4 *>(rgb + 3 * first), key);
+        else
+            for (int i = 0; i < kPackPer; i++) key[i] = first + i < n ? rgb_key(rgb + 3 * (first + i)) : 0u;
+    } else {
+        const uint32_t *k = reinterpret_cast<const uint32_t *>(src);
+        if (full && ((reinterpret_cast<uintptr_t>(k) & 15) == 0)) {
+            const uint4 *v = reinterpret_cast<const uint4 *>(k + first);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { uint4 q = v[j]; key[4 * j] = q.x; key[4 * j + 1] = q.y; key[4 * j + 2] = q.z; key[4 * j + 3] = q.w; }
+        } else {
+            for (int i = 0; i < kPackPer; i++) key[i] = first + i < n ? k[first + i] : 0u;
+        }
+    }
+    uint32_t v[kPackPer];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        v[i] = first + i < n ? code_table[key[i]] : 0u;
+        const uint32_t L = v[i] >> 26;
+        bits += L == kEscape ? (uint32_t)len[v[i] & 0x3ffffffu] : L;
+    }
+    if (full && ((reinterpret_cast<uintptr_t>(packed) & 15) == 0)) {
+        uint4 *o = reinterpret_cast<uint4 *>(packed + first);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    } else {
+        for (int i = 0; i < kPackPer; i++)
+            if (first + i < n) packed[first + i] = v[i];
+    }
+    bits = block_reduce_sum<kPackThreads>(bits);
+    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
+}
+
+__global__ __launch_bounds__(kPackThreads) void k_pack_write32(const uint32_t *__restrict__ packed, uint64_t n,
+                                                               const uint8_t *__restrict__ len, const uint64_t *__restrict__ code,
+                                                               const uint64_t *__restrict__ chunk_off,
+                                                               uint32_t *__restrict__ out_words, uint64_t bit_base) {
+    __shared__ uint32_t img[kPackWords];
+    __shared__ uint32_t wsum[kPackThreads / 64];
+    __shared__ uint32_t s_total;
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t v[kPackPer];
+    if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(packed) & 15) == 0)) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(packed + first);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { uint4 q = p[j]; v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPackPer; i++) v[i] = first + i < n ? packed[first + i] : 0u;
+    }
+    uint32_t bits = 0;
+    uint32_t l[kPackPer];
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        const uint32_t L = v[i] >> 26;
+        l[i] = L == kEscape ? (uint32_t)len[v[i] & 0x3ffffffu] : L;
+        bits += l[i];
+    }
+    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
+    const uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);
+    const uint64_t g0 = bit_base + chunk_off[blockIdx.x];
+    const uint32_t skew = (uint32_t)(g0 & 31);
+    uint32_t pos = skew + excl;
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        const uint32_t L = l[i];
+        if (L == 0) continue;
+        const uint64_t cd = (v[i] >> 26) == kEscape ? code[v[i] & 0x3ffffffu] : (uint64_t)(v[i] & 0x3ffffffu);
+        const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;
+        if (L <= room) {
+            atomicOr(&img[w], (uint32_t)(cd << (room - L)));
+        } else {
+            const uint32_t rem = L - room;
+            atomicOr(&img[w], (uint32_t)(cd >> rem));
+            if (rem <= 32) atomicOr(&img[w + 1], (uint32_t)(cd << (32 - rem)));
+            else { atomicOr(&img[w + 1], (uint32_t)(cd >> (rem - 32))); atomicOr(&img[w + 2], (uint32_t)(cd << (64 - rem))); }
+        }
+        pos += L;
+    }
+    if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total == 0) return;
+    const uint32_t nwords = (skew + total + 31) >> 5;
+    const uint64_t w0 = g0 >> 5;
+    for (uint32_t i = threadIdx.x; i < nwords; i += kPackThreads) {
+        const uint32_t o = __builtin_bswap32(img[i]);
+        if (o == 0) continue;
+        if (i == 0 || i == nwords - 1) atomicOr(&out_words[w0 + i], o);
+        else out_words[w0 + i] = o;
+    }
+}
+
+// table_d: dense symbol table (any content; overwritten).  keys_d/len_d/code_d: the U distinct symbols
+// and their codes (U < 2^26; codes longer than 26 bits escape to the per-rank tables).  src: pixels (rgb) or symbol keys; packed_d: n u32 of scratch,
+// may alias the symbol stream when that buffer is not needed afterwards.
+int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, uint32_t *table_d,
+                     const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint32_t *packed_d,
+                     uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h) {
+    *nbits_h = 0;
+    if (n == 0) return CNIIC_OK;
+    if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
+    const uint64_t nchunks64 = ceil_div(n, kPackChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: too many symbols");
+    const uint32_t nchunks = (uint32_t)nchunks64;
+    DevBuf cb, co, tot;
+    CNIIC_HIP_TRY(c, cb.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    hipLaunchKernelGGL(k_fill_code32, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
+                       table_d);
+    if (rgb_or_null_d)
+        hipLaunchKernelGGL(k_pack_count32<SRC_RGB>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, rgb_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_pack_count32<SRC_KEYS>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, syms_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
+                       reinterpret_cast<uint32_t *>(out_d), bit_base);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *nbits_h = total;
+    return CNIIC_OK;
+}
+
 // Packs at bit_base of out_d: a 4-byte aligned, PRE-ZEROED buffer that is large enough (the caller
 // knows the payload size from the histogram); bytes before bit_base may already hold the header.
 int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,

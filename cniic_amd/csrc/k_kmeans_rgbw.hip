@@ -944,6 +944,14 @@ static int read_state(KmRgbwState *s, KmDevState *h) {
     return CNIIC_OK;
 }
 
+int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done) {
+    KmDevState h;
+    CNIIC_TRY(read_state(s, &h));
+    st->iterations = h.iter; st->moved_last = h.moved_last; st->empty_reseeds = h.reseeds; st->active = h.active; st->pair_evals = h.pair_evals;
+    *done = h.done;
+    return CNIIC_OK;
+}
+
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed) {
     KmDevState h;
     CNIIC_TRY(read_state(s, &h));

@@ -48,9 +48,14 @@ class HipBackend:
         self.ctx._check(self.L.cniic_cc_assign(h))
 
     def update(self, h):
-        ch = C.c_uint64(0)
-        self.ctx._check(self.L.cniic_cc_update(h, C.byref(ch)))
-        return ch.value
+        """asynchronous centroid update (no host round trip)"""
+        self.ctx._check(self.L.cniic_cc_update(h, None))
+
+    def poll(self, h):
+        """(iterations completed, converged?) -- synchronises the stream"""
+        it, done = C.c_uint64(0), C.c_uint32(0)
+        self.ctx._check(self.L.cniic_cc_poll(h, C.byref(it), C.byref(done)))
+        return it.value, bool(done.value)
 
     def export_labels(self, h):
         U = int(self.L.cniic_cc_unique(h))
@@ -78,8 +83,9 @@ class HipBackend:
 class ShardedClusterColors:
     """encode(img, w, h, out) -> (stream bytes written to out, K-means stats), collectively on all ranks."""
 
-    def __init__(self, ctx, K, dist, device, max_iters=0, backend=None):
+    def __init__(self, ctx, K, dist, device, max_iters=0, backend=None, poll_every=4):
         self.K = K
+        self.poll_every = poll_every
         self.dist = dist
         self.max_iters = max_iters
         self.be = backend if backend is not None else HipBackend(ctx, device)
@@ -98,13 +104,13 @@ class ShardedClusterColors:
         partials = be.new_partials(self.K)
         handle = be.cc_create(glob, self.K, self.rank, self.world, partials, self.max_iters)
         try:
-            it = 0
             while True:                             # kmeans.rs:26-32 `while changed_assignment`
-                be.assign(handle)
-                self._all_reduce(partials)          # K partial centroid sums (+ moved count)
-                changed = be.update(handle)
-                it += 1
-                if changed == 0 or (self.max_iters and it >= self.max_iters):
+                for _ in range(self.poll_every):    # no host round trip inside a batch; iterations issued after
+                    be.assign(handle)               # convergence are no-ops on every rank (device-side flag)
+                    self._all_reduce(partials)      # K partial centroid sums (+ moved count), identical on all ranks
+                    be.update(handle)
+                it, done = be.poll(handle)
+                if done:
                     break
             if self.world > 1:
                 lab = be.export_labels(handle)

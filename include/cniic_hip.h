@@ -166,7 +166,7 @@ void    cniic_km_destroy(cniic_km *km);
  *   cniic_cc_create(global, K, rank, n)    -> distinct colours, K-means state; the global table
  *                                             is overwritten (key -> rank + 1)
  *   repeat: cniic_cc_assign; all-reduce(sum) the partials buffer (int64 words); cniic_cc_update
- *           until *changed == 0
+ *           until *changed == 0  (or update asynchronously and cniic_cc_poll every few iterations)
  *   cniic_cc_export_labels; all-reduce(sum) that buffer; cniic_cc_import_labels
  *   cniic_cc_finish(img, local counts)     -> this rank's Hufman stream (clusterc.rs:31-52)
  *
@@ -180,7 +180,10 @@ uint64_t cniic_cc_unique(cniic_cc *cc);        /* distinct colours U */
 uint32_t cniic_cc_label_bytes(cniic_cc *cc);   /* 1 (K <= 256) or 2: element size of the label buffers */
 int32_t  cniic_cc_partials(cniic_cc *cc, void **dev_ptr);
 int32_t  cniic_cc_assign(cniic_cc *cc);                        /* async on the ctx stream */
-int32_t  cniic_cc_update(cniic_cc *cc, uint64_t *changed);     /* syncs */
+int32_t  cniic_cc_update(cniic_cc *cc, uint64_t *changed);     /* syncs; changed == NULL: asynchronous */
+/* iterations completed so far and whether an iteration has moved nothing (syncs).  Iterations issued
+ * after convergence are no-ops on the device, so callers may poll only every few iterations. */
+int32_t  cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done);
 int32_t  cniic_cc_export_labels(cniic_cc *cc, void *dst_dev);  /* U labels, zero outside this shard */
 int32_t  cniic_cc_import_labels(cniic_cc *cc, const void *src_dev);
 int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h,

@@ -56,6 +56,8 @@ class OracleBackend:
     def assign(self, st):
         import oracle_lib as O
         lo, hi, K = st["lo"], st["hi"], st["K"]
+        if st.get("done"):     # iterations issued after convergence are no-ops
+            return
         r = O.kmeans_step(O.PT_RGBW, st["pts"][lo:hi], st["w"][lo:hi], K, st["cent"], st["labels"][lo:hi])
         st["labels"][lo:hi] = r["labels"]
         full = np.concatenate([r["sums"].reshape(-1), r["wsum"], r["members"]]).astype(np.int64)
@@ -65,18 +67,24 @@ class OracleBackend:
         p[5 * K + 1] = 0
         st["prev"] = full
 
+    def poll(self, st):
+        return st["it"], st.get("done", False)
+
     def update(self, st):
         import oracle_lib as O
         K = st["K"]
         p = st["partials"].numpy()
+        if st.get("done"):
+            p[:] = 0
+            return
         st["running"] += p[:5 * K]
         run = st["running"].astype(np.uint64)
         st["cent"], _ = O.kmeans_finalize(O.PT_RGBW, st["pts"], K, st["seed"], st["it"], run[:3 * K].reshape(K, 3), run[3 * K:4 * K],
                                           run[4 * K:5 * K])
         st["it"] += 1
-        changed = int(p[5 * K])
+        if int(p[5 * K]) == 0:
+            st["done"] = True
         p[:] = 0
-        return changed
 
     def export_labels(self, st):
         out = np.zeros(st["U"], np.uint8)
