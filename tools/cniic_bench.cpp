@@ -1,0 +1,124 @@
+// cniic_bench.cpp -- C++ counterpart of the reference's harness (src/bench.rs:15-83, src/main.rs:57-70):
+//   cniic_bench --codec=<expr> <image>...
+// per image: encode -> size -> ratio vs w*h*24 -> decode -> MSE -> CSV row
+//   name,compressed_size,compression_ratio,error            (bench.rs:68-75)
+// written to output/<codec.name()>.csv (bench.rs:85-91) and echoed to stdout.  A lossless codec whose
+// decode differs is an error (bench.rs:50-59).  Images are binary PPM (P6) files or synthetic specs
+// "synth:P:4096x4096:2" / "synth:U:512x512:1" (kind, size, seed offset).
+// The raw size is computed in 64 bits (the reference's u32 h*w*24 wraps above 13377^2 pixels).
+// Images run one per worker thread, each with its own cniic_ctx (the reference uses rayon, bench.rs:24-28).
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/cniic_hip.h"
+
+struct Image { uint32_t w = 0, h = 0; std::vector<uint8_t> rgb; bool synth = false; int kind = 0; uint64_t seed = 0; };
+
+static bool read_ppm(const std::string &path, Image &im) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    f >> magic;
+    if (magic != "P6") return false;
+    auto next_int = [&]() -> long {
+        for (;;) {
+            int ch = f.peek();
+            if (ch == '#') { std::string line; std::getline(f, line); }
+            else if (isspace(ch)) f.get();
+            else break;
+        }
+        long v; f >> v; return v;
+    };
+    long w = next_int(), h = next_int(), maxv = next_int();
+    f.get();
+    if (w <= 0 || h <= 0 || maxv != 255) return false;
+    im.w = (uint32_t)w; im.h = (uint32_t)h;
+    im.rgb.resize((size_t)w * h * 3);
+    f.read(reinterpret_cast<char *>(im.rgb.data()), (std::streamsize)im.rgb.size());
+    return (bool)f;
+}
+
+static bool parse_synth(const std::string &s, Image &im) {  // synth:P:4096x4096:2
+    char kind;
+    unsigned w, h;
+    unsigned long long off = 0;
+    if (sscanf(s.c_str(), "synth:%c:%ux%u:%llu", &kind, &w, &h, &off) < 3) return false;
+    im.synth = true; im.kind = (kind == 'U' || kind == 'u') ? CNIIC_SYNTH_UNIFORM : CNIIC_SYNTH_PHOTO;
+    im.w = w; im.h = h; im.seed = 0x636E696963ULL + off;
+    return true;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3 || strncmp(argv[1], "--codec=", 8) != 0) {
+        fprintf(stderr, "Usage: cniic_bench --codec=<codec> [<img file>..]\nAvailable codecs:\n  hufman\n  cluster-colors(<ncolors>)\n  voronoi(<k>)\n  delta\n");
+        return 2;
+    }
+    const std::string expr = argv[1] + 8;
+    char name[64];
+    if (cniic_codec_name(expr.c_str(), name, sizeof name) != CNIIC_OK) { fprintf(stderr, "Malformed codec argument: %s\n", expr.c_str()); return 2; }
+    const bool lossless = cniic_codec_is_lossless(expr.c_str()) == 1;
+    mkdir("output", 0755);
+    const std::string csv_path = std::string("output/") + name + ".csv";
+    FILE *csv = fopen(csv_path.c_str(), "w");
+    if (!csv) { perror(csv_path.c_str()); return 1; }
+    std::mutex mu;
+    bool wrote_header = false;
+    int failures = 0;
+    std::vector<std::string> paths(argv + 2, argv + argc);
+    const unsigned nthreads = std::min<unsigned>((unsigned)paths.size(), std::max(1u, std::min(4u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    size_t next = 0;
+    for (unsigned t = 0; t < nthreads; t++)
+        pool.emplace_back([&] {
+            cniic_ctx *ctx = nullptr;
+            if (cniic_ctx_create(0, nullptr, &ctx) != CNIIC_OK) { std::lock_guard<std::mutex> lk(mu); fprintf(stderr, "no usable MI355X\n"); failures++; return; }
+            for (;;) {
+                std::string p;
+                { std::lock_guard<std::mutex> lk(mu); if (next >= paths.size()) break; p = paths[next++]; }
+                Image im;
+                void *dimg = nullptr;
+                auto fail = [&](const char *what) { std::lock_guard<std::mutex> lk(mu); fprintf(stderr, "%s: %s (%s)\n", p.c_str(), what, cniic_last_error(ctx)); failures++; };
+                if (!parse_synth(p, im) && !read_ppm(p, im)) { fail("cannot read image (binary PPM or synth:<P|U>:<w>x<h>[:seed])"); continue; }
+                const uint64_t npx = (uint64_t)im.w * im.h;
+                if (cniic_dev_alloc(ctx, npx * 3, &dimg) != CNIIC_OK) { fail("device allocation"); continue; }
+                if (im.synth) cniic_synth_image(ctx, im.kind, im.seed, im.w, im.h, (uint8_t *)dimg);
+                else cniic_memcpy(ctx, dimg, im.rgb.data(), npx * 3);
+                std::vector<uint8_t> data(64 + npx * 16 + (1 << 16));
+                uint64_t len = 0;
+                cniic_kmeans_stats st{};
+                auto t0 = std::chrono::steady_clock::now();
+                int rc = cniic_codec_encode(ctx, expr.c_str(), (const uint8_t *)dimg, im.w, im.h, data.data(), data.size(), &len, &st);
+                double enc_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (rc != CNIIC_OK) { fail("encode"); cniic_dev_free(ctx, dimg); continue; }
+                const double raw_bits = (double)npx * 24.0;              // bench.rs:41 (in 64 bits)
+                const double ratio = (double)len / raw_bits;             // bench.rs:43
+                void *dback = nullptr;
+                cniic_dev_alloc(ctx, npx * 3, &dback);
+                uint32_t w2 = 0, h2 = 0;
+                rc = cniic_codec_decode(ctx, expr.c_str(), data.data(), len, (uint8_t *)dback, npx * 3, &w2, &h2);
+                if (rc != CNIIC_OK) { fail("Could not decode the image"); cniic_dev_free(ctx, dimg); cniic_dev_free(ctx, dback); continue; }
+                double mse = 0;
+                cniic_mse(ctx, (const uint8_t *)dimg, (const uint8_t *)dback, npx, &mse);   // bench.rs:95-104
+                cniic_dev_free(ctx, dimg);
+                cniic_dev_free(ctx, dback);
+                std::lock_guard<std::mutex> lk(mu);
+                if (mse != 0.0 && lossless) { fprintf(stderr, "%s: Decoded image doesn't match\n", p.c_str()); failures++; continue; }
+                if (!wrote_header) { fprintf(csv, "name,compressed_size,compression_ratio,error\n"); printf("name,compressed_size,compression_ratio,error,mpix_per_s,iters\n"); wrote_header = true; }
+                fprintf(csv, "%s,%llu,%.17g,%.17g\n", p.c_str(), (unsigned long long)len, ratio * 100.0, mse);
+                printf("%s,%llu,%.6f,%.4f,%.1f,%llu\n", p.c_str(), (unsigned long long)len, ratio * 100.0, mse, npx / enc_ms / 1e3, (unsigned long long)st.iterations);
+            }
+            cniic_ctx_destroy(ctx);
+        });
+    for (auto &th : pool) th.join();
+    fclose(csv);
+    return failures ? 1 : 0;
+}
