@@ -2,53 +2,69 @@
 // pixel of an image (reference: src/codec/clusterc.rs:148-153, 200-248; src/kmeans.rs:21-143,330-416).
 //
 // Layout: the RGB8 image stays as given (3 B/px, x and y are implicit in the pixel index) plus one
-// u16 label per pixel: 3 + 2 read, 2 written = 7 B/px/iteration.
+// u16 label per pixel: 3 + 2 read, 2 written = 7 B/px/iteration.  The centroid table is
+// an array of int4 (cx, cy, r<<16|g<<8|b, |c|^2): one 16-byte load per centroid.
 //
 // Exactness: assign is exact Lloyd under the reference's rules (stay unless STRICTLY closer,
 // kmeans.rs:375; lowest id among equidistant minima) on integer squared distances.
 //
 // Pruning (replaces the reference's per-cluster neighbour lists, kmeans.rs:150-323, which are
-// sequential and heuristic once truncated): the image is cut into 64x16-pixel tiles.  For each tile
-// and iteration the block computes the tile's 5-D bounding box (pixel extents + min/max of each
-// colour channel), then for every centroid a lower bound lb_k and an upper bound ub_k of the squared
-// distance to ANY point of the box.  With T = min_k ub_k, a centroid with lb_k > T cannot be the
-// nearest (not even tied) for any pixel of the tile, so only {k : lb_k <= T} are evaluated per
-// pixel.  This is the triangle-inequality idea of kmeans.rs:355-370 applied to a box of points
-// instead of one point at a time; it never changes the result.
+// sequential and heuristic once truncated).  The image is cut into 64x16-pixel tiles (one wave each)
+// grouped into 4x4 super-tiles (one 16-wave block each).  For a box B of pixels -- pixel extents and
+// min/max of each colour channel -- and a pivot centroid c*, the difference
+//     d(p, c*) - d(p, c_k) = sum_dim (c*_d - k_d) (c*_d + k_d - 2 p_d)
+// is linear in p, so its maximum over B is a sum of per-dimension maxima taken at the box faces.  If
+// that maximum is negative, c* is strictly closer than c_k for every pixel of B and c_k cannot win (or
+// tie) anywhere in B: it is dropped.  The pivot is the centroid nearest the box centre.  The test runs
+// twice: over the super-tile's box against all K centroids (the block builds the list S), then per tile
+// over S only (the wave builds its candidate strip).  This is the triangle-inequality idea of
+// kmeans.rs:355-370 applied to a box of points and one pivot; it never changes the result.
 //
-// Sums: per-block LDS accumulators (u32, flushed before they can overflow) -> u64 global atomics.
+// Skip schedule: a tile keeps its pivot and candidate bitmask between iterations.  When few centroids
+// moved, a tile whose candidates did not move and for which every moved centroid is still dominated by
+// the (unmoved) pivot repeats all its decisions, so it is not processed at all.  (After a tile has been
+// processed every pixel's label is one of its candidates, so a moved "current" centroid always shows.)
+//
+// Sums: running u64 sums fed by signed deltas of the pixels that moved (full sums at iteration 0),
+// collected in per-block LDS accumulators (u32, wrap-around signed) -> u64 global atomics.
+//
+// Arithmetic: coordinates are < 2^14, so every product uses the full-rate 24-bit multiplier
+// (v_mul_i32_i24 / v_mad_i32_i24); the 32-bit v_mul_lo_u32 is quarter rate on CDNA.
 #include "common.hpp"
 #include "device_utils.hpp"
 
 namespace cniic {
 
-constexpr int kTW = 64, kTH = 16;          // tile: 64 x 16 pixels, one wave per 64-px row segment
-constexpr int kXThreads = 256;
-constexpr int kXPPT = (kTW * kTH) / kXThreads;  // 4 pixels per thread
-constexpr int kMaxCand = 1024;             // LDS candidate list capacity; beyond it the tile is brute-forced
+constexpr int kTW = 64, kTH = 16;          // tile: 64 x 16 pixels = one wave, 16 pixels (a column) per lane
+constexpr int kSTX = 4, kSTY = 4;          // super-tile: 4 x 4 tiles = one block
+constexpr int kXWaves = kSTX * kSTY;
+constexpr int kXThreads = 64 * kXWaves;    // 1024
+constexpr int kXRows = 4;                  // rows of a tile evaluated together (4 groups per tile)
 constexpr uint32_t kXMaxK = 4096;
-
-struct XyCent {  // device centroid table, structure of arrays
-    int32_t  *cx, *cy;   // [K]
-    uint32_t *crgb;      // [K] packed r<<16|g<<8|b
-    int32_t  *c2;        // [K] cx^2 + cy^2 + |rgb|^2
-};
+constexpr int kXMaxR = kXMaxK / kXThreads; // centroids per thread in the super-tile pass (4)
+constexpr uint32_t kSCap = 1024;           // super-tile list capacity; beyond it the super-tile is brute-forced
+constexpr uint32_t kXMaxMovedSkip = 512;   // skip schedule when at most this many centroids moved
+constexpr uint64_t kSuperPx = (uint64_t)kSTX * kTW * kSTY * kTH;
 
 struct KmXyState {
     Ctx *c = nullptr;
     const uint8_t *rgb = nullptr;
-    uint32_t w = 0, h = 0, K = 0, nblocks = 1, tiles_x = 0, tiles_y = 0, flush_every = 1;
+    uint32_t w = 0, h = 0, K = 0, nblocks = 1, tiles_x = 0, tiles_y = 0, super_x = 0, super_y = 0, wcap = 0;
+    size_t lds = 0;
     uint64_t N = 0, seed = 0, max_iters = 0;
-    bool brute = false;
-    DevBuf labels, cx, cy, crgb, c2, partials, running, dstate, members_last, tile_box, tile_T, tile_mask, moved_list;
-    bool no_skip = false;
-    XyCent cent() const { return XyCent{cx.as<int32_t>(), cy.as<int32_t>(), crgb.as<uint32_t>(), c2.as<int32_t>()}; }
+    bool brute = false, no_skip = false;
+    DevBuf labels, cent, partials, running, dstate, members_last, tile_box, super_box, tile_piv, tile_mask, moved_list;
+    bool use_tab = false;
 };
 
 __device__ __forceinline__ uint32_t xdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
+__device__ __forceinline__ int32_t xmad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+__device__ __forceinline__ int4 make_cent(int32_t x, int32_t y, uint32_t col) {
+    return make_int4(x, y, (int32_t)col, xmad24(x, x, xmad24(y, y, (int32_t)xdot4(col, col))));
+}
 
 __global__ void k_xy_init(const uint8_t *__restrict__ rgb, uint32_t w, uint64_t N, uint32_t K,
-                          uint16_t *__restrict__ labels, XyCent ct) {
+                          uint16_t *__restrict__ labels, int4 *__restrict__ cent) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (uint64_t i = tid; i < N; i += stride) labels[i] = (uint16_t)init_label(i, N, K);  // kmeans.rs:61-78
@@ -56,245 +72,380 @@ __global__ void k_xy_init(const uint8_t *__restrict__ rgb, uint32_t w, uint64_t 
         uint32_t k = (uint32_t)tid;
         uint64_t ppc = N / K;
         uint64_t first = (k < K - 1) ? N - ((uint64_t)k + 1) * ppc : 0;  // init_centroids kmeans.rs:101-108
-        int32_t x = (int32_t)(first % w), y = (int32_t)(first / w);
-        uint32_t col = rgb_key(rgb + 3 * first);
-        ct.cx[k] = x; ct.cy[k] = y; ct.crgb[k] = col;
-        ct.c2[k] = x * x + y * y + (int32_t)xdot4(col, col);
+        cent[k] = make_cent((int32_t)(first % w), (int32_t)(first / w), rgb_key(rgb + 3 * first));
     }
 }
 
-// distance bounds from centroid coordinate c to the interval [a, b]
-__device__ __forceinline__ void bound1(int32_t c, int32_t a, int32_t b, uint32_t &lb, uint32_t &ub) {
-    int32_t da = c - a, db = c - b;
-    int32_t lo = c < a ? -da : (c > b ? db : 0);
-    int32_t hi = max(abs(da), abs(db));
-    lb += (uint32_t)(lo * lo);
-    ub += (uint32_t)(hi * hi);
+// static colour extents of every tile: x = r0 | r1<<8 | g0<<16 | g1<<24, y = b0 | b1<<8.  One wave per tile.
+__global__ __launch_bounds__(256) void k_xy_boxes(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h, uint32_t tiles_x,
+                                                  uint32_t ntiles, uint2 *__restrict__ box) {
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t x = (tile % tiles_x) * kTW + lane, y0 = (tile / tiles_x) * kTH;
+    uint32_t lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+    if (x < w) {
+        for (uint32_t y = y0; y < min(y0 + kTH, h); y++) {
+            const uint32_t p = rgb_key(rgb + 3 * ((uint64_t)y * w + x));
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const uint32_t v = (p >> (16 - 8 * s)) & 255;
+                lo[s] = min(lo[s], v); hi[s] = max(hi[s], v);
+            }
+        }
+    }
+    uint32_t m[6];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        m[2 * s] = wave_reduce_min(lo[s]);
+        m[2 * s + 1] = wave_reduce_max(hi[s]);
+    }
+    if (lane == 0) box[tile] = make_uint2(m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24), m[4] | (m[5] << 8));
 }
 
-struct TileBox { int32_t x0, x1, y0, y1, r0, r1, g0, g1, b0, b1; };
-
-__device__ __forceinline__ void cent_bounds(const XyCent &ct, uint32_t k, const TileBox &bx, uint32_t &lb, uint32_t &ub) {
-    lb = 0; ub = 0;
-    uint32_t col = ct.crgb[k];
-    bound1(ct.cx[k], bx.x0, bx.x1, lb, ub);
-    bound1(ct.cy[k], bx.y0, bx.y1, lb, ub);
-    bound1((int32_t)((col >> 16) & 255), bx.r0, bx.r1, lb, ub);
-    bound1((int32_t)((col >> 8) & 255), bx.g0, bx.g1, lb, ub);
-    bound1((int32_t)(col & 255), bx.b0, bx.b1, lb, ub);
+// the same for every super-tile: union of its tiles' extents (also static)
+__global__ void k_xy_super_boxes(const uint2 *__restrict__ box, uint32_t tiles_x, uint32_t tiles_y, uint32_t super_x, uint32_t nsuper,
+                                 uint2 *__restrict__ sbox) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsuper) return;
+    const uint32_t stx = (s % super_x) * 4, sty = (s / super_x) * 4;
+    uint32_t lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+    for (uint32_t t = 0; t < 16; t++) {
+        const uint32_t ux = stx + (t & 3), uy = sty + (t >> 2);
+        if (ux >= tiles_x || uy >= tiles_y) continue;
+        const uint2 b = box[uy * tiles_x + ux];
+        lo[0] = min(lo[0], b.x & 255); hi[0] = max(hi[0], (b.x >> 8) & 255);
+        lo[1] = min(lo[1], (b.x >> 16) & 255); hi[1] = max(hi[1], b.x >> 24);
+        lo[2] = min(lo[2], b.y & 255); hi[2] = max(hi[2], (b.y >> 8) & 255);
+    }
+    sbox[s] = make_uint2(lo[0] | (hi[0] << 8) | (lo[1] << 16) | (hi[1] << 24), lo[2] | (hi[2] << 8));
 }
+
+struct Box5 { int32_t lo[5], hi[5]; };  // x, y, r, g, b extents
+
+__device__ __forceinline__ void box_colours(Box5 &b, uint2 pb) {
+    b.lo[2] = pb.x & 255; b.hi[2] = (pb.x >> 8) & 255; b.lo[3] = (pb.x >> 16) & 255; b.hi[3] = pb.x >> 24;
+    b.lo[4] = pb.y & 255; b.hi[4] = (pb.y >> 8) & 255;
+}
+
+// squared distance from the box centre to a centroid
+__device__ __forceinline__ uint32_t centre_dist(const Box5 &b, int4 c) {
+    int32_t d = 0;
+    const int32_t v[5] = {c.x, c.y, (c.z >> 16) & 255, (c.z >> 8) & 255, c.z & 255};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int32_t e = v[i] - ((b.lo[i] + b.hi[i]) >> 1);
+        d = xmad24(e, e, d);
+    }
+    return (uint32_t)d;
+}
+
+// the pivot against one box: a[2 i] = c*_i - 2 lo_i, a[2 i + 1] = c*_i - 2 hi_i
+struct Dominance {
+    int32_t p[5], a[10];
+    __device__ __forceinline__ void set(const Box5 &b, int4 pv) {
+        p[0] = pv.x; p[1] = pv.y; p[2] = (pv.z >> 16) & 255; p[3] = (pv.z >> 8) & 255; p[4] = pv.z & 255;
+#pragma unroll
+        for (int i = 0; i < 5; i++) { a[2 * i] = p[i] - 2 * b.lo[i]; a[2 * i + 1] = p[i] - 2 * b.hi[i]; }
+    }
+    // max over the box of d(p, pivot) - d(p, c): c can be nearest (or tie) somewhere in the box only if >= 0.
+    // |c* - k| < 2^14 and |c* + k - 2p| < 2^15: 24-bit products, and the five terms sum below 2^31.
+    __device__ __forceinline__ int32_t worst(int4 c) const {
+        const int32_t v[5] = {c.x, c.y, (c.z >> 16) & 255, (c.z >> 8) & 255, c.z & 255};
+        int32_t f = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int32_t d = p[i] - v[i];
+            f += max(__mul24(d, v[i] + a[2 * i]), __mul24(d, v[i] + a[2 * i + 1]));
+        }
+        return f;
+    }
+};
 
 // partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
 // [6K] moved ; [6K+1] pair evaluations.  At iteration 0 the partials are the full sums of the new
 // assignment; afterwards they are SIGNED deltas of the pixels that moved, added to running sums.
-constexpr uint32_t kXMaxMovedSkip = 512;   // tile-skip schedule when at most this many centroids moved
-constexpr int kXMaxR = kXMaxK / kXThreads; // centroids per thread in the candidate pass (16)
-
 struct TileState {              // per tile, carried between iterations
-    uint2 *box;                 // colour extents: x = r0|r1<<8|g0<<16|g1<<24, y = b0|b1<<8   (static)
-    uint32_t *T;                // min_k ub_k of the last candidate build
+    const uint2 *box;           // colour extents (static, k_xy_boxes)
+    const uint2 *sbox;          // colour extents of every super-tile (static)
+    int4 *piv;                  // pivot of the last candidate build: (cx, cy, colour, id)
     unsigned long long *mask;   // [ntiles][K/64 rounded up] candidate bitmask of the last build
     const uint32_t *moved;      // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;         // skip schedule when moved[0] <= max_moved (0 disables it)
 };
 
+__host__ __device__ constexpr uint32_t xy_acc_words(uint32_t K) { return (6 * K + 3) & ~3u; }  // keeps the int4 arrays aligned
+
+// LDS (dynamic): acc[K][6] u32 | S_c[kSCap] int4 | W_c[16][wcap] int4 | M_c[512] int4 | W_mask[16][MW] u64 |
+//                S_k[kSCap] u16 | W_k[16][wcap] u16 | (use_tab) tab[K] int4: the centroid table itself
 __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
-                                                         uint32_t tiles_x, uint32_t ntiles, uint32_t K, XyCent ct,
+                                                         uint32_t tiles_x, uint32_t tiles_y, uint32_t super_x, uint32_t nsuper,
+                                                         uint32_t K, const int4 *__restrict__ cent,
                                                          uint16_t *__restrict__ labels,
                                                          unsigned long long *__restrict__ partials,
-                                                         const KmDevState *__restrict__ st, uint32_t flush_every,
+                                                         const KmDevState *__restrict__ st, uint32_t wcap, int use_tab,
                                                          int brute, TileState ts) {
-    extern __shared__ __align__(16) uint32_t acc[];  // [K][6] per-block partial sums (x,y,r,g,b,count), wrap-around signed
-    __shared__ int4 cand[kMaxCand];                   // (cx, cy, crgb, c2) of the tile's candidates
-    __shared__ uint16_t cand_k[kMaxCand];
-    __shared__ unsigned long long s_mask[kXMaxK / 64];
-    __shared__ int32_t red[8];
-    __shared__ uint32_t s_minub, s_ncand;
-    __shared__ uint32_t wsum[kXThreads / 64];
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t MW = (K + 63) >> 6;
+    uint32_t *acc = lds;
+    int4 *S_c = reinterpret_cast<int4 *>(acc + xy_acc_words(K));
+    int4 *W_c = S_c + kSCap;
+    int4 *M_c = W_c + (size_t)kXWaves * wcap;
+    unsigned long long *W_mask = reinterpret_cast<unsigned long long *>(M_c + kXMaxMovedSkip);
+    uint16_t *S_k = reinterpret_cast<uint16_t *>(W_mask + (size_t)kXWaves * MW);
+    uint16_t *W_k = S_k + kSCap;
+    // 16-byte aligned: the u16 arrays before it hold 16 * (64 + wcap) * 2 bytes
+    int4 *tab = reinterpret_cast<int4 *>(W_k + (size_t)kXWaves * wcap);
+    __shared__ unsigned long long s_key;
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t wsum[kXWaves];
     if (st->done) return;
-    for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) acc[i] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool first = st->iter == 0;
     const uint32_t nS = ts.moved[0];
     const bool skip_mode = !first && !brute && nS <= ts.max_moved;
-    const uint32_t MW = (K + 63) >> 6;
+    for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) acc[i] = 0;
+    if (skip_mode)
+        for (uint32_t j = threadIdx.x; j < nS; j += kXThreads) {
+            const uint32_t k = ts.moved[1 + j];
+            int4 c = cent[k];
+            c.w = (int32_t)k;
+            M_c[j] = c;
+        }
+    if (threadIdx.x == 0) s_key = ~0ull;
+    if (use_tab)
+        for (uint32_t k = threadIdx.x; k < K; k += kXThreads) tab[k] = cent[k];
+    // this thread's slice of the centroid table, for the whole launch: [t R, (t+1) R) so lists come out ascending
+    const uint32_t R = (K + kXThreads - 1) / kXThreads;
+    int4 mine[kXMaxR];
+#pragma unroll
+    for (int i = 0; i < kXMaxR; i++) {
+        const uint32_t k = threadIdx.x * R + i;
+        mine[i] = ((uint32_t)i < R && k < K) ? cent[k] : make_int4(0, 0, 0, 0);
+    }
+    int4 *const my_c = W_c + (size_t)wv * wcap;
+    uint16_t *const my_k = W_k + (size_t)wv * wcap;
+    unsigned long long *const my_mask = W_mask + (size_t)wv * MW;
     uint32_t moved = 0;
     unsigned long long evals = 0;
-    uint32_t since_flush = 0;
-    const uint32_t R = (K + kXThreads - 1) / kXThreads;  // centroids per thread in the candidate pass (<= kXMaxR)
-    const uint32_t k0 = threadIdx.x * R, k1 = min(k0 + R, K);
+    __syncthreads();
 
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t tx0 = (tile % tiles_x) * kTW, ty0 = (tile / tiles_x) * kTH;
-        const uint32_t tw = min((uint32_t)kTW, w - tx0), th = min((uint32_t)kTH, h - ty0);
-        TileBox bx{(int32_t)tx0, (int32_t)(tx0 + tw - 1), (int32_t)ty0, (int32_t)(ty0 + th - 1), 0, 0, 0, 0, 0, 0};
-        if (!first) {
-            const uint2 pb = ts.box[tile];
-            bx.r0 = pb.x & 255; bx.r1 = (pb.x >> 8) & 255; bx.g0 = (pb.x >> 16) & 255; bx.g1 = pb.x >> 24;
-            bx.b0 = pb.y & 255; bx.b1 = (pb.y >> 8) & 255;
-        }
-        // ---- skip test: did anything that matters to this tile change?
-        if (skip_mode) {
-            const uint32_t Tp = ts.T[tile];
-            int dirty = 0;
-            for (uint32_t j = threadIdx.x; j < nS; j += kXThreads) {
-                const uint32_t k = ts.moved[1 + j];
-                uint32_t lb, ub;
-                cent_bounds(ct, k, bx, lb, ub);
-                dirty |= lb <= Tp || ((ts.mask[(size_t)tile * MW + (k >> 6)] >> (k & 63)) & 1ull);
+    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+        const uint32_t stx = (sup % super_x) * kSTX, sty = (sup / super_x) * kSTY;
+        const uint32_t tix = stx + (wv & (kSTX - 1)), tiy = sty + wv / kSTX;
+        const bool has_tile = tix < tiles_x && tiy < tiles_y;
+        const uint32_t tile = has_tile ? tiy * tiles_x + tix : 0;
+        const uint32_t tx0 = tix * kTW, ty0 = tiy * kTH;
+        const uint32_t tw = has_tile ? min((uint32_t)kTW, w - tx0) : 0, th = has_tile ? min((uint32_t)kTH, h - ty0) : 0;
+        Box5 tb;
+        tb.lo[0] = (int32_t)tx0; tb.hi[0] = (int32_t)(tx0 + tw) - 1; tb.lo[1] = (int32_t)ty0; tb.hi[1] = (int32_t)(ty0 + th) - 1;
+        box_colours(tb, has_tile ? ts.box[tile] : make_uint2(0, 0));
+
+        // ---- skip test (per wave): did anything that matters to this tile change?
+        bool dirty = has_tile;
+        if (skip_mode && has_tile) {
+            Dominance dm;
+            dm.set(tb, ts.piv[tile]);
+            const unsigned long long mword = lane < MW ? ts.mask[(size_t)tile * MW + lane] : 0ull;
+            bool d = false;
+            for (uint32_t j0 = 0; j0 < nS; j0 += 64) {  // wave-uniform trip count: the shuffle needs every lane
+                const uint32_t j = j0 + lane;
+                const int4 m = M_c[min(j, nS - 1)];
+                const unsigned long long wd = __shfl(mword, (m.w >> 6) & 63, 64);
+                d |= j < nS && (((wd >> (m.w & 63)) & 1ull) || dm.worst(m) >= 0);
             }
-            if (!__syncthreads_or(dirty)) continue;  // same T, same candidates, same centroid values: every pixel repeats its decision
+            dirty = __ballot(d) != 0ull;
         }
-        // ---- load this thread's pixels: pixel j of thread t is (t & 63, (t >> 6) + 4 j)
-        uint32_t px[kXPPT];
-        bool valid[kXPPT];
-        int32_t r0 = 255, r1 = 0, g0 = 255, g1 = 0, b0 = 255, b1 = 0;
+        // pixel (lane, row): x = tx0 + lane, y = ty0 + row; rows go in groups of kXRows.  The first group's
+        // pixels and labels are requested now and arrive while the block builds S.
+        const int32_t x = (int32_t)(tx0 + lane);
+        const bool okx = lane < tw;
+        uint32_t px[2][kXRows], cur[2][kXRows];
+        auto load_rows = [&](int g, uint32_t (&p)[kXRows], uint32_t (&c)[kXRows]) {
 #pragma unroll
-        for (int j = 0; j < kXPPT; j++) {
-            const uint32_t lx = threadIdx.x & 63, ly = (threadIdx.x >> 6) + 4 * j;
-            valid[j] = lx < tw && ly < th;
-            px[j] = 0;
-            if (valid[j]) {
-                px[j] = rgb_key(rgb + 3 * ((uint64_t)(ty0 + ly) * w + tx0 + lx));
-                int32_t r = (px[j] >> 16) & 255, g = (px[j] >> 8) & 255, b = px[j] & 255;
-                r0 = min(r0, r); r1 = max(r1, r); g0 = min(g0, g); g1 = max(g1, g); b0 = min(b0, b); b1 = max(b1, b);
-            }
-        }
-        if (threadIdx.x == 0) {
-            red[0] = 255; red[1] = 0; red[2] = 255; red[3] = 0; red[4] = 255; red[5] = 0;
-            s_minub = 0xffffffffu; s_ncand = 0;
-        }
-        for (uint32_t i = threadIdx.x; i < MW; i += kXThreads) s_mask[i] = 0ull;
-        __syncthreads();
-        if (first) {  // tile bounding box (block reduction of the colour extents); static, kept for later iterations
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                r0 = min(r0, __shfl_down(r0, off, 64)); r1 = max(r1, __shfl_down(r1, off, 64));
-                g0 = min(g0, __shfl_down(g0, off, 64)); g1 = max(g1, __shfl_down(g1, off, 64));
-                b0 = min(b0, __shfl_down(b0, off, 64)); b1 = max(b1, __shfl_down(b1, off, 64));
-            }
-            if (lane == 0) {
-                atomicMin(&red[0], r0); atomicMax(&red[1], r1); atomicMin(&red[2], g0);
-                atomicMax(&red[3], g1); atomicMin(&red[4], b0); atomicMax(&red[5], b1);
-            }
-            __syncthreads();
-            bx.r0 = red[0]; bx.r1 = red[1]; bx.g0 = red[2]; bx.g1 = red[3]; bx.b0 = red[4]; bx.b1 = red[5];
-            if (threadIdx.x == 0)
-                ts.box[tile] = make_uint2((uint32_t)bx.r0 | ((uint32_t)bx.r1 << 8) | ((uint32_t)bx.g0 << 16) | ((uint32_t)bx.g1 << 24),
-                                          (uint32_t)bx.b0 | ((uint32_t)bx.b1 << 8));
-        }
-        // ---- candidate set: thread t owns centroids [t R, (t+1) R) so the list comes out in ascending k
-        uint32_t ncand = K;
-        bool use_list = !brute;
-        if (use_list) {
-            uint32_t lbv[kXMaxR];
-            uint32_t mub = 0xffffffffu;
-#pragma unroll
-            for (int i = 0; i < kXMaxR; i++) {
-                lbv[i] = 0xffffffffu;
-                const uint32_t k = k0 + i;
-                if ((uint32_t)i < R && k < k1) {
-                    uint32_t ub;
-                    cent_bounds(ct, k, bx, lbv[i], ub);
-                    mub = min(mub, ub);
+            for (int j = 0; j < kXRows; j++) {
+                const uint32_t ly = g * kXRows + j;
+                p[j] = 0; c[j] = 0;
+                if (okx && ly < th) {
+                    const uint64_t idx = (uint64_t)(ty0 + ly) * w + (uint32_t)x;
+                    p[j] = rgb_key(rgb + 3 * idx);
+                    c[j] = labels[idx];
                 }
             }
-            mub = wave_reduce_min(mub);
-            if (lane == 0) atomicMin(&s_minub, mub);
-            __syncthreads();
-            const uint32_t T = s_minub;
-            uint32_t mine = 0;
-#pragma unroll
-            for (int i = 0; i < kXMaxR; i++) mine += lbv[i] <= T;
-            uint32_t off = block_exclusive_scan<kXThreads>(mine, wsum);
-            if (threadIdx.x == kXThreads - 1) s_ncand = off + mine;
-            const bool fits = off + mine <= kMaxCand;
+        };
+        if (dirty) load_rows(0, px[0], cur[0]);
+        if (!__syncthreads_or(dirty)) continue;  // (also the barrier that frees S of the previous super-tile)
+
+        // ---- super-tile list S (whole block): pivot = centroid nearest the super-tile's box centre
+        bool s_over = brute != 0;
+        uint32_t nSl = 0;
+        if (!brute) {
+            Box5 sb;
+            sb.lo[0] = (int32_t)(stx * kTW); sb.hi[0] = (int32_t)min(w, (stx + kSTX) * kTW) - 1;
+            sb.lo[1] = (int32_t)(sty * kTH); sb.hi[1] = (int32_t)min(h, (sty + kSTY) * kTH) - 1;
+            box_colours(sb, ts.sbox[sup]);
+            unsigned long long key = ~0ull;
 #pragma unroll
             for (int i = 0; i < kXMaxR; i++) {
-                if (lbv[i] <= T) {
-                    const uint32_t k = k0 + i;
-                    atomicOr(&s_mask[k >> 6], 1ull << (k & 63));
-                    if (fits) {
-                        cand[off] = make_int4(ct.cx[k], ct.cy[k], (int32_t)ct.crgb[k], ct.c2[k]);
-                        cand_k[off] = (uint16_t)k;
-                        off++;
+                const uint32_t k = threadIdx.x * R + i;
+                if ((uint32_t)i < R && k < K) key = min(key, ((unsigned long long)centre_dist(sb, mine[i]) << 12) | k);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned long long)__shfl_xor(key, off, 64));
+            if (lane == 0) atomicMin(&s_key, key);
+            __syncthreads();
+            const uint32_t pk = (uint32_t)(s_key & 4095ull);
+            Dominance dm;
+            dm.set(sb, use_tab ? tab[pk] : cent[pk]);
+            bool keep[kXMaxR];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < kXMaxR; i++) {
+                const uint32_t k = threadIdx.x * R + i;
+                keep[i] = (uint32_t)i < R && k < K && dm.worst(mine[i]) >= 0;
+                cnt += keep[i];
+            }
+            uint32_t off = block_exclusive_scan<kXThreads>(cnt, wsum);  // (two barriers: every wave has read s_key)
+            if (threadIdx.x == kXThreads - 1) { s_n = off + cnt; s_key = ~0ull; }
+#pragma unroll
+            for (int i = 0; i < kXMaxR; i++)
+                if (keep[i]) {
+                    if (off < kSCap) { S_c[off] = mine[i]; S_k[off] = (uint16_t)(threadIdx.x * R + i); }
+                    off++;
+                }
+            __syncthreads();
+            nSl = s_n;
+            s_over = nSl > kSCap;
+        }
+        if (!dirty) continue;
+
+        // ================================================================= one wave, one tile
+
+        // ---- candidate strip: pivot = member of S nearest the tile's box centre, then the dominance test over S
+        const int4 *list_c = S_c;
+        const uint16_t *list_k = S_k;
+        uint32_t ncand = K;
+        if (!s_over) {
+            uint32_t bd = 0xffffffffu, be = 0;
+            for (uint32_t e = lane; e < nSl; e += 64) {
+                const uint32_t d = centre_dist(tb, S_c[e]);
+                if (d < bd) { bd = d; be = e; }
+            }
+            const uint32_t dmin = __shfl(wave_reduce_min(bd), 0, 64);
+            const uint32_t pe = __shfl(wave_reduce_min(bd == dmin ? be : 0xffffffffu), 0, 64);
+            int4 pv = S_c[pe];
+            Dominance dm;
+            dm.set(tb, pv);
+            for (uint32_t i = lane; i < MW; i += 64) my_mask[i] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t n = 0;
+            for (uint32_t e0 = 0; e0 < nSl; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                int4 c = make_int4(0, 0, 0, 0);
+                bool kp = false;
+                if (e < nSl) { c = S_c[e]; kp = dm.worst(c) >= 0; }
+                const unsigned long long bm = __ballot(kp);
+                if (kp) {
+                    const uint32_t pos = n + (uint32_t)__popcll(bm & lt_mask);
+                    const uint32_t k = S_k[e];
+                    if (pos < wcap) { my_c[pos] = c; my_k[pos] = (uint16_t)k; }
+                    atomicOr(&my_mask[k >> 6], 1ull << (k & 63));
+                }
+                n += (uint32_t)__popcll(bm);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (n <= wcap) { list_c = my_c; list_k = my_k; ncand = n; } else ncand = nSl;  // S is a superset in the same order
+            pv.w = (int32_t)S_k[pe];
+            if (lane == 0) ts.piv[tile] = pv;
+            for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = my_mask[i];
+        } else {
+            if (lane == 0) ts.piv[tile] = cent[0];                      // every centroid is a candidate:
+            for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = ~0ull;  // any move makes the tile dirty
+        }
+
+        // ---- assign, kXRows rows at a time; the next group's pixels and labels are in flight meanwhile
+#pragma unroll
+        for (int g = 0; g < kTH / kXRows; g++) {
+            const uint32_t (&p)[kXRows] = px[g & 1];
+            const uint32_t (&c)[kXRows] = cur[g & 1];
+            if (g + 1 < kTH / kXRows) load_rows(g + 1, px[(g + 1) & 1], cur[(g + 1) & 1]);
+            if ((uint32_t)(g * kXRows) >= th) continue;  // wave-uniform
+            int4 own[kXRows];  // the centroid each pixel belongs to now
+#pragma unroll
+            for (int j = 0; j < kXRows; j++) own[j] = use_tab ? tab[c[j]] : cent[c[j]];
+            int32_t best[kXRows];
+            uint32_t bpos[kXRows];
+#pragma unroll
+            for (int j = 0; j < kXRows; j++) { best[j] = INT32_MIN; bpos[j] = 0; }
+            // maximise 2 p.c - |c|^2; ascending k and a strict compare: first maximum = lowest id
+            if (!s_over) {
+                for (uint32_t q = 0; q < ncand; q++) {
+                    const int4 cc = list_c[q];  // LDS broadcast
+                    const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
+#pragma unroll
+                    for (int j = 0; j < kXRows; j++) {
+                        const int32_t y2 = 2 * (int32_t)(ty0 + g * kXRows + j);
+                        const int32_t gq = (int32_t)(xdot4(p[j], (uint32_t)cc.z) << 1) + xmad24(y2, cc.y, ax);
+                        if (gq > best[j]) { best[j] = gq; bpos[j] = q; }
+                    }
+                }
+            } else {
+                for (uint32_t q = 0; q < K; q++) {  // q wave-uniform: scalar loads
+                    const int4 cc = cent[q];
+                    const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
+#pragma unroll
+                    for (int j = 0; j < kXRows; j++) {
+                        const int32_t y2 = 2 * (int32_t)(ty0 + g * kXRows + j);
+                        const int32_t gq = (int32_t)(xdot4(p[j], (uint32_t)cc.z) << 1) + xmad24(y2, cc.y, ax);
+                        if (gq > best[j]) { best[j] = gq; bpos[j] = q; }
                     }
                 }
             }
-            __syncthreads();
-            ncand = s_ncand;
-            use_list = ncand <= kMaxCand;
-            if (!use_list) ncand = K;
-            if (threadIdx.x == 0) ts.T[tile] = T;
-            for (uint32_t i = threadIdx.x; i < MW; i += kXThreads) ts.mask[(size_t)tile * MW + i] = s_mask[i];
-        }
-        // ---- assign
 #pragma unroll
-        for (int j = 0; j < kXPPT; j++) {
-            if (!valid[j]) continue;
-            const uint32_t lx = threadIdx.x & 63, ly = (threadIdx.x >> 6) + 4 * j;
-            const int32_t x = (int32_t)(tx0 + lx), y = (int32_t)(ty0 + ly);
-            const uint64_t idx = (uint64_t)y * w + x;
-            int32_t best = INT32_MIN;
-            uint32_t bk = 0;
-            if (use_list) {
-                uint32_t bpos = 0;
-                for (uint32_t q = 0; q < ncand; q++) {
-                    int4 cc = cand[q];  // LDS broadcast
-                    int32_t dot = x * cc.x + y * cc.y + (int32_t)xdot4(px[j], (uint32_t)cc.z);
-                    int32_t g = 2 * dot - cc.w;
-                    if (g > best) { best = g; bpos = q; }  // ascending k: first maximum = lowest id
+            for (int j = 0; j < kXRows; j++) {
+                const uint32_t ly = g * kXRows + j;
+                const bool ok = okx && ly < th;
+                const int32_t y = (int32_t)(ty0 + ly);
+                const uint32_t bk = s_over ? bpos[j] : (uint32_t)list_k[bpos[j]];
+                const int32_t gcur = (int32_t)(xdot4(p[j], (uint32_t)own[j].z) << 1) +
+                                     xmad24(2 * y, own[j].y, xmad24(2 * x, own[j].x, -own[j].w));
+                const bool mv = ok && best[j] > gcur;  // strictly closer (kmeans.rs:375)
+                const uint32_t nl = mv ? bk : c[j];
+                if (mv) { labels[(uint64_t)y * w + (uint32_t)x] = (uint16_t)nl; moved++; }
+                const uint32_t r = (p[j] >> 16) & 255, gg = (p[j] >> 8) & 255, b = p[j] & 255;
+                if (first) {
+                    // vector_add clusterc.rs:221-228 for every pixel.  A row of 64 pixels holds few distinct
+                    // labels: one wave reduction per label instead of 64 colliding LDS atomics.
+                    unsigned long long todo = __ballot(ok);
+                    while (todo) {
+                        const uint32_t lk = __shfl(nl, __ffsll((long long)todo) - 1, 64);
+                        const bool in = ok && nl == lk;
+                        const unsigned long long grp = __ballot(in);
+                        const uint32_t cn = (uint32_t)__popcll(grp);
+                        const uint32_t sx = wave_reduce_sum(in ? (uint32_t)x : 0u), sr = wave_reduce_sum(in ? r : 0u);
+                        const uint32_t sg = wave_reduce_sum(in ? gg : 0u), sbb = wave_reduce_sum(in ? b : 0u);
+                        if (lane == 0) {
+                            uint32_t *a = acc + 6 * lk;
+                            atomicAdd(a + 0, sx); atomicAdd(a + 1, (uint32_t)y * cn); atomicAdd(a + 2, sr);
+                            atomicAdd(a + 3, sg); atomicAdd(a + 4, sbb); atomicAdd(a + 5, cn);
+                        }
+                        todo &= ~grp;
+                    }
+                } else if (mv) {  // +pixel to its new cluster, -pixel from its old one
+                    uint32_t *a = acc + 6 * nl, *o = acc + 6 * c[j];
+                    atomicAdd(a + 0, (uint32_t)x); atomicAdd(a + 1, (uint32_t)y); atomicAdd(a + 2, r);
+                    atomicAdd(a + 3, gg); atomicAdd(a + 4, b); atomicAdd(a + 5, 1u);
+                    atomicAdd(o + 0, 0u - (uint32_t)x); atomicAdd(o + 1, 0u - (uint32_t)y); atomicAdd(o + 2, 0u - r);
+                    atomicAdd(o + 3, 0u - gg); atomicAdd(o + 4, 0u - b); atomicAdd(o + 5, 0u - 1u);
                 }
-                bk = cand_k[bpos];
-            } else {
-                for (uint32_t k = 0; k < K; k++) {  // k wave-uniform: scalar loads
-                    int32_t dot = x * ct.cx[k] + y * ct.cy[k] + (int32_t)xdot4(px[j], ct.crgb[k]);
-                    int32_t g = 2 * dot - ct.c2[k];
-                    if (g > best) { best = g; bk = k; }
-                }
+                if (ok) evals += ncand + 1;
             }
-            const uint32_t cur = labels[idx];
-            const int32_t gcur = 2 * (x * ct.cx[cur] + y * ct.cy[cur] + (int32_t)xdot4(px[j], ct.crgb[cur])) - ct.c2[cur];
-            const bool mv = best > gcur;  // strictly closer (kmeans.rs:375)
-            const uint32_t nl = mv ? bk : cur;
-            if (mv) { labels[idx] = (uint16_t)nl; moved++; }
-            if (mv || first) {  // vector_add clusterc.rs:221-228, as +new / -old
-                uint32_t *a = acc + 6 * nl;
-                atomicAdd(a + 0, (uint32_t)x);
-                atomicAdd(a + 1, (uint32_t)y);
-                atomicAdd(a + 2, (px[j] >> 16) & 255);
-                atomicAdd(a + 3, (px[j] >> 8) & 255);
-                atomicAdd(a + 4, px[j] & 255);
-                atomicAdd(a + 5, 1u);
-                if (!first) {
-                    uint32_t *o = acc + 6 * cur;
-                    atomicAdd(o + 0, 0u - (uint32_t)x);
-                    atomicAdd(o + 1, 0u - (uint32_t)y);
-                    atomicAdd(o + 2, 0u - ((px[j] >> 16) & 255));
-                    atomicAdd(o + 3, 0u - ((px[j] >> 8) & 255));
-                    atomicAdd(o + 4, 0u - (px[j] & 255));
-                    atomicAdd(o + 5, 0u - 1u);
-                }
-            }
-            evals += ncand + 1;
         }
-        // ---- flush the LDS partials before a signed 32-bit lane can overflow
-        if (++since_flush >= flush_every) {
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) {
-                const uint32_t v = acc[i];
-                if (v) {
-                    const uint32_t k = i / 6, d = i % 6;
-                    atomicAdd(&partials[d < 5 ? 5 * (size_t)k + d : 5 * (size_t)K + k], (unsigned long long)(long long)(int32_t)v);
-                    acc[i] = 0;
-                }
-            }
-            since_flush = 0;
-        }
-        __syncthreads();
     }
     __syncthreads();
+    // the host sizes the grid so that one block's pixels * max coordinate stays below 2^31: one flush at the end
     for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) {
         const uint32_t v = acc[i];
         if (v) {
@@ -308,48 +459,65 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     if (lane == 0 && evals) atomicAdd(&partials[6 * (size_t)K + 1], evals);
 }
 
-// Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137)
-__global__ __launch_bounds__(256) void k_xy_update(unsigned long long *__restrict__ partials,
-                                                   unsigned long long *__restrict__ running,
-                                                   const uint8_t *__restrict__ rgb, uint32_t w, uint64_t N,
-                                                   uint32_t K, uint64_t seed, uint64_t max_iters, XyCent ct,
-                                                   uint64_t *__restrict__ members_out, uint32_t *__restrict__ moved_list,
-                                                   KmDevState *__restrict__ st) {
+// Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137).
+// A cluster whose partials are all zero keeps members and sums, hence its centroid: no division.
+__global__ __launch_bounds__(1024) void k_xy_update(unsigned long long *__restrict__ partials,
+                                                    unsigned long long *__restrict__ running,
+                                                    const uint8_t *__restrict__ rgb, uint32_t w, uint64_t N,
+                                                    uint32_t K, uint64_t seed, uint64_t max_iters, int4 *__restrict__ cent,
+                                                    uint64_t *__restrict__ members_out, uint32_t *__restrict__ moved_list,
+                                                    KmDevState *__restrict__ st) {
     if (st->done) return;
     __shared__ uint32_t s_reseed, s_active, s_nmoved;
     if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
-    for (uint32_t i = threadIdx.x; i < 6 * K; i += blockDim.x) running[i] += partials[i];
     __syncthreads();
     const uint64_t iter = st->iter;
-    for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-        const unsigned long long m = running[5 * (size_t)K + k];
-        members_out[k] = m;
-        int32_t x, y;
-        uint32_t col;
-        if (m == 0) {
-            uint64_t idx = reseed_index(seed, iter, k, N);  // fake_clone of the stolen pixel
-            x = (int32_t)(idx % w); y = (int32_t)(idx / w);
-            col = rgb_key(rgb + 3 * idx);
-            atomicAdd(&s_reseed, 1u);
-        } else {
-            x = (int32_t)(uint32_t)(running[5 * (size_t)k + 0] / m);
-            y = (int32_t)(uint32_t)(running[5 * (size_t)k + 1] / m);
-            uint32_t r = (uint32_t)(running[5 * (size_t)k + 2] / m) & 255;
-            uint32_t g = (uint32_t)(running[5 * (size_t)k + 3] / m) & 255;
-            uint32_t b = (uint32_t)(running[5 * (size_t)k + 4] / m) & 255;
-            col = (r << 16) | (g << 8) | b;
-            atomicAdd(&s_active, 1u);
-        }
-        if (ct.cx[k] != x || ct.cy[k] != y || ct.crgb[k] != col) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
-        ct.cx[k] = x; ct.cy[k] = y; ct.crgb[k] = col;
-        ct.c2[k] = x * x + y * y + (int32_t)xdot4(col, col);
-    }
-    __syncthreads();
     const unsigned long long changed = partials[6 * (size_t)K];
     const unsigned long long evals = partials[6 * (size_t)K + 1];
+    for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
+        unsigned long long d[6];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const size_t at = i < 5 ? 5 * (size_t)k + i : 5 * (size_t)K + k;
+            d[i] = partials[at];
+            partials[at] = 0;
+            any |= d[i] != 0;
+        }
+        unsigned long long m = running[5 * (size_t)K + k];
+        if (any) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const size_t at = i < 5 ? 5 * (size_t)k + i : 5 * (size_t)K + k;
+                running[at] += d[i];
+            }
+            m += d[5];
+        }
+        members_out[k] = m;
+        if (m == 0) {  // reseeded every iteration it stays empty (the index depends on iter)
+            const uint64_t idx = reseed_index(seed, iter, k, N);  // fake_clone of the stolen pixel
+            const int4 nc = make_cent((int32_t)(idx % w), (int32_t)(idx / w), rgb_key(rgb + 3 * idx));
+            const int4 oc = cent[k];
+            if (oc.x != nc.x || oc.y != nc.y || oc.z != nc.z) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
+            cent[k] = nc;
+            atomicAdd(&s_reseed, 1u);
+        } else {
+            atomicAdd(&s_active, 1u);
+            if (any) {
+                uint32_t q[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) q[i] = (uint32_t)(running[5 * (size_t)k + i] / m);
+                const int4 nc = make_cent((int32_t)q[0], (int32_t)q[1], ((q[2] & 255) << 16) | ((q[3] & 255) << 8) | (q[4] & 255));
+                const int4 oc = cent[k];
+                if (oc.x != nc.x || oc.y != nc.y || oc.z != nc.z) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
+                cent[k] = nc;
+            }
+        }
+    }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += blockDim.x) partials[i] = 0;
     if (threadIdx.x == 0) {
+        partials[6 * (size_t)K] = 0;
+        partials[6 * (size_t)K + 1] = 0;
         moved_list[0] = s_nmoved;
         st->changed_ring[iter % kHistRing] = changed;
         st->moved_last = changed;
@@ -385,22 +553,33 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     s.brute = opts && (opts->flags & CNIIC_KM_BRUTE_FORCE);
     s.tiles_x = (uint32_t)ceil_div(w, kTW);
     s.tiles_y = (uint32_t)ceil_div(h, kTH);
-    const uint32_t ntiles = s.tiles_x * s.tiles_y;
-    s.nblocks = std::min<uint32_t>(ntiles, 512);
-    // signed 32-bit LDS partials: (pixels between flushes) * max coordinate < 2^31
-    s.flush_every = std::max<uint32_t>(1, (uint32_t)((1ull << 31) / ((uint64_t)std::max(w, h) * kTW * kTH)) - 1);
+    s.super_x = (uint32_t)ceil_div(s.tiles_x, kSTX);
+    s.super_y = (uint32_t)ceil_div(s.tiles_y, kSTY);
+    const uint32_t ntiles = s.tiles_x * s.tiles_y, nsuper = s.super_x * s.super_y;
+    // One 16-wave block per CU (the LDS accumulators allow no more).  The accumulators are signed 32-bit and
+    // flushed once, so (pixels one block sees) * max coordinate must stay below 2^31; a larger image gets
+    // more blocks than CUs and the surplus queues behind the resident ones.
+    const uint64_t per_block_max = std::max<uint64_t>(((1ull << 31) - 1) / ((uint64_t)std::max(w, h) * kSuperPx), 1);
+    s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256), ceil_div(nsuper, per_block_max));
+    const uint32_t MW = (K + 63) / 64;
+    // LDS budget (159 KiB): accumulators, S, the moved list, the masks, then the centroid table if it fits next
+    // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
+    const size_t lds_max = 159 * 1024;
+    size_t fixed = (size_t)xy_acc_words(K) * 4 + (size_t)kSCap * 18 + (size_t)kXMaxMovedSkip * 16 + (size_t)kXWaves * MW * 8;
+    s.use_tab = fixed + (size_t)K * 16 + (size_t)kXWaves * 64 * 18 <= lds_max;
+    if (s.use_tab) fixed += (size_t)K * 16;
+    s.wcap = (uint32_t)std::min<size_t>(256, (lds_max - fixed) / ((size_t)kXWaves * 18) / 32 * 32);
+    s.lds = fixed + (size_t)kXWaves * s.wcap * 18;
     CNIIC_HIP_TRY(c, s.labels.alloc(N * 2));
-    CNIIC_HIP_TRY(c, s.cx.alloc((uint64_t)K * 4));
-    CNIIC_HIP_TRY(c, s.cy.alloc((uint64_t)K * 4));
-    CNIIC_HIP_TRY(c, s.crgb.alloc((uint64_t)K * 4));
-    CNIIC_HIP_TRY(c, s.c2.alloc((uint64_t)K * 4));
+    CNIIC_HIP_TRY(c, s.cent.alloc((uint64_t)K * 16));
     CNIIC_HIP_TRY(c, s.partials.alloc((6 * (uint64_t)K + 2) * 8));
     CNIIC_HIP_TRY(c, s.members_last.alloc((uint64_t)K * 8));
     CNIIC_HIP_TRY(c, s.dstate.alloc(sizeof(KmDevState)));
     CNIIC_HIP_TRY(c, s.running.alloc((6 * (uint64_t)K + 2) * 8));
     CNIIC_HIP_TRY(c, s.tile_box.alloc((uint64_t)ntiles * 8));
-    CNIIC_HIP_TRY(c, s.tile_T.alloc((uint64_t)ntiles * 4));
-    CNIIC_HIP_TRY(c, s.tile_mask.alloc((uint64_t)ntiles * ((K + 63) / 64) * 8));
+    CNIIC_HIP_TRY(c, s.super_box.alloc((uint64_t)nsuper * 8));
+    CNIIC_HIP_TRY(c, s.tile_piv.alloc((uint64_t)ntiles * 16));
+    CNIIC_HIP_TRY(c, s.tile_mask.alloc((uint64_t)ntiles * MW * 8));
     CNIIC_HIP_TRY(c, s.moved_list.alloc(((uint64_t)K + 1) * 4));
     s.no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.partials.p, 0, (6 * (uint64_t)K + 2) * 8, c->stream));
@@ -408,16 +587,24 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.dstate.p, 0, sizeof(KmDevState), c->stream));
     const uint32_t all = K;  // before the first update every centroid counts as moved
     CNIIC_HIP_TRY(c, hipMemcpyAsync(s.moved_list.p, &all, 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_xy_boxes, dim3((uint32_t)ceil_div(ntiles, 4)), dim3(256), 0, c->stream, rgb_d, w, h, s.tiles_x, ntiles,
+                       s.tile_box.as<uint2>());
+    hipLaunchKernelGGL(k_xy_super_boxes, dim3((uint32_t)ceil_div(nsuper, 256)), dim3(256), 0, c->stream, s.tile_box.as<uint2>(),
+                       s.tiles_x, s.tiles_y, s.super_x, nsuper, s.super_box.as<uint2>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    // the assign kernel carves up to ~150 KiB of the CU's 160 KiB LDS
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         159 * 1024));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
 
 static int xy_assign(KmXyState &s) {
     Ctx *c = s.c;
-    hipLaunchKernelGGL(k_xy_assign, dim3(s.nblocks), dim3(kXThreads), (size_t)s.K * 6 * 4, c->stream, s.rgb, s.w, s.h,
-                       s.tiles_x, s.tiles_x * s.tiles_y, s.K, s.cent(), s.labels.as<uint16_t>(),
-                       s.partials.as<unsigned long long>(), s.dstate.as<KmDevState>(), s.flush_every, s.brute ? 1 : 0,
-                       TileState{s.tile_box.as<uint2>(), s.tile_T.as<uint32_t>(), s.tile_mask.as<unsigned long long>(),
+    hipLaunchKernelGGL(k_xy_assign, dim3(s.nblocks), dim3(kXThreads), s.lds, c->stream, s.rgb, s.w, s.h, s.tiles_x, s.tiles_y,
+                       s.super_x, s.super_x * s.super_y, s.K, s.cent.as<int4>(), s.labels.as<uint16_t>(),
+                       s.partials.as<unsigned long long>(), s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
+                       TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),
                                  s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip});
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
@@ -425,8 +612,8 @@ static int xy_assign(KmXyState &s) {
 
 static int xy_update(KmXyState &s) {
     Ctx *c = s.c;
-    hipLaunchKernelGGL(k_xy_update, dim3(1), dim3(256), 0, c->stream, s.partials.as<unsigned long long>(),
-                       s.running.as<unsigned long long>(), s.rgb, s.w, s.N, s.K, s.seed, s.max_iters, s.cent(),
+    hipLaunchKernelGGL(k_xy_update, dim3(1), dim3(1024), 0, c->stream, s.partials.as<unsigned long long>(),
+                       s.running.as<unsigned long long>(), s.rgb, s.w, s.N, s.K, s.seed, s.max_iters, s.cent.as<int4>(),
                        s.members_last.as<uint64_t>(), s.moved_list.as<uint32_t>(), s.dstate.as<KmDevState>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
@@ -439,7 +626,7 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
     KmXyState s;
     CNIIC_TRY(xy_create(c, rgb_d, w, h, K, opts, s));
     hipLaunchKernelGGL(k_xy_init, dim3(xy_grid(std::max<uint64_t>(s.N, K))), dim3(256), 0, c->stream, rgb_d, w, s.N, K,
-                       s.labels.as<uint16_t>(), s.cent());
+                       s.labels.as<uint16_t>(), s.cent.as<int4>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     KmDevState hst;
     ScopedKernelTimer timer(c, "kmeans_xyrgb_iter");
@@ -453,15 +640,13 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
         if (hst.done) break;
     }
     timer.stop(hst.iter);
-    std::vector<int32_t> cx(K), cy(K);
-    std::vector<uint32_t> col(K);
-    CNIIC_HIP_TRY(c, hipMemcpy(cx.data(), s.cx.p, (size_t)K * 4, hipMemcpyDeviceToHost));
-    CNIIC_HIP_TRY(c, hipMemcpy(cy.data(), s.cy.p, (size_t)K * 4, hipMemcpyDeviceToHost));
-    CNIIC_HIP_TRY(c, hipMemcpy(col.data(), s.crgb.p, (size_t)K * 4, hipMemcpyDeviceToHost));
+    std::vector<int4> cent(K);
+    CNIIC_HIP_TRY(c, hipMemcpy(cent.data(), s.cent.p, (size_t)K * 16, hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < K; k++) {
-        centroids_h[k].x = (uint32_t)cx[k]; centroids_h[k].y = (uint32_t)cy[k];
-        centroids_h[k].rgb[0] = (uint8_t)(col[k] >> 16); centroids_h[k].rgb[1] = (uint8_t)(col[k] >> 8);
-        centroids_h[k].rgb[2] = (uint8_t)col[k]; centroids_h[k].pad = 0;
+        const uint32_t col = (uint32_t)cent[k].z;
+        centroids_h[k].x = (uint32_t)cent[k].x; centroids_h[k].y = (uint32_t)cent[k].y;
+        centroids_h[k].rgb[0] = (uint8_t)(col >> 16); centroids_h[k].rgb[1] = (uint8_t)(col >> 8);
+        centroids_h[k].rgb[2] = (uint8_t)col; centroids_h[k].pad = 0;
     }
     if (members_h) CNIIC_HIP_TRY(c, hipMemcpy(members_h, s.members_last.p, (size_t)K * 8, hipMemcpyDeviceToHost));
     if (labels_d_u32) {
@@ -484,18 +669,14 @@ int km_xyrgb_step(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
                   const cniic_kmeans_opts *opts) {
     KmXyState s;
     CNIIC_TRY(xy_create(c, rgb_d, w, h, K, opts, s));
-    std::vector<int32_t> cx(K), cy(K), c2(K);
-    std::vector<uint32_t> col(K);
+    std::vector<int4> cent(K);
     for (uint32_t k = 0; k < K; k++) {
-        cx[k] = (int32_t)centroids_h[k].x; cy[k] = (int32_t)centroids_h[k].y;
+        const int32_t cx = (int32_t)centroids_h[k].x, cy = (int32_t)centroids_h[k].y;
         const uint8_t *q = centroids_h[k].rgb;
-        col[k] = ((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | q[2];
-        c2[k] = cx[k] * cx[k] + cy[k] * cy[k] + q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        cent[k] = make_int4(cx, cy, (int32_t)(((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | q[2]),
+                            cx * cx + cy * cy + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
     }
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.cx.p, cx.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.cy.p, cy.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.crgb.p, col.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.c2.p, c2.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(s.cent.p, cent.data(), (size_t)K * 16, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_xy_narrow, dim3(xy_grid(s.N)), dim3(256), 0, c->stream, labels_d_u32, s.labels.as<uint16_t>(), s.N);
     CNIIC_TRY(xy_assign(s));
     hipLaunchKernelGGL(k_xy_widen, dim3(xy_grid(s.N)), dim3(256), 0, c->stream, s.labels.as<uint16_t>(), labels_d_u32, s.N);
