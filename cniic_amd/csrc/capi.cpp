@@ -80,6 +80,8 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     c->pool.trim();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto e : c->poll_ev) if (e) (void)hipEventDestroy(e);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -116,8 +116,8 @@ struct Ctx {
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
     DevBuf hilbert_lut;     // state-machine tables of the 2^n Hilbert scan (k_hilbert.hip)
-    void  *pinned = nullptr; // 4 KiB of mapped host memory for lagged flag polling
-    uint64_t pinned_bytes = 0;
+    void  *pinned = nullptr; // 4 KiB of pinned host memory: two KmDevState slots for lagged convergence polling
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -205,6 +205,45 @@ struct KmDevState {
     uint64_t active;
     uint64_t pair_evals;
     uint64_t changed_ring[kHistRing];
+};
+
+// Lagged convergence polling.  The K-means loops enqueue batches of (assign, update) launches; every
+// kernel exits at once when the device-side `done` flag is set.  After each batch the state is copied to
+// a pinned slot and an event recorded, but the host only waits for the copy of the PREVIOUS batch, so the
+// GPU never idles for a host round trip; the price is at most one extra batch of no-op launches.
+struct LaggedPoll {
+    Ctx *c;
+    const void *dstate;
+    int slot = 0, pending = 0;
+    LaggedPoll(Ctx *ctx, const void *dstate_d) : c(ctx), dstate(dstate_d) {}
+    int prepare() {
+        static_assert(2 * sizeof(KmDevState) <= 4096, "two poll slots must fit the pinned page");
+        if (!c->pinned) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+        for (int i = 0; i < 2; i++)
+            if (!c->poll_ev[i]) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
+        return CNIIC_OK;
+    }
+    // call after enqueuing a batch; returns the state as of the batch BEFORE it in *h (valid when *have)
+    int after_batch(KmDevState *h, bool *have) {
+        KmDevState *slots = static_cast<KmDevState *>(c->pinned);
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(&slots[slot], dstate, sizeof(KmDevState), hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipEventRecord(c->poll_ev[slot], c->stream));
+        *have = pending > 0;
+        if (pending) {
+            CNIIC_HIP_TRY(c, hipEventSynchronize(c->poll_ev[slot ^ 1]));
+            *h = slots[slot ^ 1];
+        }
+        slot ^= 1;
+        pending = 1;
+        return CNIIC_OK;
+    }
+    // state after everything enqueued so far
+    int drain(KmDevState *h) {
+        KmDevState *slots = static_cast<KmDevState *>(c->pinned);
+        CNIIC_HIP_TRY(c, hipEventSynchronize(c->poll_ev[slot ^ 1]));
+        *h = slots[slot ^ 1];
+        return CNIIC_OK;
+    }
 };
 
 // ---- kernel timing of the dominant kernels (HIP events on the ctx stream) ----

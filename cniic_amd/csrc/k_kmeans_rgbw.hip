@@ -17,14 +17,17 @@
 // Two assign kernels, identical results:
 //   * k_rgbw_assign        brute force over all K centroids (3 VALU per pair; constants arrive by
 //                          scalar loads).  VALU-bound.  Used by the single-step ABI and for A/B.
-//   * k_rgbw_assign_cells  colour space is cut into 8x8x8 cells and the points are kept in
-//                          cell-major order.  Per cell and iteration the block bounds every
-//                          centroid's squared distance to the cell's cube (lb_k, ub_k) and keeps
-//                          only {k : lb_k <= min_j ub_j}: no other centroid can be nearest - or
-//                          tied - for any colour of the cell.  This is the reference's
+//   * k_rgbw_assign_cells  colour space is cut into 8x8x8 cells, grouped 4x4x4 into super-cells,
+//                          and the points are kept in cell-major order.  For a cube B and a pivot
+//                          centroid c*, d(p,c*) - d(p,c_k) = sum_dim (c*_d - k_d)(c*_d + k_d - 2 p_d)
+//                          is linear in p: its maximum over B is a sum of per-axis maxima at the
+//                          cube faces.  If that maximum is negative c_k cannot be nearest - or tied
+//                          - for any colour of B and is dropped.  A wave runs the test once per
+//                          super-cell over all K (list S, pivot = centroid nearest the cube centre)
+//                          and once per cell over S only.  This is the reference's
 //                          triangle-inequality pruning (kmeans.rs:355-370) applied to a box of
-//                          points instead of one point against a neighbour list; it is exact at
-//                          every iteration (the reference's truncated lists are not).
+//                          points and one pivot instead of one point against a neighbour list; it
+//                          is exact at every iteration (the reference's truncated lists are not).
 //
 // Centroid update is exact u64 integer arithmetic (clusterc.rs:92-105).  The cells path keeps
 // RUNNING per-cluster sums and feeds them signed deltas from the points that moved (integer adds
@@ -33,6 +36,10 @@
 // order and GPU count.
 #include <cstdlib>
 #include <vector>
+
+#ifndef CNIIC_CELL_SHIFT
+#define CNIIC_CELL_SHIFT 3
+#endif
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -43,10 +50,10 @@ constexpr uint32_t kBias = 1u << 18;  // > max |c|^2 = 195075
 constexpr int kPPT = 8;               // colours per thread per sweep (brute kernel)
 constexpr int kAssignThreads = 256;
 constexpr uint32_t kMaxBlocks = 512;
-constexpr int kCellShift = 3;                                  // 8x8x8 colours per cell
+constexpr int kCellShift = CNIIC_CELL_SHIFT;                    // 2^shift colours per cell side
 constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
-constexpr uint32_t kCellBlocks = 1536;     // 6 blocks of 4 waves per CU: every wave resident at once
+constexpr uint32_t kCellBlocks = 1280;     // 5 blocks of 4 waves per CU: every wave resident at once
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
 constexpr uint32_t kCellFixedCost = 1024; // per-cell overhead in point-equivalents (work split between waves)
 
@@ -62,7 +69,7 @@ struct KmRgbwState {
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
-    DevBuf cell_T, cell_mask, moved_list, queue;  // skip schedule state
+    DevBuf cell_piv, cell_mask, moved_list, queue;  // skip schedule state
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -78,9 +85,26 @@ __device__ __forceinline__ uint2 make_cconst(uint32_t ckey, uint32_t k, uint32_t
     return make_uint2(ckey, ((kBias - h) << idbits) | (idmask - k));
 }
 
+// Cell id = super-cell (4x4x4 cells = a 32^3 cube of colours; 9 bits, r-major) << 6 | cell within it (6 bits,
+// r-major): the 64 cells of a super-cell are consecutive, so a wave walking its cell range changes
+// super-cell rarely.
+constexpr int kSuperShift = 6;
+constexpr uint32_t kSupersPerDim = kCellsPerDim / 4;
 __device__ __forceinline__ uint32_t cell_of(uint32_t key) {
-    return (((key >> 16) & 255) >> kCellShift) * kCellsPerDim * kCellsPerDim + (((key >> 8) & 255) >> kCellShift) * kCellsPerDim +
-           ((key & 255) >> kCellShift);
+    const uint32_t rc = ((key >> 16) & 255) >> kCellShift, gc = ((key >> 8) & 255) >> kCellShift, bc = (key & 255) >> kCellShift;
+    const uint32_t sup = ((rc >> 2) * kSupersPerDim + (gc >> 2)) * kSupersPerDim + (bc >> 2);
+    return (sup << kSuperShift) | ((rc & 3) << 4) | ((gc & 3) << 2) | (bc & 3);
+}
+struct CellBox { int32_t r0, g0, b0; };  // low corner of a cube of colours
+__device__ __forceinline__ CellBox super_box(uint32_t sup) {
+    return CellBox{(int32_t)((sup / (kSupersPerDim * kSupersPerDim)) << (kCellShift + 2)),
+                   (int32_t)(((sup / kSupersPerDim) % kSupersPerDim) << (kCellShift + 2)),
+                   (int32_t)((sup % kSupersPerDim) << (kCellShift + 2))};
+}
+__device__ __forceinline__ CellBox cell_box(uint32_t c) {
+    const CellBox sb = super_box(c >> kSuperShift);
+    return CellBox{sb.r0 + (int32_t)(((c >> 4) & 3) << kCellShift), sb.g0 + (int32_t)(((c >> 2) & 3) << kCellShift),
+                   sb.b0 + (int32_t)((c & 3) << kCellShift)};
 }
 
 // ---------------------------------------------------------------- init (kmeans.rs:61-108)
@@ -278,17 +302,21 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__
 }
 
 // ---- cell-major order straight from the dense colour table (codec path).  After the canonical
-// compaction table[key] = rank + 1 for every colour that occurs.  One 512-thread block per cell:
-// thread t owns colour (r_lo, g_lo, b_lo) = (t >> 6, (t >> 3) & 7, t & 7) of the cell.
+// compaction table[key] = rank + 1 for every colour that occurs.  One 512-thread block per cell walks the
+// cell's colours t = (r_lo, g_lo, b_lo) in ascending order, 512 at a time.
+constexpr uint32_t kCellColours = 1u << (3 * kCellShift);
 __device__ __forceinline__ uint32_t cell_key(uint32_t cell, uint32_t t) {
-    const uint32_t r = ((cell / (kCellsPerDim * kCellsPerDim)) << kCellShift) | (t >> 6);
-    const uint32_t g = (((cell / kCellsPerDim) % kCellsPerDim) << kCellShift) | ((t >> 3) & 7);
-    const uint32_t b = ((cell % kCellsPerDim) << kCellShift) | (t & 7);
+    constexpr uint32_t lm = (1u << kCellShift) - 1;
+    const CellBox bx = cell_box(cell);
+    const uint32_t r = (uint32_t)bx.r0 | (t >> (2 * kCellShift));
+    const uint32_t g = (uint32_t)bx.g0 | ((t >> kCellShift) & lm);
+    const uint32_t b = (uint32_t)bx.b0 | (t & lm);
     return (r << 16) | (g << 8) | b;
 }
 __global__ __launch_bounds__(512) void k_cells_count_tbl(const uint32_t *__restrict__ table, uint32_t *__restrict__ cell_count) {
-    const uint32_t v = table[cell_key(blockIdx.x, threadIdx.x)];
-    const uint32_t n = block_reduce_sum<512>(v != 0);
+    uint32_t mine = 0;
+    for (uint32_t t = threadIdx.x; t < kCellColours; t += 512) mine += table[cell_key(blockIdx.x, t)] != 0;
+    const uint32_t n = block_reduce_sum<512>(mine);
     if (threadIdx.x == 0) cell_count[blockIdx.x] = n;
 }
 template <typename LabelT>
@@ -297,17 +325,25 @@ __global__ __launch_bounds__(512) void k_cells_write_tbl(const uint32_t *__restr
                                                          uint32_t *__restrict__ ckeys, uint32_t *__restrict__ cweight,
                                                          uint32_t *__restrict__ crank, LabelT *__restrict__ labels) {
     __shared__ uint32_t wsum[512 / 64];
+    __shared__ uint32_t s_run;
     const uint32_t s = cell_start[blockIdx.x], e = cell_start[blockIdx.x + 1];
     if (s == e) return;
-    const uint32_t key = cell_key(blockIdx.x, threadIdx.x);
-    const uint32_t v = table[key];
-    const uint32_t pos = s + block_exclusive_scan<512>(v != 0, wsum);
-    if (v) {
-        const uint32_t rank = v - 1;
-        ckeys[pos] = key;
-        cweight[pos] = weight[rank];
-        crank[pos] = rank;
-        labels[pos] = (LabelT)init_label(rank, U, K);  // init_assignment kmeans.rs:61-78
+    if (threadIdx.x == 0) s_run = s;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < kCellColours; t0 += 512) {
+        const uint32_t key = cell_key(blockIdx.x, t0 + threadIdx.x);
+        const uint32_t v = table[key];
+        const uint32_t run = s_run;
+        const uint32_t pos = run + block_exclusive_scan<512>(v != 0, wsum);  // (its barriers: every thread has read s_run)
+        if (v) {
+            const uint32_t rank = v - 1;
+            ckeys[pos] = key;
+            cweight[pos] = weight[rank];
+            crank[pos] = rank;
+            labels[pos] = (LabelT)init_label(rank, U, K);  // init_assignment kmeans.rs:61-78
+        }
+        if (threadIdx.x == 511) s_run = pos + (v != 0);
+        __syncthreads();
     }
 }
 
@@ -377,68 +413,106 @@ __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict_
 
 constexpr uint32_t kMaxMovedSkip = 128;  // skip schedule when at most this many centroids moved (2 per lane)
 
-struct CellBox { int32_t r0, g0, b0; };
-__device__ __forceinline__ CellBox cell_box(uint32_t c) {
-    return CellBox{(int32_t)((c / (kCellsPerDim * kCellsPerDim)) << kCellShift), (int32_t)(((c / kCellsPerDim) % kCellsPerDim) << kCellShift),
-                   (int32_t)((c % kCellsPerDim) << kCellShift)};
-}
-// squared distance bounds of centroid colour ck to the cube [r0,r0+7] x [g0,g0+7] x [b0,b0+7]
-__device__ __forceinline__ void cube_bounds(uint32_t ck, const CellBox &bx, uint32_t &lb, uint32_t &ub) {
-    constexpr int32_t ext = (1 << kCellShift) - 1;
-    const int32_t dr0 = (int32_t)((ck >> 16) & 255) - bx.r0, dg0 = (int32_t)((ck >> 8) & 255) - bx.g0, db0 = (int32_t)(ck & 255) - bx.b0;
-    const int32_t hr = max(abs(dr0), abs(dr0 - ext)), hg = max(abs(dg0), abs(dg0 - ext)), hb = max(abs(db0), abs(db0 - ext));
-    const int32_t lr = dr0 < 0 ? -dr0 : max(dr0 - ext, 0), lg = dg0 < 0 ? -dg0 : max(dg0 - ext, 0), lbb = db0 < 0 ? -db0 : max(db0 - ext, 0);
-    ub = (uint32_t)(hr * hr + hg * hg + hb * hb);
-    lb = (uint32_t)(lr * lr + lg * lg + lbb * lbb);
+// squared distance from colour key ck to the centre of the cube with low corner bx and side ext + 1
+__device__ __forceinline__ uint32_t centre_dist(uint32_t ck, const CellBox &bx, int32_t ext) {
+    const int32_t h = (ext + 1) >> 1;
+    const int32_t dr = (int32_t)((ck >> 16) & 255) - bx.r0 - h, dg = (int32_t)((ck >> 8) & 255) - bx.g0 - h,
+                  db = (int32_t)(ck & 255) - bx.b0 - h;
+    return (uint32_t)(__mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db));
 }
 
-// bounds of all K centroids, T = min ub, candidates {k : lb_k <= T} into the wave's strip; the
-// candidate bitmask (bit `lane` of word r <=> centroid r*64+lane) and T are stored for the skip test
-template <int RSTORE>
-__device__ __forceinline__ uint32_t build_candidates(const uint2 *tab, uint32_t K, uint32_t R, uint32_t c, int lane,
-                                                     unsigned long long lt_mask, uint2 *cand, uint32_t *cell_T,
-                                                     unsigned long long *cell_mask, uint32_t m, uint32_t MW) {
-    const CellBox bx = cell_box(c);
-    uint32_t mub = 0xffffffffu;
-    uint32_t lbv[RSTORE];
+// a pivot centroid against one cube: a[2 i] = c*_i - 2 lo_i, a[2 i + 1] = c*_i - 2 hi_i
+struct Dominance {
+    int32_t p[3], a[6];
+    __device__ __forceinline__ void set(const CellBox &bx, int32_t ext, uint32_t pivot) {
+        p[0] = (pivot >> 16) & 255; p[1] = (pivot >> 8) & 255; p[2] = pivot & 255;
+        const int32_t lo[3] = {bx.r0, bx.g0, bx.b0};
 #pragma unroll
-    for (int r = 0; r < RSTORE; r++) lbv[r] = 0xffffffffu;
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t k = r * 64 + lane;
-        if (k < K) {
-            uint32_t lb, ub;
-            cube_bounds(tab[k].x, bx, lb, ub);
-            mub = min(mub, ub);
-            if (RSTORE > 1) {
-#pragma unroll
-                for (int rr = 0; rr < RSTORE; rr++)
-                    if (rr == (int)r) lbv[rr] = lb;
-            }
-        }
+        for (int i = 0; i < 3; i++) { a[2 * i] = p[i] - 2 * lo[i]; a[2 * i + 1] = p[i] - 2 * (lo[i] + ext); }
     }
+    // max over the cube of d(p, pivot) - d(p, c): c can be nearest (or tie) somewhere in the cube only if >= 0
+    __device__ __forceinline__ int32_t worst(uint32_t ck) const {
+        const int32_t v[3] = {(int32_t)((ck >> 16) & 255), (int32_t)((ck >> 8) & 255), (int32_t)(ck & 255)};
+        int32_t f = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mub = min(mub, (uint32_t)__shfl_xor(mub, off, 64));
-    const uint32_t T = mub;
-    uint32_t ncand = 0;
-    for (uint32_t r = 0; r < R; r++) {
-        const uint32_t k = r * 64 + lane;
-        bool keep = false;
-        if (RSTORE > 1) {
-#pragma unroll
-            for (int rr = 0; rr < RSTORE; rr++)
-                if (rr == (int)r) keep = lbv[rr] <= T;   // 0xffffffff for k >= K never passes (T < 2^18)
-        } else if (k < K) {
-            uint32_t lb, ub;
-            cube_bounds(tab[k].x, bx, lb, ub);
-            keep = lb <= T;
+        for (int i = 0; i < 3; i++) {
+            const int32_t d = p[i] - v[i];
+            f += max(__mul24(d, v[i] + a[2 * i]), __mul24(d, v[i] + a[2 * i + 1]));
         }
+        return f;
+    }
+};
+
+__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor(v, off, 64));
+    return v;
+}
+
+// position in `list` (n entries, ascending cluster id) of the centroid nearest the cube centre; lowest position on ties
+__device__ __forceinline__ uint32_t nearest_to_centre(const uint2 *list, uint32_t n, const CellBox &bx, int32_t ext, int lane) {
+    uint32_t bd = 0xffffffffu, be = 0xffffffffu;
+    for (uint32_t e = lane; e < n; e += 64) {
+        const uint32_t d = centre_dist(list[e].x, bx, ext);
+        if (d < bd) { bd = d; be = e; }
+    }
+    const uint32_t dmin = wave_all_min(bd);
+    return wave_all_min(bd == dmin ? be : 0xffffffffu);
+}
+
+// S = the centroids of `tab` (ascending id) that can be nearest somewhere in super-cell `sup`; returns |S| >= 1
+__device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, uint32_t sup, int lane, unsigned long long lt_mask,
+                                                uint2 *S) {
+    constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
+    const CellBox bx = super_box(sup);
+    Dominance dm;
+    dm.set(bx, ext, tab[nearest_to_centre(tab, K, bx, ext, lane)].x);
+    uint32_t n = 0;
+    for (uint32_t k0 = 0; k0 < K; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint2 cc = make_uint2(0u, 0u);
+        bool keep = false;
+        if (k < K) { cc = tab[k]; keep = dm.worst(cc.x) >= 0; }
         const unsigned long long bm = __ballot(keep);
-        if (keep) cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = tab[k];
-        if (lane == 0) cell_mask[(size_t)m * MW + r] = bm;
+        if (keep) S[n + (uint32_t)__popcll(bm & lt_mask)] = cc;
+        n += (uint32_t)__popcll(bm);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return n;
+}
+
+// candidates of cell c = the members of `list` that can be nearest somewhere in the cell's cube, into the
+// wave's strip (ascending id).  The pivot's colour and the candidate bitmask (bit k <=> centroid k) are
+// stored for the skip test.
+template <int IDBITS>
+__device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t n, uint32_t c, int lane, unsigned long long lt_mask,
+                                                     uint2 *cand, unsigned long long *wmask, uint32_t *cell_piv,
+                                                     unsigned long long *cell_mask, uint32_t m, uint32_t MW) {
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    constexpr int32_t ext = (1 << kCellShift) - 1;
+    const CellBox bx = cell_box(c);
+    const uint32_t pv = list[nearest_to_centre(list, n, bx, ext, lane)].x;
+    Dominance dm;
+    dm.set(bx, ext, pv);
+    for (uint32_t i = lane; i < MW; i += 64) wmask[i] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t ncand = 0;
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        uint2 cc = make_uint2(0u, 0u);
+        bool keep = false;
+        if (e < n) { cc = list[e]; keep = dm.worst(cc.x) >= 0; }
+        const unsigned long long bm = __ballot(keep);
+        if (keep) {
+            cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = cc;
+            const uint32_t k = IDMASK - (cc.y & IDMASK);
+            atomicOr(&wmask[k >> 6], 1ull << (k & 63));
+        }
         ncand += (uint32_t)__popcll(bm);
     }
-    if (lane == 0) cell_T[m] = T;
     __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < MW; i += 64) cell_mask[(size_t)m * MW + i] = wmask[i];
+    if (lane == 0) cell_piv[m] = pv;
     return ncand;
 }
 
@@ -488,20 +562,20 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
 }
 
 struct CellState {          // per non-empty cell, carried between iterations (skip schedule)
-    uint32_t *T;            // [M]
+    uint32_t *piv;          // [M] colour of the pivot of the last candidate build
     unsigned long long *mask;  // [M][MW]
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
     uint32_t *queue;        // work queue cursor (zeroed by the update kernel)
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
 };
 
-template <typename LabelT, int IDBITS, int WAVES, int RSTORE>
+template <typename LabelT, int IDBITS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
     unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs) {
-    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x uint2 cand[K]
+    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[K], uint2 cand[K], u64 mask[MW])
     __shared__ uint32_t s_moved;
     __shared__ unsigned long long s_evals;
     if (st->done) return;
@@ -509,7 +583,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint2 *cand = tab + K + (size_t)wid * K;
+    const uint32_t MW = (K + 63) >> 6;  // mask words per cell
+    uint2 *S = tab + K + (size_t)wid * 2 * K;
+    uint2 *cand = S + K;
+    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(tab + K + (size_t)WAVES * 2 * K) + (size_t)wid * MW;
     const uint32_t gw0 = shard * gridDim.x * WAVES;          // first wave index of this shard
     const uint32_t g = gw0 + blockIdx.x * WAVES + wid;
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
@@ -518,8 +595,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const bool first = st->iter == 0;
     const uint32_t nS = cs.moved[0];
     const bool skip_mode = !first && nS <= cs.max_moved;
-    const uint32_t R = (K + 63) >> 6;  // centroids per lane
-    const uint32_t MW = R;             // mask words per cell
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t moved = 0;
     unsigned long long evals = 0;
@@ -543,10 +618,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
         if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
         __syncthreads();
+        uint32_t sup = 0xffffffffu, nSup = 0;
         for (uint32_t m = m0; m < m1; m++) {
             const bool has_next = m + 1 < m1;
             if (has_next) { e_next = ne_start[m + 2]; c_next = ne_cell[m + 1]; }  // consumed at the end of this cell
-            const uint32_t ncand = build_candidates<RSTORE>(tab, K, R, c, lane, lt_mask, cand, cs.T, cs.mask, m, MW);
+            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S); }
+            const uint32_t ncand = build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
             // the cell's points; the next sweep (of this cell or of the next) loads meanwhile
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
@@ -585,19 +662,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         {
             for (uint32_t m = m_lo + blockIdx.x * WAVES + wid; m < m_hi; m += nwaves) {
                 const uint32_t c = ne_cell[m];
-                const uint32_t Tp = cs.T[m];
-                const CellBox bx = cell_box(c);
-                bool dirty = false;
-                if (k1 != 0xffffffffu) {
-                    uint32_t lb, ub;
-                    cube_bounds(ck1, bx, lb, ub);
-                    dirty = lb <= Tp || ((cs.mask[(size_t)m * MW + (k1 >> 6)] >> (k1 & 63)) & 1ull);
-                }
-                if (k2 != 0xffffffffu) {
-                    uint32_t lb, ub;
-                    cube_bounds(ck2, bx, lb, ub);
-                    dirty = dirty || lb <= Tp || ((cs.mask[(size_t)m * MW + (k2 >> 6)] >> (k2 & 63)) & 1ull);
-                }
+                Dominance dm;
+                dm.set(cell_box(c), (1 << kCellShift) - 1, cs.piv[m]);
+                bool dirty = false;  // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                if (k1 != 0xffffffffu)
+                    dirty = dm.worst(ck1) >= 0 || ((cs.mask[(size_t)m * MW + (k1 >> 6)] >> (k1 & 63)) & 1ull);
+                if (k2 != 0xffffffffu)
+                    dirty = dirty || dm.worst(ck2) >= 0 || ((cs.mask[(size_t)m * MW + (k2 >> 6)] >> (k2 & 63)) & 1ull);
                 if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep];
@@ -607,7 +678,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                     p[u] = q < e ? ckeys[q] : 0u;
                     cur[u] = q < e ? (uint32_t)labels[q] : 0u;
                 }
-                const uint32_t ncand = build_candidates<RSTORE>(tab, K, R, c, lane, lt_mask, cand, cs.T, cs.mask, m, MW);
+                // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
+                const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep];
 #pragma unroll
@@ -784,7 +856,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_count, 4);
         const uint32_t G = s->nblocks * (s->wide ? 1u : 4u) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
-        KM_ALLOC(s->cell_T, (uint64_t)kNumCells * 4);
+        KM_ALLOC(s->cell_piv, (uint64_t)kNumCells * 4);
         KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
         KM_ALLOC(s->moved_list, ((uint64_t)K + 1) * 4);
         KM_ALLOC(s->queue, 16);
@@ -896,16 +968,16 @@ static void launch_assign(KmRgbwState *s) {
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = reinterpret_cast<unsigned long long *>(s->partials);
-        CellState cs{s->cell_T.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(), s->queue.as<uint32_t>(),
+        CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(), s->queue.as<uint32_t>(),
                      s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
-            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
+            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 2 * 8) + (size_t)((s->K + 63) / 64) * 8;
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs);
         } else {
-            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 8);
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
+            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 2 * 8) + (size_t)4 * ((s->K + 63) / 64) * 8;
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
         }
@@ -982,10 +1054,12 @@ struct LaunchTimer {
 // summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
 int km_rgbw_run(KmRgbwState *s) {
     Ctx *c = s->c;
-    const int batch = 8;
+    const int batch = 4;
     KmDevState h;
     LaunchTimer lt;
-    ScopedKernelTimer timer(c, "kmeans_rgbw_iter");
+    LaggedPoll poll(c, s->dstate.p);
+    CNIIC_TRY(poll.prepare());
+    ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     for (;;) {
         for (int b = 0; b < batch; b++) {
             if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
@@ -1000,8 +1074,9 @@ int km_rgbw_run(KmRgbwState *s) {
             CNIIC_TRY(km_rgbw_update(s));
         }
         CNIIC_HIP_TRY(c, hipGetLastError());
-        CNIIC_TRY(read_state(s, &h));
-        if (h.done) break;
+        bool have = false;
+        CNIIC_TRY(poll.after_batch(&h, &have));
+        if (have && h.done) break;
     }
     timer.stop(h.iter);
     if (s->profile) {

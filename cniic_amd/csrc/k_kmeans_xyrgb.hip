@@ -408,12 +408,15 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 const uint32_t ly = g * kXRows + j;
                 const bool ok = okx && ly < th;
                 const int32_t y = (int32_t)(ty0 + ly);
-                const uint32_t bk = s_over ? bpos[j] : (uint32_t)list_k[bpos[j]];
                 const int32_t gcur = (int32_t)(xdot4(p[j], (uint32_t)own[j].z) << 1) +
                                      xmad24(2 * y, own[j].y, xmad24(2 * x, own[j].x, -own[j].w));
                 const bool mv = ok && best[j] > gcur;  // strictly closer (kmeans.rs:375)
-                const uint32_t nl = mv ? bk : c[j];
-                if (mv) { labels[(uint64_t)y * w + (uint32_t)x] = (uint16_t)nl; moved++; }
+                uint32_t nl = c[j];
+                if (mv) {
+                    nl = s_over ? bpos[j] : (uint32_t)list_k[bpos[j]];
+                    labels[(uint64_t)y * w + (uint32_t)x] = (uint16_t)nl;
+                    moved++;
+                }
                 const uint32_t r = (p[j] >> 16) & 255, gg = (p[j] >> 8) & 255, b = p[j] & 255;
                 if (first) {
                     // vector_add clusterc.rs:221-228 for every pixel.  A row of 64 pixels holds few distinct
@@ -440,9 +443,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     atomicAdd(o + 0, 0u - (uint32_t)x); atomicAdd(o + 1, 0u - (uint32_t)y); atomicAdd(o + 2, 0u - r);
                     atomicAdd(o + 3, 0u - gg); atomicAdd(o + 4, 0u - b); atomicAdd(o + 5, 0u - 1u);
                 }
-                if (ok) evals += ncand + 1;
             }
         }
+        if (lane == 0) evals += (unsigned long long)(ncand + 1) * tw * th;
     }
     __syncthreads();
     // the host sizes the grid so that one block's pixels * max coordinate stays below 2^31: one flush at the end
@@ -454,7 +457,6 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
     }
     moved = block_reduce_sum<kXThreads>(moved);
-    evals = wave_reduce_sum64(evals);
     if (threadIdx.x == 0 && moved) atomicAdd(&partials[6 * (size_t)K], (unsigned long long)moved);
     if (lane == 0 && evals) atomicAdd(&partials[6 * (size_t)K + 1], evals);
 }
@@ -629,15 +631,17 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
                        s.labels.as<uint16_t>(), s.cent.as<int4>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     KmDevState hst;
-    ScopedKernelTimer timer(c, "kmeans_xyrgb_iter");
+    LaggedPoll poll(c, s.dstate.p);
+    CNIIC_TRY(poll.prepare());
+    ScopedKernelTimer timer(c, "kmeans_xyrgb_iter", opts && (opts->flags & CNIIC_KM_PROFILE));  // (stop() synchronises)
     for (;;) {
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < 4; b++) {
             CNIIC_TRY(xy_assign(s));
             CNIIC_TRY(xy_update(s));
         }
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(&hst, s.dstate.p, sizeof hst, hipMemcpyDeviceToHost, c->stream));
-        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (hst.done) break;
+        bool have = false;
+        CNIIC_TRY(poll.after_batch(&hst, &have));
+        if (have && hst.done) break;
     }
     timer.stop(hst.iter);
     std::vector<int4> cent(K);
