@@ -9,6 +9,8 @@
 //
 // Roofline: the fill pass is HBM-bound on its input (3 B/px RGB or 4 B/symbol); the table clear
 // and compaction stream the table twice (reported separately in DESIGN.md).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -34,6 +36,120 @@ __global__ __launch_bounds__(256) void k_hist_rgb(const uint8_t *__restrict__ rg
     }
 }
 
+// ---------------------------------------------------------------- fill by partition (large images)
+// A random atomic on the 64 MiB table moves a whole cache line to the atomic unit and back: ~27 G
+// atomics/s however they are scoped (measured: device scope and XCD-local scope cost the same), i.e.
+// 630 us for 4096^2 pixels.  Instead the pixels are first PARTITIONED by the top 12 bits of their key
+// (4096 buckets = the 4096-entry slices of the table) with LDS counters and cursors, then every bucket's
+// 12-bit remainders are counted in an LDS histogram and the slice is written once:
+//   k_part_count    per-block bucket counts (LDS atomics)            reads 3 B/px
+//   k_part_colscan  per-bucket exclusive prefix over the blocks      8 MiB
+//   k_part_starts   bucket starts + work items of the last pass      16 KiB
+//   k_part_scatter  remainder (u16) of every pixel to its bucket     reads 3 B/px, writes 2 B/px
+//   k_part_hist     LDS histogram per bucket (or per 16 Ki entries of a crowded one) -> table slice
+// Counts are exact and order-free, so the result is the table the atomics would have produced.
+constexpr int kPartBits = 12;
+constexpr uint32_t kPartBuckets = 1u << (24 - kPartBits);   // 4096
+constexpr uint32_t kPartBins = 1u << kPartBits;              // 4096 table entries per bucket
+constexpr uint32_t kPartBlocks = 512;                        // blocks of the two passes over the image
+constexpr uint32_t kPartSub = 16384;                         // entries per work item of k_part_hist
+constexpr int kPartCols = 32;                                // buckets per block of k_part_colscan
+
+// block b owns the 16-pixel groups [b gpb, (b+1) gpb); the last block also owns the < 16 tail pixels
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_part_pass(const uint8_t *__restrict__ rgb, uint64_t npx, uint64_t ngroups, uint64_t gpb,
+                                                   uint32_t *__restrict__ counts, const uint32_t *__restrict__ start,
+                                                   uint16_t *__restrict__ payload) {
+    __shared__ uint32_t cur[kPartBuckets];
+    uint32_t *mine = counts + (size_t)blockIdx.x * kPartBuckets;
+    for (uint32_t k = threadIdx.x; k < kPartBuckets; k += 256) cur[k] = SCATTER ? start[k] + mine[k] : 0u;
+    __syncthreads();
+    const uint64_t g0 = blockIdx.x * gpb, g1 = min(g0 + gpb, ngroups);
+    const uint4 *v = reinterpret_cast<const uint4 *>(rgb);
+    for (uint64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+        uint32_t key[16];
+        load16px_keys(v + 3 * g, key);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (SCATTER) payload[atomicAdd(&cur[key[i] >> kPartBits], 1u)] = (uint16_t)(key[i] & (kPartBins - 1));
+            else atomicAdd(&cur[key[i] >> kPartBits], 1u);
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        const uint64_t i = ngroups * 16 + threadIdx.x;
+        if (i < npx) {
+            const uint32_t key = rgb_key(rgb + 3 * i);
+            if (SCATTER) payload[atomicAdd(&cur[key >> kPartBits], 1u)] = (uint16_t)(key & (kPartBins - 1));
+            else atomicAdd(&cur[key >> kPartBits], 1u);
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < kPartBuckets; k += 256) mine[k] = cur[k];
+    }
+}
+
+// counts[b][k] -> sum over b' < b of counts[b'][k]; total[k] = column sum.  One block per kPartCols buckets.
+__global__ __launch_bounds__(256) void k_part_colscan(uint32_t *__restrict__ counts, uint32_t *__restrict__ total) {
+    __shared__ uint32_t tile[kPartBlocks][kPartCols];        // 64 KiB
+    __shared__ uint32_t part[256 / kPartCols][kPartCols];
+    const uint32_t k0 = blockIdx.x * kPartCols;
+    for (uint32_t idx = threadIdx.x; idx < kPartBlocks * kPartCols; idx += 256)
+        tile[idx / kPartCols][idx % kPartCols] = counts[(size_t)(idx / kPartCols) * kPartBuckets + k0 + idx % kPartCols];
+    __syncthreads();
+    constexpr uint32_t segs = 256 / kPartCols, rows = kPartBlocks / segs;   // 8 segments of 64 rows per column
+    const uint32_t j = threadIdx.x % kPartCols, sgm = threadIdx.x / kPartCols;
+    uint32_t sum = 0;
+    for (uint32_t r = sgm * rows; r < (sgm + 1) * rows; r++) sum += tile[r][j];
+    part[sgm][j] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < sgm; q++) run += part[q][j];
+    for (uint32_t r = sgm * rows; r < (sgm + 1) * rows; r++) { const uint32_t c = tile[r][j]; tile[r][j] = run; run += c; }
+    if (sgm == segs - 1) total[k0 + j] = run;
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < kPartBlocks * kPartCols; idx += 256)
+        counts[(size_t)(idx / kPartCols) * kPartBuckets + k0 + idx % kPartCols] = tile[idx / kPartCols][idx % kPartCols];
+}
+
+// exclusive scans over the buckets: start[k] (entries) and item[k] (work items of k_part_hist); [kPartBuckets] = totals
+__global__ __launch_bounds__(1024) void k_part_starts(const uint32_t *__restrict__ total, uint32_t *__restrict__ start,
+                                                      uint32_t *__restrict__ item) {
+    __shared__ uint32_t wsum[1024 / 64];
+    constexpr uint32_t per = kPartBuckets / 1024;
+    uint32_t t[per], e = 0, w = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < per; i++) { t[i] = total[threadIdx.x * per + i]; e += t[i]; w += (t[i] + kPartSub - 1) / kPartSub; }
+    uint32_t es = block_exclusive_scan<1024>(e, wsum);
+    uint32_t ws = block_exclusive_scan<1024>(w, wsum);
+#pragma unroll
+    for (uint32_t i = 0; i < per; i++) {
+        start[threadIdx.x * per + i] = es; item[threadIdx.x * per + i] = ws;
+        es += t[i]; ws += (t[i] + kPartSub - 1) / kPartSub;
+    }
+    if (threadIdx.x == 1023) { start[kPartBuckets] = es; item[kPartBuckets] = ws; }
+}
+
+__global__ __launch_bounds__(256) void k_part_hist(const uint16_t *__restrict__ payload, const uint32_t *__restrict__ start,
+                                                   const uint32_t *__restrict__ item, uint32_t *__restrict__ table) {
+    __shared__ uint32_t hist[kPartBins];
+    const uint32_t it = blockIdx.x;
+    if (it >= item[kPartBuckets]) return;
+    uint32_t a = 0, b = kPartBuckets;  // last bucket whose first item is <= it (buckets without entries have no items)
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (item[mid] <= it) a = mid; else b = mid; }
+    const uint32_t k = a, nsub = item[k + 1] - item[k];
+    const uint32_t e0 = start[k] + (it - item[k]) * kPartSub, e1 = min(e0 + kPartSub, start[k + 1]);
+    for (uint32_t i = threadIdx.x; i < kPartBins; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) atomicAdd(&hist[payload[e]], 1u);
+    __syncthreads();
+    uint32_t *slice = table + ((size_t)k << kPartBits);
+    for (uint32_t i = threadIdx.x; i < kPartBins; i += 256) {
+        const uint32_t cnt = hist[i];
+        if (cnt) { if (nsub == 1) slice[i] = cnt; else atomicAdd(&slice[i], cnt); }
+    }
+}
+
 // unaligned base pointer: plain per-pixel byte loads
 __global__ __launch_bounds__(256) void k_hist_rgb_bytes(const uint8_t *__restrict__ rgb, uint64_t npx,
                                                         uint32_t *__restrict__ table) {
@@ -51,7 +167,27 @@ __global__ __launch_bounds__(256) void k_hist_syms(const uint32_t *__restrict__ 
 
 int hist_rgb_dense(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *table_d) {
     if (npx == 0) return CNIIC_OK;
-    if ((reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0) {
+    static const bool partition = !(getenv("CNIIC_HIST_PARTITION") && atoi(getenv("CNIIC_HIST_PARTITION")) == 0);
+    if ((reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && partition && npx >= (1u << 20) && npx < (1ull << 32)) {
+        const uint64_t groups = npx / 16, gpb = ceil_div(groups, kPartBlocks);
+        DevBuf counts, total, start, item, payload;
+        CNIIC_HIP_TRY(c, counts.alloc((uint64_t)kPartBlocks * kPartBuckets * 4));
+        CNIIC_HIP_TRY(c, total.alloc((uint64_t)kPartBuckets * 4));
+        CNIIC_HIP_TRY(c, start.alloc(((uint64_t)kPartBuckets + 1) * 4));
+        CNIIC_HIP_TRY(c, item.alloc(((uint64_t)kPartBuckets + 1) * 4));
+        CNIIC_HIP_TRY(c, payload.alloc(npx * 2));
+        hipLaunchKernelGGL(k_part_pass<false>, dim3(kPartBlocks), dim3(256), 0, c->stream, rgb_d, npx, groups, gpb,
+                           counts.as<uint32_t>(), (const uint32_t *)nullptr, (uint16_t *)nullptr);
+        hipLaunchKernelGGL(k_part_colscan, dim3(kPartBuckets / kPartCols), dim3(256), 0, c->stream, counts.as<uint32_t>(),
+                           total.as<uint32_t>());
+        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, c->stream, total.as<uint32_t>(), start.as<uint32_t>(),
+                           item.as<uint32_t>());
+        hipLaunchKernelGGL(k_part_pass<true>, dim3(kPartBlocks), dim3(256), 0, c->stream, rgb_d, npx, groups, gpb,
+                           counts.as<uint32_t>(), start.as<uint32_t>(), payload.as<uint16_t>());
+        const uint32_t max_items = kPartBuckets + (uint32_t)(npx / kPartSub);  // blocks beyond the item count exit at once
+        hipLaunchKernelGGL(k_part_hist, dim3(max_items), dim3(256), 0, c->stream, payload.as<uint16_t>(), start.as<uint32_t>(),
+                           item.as<uint32_t>(), table_d);
+    } else if ((reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0) {
         uint64_t groups = npx / 16;
         uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(groups, 256), 1), 256 * 8);
         hipLaunchKernelGGL(k_hist_rgb, dim3(grid), dim3(256), 0, c->stream, rgb_d, npx, table_d);
