@@ -53,7 +53,11 @@ constexpr uint32_t kMaxBlocks = 512;
 constexpr int kCellShift = CNIIC_CELL_SHIFT;                    // 2^shift colours per cell side
 constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
-constexpr uint32_t kCellBlocks = 1280;     // 5 blocks of 4 waves per CU: every wave resident at once
+#ifndef CNIIC_CELL_WAVES
+#define CNIIC_CELL_WAVES 8
+#endif
+constexpr int kCellWaves = CNIIC_CELL_WAVES;                  // waves per block (narrow labels); they share the block's cell range
+constexpr uint32_t kCellBlocks = 256 * (kCellWaves == 4 ? 6 : kCellWaves == 8 ? 3 : 2);  // every block resident at once (LDS, K <= 256)
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
 constexpr uint32_t kCellFixedCost = 1024; // per-cell overhead in point-equivalents (work split between waves)
 
@@ -462,7 +466,7 @@ __device__ __forceinline__ uint32_t nearest_to_centre(const uint2 *list, uint32_
 
 // S = the centroids of `tab` (ascending id) that can be nearest somewhere in super-cell `sup`; returns |S| >= 1
 __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, uint32_t sup, int lane, unsigned long long lt_mask,
-                                                uint2 *S) {
+                                                uint2 *S, uint32_t cap) {
     constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
     const CellBox bx = super_box(sup);
     Dominance dm;
@@ -474,7 +478,8 @@ __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, ui
         bool keep = false;
         if (k < K) { cc = tab[k]; keep = dm.worst(cc.x) >= 0; }
         const unsigned long long bm = __ballot(keep);
-        if (keep) S[n + (uint32_t)__popcll(bm & lt_mask)] = cc;
+        const uint32_t pos = n + (uint32_t)__popcll(bm & lt_mask);
+        if (keep && pos < cap) S[pos] = cc;  // a longer list is not kept: the caller falls back to the whole table
         n += (uint32_t)__popcll(bm);
     }
     __builtin_amdgcn_wave_barrier();
@@ -518,10 +523,10 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
 
 // one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip
 template <typename LabelT, int IDBITS>
-__device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], uint32_t base, uint32_t e, int lane,
+__device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
+                                             uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
-                                             LabelT *__restrict__ labels, const uint32_t *__restrict__ cweight,
-                                             unsigned long long *acc, uint32_t &moved) {
+                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     uint32_t best[kSweep];
 #pragma unroll
@@ -542,7 +547,7 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
             const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
             if (mv) { labels[q] = (LabelT)nl; moved++; }
             if (mv || first) {
-                const uint64_t w = cweight[q];
+                const uint64_t w = wt[u];  // loaded with the key: a gather here would stall every sweep that moves a point
                 const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
                 atomicAdd(&acc[3 * nl + 0], rw);
                 atomicAdd(&acc[3 * nl + 1], gw);
@@ -575,8 +580,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
     unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs) {
-    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[K], uint2 cand[K], u64 mask[MW])
-    __shared__ uint32_t s_moved;
+    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
+    __shared__ uint32_t s_moved, s_cell;
     __shared__ unsigned long long s_evals;
     if (st->done) return;
     constexpr int THREADS = WAVES * 64;
@@ -584,11 +589,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t MW = (K + 63) >> 6;  // mask words per cell
-    uint2 *S = tab + K + (size_t)wid * 2 * K;
-    uint2 *cand = S + K;
-    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(tab + K + (size_t)WAVES * 2 * K) + (size_t)wid * MW;
+    const uint32_t scap = (K + 1) / 2;  // super-cell list capacity (it rarely holds more than a quarter of the table)
+    uint2 *S = tab + K + (size_t)wid * (scap + K);
+    uint2 *cand = S + scap;
+    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(tab + K + (size_t)WAVES * (scap + K)) + (size_t)wid * MW;
     const uint32_t gw0 = shard * gridDim.x * WAVES;          // first wave index of this shard
-    const uint32_t g = gw0 + blockIdx.x * WAVES + wid;
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
     // iterations add/subtract only the points that moved.
@@ -601,48 +606,61 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
 
     if (!skip_mode) {
         // ================================================================= FULL schedule
-        const uint32_t m0 = wfirst[g], m1 = wfirst[g + 1];
-        // descriptors of the first cell and the loads of its first sweep go out before the LDS set-up
-        uint32_t s = 0, e = 0, c = 0, e_next = 0, c_next = 0;
-        uint32_t p[kSweep], cur[kSweep];
-        if (m0 < m1) {
-            s = ne_start[m0]; e = ne_start[m0 + 1]; c = ne_cell[m0];
+        // The block owns the cells [mb0, mb1) (equal-cost ranges, k_wave_ranges) and its waves draw them one
+        // at a time from an LDS counter: what a cell costs depends on how many of its points move, which no
+        // static split predicts (with one fixed range per wave the slowest wave ran 2x the mean).
+        const uint32_t bg = gw0 + blockIdx.x * WAVES;
+        const uint32_t mb0 = wfirst[bg], mb1 = wfirst[bg + WAVES];
+        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_cell = mb0; }
+        __syncthreads();
+        auto draw = [&]() -> uint32_t {
+            uint32_t v = 0;
+            if (lane == 0) v = atomicAdd(&s_cell, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        };
+        uint32_t m = draw();
+        uint32_t s = 0, e = 0, c = 0;
+        uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+        if (m < mb1) {
+            s = ne_start[m]; e = ne_start[m + 1]; c = ne_cell[m];
 #pragma unroll
             for (int u = 0; u < kSweep; u++) {
                 const uint32_t q = s + u * 64 + lane;
                 p[u] = q < e ? ckeys[q] : 0u;
                 cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+                wt[u] = q < e ? cweight[q] : 0u;
             }
         }
-        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
-        __syncthreads();
         uint32_t sup = 0xffffffffu, nSup = 0;
-        for (uint32_t m = m0; m < m1; m++) {
-            const bool has_next = m + 1 < m1;
-            if (has_next) { e_next = ne_start[m + 2]; c_next = ne_cell[m + 1]; }  // consumed at the end of this cell
-            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S); }
-            const uint32_t ncand = build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
-            // the cell's points; the next sweep (of this cell or of the next) loads meanwhile
+        while (m < mb1) {
+            // the next cell of this wave: its descriptors now, the loads of its first sweep during this cell's last sweep
+            const uint32_t mn = draw();
+            uint32_t s_next = 0, e_next = 0, c_next = 0;
+            if (mn < mb1) { s_next = ne_start[mn]; e_next = ne_start[mn + 1]; c_next = ne_cell[mn]; }
+            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); }
+            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW)
+                                                : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
-                const uint32_t nts = more ? base + 64 * kSweep : e;
-                const uint32_t nte = more ? e : (has_next ? e_next : e);
-                uint32_t pn[kSweep], curn[kSweep];
+                const uint32_t nts = more ? base + 64 * kSweep : s_next;
+                const uint32_t nte = more ? e : e_next;
+                uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) {
                     const uint32_t qn = nts + u * 64 + lane;
                     pn[u] = qn < nte ? ckeys[qn] : 0u;
                     curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
+                    wtn[u] = qn < nte ? cweight[qn] : 0u;
                 }
-                sweep_points<LabelT, IDBITS>(p, cur, base, e, lane, cand, ncand, tab, K, first, labels, cweight, acc, moved);
+                sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, first, labels, acc, moved);
 #pragma unroll
-                for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
+                for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
             evals += (unsigned long long)(e - s) * (ncand + 1);
             __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
-            s = e; e = e_next; c = c_next;
+            m = mn; s = s_next; e = e_next; c = c_next;
         }
     } else {
         // ================================================================= SKIP schedule
@@ -671,26 +689,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                     dirty = dirty || dm.worst(ck2) >= 0 || ((cs.mask[(size_t)m * MW + (k2 >> 6)] >> (k2 & 63)) & 1ull);
                 if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
-                uint32_t p[kSweep], cur[kSweep];
+                uint32_t p[kSweep], cur[kSweep], wt[kSweep];
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) {
                     const uint32_t q = s + u * 64 + lane;
                     p[u] = q < e ? ckeys[q] : 0u;
                     cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+                    wt[u] = q < e ? cweight[q] : 0u;
                 }
                 // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
                 const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                    uint32_t pn[kSweep], curn[kSweep];
+                    uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) {
                         const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
                         pn[u] = qn < e ? ckeys[qn] : 0u;
                         curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
+                        wtn[u] = qn < e ? cweight[qn] : 0u;
                     }
-                    sweep_points<LabelT, IDBITS>(p, cur, base, e, lane, cand, ncand, tab, K, false, labels, cweight, acc, moved);
+                    sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
-                    for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; }
+                    for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                 }
                 evals += (unsigned long long)(e - s) * (ncand + 1);
                 __builtin_amdgcn_wave_barrier();
@@ -854,7 +874,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_start, ((uint64_t)kNumCells + 1) * 4);
         KM_ALLOC(s->ne_cost, ((uint64_t)kNumCells + 1) * 4);
         KM_ALLOC(s->ne_count, 4);
-        const uint32_t G = s->nblocks * (s->wide ? 1u : 4u) * nshards;   // waves over all shards
+        const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->cell_piv, (uint64_t)kNumCells * 4);
         KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
@@ -971,13 +991,14 @@ static void launch_assign(KmRgbwState *s) {
         CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(), s->queue.as<uint32_t>(),
                      s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
-            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 2 * 8) + (size_t)((s->K + 63) / 64) * 8;
+            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs);
         } else {
-            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 4 * 2 * 8) + (size_t)4 * ((s->K + 63) / 64) * 8;
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, 4>), dim3(s->nblocks), dim3(256), lds, c->stream,
+            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
+                               (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
+            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
         }
@@ -1158,7 +1179,7 @@ __global__ void k_export_labels(const LabelT *__restrict__ labels, const uint32_
 int km_rgbw_export_labels(KmRgbwState *s, void *dst_d) {
     Ctx *c = s->c;
     if (!s->cells) return c->fail(CNIIC_ERR_BAD_ARG, "export_labels needs the cells path");
-    const uint32_t wpb = s->wide ? 1u : 4u;
+    const uint32_t wpb = s->wide ? 1u : (uint32_t)kCellWaves;
     const uint32_t g_lo = s->shard * s->nblocks * wpb, g_hi = (s->shard + 1) * s->nblocks * wpb;
     if (s->wide)
         hipLaunchKernelGGL(k_export_labels<uint16_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(),
