@@ -82,6 +82,8 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->poll_ev) if (e) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_res) (void)hipHostFree(c->pinned_res);
+    if (c->res_ev) (void)hipEventDestroy(c->res_ev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -186,6 +186,8 @@ static int encode_hufman(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, u
 //   (K-means loop: km_rgbw_run on one GPU, or assign / all-reduce / update driven by the caller)
 //   cc_finish   clusters -> colour lookup -> Hufman.encode of the reduced image (clusterc.rs:31-52)
 CcSession::~CcSession() { if (km) km_rgbw_destroy(km); }
+HostTrace &host_trace() { static thread_local HostTrace t; return t; }
+
 
 int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard, uint32_t nshards,
                void *partials_dev, CcSession **out) {
@@ -194,6 +196,7 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     s->c = c; s->K = K; s->table = table_counts_d;
     CompactPlan plan;
     CNIIC_TRY(hist_compact_count(c, table_counts_d, 24, &plan));
+    host_trace().mark("compact_count+sync");
     const uint64_t U = plan.n_unique;
     s->U = U;
     if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)",
@@ -201,9 +204,11 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     CNIIC_HIP_TRY(c, s->keys_d.alloc(U * 4));
     CNIIC_HIP_TRY(c, s->weight_d.alloc(U * 4));
     CNIIC_TRY(hist_compact_write(c, table_counts_d, &plan, s->keys_d.as<uint32_t>(), nullptr, s->weight_d.as<uint32_t>()));
+    host_trace().mark("compact_write enq");
     // kmeans::cluster (clusterc.rs:28); the table now maps key -> rank + 1
     CNIIC_TRY(km_rgbw_create(c, s->keys_d.as<uint32_t>(), s->weight_d.as<uint32_t>(), U, shard, nshards, K, opts, partials_dev,
                              table_counts_d, &s->km));
+    host_trace().mark("km_create");
     *out = s.release();
     return CNIIC_OK;
 }
@@ -217,7 +222,21 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     std::vector<uint8_t> cent(3 * (size_t)K);
     std::vector<uint64_t> members(K), wsum(K);
     cniic_kmeans_stats st{};
-    CNIIC_TRY(km_rgbw_result(km, cent.data(), nullptr, members.data(), wsum.data(), &st));
+    // The result block starts towards the host; behind it goes everything that needs no code table - the
+    // colour -> label table and the label of every pixel (the one random read per pixel) - so that the GPU
+    // is busy while the host waits for the block and builds the tree.
+    CNIIC_TRY(km_rgbw_result_begin(km));
+    const bool wide = km_rgbw_is_wide(km);
+    DevBuf lab_d, key2label, pixlab;
+    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
+    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
+    CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
+    CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
+    CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
+    CNIIC_TRY(pixel_labels(c, rgb_d, n, key2label.p, wide, pixlab.p));
+    host_trace().mark("labels + pixel labels enq");
+    CNIIC_TRY(km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st));
+    host_trace().mark("km_result");
     if (stats) *stats = st;
     // check_enough_active_clusters (kmeans.rs:41-57)
     uint64_t min_cc = (uint64_t)(0.99 * (double)K);
@@ -225,10 +244,6 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     if (st.active < min_cc)
         return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
                        (unsigned long long)st.active, (unsigned long long)min_cc);
-    const bool wide = km_rgbw_is_wide(km);
-    DevBuf lab_d, key2label;
-    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
-    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
     if (local_counts_d) {
         // shared palette over several images: THIS image's pixels per cluster (its reduced image is
         // what Hufman.encode sees, clusterc.rs:52), from its own colour counts
@@ -242,17 +257,24 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     }
     // Histogram of the colour-reduced image = per-centroid-colour sum of member weights
     // (what count_freqs inside Hufman.encode would find, clusterc.rs:52 -> huf.rs:30).
-    std::map<uint32_t, uint64_t> hist;
+    std::vector<std::pair<uint32_t, uint64_t>> kc;
+    kc.reserve(K);
     for (uint32_t k = 0; k < K; k++)
-        if (members[k]) hist[((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2]] += wsum[k];
+        if (members[k]) kc.emplace_back(((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2], wsum[k]);
+    std::sort(kc.begin(), kc.end());  // ascending colour, equal colours (two clusters with one mean) adjacent in cluster order
     std::vector<uint32_t> skeys;
     std::vector<uint64_t> scounts;
-    for (auto &kv : hist) { skeys.push_back(kv.first); scounts.push_back(kv.second); }
+    for (auto &e : kc) {
+        if (!skeys.empty() && skeys.back() == e.first) scounts.back() += e.second;
+        else { skeys.push_back(e.first); scounts.push_back(e.second); }
+    }
+    host_trace().mark("map");
     HuffTree tree;
     std::vector<uint8_t> slen;
     std::vector<uint64_t> scode;
     if (!huff_build_tree(scounts.data(), scounts.size(), tree) || !huff_codes(tree, slen, scode))
         return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code");
+    host_trace().mark("build+codes");
     std::vector<uint8_t> header;
     put_u32(header, w);
     put_u32(header, h);
@@ -270,32 +292,36 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
         clen[k] = slen[si];
         ccode[k] = scode[si];
     }
+    host_trace().mark("tree+codes (host)");
     StreamOut so(c, out, cap, len);
     CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
+    host_trace().mark("so.begin");
     DevBuf clen_d, ccode_d;
     CNIIC_HIP_TRY(c, clen_d.alloc(K));
     CNIIC_HIP_TRY(c, ccode_d.alloc((uint64_t)K * 8));
-    CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), K, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
     uint64_t packed_bits = 0;
     {
         ScopedKernelTimer t(c, "huff_pack");
-        CNIIC_TRY(huff_pack_labels(c, rgb_d, n, key2label.p, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), so.dev,
+        CNIIC_TRY(huff_pack_labels(c, pixlab.p, n, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), so.dev,
                                    (uint64_t)header.size() * 8, &packed_bits));
         t.stop(1);
     }
+    host_trace().mark("pack (+sync)");
     if (packed_bits != nbits)
         return c->fail(CNIIC_ERR_HIP, "cluster-colors: packed %llu bits, histogram predicts %llu",
                        (unsigned long long)packed_bits, (unsigned long long)nbits);
-    return so.finish();
+    const int rc_fin = so.finish();
+    host_trace().mark("so.finish");
+    return rc_fin;
 }
 
 static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
                                  const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
                                  cniic_kmeans_stats *stats) {
     const uint64_t n = (uint64_t)w * h;
+    host_trace().mark("enter");
     // count_freqs over the pixels (clusterc.rs:21)
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, 24, &table));
@@ -304,11 +330,15 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
         CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table));
         t.stop(1);
     }
+    host_trace().mark("hist (+timer sync)");
     CcSession *raw = nullptr;
     CNIIC_TRY(cc_prepare(c, table, K, opts, 0, 1, nullptr, &raw));
     std::unique_ptr<CcSession> s(raw);
     CNIIC_TRY(km_rgbw_run(s->km));
-    return cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
+    host_trace().mark("km_run");
+    const int rc_all = cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
+    host_trace().dump();
+    return rc_all;
 }
 
 // ------------------------------------------------------------------ VoronoiCluster::encode (clusterc.rs:148-166)

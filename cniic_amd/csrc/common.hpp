@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -77,12 +78,13 @@ struct DevBuf {
     uint64_t bytes = 0;
     uint64_t cap = 0;
     DevPool *pool = nullptr;
+    bool     owned = true;   // false: a view into another DevBuf (never released)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool), owned(o.owned) { o.p = nullptr; o.bytes = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; owned = o.owned; o.p = nullptr; o.bytes = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
@@ -96,10 +98,11 @@ struct DevBuf {
         if (e == hipSuccess) bytes = n; else p = nullptr;
         return e;
     }
+    void view(void *ptr, uint64_t n) { release(); p = ptr; bytes = n; cap = 0; pool = nullptr; owned = false; }
     void release() {
         if (!p) return;
-        if (pool) pool->put(p, cap); else (void)hipFree(p);
-        p = nullptr; bytes = 0;
+        if (owned) { if (pool) pool->put(p, cap); else (void)hipFree(p); }
+        p = nullptr; bytes = 0; owned = true;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -118,6 +121,9 @@ struct Ctx {
     DevBuf hilbert_lut;     // state-machine tables of the 2^n Hilbert scan (k_hilbert.hip)
     void  *pinned = nullptr; // 4 KiB of pinned host memory: two KmDevState slots for lagged convergence polling
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    void  *pinned_res = nullptr;  // pinned landing area of K-means result blocks (grown on demand)
+    uint64_t pinned_res_bytes = 0;
+    hipEvent_t res_ev = nullptr;
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -246,6 +252,22 @@ struct LaggedPoll {
     }
 };
 
+// ---- host-side stage marks (CNIIC_TRACE_HOST=1): where an ABI call spends its wall time ----
+struct HostTrace {
+    bool on;
+    std::vector<std::pair<const char *, double>> marks;
+    HostTrace() : on(getenv("CNIIC_TRACE_HOST") != nullptr) {}
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(const char *what) { if (on) marks.emplace_back(what, now()); }
+    void dump() {
+        if (!on || marks.empty()) return;
+        for (size_t i = 1; i < marks.size(); i++) fprintf(stderr, "[host] %-28s %8.1f us\n", marks[i].first, marks[i].second - marks[i - 1].second);
+        fprintf(stderr, "[host] %-28s %8.1f us\n", "total", marks.back().second - marks.front().second);
+        marks.clear();
+    }
+};
+HostTrace &host_trace();
+
 // ---- kernel timing of the dominant kernels (HIP events on the ctx stream) ----
 struct ScopedKernelTimer {
     Ctx        *c;
@@ -302,6 +324,10 @@ int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
 int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats);
+// the same in two halves: _begin enqueues the copy of the result block, _end waits for it (work enqueued
+// in between overlaps the wait and whatever the host does with the result)
+int km_rgbw_result_begin(KmRgbwState *s);
+int km_rgbw_result_end(KmRgbwState *s, uint8_t *centroids_h, uint64_t *members_h, uint64_t *wsum_h, cniic_kmeans_stats *stats);
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch);
 int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h);
 void *km_rgbw_partials_dev(KmRgbwState *s);
@@ -357,8 +383,9 @@ int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_
                      const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint32_t *packed_d,
                      uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
 // cluster-colors path: pixel -> cluster label through a dense colour->label table, codes per cluster
-int huff_pack_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, uint32_t K,
-                     const uint8_t *clen_d, const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+int pixel_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, void *pixlab_d);
+int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32_t K, const uint8_t *clen_d,
+                     const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
 int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U, void *key2label_d);
 
 }  // namespace cniic

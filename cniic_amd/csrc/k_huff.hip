@@ -149,26 +149,20 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restr
 }
 
 // ---------------------------------------------------------------- cluster-colors fast path
-// Symbols are cluster labels (<= K distinct): pass 1 turns every pixel into its label through a
-// dense colour -> label table (ONE random read per pixel), stores the label stream and sums code
-// lengths from an LDS table; pass 2 streams the labels back and packs from an LDS (len, code) table.
+// Symbols are cluster labels (<= K distinct): the pixels become a label stream (pass 0), whose code
+// lengths are summed per chunk (pass 1) and which is packed from an LDS (len, code) table (pass 2).
+// pass 0 (needs no code table, so it runs while the host builds the tree): every pixel's cluster label
+// through the dense colour -> label table, ONE random read per pixel, stored as a linear label stream
 template <typename LabelT>
-__global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const uint8_t *__restrict__ rgb, uint64_t n,
-                                                                 const LabelT *__restrict__ key2label, uint32_t K,
-                                                                 const uint8_t *__restrict__ clen,
-                                                                 LabelT *__restrict__ pixlab,
-                                                                 uint32_t *__restrict__ chunk_bits) {
-    extern __shared__ uint8_t s_len[];  // [K]
-    for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) s_len[i] = clen[i];
-    __syncthreads();
+__global__ __launch_bounds__(kPackThreads) void k_pixel_labels(const uint8_t *__restrict__ rgb, uint64_t n,
+                                                               const LabelT *__restrict__ key2label, LabelT *__restrict__ pixlab) {
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
-    uint32_t bits = 0;
     if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(rgb) & 15) == 0)) {
         uint32_t key[16];
         load16px_keys(reinterpret_cast<const uint4 *>(rgb + 3 * first), key);
         LabelT lab[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) { lab[i] = key2label[key[i]]; bits += s_len[lab[i]]; }
+        for (int i = 0; i < 16; i++) lab[i] = key2label[key[i]];
         if (sizeof(LabelT) == 1) {
             uint32_t w[4];
 #pragma unroll
@@ -180,11 +174,28 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const uint8_t *
         }
     } else {
         for (int i = 0; i < kPackPer; i++)
-            if (first + i < n) {
-                LabelT l = key2label[rgb_key(rgb + 3 * (first + i))];
-                pixlab[first + i] = l;
-                bits += s_len[l];
-            }
+            if (first + i < n) pixlab[first + i] = key2label[rgb_key(rgb + 3 * (first + i))];
+    }
+}
+
+// pass 1: code lengths of a chunk's labels, from an LDS table
+template <typename LabelT>
+__global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const LabelT *__restrict__ pixlab, uint64_t n, uint32_t K,
+                                                                 const uint8_t *__restrict__ clen,
+                                                                 uint32_t *__restrict__ chunk_bits) {
+    extern __shared__ uint8_t s_len[];  // [K]
+    for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) s_len[i] = clen[i];
+    __syncthreads();
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t bits = 0;
+    if (sizeof(LabelT) == 1 && first + kPackPer <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pixlab + first);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) bits += s_len[(w[i >> 2] >> (8 * (i & 3))) & 255];
+    } else {
+        for (int i = 0; i < kPackPer; i++)
+            if (first + i < n) bits += s_len[pixlab[first + i]];
     }
     bits = block_reduce_sum<kPackThreads>(bits);
     if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
@@ -252,32 +263,47 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *_
     }
 }
 
-// key2label_d: LabelT[2^24] dense colour -> cluster label.  Packs directly at bit_base of out_d
-// (a 4-byte aligned, pre-zeroed buffer; the bytes before bit_base may already hold the header).
-int huff_pack_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, uint32_t K,
+// key2label_d: LabelT[2^24] dense colour -> cluster label; pixlab_d receives n labels (+16 bytes of slack)
+int pixel_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, void *pixlab_d) {
+    if (n == 0) return CNIIC_OK;
+    const uint32_t nchunks = (uint32_t)ceil_div(n, kPackChunk);
+    if (wide)
+        hipLaunchKernelGGL(k_pixel_labels<uint16_t>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, rgb_d, n,
+                           reinterpret_cast<const uint16_t *>(key2label_d), reinterpret_cast<uint16_t *>(pixlab_d));
+    else
+        hipLaunchKernelGGL(k_pixel_labels<uint8_t>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, rgb_d, n,
+                           reinterpret_cast<const uint8_t *>(key2label_d), reinterpret_cast<uint8_t *>(pixlab_d));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// Packs the label stream directly at bit_base of out_d (a 4-byte aligned, pre-zeroed buffer; the bytes
+// before bit_base may already hold the header).
+int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32_t K,
                      const uint8_t *clen_d, const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h) {
     *nbits_h = 0;
     if (n == 0) return CNIIC_OK;
     if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
     const uint32_t nchunks = (uint32_t)ceil_div(n, kPackChunk);
-    DevBuf cb, co, tot, pixlab;
+    DevBuf cb, co, tot;
     CNIIC_HIP_TRY(c, cb.alloc((uint64_t)nchunks * 4));
     CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
     CNIIC_HIP_TRY(c, tot.alloc(8));
-    CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
     if (wide)
-        hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, rgb_d, n,
-                           reinterpret_cast<const uint16_t *>(key2label_d), K, clen_d, pixlab.as<uint16_t>(), cb.as<uint32_t>());
+        hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream,
+                           reinterpret_cast<const uint16_t *>(pixlab_d), n, K, clen_d, cb.as<uint32_t>());
     else
-        hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, rgb_d, n,
-                           reinterpret_cast<const uint8_t *>(key2label_d), K, clen_d, pixlab.as<uint8_t>(), cb.as<uint32_t>());
+        hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream,
+                           reinterpret_cast<const uint8_t *>(pixlab_d), n, K, clen_d, cb.as<uint32_t>());
     hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
     if (wide)
-        hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, pixlab.as<uint16_t>(), n, K,
-                           clen_d, ccode_d, co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
+        hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
+                           reinterpret_cast<const uint16_t *>(pixlab_d), n, K, clen_d, ccode_d, co.as<uint64_t>(),
+                           reinterpret_cast<uint32_t *>(out_d), bit_base);
     else
-        hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, pixlab.as<uint8_t>(), n, K,
-                           clen_d, ccode_d, co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
+        hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
+                           reinterpret_cast<const uint8_t *>(pixlab_d), n, K, clen_d, ccode_d, co.as<uint64_t>(),
+                           reinterpret_cast<uint32_t *>(out_d), bit_base);
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));

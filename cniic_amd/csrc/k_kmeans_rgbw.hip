@@ -71,7 +71,9 @@ struct KmRgbwState {
     bool no_skip = false; // CNIIC_KM_NO_SKIP: always run the full schedule (A/B measurement)
     const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
-    DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;
+    DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;  // the last four are views into resblk
+    DevBuf resblk;       // [KmDevState | cent u32[K] | members u64[K] | wsum u64[K]]: one copy brings the result to the host
+    uint64_t res_cent = 0, res_members = 0, res_wsum = 0, res_bytes = 0;
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     DevBuf cell_piv, cell_mask, moved_list, queue;  // skip schedule state
     uint32_t shard = 0, nshards = 1;
@@ -852,10 +854,15 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     const uint64_t W = 5 * (uint64_t)K + 2;
     const uint64_t lab_bytes = s->wide ? 2 : 1;
     KM_ALLOC(s->cconst, (uint64_t)s->Kpad * 8);
-    KM_ALLOC(s->cent, (uint64_t)K * 4);
-    KM_ALLOC(s->members_last, (uint64_t)K * 8);
-    KM_ALLOC(s->wsum_last, (uint64_t)K * 8);
-    KM_ALLOC(s->dstate, sizeof(KmDevState));
+    s->res_cent = (sizeof(KmDevState) + 255) & ~255ull;
+    s->res_members = s->res_cent + (((uint64_t)K * 4 + 7) & ~7ull);
+    s->res_wsum = s->res_members + (uint64_t)K * 8;
+    s->res_bytes = s->res_wsum + (uint64_t)K * 8;
+    KM_ALLOC(s->resblk, s->res_bytes);
+    s->dstate.view(s->resblk.p, sizeof(KmDevState));
+    s->cent.view(static_cast<uint8_t *>(s->resblk.p) + s->res_cent, (uint64_t)K * 4);
+    s->members_last.view(static_cast<uint8_t *>(s->resblk.p) + s->res_members, (uint64_t)K * 8);
+    s->wsum_last.view(static_cast<uint8_t *>(s->resblk.p) + s->res_wsum, (uint64_t)K * 8);
     if (partials_dev) s->partials = reinterpret_cast<uint64_t *>(partials_dev);
     else { KM_ALLOC(s->partials_own, W * 8); s->partials = s->partials_own.as<uint64_t>(); }
     (void)hipMemsetAsync(s->partials, 0, W * 8, c->stream);
@@ -881,11 +888,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->moved_list, ((uint64_t)K + 1) * 4);
         KM_ALLOC(s->queue, 16);
         (void)hipMemsetAsync(s->queue.p, 0, 16, c->stream);
-        {   // before the first update every centroid counts as moved
-            const uint32_t all = K;
-            (void)hipMemcpyAsync(s->moved_list.p, &all, 4, hipMemcpyHostToDevice, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-        }
+        // before the first update every centroid counts as moved
+        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->moved_list.p), (int)K, 1, c->stream);
         KM_ALLOC(s->running, W * 8);
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
@@ -927,7 +931,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         }
         hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)G + 1, 256)), dim3(256), 0, c->stream, s->ne_cost.as<uint32_t>(),
                            s->ne_count.as<uint32_t>(), G, s->wfirst.as<uint32_t>());
-        hipError_t e = hipStreamSynchronize(c->stream);  // count / cursor are released on scope exit
+        // (count / cursor go back to the context's pool here; it hands them out again in stream order)
+        hipError_t e = hipGetLastError();
         if (e != hipSuccess) { delete s; return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw setup: %s", hipGetErrorString(e)); }
     } else {
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(n, (uint64_t)kAssignThreads * kPPT), 1), kMaxBlocks);
@@ -1220,16 +1225,38 @@ int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32,
             hipLaunchKernelGGL(k_widen_labels<uint8_t>, dim3(grid_1d(b - a)), dim3(256), 0, c->stream, s->labels.as<uint8_t>(), rank, labels_d_u32, a, b);
         CNIIC_HIP_TRY(c, hipGetLastError());
     }
-    std::vector<uint32_t> ck(s->K);
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(ck.data(), s->cent.p, (size_t)s->K * 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_TRY(km_rgbw_result_begin(s));
+    return km_rgbw_result_end(s, centroids_h, members_h, wsum_h, stats);
+}
+
+// state, centroids, members, weight sums are one block: one copy into pinned memory, one event
+int km_rgbw_result_begin(KmRgbwState *s) {
+    Ctx *c = s->c;
+    if (c->pinned_res_bytes < s->res_bytes) {
+        if (c->pinned_res) CNIIC_HIP_TRY(c, hipHostFree(c->pinned_res));
+        c->pinned_res = nullptr; c->pinned_res_bytes = 0;
+        CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned_res, s->res_bytes, hipHostMallocDefault));
+        c->pinned_res_bytes = s->res_bytes;
+    }
+    if (!c->res_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->res_ev, hipEventDisableTiming));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(c->pinned_res, s->resblk.p, s->res_bytes, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipEventRecord(c->res_ev, c->stream));
+    return CNIIC_OK;
+}
+
+int km_rgbw_result_end(KmRgbwState *s, uint8_t *centroids_h, uint64_t *members_h, uint64_t *wsum_h, cniic_kmeans_stats *stats) {
+    Ctx *c = s->c;
+    CNIIC_HIP_TRY(c, hipEventSynchronize(c->res_ev));
+    const uint8_t *blk = static_cast<const uint8_t *>(c->pinned_res);
     KmDevState h;
-    CNIIC_TRY(read_state(s, &h));
+    memcpy(&h, blk, sizeof h);
+    const uint32_t *ck = reinterpret_cast<const uint32_t *>(blk + s->res_cent);
     if (centroids_h)
         for (uint32_t k = 0; k < s->K; k++) {
             centroids_h[3 * k] = (uint8_t)(ck[k] >> 16); centroids_h[3 * k + 1] = (uint8_t)(ck[k] >> 8); centroids_h[3 * k + 2] = (uint8_t)ck[k];
         }
-    if (members_h) CNIIC_HIP_TRY(c, hipMemcpy(members_h, s->members_last.p, (size_t)s->K * 8, hipMemcpyDeviceToHost));
-    if (wsum_h) CNIIC_HIP_TRY(c, hipMemcpy(wsum_h, s->wsum_last.p, (size_t)s->K * 8, hipMemcpyDeviceToHost));
+    if (members_h) memcpy(members_h, blk + s->res_members, (size_t)s->K * 8);
+    if (wsum_h) memcpy(wsum_h, blk + s->res_wsum, (size_t)s->K * 8);
     if (stats) {
         stats->iterations = h.iter;
         stats->moved_last = h.moved_last;
