@@ -391,6 +391,11 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
                  uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
     if ((uint64_t)w * h >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "image too large");
+    struct TimersScope {  // stage timers for this call when the options ask for profiling
+        Ctx *c; bool saved;
+        TimersScope(Ctx *ctx, bool on) : c(ctx), saved(ctx->timers) { c->timers = saved || on; }
+        ~TimersScope() { c->timers = saved; }
+    } timers_scope(c, opts && (opts->flags & CNIIC_KM_PROFILE));
     switch (d.kind) {
     case CODEC_HUFMAN: return encode_hufman(c, rgb_d, w, h, out, cap, len);
     case CODEC_CLUSTER_COLORS: return encode_cluster_colors(c, rgb_d, w, h, d.arg, opts, out, cap, len, stats);

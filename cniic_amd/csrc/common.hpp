@@ -115,6 +115,7 @@ struct Ctx {
     std::string err;
     std::map<std::string, KernelTime> ktimes;  // per-call dominant-kernel timings (HIP events)
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    bool    timers = getenv("CNIIC_KERNEL_TIMERS") != nullptr;  // per-stage HIP-event timers (they synchronise)
     DevPool pool;           // recycled scratch HBM (all DevBufs created inside an ABI call)
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
@@ -273,7 +274,10 @@ struct ScopedKernelTimer {
     Ctx        *c;
     const char *name;
     bool        on;
-    ScopedKernelTimer(Ctx *ctx, const char *nm, bool enable = true) : c(ctx), name(nm), on(enable) {
+    // stop() waits for the GPU, so stage timers are off unless asked for (CNIIC_KM_PROFILE in the call's
+    // options, or CNIIC_KERNEL_TIMERS=1 in the environment)
+    ScopedKernelTimer(Ctx *ctx, const char *nm) : ScopedKernelTimer(ctx, nm, ctx->timers) {}
+    ScopedKernelTimer(Ctx *ctx, const char *nm, bool enable) : c(ctx), name(nm), on(enable) {
         if (on) (void)hipEventRecord(c->ev0, c->stream);
     }
     // must be called after the launch; synchronises on the stop event
