@@ -585,7 +585,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
     __shared__ uint32_t s_moved, s_cell;
     __shared__ unsigned long long s_evals;
-    if (st->done) return;
+    const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
     constexpr int THREADS = WAVES * 64;
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
@@ -616,6 +616,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
         for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
         if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_cell = mb0; }
+        if (done) return;
         __syncthreads();
         auto draw = [&]() -> uint32_t {
             uint32_t v = 0;
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
         for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
         if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
+        if (done) return;
         __syncthreads();
         // this shard's cells: [m_lo, m_hi); the (up to 2 per lane) centroids that moved
         const uint32_t m_lo = wfirst[gw0], m_hi = wfirst[gw0 + gridDim.x * WAVES];
@@ -745,27 +747,34 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
                                                      uint64_t *__restrict__ wsum_out,
                                                      uint32_t *__restrict__ moved_list, uint32_t *__restrict__ queue,
                                                      KmDevState *__restrict__ st) {
-    if (st->done) return;
+    // everything this launch reads is requested before the `done` flag is looked at: one memory round trip
+    const uint32_t done = st->done;
+    const uint64_t iter = st->iter;
+    const uint64_t changed = partials[5 * (size_t)K];
+    const uint64_t evals = partials[5 * (size_t)K + 1];
     __shared__ uint32_t s_reseed, s_active, s_nmoved;
     if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
-    if (mode == 1)
-        for (uint32_t i = threadIdx.x; i < 5 * K; i += blockDim.x) running[i] += partials[i];
     __syncthreads();
-    const uint64_t *src = mode == 1 ? running : partials;
-    const uint64_t iter = st->iter;
+    if (done) return;
     for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-        uint64_t members = src[4 * (size_t)K + k];
+        // the cluster's five sums: this iteration's partials, on top of the running sums in delta mode
+        const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
+        uint64_t v[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) { v[i] = partials[at[i]]; partials[at[i]] = 0; }  // zero: ready for the next iteration
+        if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) { v[i] += running[at[i]]; running[at[i]] = v[i]; }
+        }
+        const uint64_t members = v[4], w = v[3];
         members_out[k] = members;
-        wsum_out[k] = src[3 * (size_t)K + k];
+        wsum_out[k] = w;
         uint32_t ck;
         if (members == 0) {
             ck = keys[reseed_index(seed, iter, k, U)];  // fake_clone of the stolen point
             atomicAdd(&s_reseed, 1u);
         } else {
-            uint64_t w = src[3 * (size_t)K + k];
-            uint32_t r = (uint32_t)(src[3 * (size_t)k + 0] / w) & 255;
-            uint32_t g = (uint32_t)(src[3 * (size_t)k + 1] / w) & 255;
-            uint32_t b = (uint32_t)(src[3 * (size_t)k + 2] / w) & 255;
+            const uint32_t r = (uint32_t)(v[0] / w) & 255, g = (uint32_t)(v[1] / w) & 255, b = (uint32_t)(v[2] / w) & 255;
             ck = (r << 16) | (g << 8) | b;
             atomicAdd(&s_active, 1u);
         }
@@ -775,11 +784,9 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
     }
     __syncthreads();
     if (threadIdx.x == 0 && moved_list) { moved_list[0] = s_nmoved; *queue = 0; }
-    const uint64_t changed = partials[5 * (size_t)K];
-    const uint64_t evals = partials[5 * (size_t)K + 1];
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += blockDim.x) partials[i] = 0;  // ready for the next iteration
     if (threadIdx.x == 0) {
+        partials[5 * (size_t)K] = 0;
+        partials[5 * (size_t)K + 1] = 0;
         st->changed_ring[iter % kHistRing] = changed;
         st->moved_last = changed;
         st->reseeds += s_reseed;
