@@ -568,6 +568,78 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
     }
 }
 
+// the same sweep at iteration 0, where every point adds to the sums of its cluster (kept apart from
+// sweep_points: sharing the code cost the later iterations 30 % through the register allocation)
+template <typename LabelT, int IDBITS>
+__device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
+                                             uint32_t base, uint32_t e, int lane,
+                                             const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K,
+                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    uint32_t best[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) best[u] = 0;
+    for (uint32_t j = 0; j < ncand; j++) {
+        const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
+    }
+    uint32_t nl[kSweep];
+    bool mvd[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        const uint32_t q = base + u * 64 + lane;
+        nl[u] = cur[u];
+        mvd[u] = false;
+        if (q < e) {
+            const uint2 cc = tab[cur[u]];
+            const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
+            mvd[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
+        }
+    }
+    {
+        // Iteration 0: every point adds to the sums of its cluster.  A sweep lies inside one 8^3 cell, so as a
+        // rule all its points join the same cluster: one wave reduction and five LDS atomics instead of five
+        // 64-way colliding atomics per slot.
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nl[0]);  // lane 0, slot 0 is always a point of the sweep
+        bool same = true;
+        unsigned long long rw = 0, gw = 0, bw = 0, ww = 0, cn = 0;
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) {
+            const uint32_t q = base + u * 64 + lane;
+            if (q < e) {
+                same = same && nl[u] == l0;
+                const uint64_t w = wt[u];
+                rw += ((p[u] >> 16) & 255) * w; gw += ((p[u] >> 8) & 255) * w; bw += (p[u] & 255) * w; ww += w; cn += 1;
+            }
+        }
+        if (__ballot(!same) == 0ull) {
+            rw = wave_reduce_sum64(rw); gw = wave_reduce_sum64(gw); bw = wave_reduce_sum64(bw);
+            ww = wave_reduce_sum64(ww); cn = wave_reduce_sum64(cn);
+            if (lane == 0) {
+                atomicAdd(&acc[3 * l0 + 0], rw); atomicAdd(&acc[3 * l0 + 1], gw); atomicAdd(&acc[3 * l0 + 2], bw);
+                atomicAdd(&acc[3 * K + l0], ww); atomicAdd(&acc[4 * K + l0], cn);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        const uint32_t q = base + u * 64 + lane;
+        if (q < e) {
+            const uint32_t pp = p[u], n_ = nl[u];
+            const uint64_t w = wt[u];  // loaded with the key: a gather here would stall every sweep that moves a point
+            const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
+            atomicAdd(&acc[3 * n_ + 0], rw);
+            atomicAdd(&acc[3 * n_ + 1], gw);
+            atomicAdd(&acc[3 * n_ + 2], bw);
+            atomicAdd(&acc[3 * K + n_], (unsigned long long)w);
+            atomicAdd(&acc[4 * K + n_], 1ull);
+        }
+    }
+}
+
 struct CellState {          // per non-empty cell, carried between iterations (skip schedule)
     uint32_t *piv;          // [M] colour of the pivot of the last candidate build
     unsigned long long *mask;  // [M][MW]
@@ -657,7 +729,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                     curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
                     wtn[u] = qn < nte ? cweight[qn] : 0u;
                 }
-                sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, first, labels, acc, moved);
+                if (first) sweep_points_first<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved);
+                else sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
