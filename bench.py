@@ -120,8 +120,9 @@ def main():
         keys, counts = ctx.hist_rgb24(img, npx=W * H)
         U = int(keys.size)
         del keys, counts
-        # one more encode of the same image with a HIP-event pair around every assign launch (on the
-        # stream the kernel runs on): average launch duration over ALL iterations of a real encode
+        # one more encode of the same image with a HIP start/stop event pair attached to every assign dispatch
+        # (hipExtLaunchKernelGGL, on the stream the kernel runs on: the kernel's own begin and end, without the
+        # ~4 us of dispatch an event pair AROUND a launch adds): average over ALL launches of a real encode
         rc, ln, stp = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE)
         ms_sum, launches = ctx.kernel_time("kmeans_rgbw_assign")
         launch_ms = ms_sum / max(1, launches)
@@ -136,8 +137,8 @@ def main():
         roofline = {"kernel": "k_rgbw_assign_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "launch_ms": round(launch_ms, 5), "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes,
-                    "note": "average over all %d assign launches of one encode (%d iterations + launches that exit on the "
-                            "device-side done flag, as rocprofv3 --stats counts them); exact cell-pruned assign over %d distinct "
+                    "note": "HIP start/stop events on each of the %d assign dispatches of one encode (%d iterations + launches that exit "
+                            "on the device-side done flag, as rocprofv3 --stats counts them); exact cell-pruned assign over %d distinct "
                             "colours, K=%d; algorithmic bytes = 10 B/colour (SURVEY 8(d) dedup form); traffic = PMC "
                             "2*FETCH_SIZE+WRITE_SIZE of a steady-state launch (profiles/traffic.json)" % (launches, stp["iterations"], U, K)}
 

@@ -41,6 +41,8 @@
 #define CNIIC_CELL_SHIFT 3
 #endif
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -272,18 +274,10 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__
     uint32_t s = 0, z = 0;
 #pragma unroll
     for (uint32_t i = 0; i < per; i++) { s += v[i]; z += v[i] != 0; }
-    sh[threadIdx.x] = s;
-    sh2[threadIdx.x] = z;
+    // two block scans by wave shuffles (a Hillis-Steele loop over LDS took 20 barriers and 58 us)
+    uint32_t run = block_exclusive_scan<1024>(s, sh), m = block_exclusive_scan<1024>(z, sh2);
+    if (threadIdx.x == 1023) { sh[1023] = run + s; sh2[1023] = m + z; }
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        uint32_t add2 = threadIdx.x >= off ? sh2[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += add;
-        sh2[threadIdx.x] += add2;
-        __syncthreads();
-    }
-    uint32_t run = sh[threadIdx.x] - s, m = sh2[threadIdx.x] - z;
     uint32_t st[per];
 #pragma unroll
     for (uint32_t i = 0; i < per; i++) {
@@ -1068,7 +1062,9 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
     return CNIIC_OK;
 }
 
-static void launch_assign(KmRgbwState *s) {
+// ev_start / ev_stop (profiling): events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's
+// own begin and end as a profiler sees them, not an event pair around it (which adds ~4 us of dispatch per launch)
+static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     Ctx *c = s->c;
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
@@ -1083,6 +1079,13 @@ static void launch_assign(KmRgbwState *s) {
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
                                (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
+            if (ev_start)
+                hipExtLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), (uint32_t)lds,
+                                      c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
+                                      (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
+                                      (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
+                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
+            else
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
@@ -1168,9 +1171,14 @@ int km_rgbw_run(KmRgbwState *s) {
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     for (;;) {
         for (int b = 0; b < batch; b++) {
-            if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
-            launch_assign(s);
-            if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
+            if (s->profile && s->cells && !s->wide) {
+                hipEvent_t a = lt.next(), b = lt.next();
+                launch_assign(s, a, b);
+            } else {
+                if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
+                launch_assign(s);
+                if (s->profile) (void)hipEventRecord(lt.next(), c->stream);
+            }
             if (!s->cells) {
                 const uint32_t W = 5 * s->K + 2;
                 const uint32_t ry = std::max(1u, std::min(16u, s->nblocks / 4));
