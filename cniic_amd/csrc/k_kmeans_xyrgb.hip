@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_n;
     __shared__ uint32_t wsum[kXWaves];
-    if (st->done) return;
+    const uint32_t done = st->done;  // acted on once the set-up loads are out
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     unsigned long long *const my_mask = W_mask + (size_t)wv * MW;
     uint32_t moved = 0;
     unsigned long long evals = 0;
+    if (done) return;
     __syncthreads();
 
     for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
@@ -469,48 +470,58 @@ __global__ __launch_bounds__(1024) void k_xy_update(unsigned long long *__restri
                                                     uint32_t K, uint64_t seed, uint64_t max_iters, int4 *__restrict__ cent,
                                                     uint64_t *__restrict__ members_out, uint32_t *__restrict__ moved_list,
                                                     KmDevState *__restrict__ st) {
-    if (st->done) return;
-    __shared__ uint32_t s_reseed, s_active, s_nmoved;
-    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
-    __syncthreads();
+    // everything a cluster needs is requested before anything is looked at: one memory round trip per launch
+    const uint32_t done = st->done;
     const uint64_t iter = st->iter;
     const unsigned long long changed = partials[6 * (size_t)K];
     const unsigned long long evals = partials[6 * (size_t)K + 1];
+    __shared__ uint32_t s_reseed, s_active, s_nmoved;
+    if (threadIdx.x == 0) { s_reseed = 0; s_active = 0; s_nmoved = 0; }
+    __syncthreads();
+    if (done) return;
     for (uint32_t k = threadIdx.x; k < K; k += blockDim.x) {
-        unsigned long long d[6];
-        bool any = false;
+        unsigned long long d[6], r[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const size_t at = i < 5 ? 5 * (size_t)k + i : 5 * (size_t)K + k;
             d[i] = partials[at];
-            partials[at] = 0;
-            any |= d[i] != 0;
+            r[i] = running[at];
         }
-        unsigned long long m = running[5 * (size_t)K + k];
+        const int4 oc = cent[k];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) any |= d[i] != 0;
         if (any) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const size_t at = i < 5 ? 5 * (size_t)k + i : 5 * (size_t)K + k;
-                running[at] += d[i];
+                r[i] += d[i];
+                running[at] = r[i];
+                partials[at] = 0;
             }
-            m += d[5];
         }
+        const unsigned long long m = r[5];
         members_out[k] = m;
         if (m == 0) {  // reseeded every iteration it stays empty (the index depends on iter)
             const uint64_t idx = reseed_index(seed, iter, k, N);  // fake_clone of the stolen pixel
             const int4 nc = make_cent((int32_t)(idx % w), (int32_t)(idx / w), rgb_key(rgb + 3 * idx));
-            const int4 oc = cent[k];
             if (oc.x != nc.x || oc.y != nc.y || oc.z != nc.z) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
             cent[k] = nc;
             atomicAdd(&s_reseed, 1u);
         } else {
             atomicAdd(&s_active, 1u);
             if (any) {
+                // floor(sum / m) with sum < 2^42 and m < 2^28: a double quotient is within one of it
                 uint32_t q[5];
+                const double md = (double)m;
 #pragma unroll
-                for (int i = 0; i < 5; i++) q[i] = (uint32_t)(running[5 * (size_t)k + i] / m);
+                for (int i = 0; i < 5; i++) {
+                    unsigned long long e = (unsigned long long)((double)r[i] / md);
+                    if (e * m > r[i]) e--;
+                    else if ((e + 1) * m <= r[i]) e++;
+                    q[i] = (uint32_t)e;
+                }
                 const int4 nc = make_cent((int32_t)q[0], (int32_t)q[1], ((q[2] & 255) << 16) | ((q[3] & 255) << 8) | (q[4] & 255));
-                const int4 oc = cent[k];
                 if (oc.x != nc.x || oc.y != nc.y || oc.z != nc.z) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
                 cent[k] = nc;
             }
