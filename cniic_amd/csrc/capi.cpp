@@ -468,6 +468,16 @@ int32_t cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done) {
     return CNIIC_OK;
 }
 
+int32_t cniic_cc_poll_lagged(cniic_cc *cc, uint64_t *iterations, uint32_t *done, uint32_t *valid) {
+    if (!cc || !done || !valid) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_rgbw_poll_lagged(cc->s->km, &st, done, valid));
+    if (iterations) *iterations = st.iterations;
+    return CNIIC_OK;
+}
+
 int32_t cniic_cc_partials(cniic_cc *cc, void **dev_ptr) {
     if (!cc || !dev_ptr) return CNIIC_ERR_BAD_ARG;
     *dev_ptr = km_rgbw_partials_dev(cc->s->km);

@@ -326,6 +326,7 @@ int km_rgbw_update(KmRgbwState *s);                       // async: centroids fr
 int km_rgbw_run(KmRgbwState *s);                          // full loop to convergence (single GPU)
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
+int km_rgbw_poll_lagged(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done, uint32_t *have);  // waits for the previous call's copy only
 int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats);
 // the same in two halves: _begin enqueues the copy of the result block, _end waits for it (work enqueued

@@ -35,6 +35,7 @@
 // non-zero entries flushed with global u64 atomics.  Sums are independent of block count, launch
 // order and GPU count.
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #ifndef CNIIC_CELL_SHIFT
@@ -76,6 +77,7 @@ struct KmRgbwState {
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;  // the last four are views into resblk
     DevBuf resblk;       // [KmDevState | cent u32[K] | members u64[K] | wsum u64[K]]: one copy brings the result to the host
     uint64_t res_cent = 0, res_members = 0, res_wsum = 0, res_bytes = 0;
+    std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     DevBuf cell_piv, cell_mask, moved_list, queue;  // skip schedule state
     uint32_t shard = 0, nshards = 1;
@@ -1130,6 +1132,22 @@ int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done) {
     CNIIC_TRY(read_state(s, &h));
     st->iterations = h.iter; st->moved_last = h.moved_last; st->empty_reseeds = h.reseeds; st->active = h.active; st->pair_evals = h.pair_evals;
     *done = h.done;
+    return CNIIC_OK;
+}
+
+// The state as of the PREVIOUS call (have = false on the first one): the copy enqueued by this call is waited for
+// by the next, so a caller that polls after every batch of iterations never makes the GPU wait for the host.
+int km_rgbw_poll_lagged(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done, uint32_t *have) {
+    if (!s->lagged) {
+        s->lagged = std::make_unique<LaggedPoll>(s->c, s->dstate.p);
+        CNIIC_TRY(s->lagged->prepare());
+    }
+    KmDevState h{};
+    bool got = false;
+    CNIIC_TRY(s->lagged->after_batch(&h, &got));
+    *have = got ? 1u : 0u;
+    *done = got ? h.done : 0u;
+    if (got) { st->iterations = h.iter; st->moved_last = h.moved_last; st->empty_reseeds = h.reseeds; st->active = h.active; st->pair_evals = h.pair_evals; }
     return CNIIC_OK;
 }
 

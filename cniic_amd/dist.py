@@ -57,6 +57,12 @@ class HipBackend:
         self.ctx._check(self.L.cniic_cc_poll(h, C.byref(it), C.byref(done)))
         return it.value, bool(done.value)
 
+    def poll_lagged(self, h):
+        """(valid?, iterations, converged?) as of the PREVIOUS call: no GPU stall"""
+        it, done, valid = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        self.ctx._check(self.L.cniic_cc_poll_lagged(h, C.byref(it), C.byref(done), C.byref(valid)))
+        return bool(valid.value), it.value, bool(done.value)
+
     def export_labels(self, h):
         U = int(self.L.cniic_cc_unique(h))
         dt = self.torch.uint8 if self.L.cniic_cc_label_bytes(h) == 1 else self.torch.int16
@@ -109,12 +115,23 @@ class ShardedClusterColors:
                     be.assign(handle)               # convergence are no-ops on every rank (device-side flag)
                     self._all_reduce(partials)      # K partial centroid sums (+ moved count), identical on all ranks
                     be.update(handle)
-                it, done = be.poll(handle)
+                # the answer lags one batch (the state after the previous batch), the same on every rank, so the
+                # GPU never waits for the host; a backend without it polls synchronously
+                if hasattr(be, "poll_lagged"):
+                    valid, it, done = be.poll_lagged(handle)
+                    done = valid and done
+                else:
+                    it, done = be.poll(handle)
                 if done:
                     break
             if self.world > 1:
                 lab = be.export_labels(handle)
-                self._all_reduce(lab)               # one owner per element, zeros elsewhere
+                if getattr(lab, "element_size", lambda: 1)() == 2:   # K > 256: RCCL has no 16-bit integer type
+                    wide = lab.to(dtype=self.be.torch.int32) if hasattr(self.be, "torch") else lab.astype("int32")
+                    self._all_reduce(wide)
+                    lab = wide.to(dtype=lab.dtype) if hasattr(self.be, "torch") else wide.astype(lab.dtype)
+                else:
+                    self._all_reduce(lab)           # one owner per element, zeros elsewhere
                 be.import_labels(handle, lab)
             return be.finish(handle, img, w, h, local if self.world > 1 else None, out)
         finally:

@@ -184,6 +184,10 @@ int32_t  cniic_cc_update(cniic_cc *cc, uint64_t *changed);     /* syncs; changed
 /* iterations completed so far and whether an iteration has moved nothing (syncs).  Iterations issued
  * after convergence are no-ops on the device, so callers may poll only every few iterations. */
 int32_t  cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done);
+/* The same without a GPU stall: returns the state as of the PREVIOUS call (*valid = 0 on the first call) and
+ * enqueues the copy the next call will read.  Call it after every batch of iterations; every rank sees the
+ * same sequence of answers, so all ranks stop after the same batch. */
+int32_t  cniic_cc_poll_lagged(cniic_cc *cc, uint64_t *iterations, uint32_t *done, uint32_t *valid);
 int32_t  cniic_cc_export_labels(cniic_cc *cc, void *dst_dev);  /* U labels, zero outside this shard */
 int32_t  cniic_cc_import_labels(cniic_cc *cc, const void *src_dev);
 int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h,

@@ -1,0 +1,19 @@
+"""Decode timings of the four codecs (host buffers in and out, as bench.rs calls decode); tools only."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, cniic_amd
+from cniic_amd import _lib, synth
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+which = sys.argv[2:] or ["voronoi(2048)", "cluster-colors(256)", "delta", "hufman"]
+dev = torch.device("cuda", 0); torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev); ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
+img_h = img.cpu().numpy()
+out = torch.empty(size * size * 12 + (1 << 24), dtype=torch.uint8, device=dev)
+for expr in which:
+    rc, ln, st = ctx.encode(expr, img, w=size, h=size, out=out, allow=(_lib.FEW_ACTIVE,))
+    data = out[:ln].cpu().numpy().tobytes()
+    for rep in range(2):
+        t = time.perf_counter(); rc2, dec = ctx.decode(expr, data); dt = time.perf_counter() - t
+    t = time.perf_counter(); mse = ctx.mse(img_h, dec); dm = time.perf_counter() - t
+    print(json.dumps(dict(codec=expr, size=size, bytes=ln, decode_ms=round(dt * 1e3, 2), mse=round(mse, 3), mse_ms=round(dm * 1e3, 2), rc=rc2)))
