@@ -168,10 +168,14 @@ def main():
                        "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2),
                        "bytes_per_px": round(nbytes / (W * H), 4),
                        "parallelism": "1 GPU" if world == 1 else "pixels sharded over %d GPUs, shared palette, RCCL all-reduce "
-                                                                   "of histogram + K partial sums per iteration" % world},
+                                                                   "of histogram + K partial sums per iteration (%s)"
+                                                                   % (world, "library communicator, in-stream" if enc.collectives == "native"
+                                                                      else "torch.distributed")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if world > 1:
+        enc.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

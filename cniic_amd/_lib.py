@@ -26,7 +26,8 @@ SYMBOLS = [
     "cniic_km_labels_internal", "cniic_km_assign", "cniic_km_update",
     "cniic_km_result", "cniic_km_time_assign", "cniic_km_destroy", "cniic_hist_rgb24_dense", "cniic_cc_create",
     "cniic_cc_unique", "cniic_cc_label_bytes", "cniic_cc_partials", "cniic_cc_assign", "cniic_cc_update", "cniic_cc_poll", "cniic_cc_poll_lagged",
-    "cniic_cc_export_labels", "cniic_cc_import_labels", "cniic_cc_finish", "cniic_cc_destroy", "cniic_remap_rgb", "cniic_hilbert_xy",
+    "cniic_cc_export_labels", "cniic_cc_import_labels", "cniic_cc_finish", "cniic_cc_destroy", "cniic_comm_unique_id",
+    "cniic_comm_create", "cniic_comm_destroy", "cniic_comm_all_reduce", "cniic_cc_run", "cniic_remap_rgb", "cniic_hilbert_xy",
     "cniic_hilbert_linearize", "cniic_hilbert_delta", "cniic_hilbert_delta_hist", "cniic_huf_encode_all",
     "cniic_huf_size", "cniic_codec_parse", "cniic_codec_name", "cniic_codec_is_lossless", "cniic_codec_encode",
     "cniic_codec_encode_opts", "cniic_codec_decode", "cniic_mse", "cniic_synth_image",
@@ -79,6 +80,8 @@ def lib():
         L.cniic_km_destroy.argtypes = [C.c_void_p]
         L.cniic_cc_destroy.restype = None
         L.cniic_cc_destroy.argtypes = [C.c_void_p]
+        L.cniic_comm_destroy.restype = None
+        L.cniic_comm_destroy.argtypes = [C.c_void_p]
         L.cniic_cc_unique.restype = C.c_uint64
         L.cniic_cc_unique.argtypes = [C.c_void_p]
         L.cniic_cc_label_bytes.restype = C.c_uint32

@@ -478,6 +478,57 @@ int32_t cniic_cc_poll_lagged(cniic_cc *cc, uint64_t *iterations, uint32_t *done,
     return CNIIC_OK;
 }
 
+// ---- RCCL communicator on the context's stream
+struct cniic_comm { Comm *m = nullptr; };
+
+int32_t cniic_comm_unique_id(uint8_t id[128]) {
+    if (!id) return CNIIC_ERR_BAD_ARG;
+    return comm_unique_id(id);
+}
+
+int32_t cniic_comm_create(cniic_ctx *c, const uint8_t id[128], uint32_t rank, uint32_t nranks, cniic_comm **out) {
+    if (!c || !id || !out) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    Comm *m = nullptr;
+    CNIIC_TRY(comm_create(c, id, rank, nranks, &m));
+    *out = new cniic_comm{m};
+    return CNIIC_OK;
+}
+
+void cniic_comm_destroy(cniic_comm *cm) {
+    if (!cm) return;
+    if (cm->m) {
+        Ctx *c = comm_ctx(cm->m);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        comm_destroy(cm->m);
+    }
+    delete cm;
+}
+
+int32_t cniic_comm_all_reduce(cniic_comm *cm, void *buf_dev, uint64_t count, int32_t elem_bytes) {
+    if (!cm || !cm->m || !buf_dev) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(comm_ctx(cm->m));
+    LOCK(c);
+    if (!is_device_ptr(buf_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "comm_all_reduce: buffer must be device memory");
+    const int kind = elem_bytes == 1 ? 0 : elem_bytes == 4 ? 1 : elem_bytes == 8 ? 2 : -1;
+    if (kind < 0) return c->fail(CNIIC_ERR_BAD_ARG, "comm_all_reduce: elements of 1, 4 or 8 bytes (unsigned sum)");
+    return comm_all_reduce(cm->m, buf_dev, count, kind);
+}
+
+int32_t cniic_cc_run(cniic_cc *cc, cniic_comm *cm, cniic_kmeans_stats *stats) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    if (cm && cm->m && comm_ctx(cm->m) != cc->c) return c->fail(CNIIC_ERR_BAD_ARG, "cc_run: communicator of another context");
+    CNIIC_TRY(km_rgbw_run(cc->s->km, cm ? cm->m : nullptr));
+    if (stats) {
+        uint32_t d = 0;
+        CNIIC_TRY(km_rgbw_poll(cc->s->km, stats, &d));
+    }
+    return CNIIC_OK;
+}
+
 int32_t cniic_cc_partials(cniic_cc *cc, void **dev_ptr) {
     if (!cc || !dev_ptr) return CNIIC_ERR_BAD_ARG;
     *dev_ptr = km_rgbw_partials_dev(cc->s->km);

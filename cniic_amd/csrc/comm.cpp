@@ -1,0 +1,95 @@
+// comm.cpp -- RCCL collectives enqueued on the context's own stream (the all-reduce of the K
+// partial centroid sums sits between the assign and the update kernels with no host round trip).
+//
+// librccl is bound at run time (dlopen): the library loads and every single-GPU entry point works on a box
+// without RCCL; cniic_comm_* then returns CNIIC_ERR_UNSUPPORTED.  In a Python process torch has already
+// mapped its own librccl.so.1, and dlopen by soname returns that copy, so the process holds one RCCL.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "common.hpp"
+
+namespace cniic {
+
+namespace {
+struct Rccl {
+    bool ok = false;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    });
+    return r;
+}
+}  // namespace
+
+struct Comm {
+    Ctx *c = nullptr;
+    ncclComm_t comm = nullptr;
+    uint32_t rank = 0, nranks = 1;
+};
+
+int comm_unique_id(uint8_t *id128) {
+    const Rccl &r = rccl();
+    if (!r.ok) return CNIIC_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (r.GetUniqueId(&id) != ncclSuccess) return CNIIC_ERR_HIP;
+    memcpy(id128, &id, 128);
+    return CNIIC_OK;
+}
+
+int comm_create(Ctx *c, const uint8_t *id128, uint32_t rank, uint32_t nranks, Comm **out) {
+    const Rccl &r = rccl();
+    if (!r.ok) return c->fail(CNIIC_ERR_UNSUPPORTED, "comm_create: librccl not found");
+    if (nranks == 0 || rank >= nranks) return c->fail(CNIIC_ERR_BAD_ARG, "comm_create: rank %u of %u", rank, nranks);
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t cm = nullptr;
+    const ncclResult_t e = r.CommInitRank(&cm, (int)nranks, id, (int)rank);
+    if (e != ncclSuccess) return c->fail(CNIIC_ERR_HIP, "ncclCommInitRank: %s", r.GetErrorString(e));
+    *out = new Comm{c, cm, rank, nranks};
+    return CNIIC_OK;
+}
+
+void comm_destroy(Comm *cm) {
+    if (!cm) return;
+    if (cm->comm) (void)rccl().CommDestroy(cm->comm);
+    delete cm;
+}
+
+Ctx *comm_ctx(Comm *cm) { return cm->c; }
+uint32_t comm_size(const Comm *cm) { return cm->nranks; }
+
+// in-place sum over the ranks, on the context's stream; kind: 0 = u8, 1 = u32, 2 = u64
+int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind) {
+    Ctx *c = cm->c;
+    const ncclDataType_t dt = kind == 0 ? ncclUint8 : kind == 1 ? ncclUint32 : ncclUint64;
+    if (kind < 0 || kind > 2) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce: unknown element kind %d", kind);
+    const ncclResult_t e = rccl().AllReduce(buf_d, buf_d, (size_t)count, dt, ncclSum, cm->comm, c->stream);
+    if (e != ncclSuccess) return c->fail(CNIIC_ERR_HIP, "ncclAllReduce: %s", rccl().GetErrorString(e));
+    return CNIIC_OK;
+}
+
+}  // namespace cniic

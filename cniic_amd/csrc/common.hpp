@@ -323,7 +323,16 @@ void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
 int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials
 int km_rgbw_update(KmRgbwState *s);                       // async: centroids from partials
-int km_rgbw_run(KmRgbwState *s);                          // full loop to convergence (single GPU)
+// ---- comm.cpp: RCCL on the context's stream (bound at run time) ----
+struct Comm;
+int comm_unique_id(uint8_t *id128);
+int comm_create(Ctx *c, const uint8_t *id128, uint32_t rank, uint32_t nranks, Comm **out);
+void comm_destroy(Comm *cm);
+Ctx *comm_ctx(Comm *cm);
+uint32_t comm_size(const Comm *cm);
+int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind);  // in place, sum; kind 0 = u8, 1 = u32, 2 = u64
+
+int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
 int km_rgbw_poll_lagged(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done, uint32_t *have);  // waits for the previous call's copy only

@@ -1179,7 +1179,7 @@ struct LaunchTimer {
 // result is exactly that of the reference's `while changed_assignment` loop (kmeans.rs:26-32).
 // With CNIIC_KM_PROFILE every assign launch is bracketed by HIP events on the ctx stream and the
 // summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
-int km_rgbw_run(KmRgbwState *s) {
+int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
     const int batch = 4;
     KmDevState h;
@@ -1203,6 +1203,9 @@ int km_rgbw_run(KmRgbwState *s) {
                 hipLaunchKernelGGL(k_slab_reduce, dim3(ceil_div(W, 64), ry), dim3(256), 0, c->stream, s->slabs.as<uint64_t>(),
                                    s->nblocks, W, s->partials, s->dstate.as<KmDevState>());
             }
+            // several GPUs: the K partial sums (and the moved count) of all shards, summed in place on this stream;
+            // integer sums, so every rank updates to identical centroids and sees the same convergence flag
+            if (cm) CNIIC_TRY(comm_all_reduce(cm, s->partials, 5 * (uint64_t)s->K + 2, 2));
             CNIIC_TRY(km_rgbw_update(s));
         }
         CNIIC_HIP_TRY(c, hipGetLastError());

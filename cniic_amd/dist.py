@@ -9,11 +9,18 @@ palette and each encodes its own image with it:
     labels of the shards are merged (all-reduce of a byte array with one owner per element)
     each rank Huffman-codes its own colour-reduced image (clusterc.rs:31-52)
 
-Sums are integers, so the palette is bit-identical for 1, 2, 4 or 8 ranks.  The collectives are
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests); the
-compute is behind a small backend interface: HipBackend drives the C ABI (the product), the
-tests plug a CPU checker in to exercise this driver without a GPU.
+Sums are integers, so the palette is bit-identical for 1, 2, 4 or 8 ranks.
+
+Collectives, two ways:
+  * native (default on GPUs): the library's own RCCL communicator on the context's stream
+    (cniic_comm_*); the whole K-means loop is one C call (cniic_cc_run) that enqueues
+    assign -> ncclAllReduce -> update per iteration with no host round trip.  torch.distributed
+    only carries the 128-byte RCCL id at set-up.
+  * torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests), driven from
+    Python per iteration.  Used when RCCL cannot be bound, with CNIIC_COLLECTIVES=torch, and by the
+    CPU tests, which plug a CPU checker in as compute backend to exercise this driver without a GPU.
 """
+import os
 import ctypes as C
 
 from . import _lib
@@ -85,11 +92,58 @@ class HipBackend:
     def destroy(self, h):
         self.L.cniic_cc_destroy(h)
 
+    # ---- native RCCL on the context's stream
+    def comm_create(self, dist, rank, world):
+        """the library's communicator, or None when RCCL cannot be bound (the id travels over torch.distributed)"""
+        torch = self.torch
+        idbuf = (C.c_uint8 * 128)()
+        ok = 1
+        if rank == 0:
+            ok = 1 if self.L.cniic_comm_unique_id(idbuf) == _lib.OK else 0
+        # one small CPU/GPU tensor broadcast; its first element says whether rank 0 could make an id
+        backend = dist.get_backend() if dist is not None else "gloo"
+        t = torch.zeros(129, dtype=torch.uint8, device=self.dev if backend == "nccl" else "cpu")
+        if rank == 0:
+            t[0] = ok
+            t[1:] = torch.tensor(list(idbuf), dtype=torch.uint8)
+        if dist is not None and world > 1:
+            dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        if raw[0] != 1:
+            return None
+        idb = (C.c_uint8 * 128)(*raw[1:])
+        h = C.c_void_p()
+        rc = self.L.cniic_comm_create(self.ctx.h, idb, C.c_uint32(rank), C.c_uint32(world), C.byref(h))
+        mine = 1 if rc == _lib.OK else 0
+        if dist is not None and world > 1:  # all ranks or none
+            f = torch.tensor([mine], dtype=torch.int32, device=self.dev if backend == "nccl" else "cpu")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            agreed = int(f.item())
+        else:
+            agreed = mine
+        if not agreed:
+            if mine:
+                self.L.cniic_comm_destroy(h)
+            return None
+        return h
+
+    def comm_destroy(self, comm):
+        if comm is not None:
+            self.L.cniic_comm_destroy(comm)
+
+    def comm_all_reduce(self, comm, t):
+        self.ctx._check(self.L.cniic_comm_all_reduce(comm, C.c_void_p(t.data_ptr()), C.c_uint64(t.numel()), C.c_int32(t.element_size())))
+
+    def run(self, h, comm):
+        st = _lib.KmStats()
+        self.ctx._check(self.L.cniic_cc_run(h, comm, C.byref(st)))
+        return st.as_dict()
+
 
 class ShardedClusterColors:
     """encode(img, w, h, out) -> (stream bytes written to out, K-means stats), collectively on all ranks."""
 
-    def __init__(self, ctx, K, dist, device, max_iters=0, backend=None, poll_every=4):
+    def __init__(self, ctx, K, dist, device, max_iters=0, backend=None, poll_every=4, collectives=None):
         self.K = K
         self.poll_every = poll_every
         self.dist = dist
@@ -97,9 +151,22 @@ class ShardedClusterColors:
         self.be = backend if backend is not None else HipBackend(ctx, device)
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
+        # "native": the library's RCCL communicator; "torch": torch.distributed per iteration
+        want = collectives or os.environ.get("CNIIC_COLLECTIVES", "native")
+        self.comm = None
+        if want == "native" and hasattr(self.be, "comm_create") and (self.world > 1 or collectives == "native"):
+            self.comm = self.be.comm_create(dist, self.rank, self.world)
+        self.collectives = "native" if self.comm is not None else "torch"
+
+    def close(self):
+        if self.comm is not None:
+            self.be.comm_destroy(self.comm)
+            self.comm = None
 
     def _all_reduce(self, t):
-        if self.dist is not None and self.world > 1:
+        if self.comm is not None:
+            self.be.comm_all_reduce(self.comm, t)  # in-stream, unsigned SUM
+        elif self.dist is not None and self.world > 1:
             self.dist.all_reduce(t)  # SUM
 
     def encode(self, img, w, h, out):
@@ -110,7 +177,9 @@ class ShardedClusterColors:
         partials = be.new_partials(self.K)
         handle = be.cc_create(glob, self.K, self.rank, self.world, partials, self.max_iters)
         try:
-            while True:                             # kmeans.rs:26-32 `while changed_assignment`
+            if self.comm is not None:               # one C call: assign -> ncclAllReduce -> update per iteration, in-stream
+                be.run(handle, self.comm)
+            while self.comm is None:                # kmeans.rs:26-32 `while changed_assignment`
                 for _ in range(self.poll_every):    # no host round trip inside a batch; iterations issued after
                     be.assign(handle)               # convergence are no-ops on every rank (device-side flag)
                     self._all_reduce(partials)      # K partial centroid sums (+ moved count), identical on all ranks
@@ -126,10 +195,10 @@ class ShardedClusterColors:
                     break
             if self.world > 1:
                 lab = be.export_labels(handle)
-                if getattr(lab, "element_size", lambda: 1)() == 2:   # K > 256: RCCL has no 16-bit integer type
-                    wide = lab.to(dtype=self.be.torch.int32) if hasattr(self.be, "torch") else lab.astype("int32")
+                if lab.element_size() == 2:         # K > 256: RCCL has no 16-bit integer type
+                    wide = lab.to(dtype=be.torch.int32)
                     self._all_reduce(wide)
-                    lab = wide.to(dtype=lab.dtype) if hasattr(self.be, "torch") else wide.astype(lab.dtype)
+                    lab = wide.to(dtype=lab.dtype)
                 else:
                     self._all_reduce(lab)           # one owner per element, zeros elsewhere
                 be.import_labels(handle, lab)

@@ -195,6 +195,20 @@ int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t 
                          uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
 void     cniic_cc_destroy(cniic_cc *cc);
 
+/* ---- RCCL on the context's own stream (ncclAllReduce of the K partial sums between assign and
+ * update, no host round trip).  librccl is bound at run time; without it these return CNIIC_ERR_UNSUPPORTED
+ * and the caller all-reduces the buffers itself (cniic_cc_assign / cniic_cc_update above).
+ *   rank 0: cniic_comm_unique_id -> broadcast the 128 bytes by any means -> every rank: cniic_comm_create
+ *   cniic_comm_all_reduce : in-place unsigned sum of a device buffer (elements of 1, 4 or 8 bytes)
+ *   cniic_cc_run          : the whole `while changed_assignment` loop (kmeans.rs:26-32) of a cc session, with
+ *                           the all-reduce in-stream when comm != NULL; identical on every rank */
+typedef struct cniic_comm cniic_comm;
+int32_t  cniic_comm_unique_id(uint8_t id[128]);
+int32_t  cniic_comm_create(cniic_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t nranks, cniic_comm **out);
+void     cniic_comm_destroy(cniic_comm *comm);
+int32_t  cniic_comm_all_reduce(cniic_comm *comm, void *buf_dev, uint64_t count, int32_t elem_bytes);
+int32_t  cniic_cc_run(cniic_cc *cc, cniic_comm *comm /* NULL: one rank */, cniic_kmeans_stats *stats);
+
 /* ------------------------------------------------------------------ cluster-colors remap */
 /* src/codec/clusterc.rs:31-47: every pixel's colour -> the centroid colour of its cluster.
  * keys[U] ascending (as returned by cniic_hist_rgb24), labels[U], centroids[K x 3]. */

@@ -209,6 +209,34 @@ def test_sharded_hip_world1_equals_plain_encode():
 
 
 @pytest.mark.gpu
+def test_native_rccl_world1_equals_plain_encode():
+    """the library's own RCCL communicator (nranks = 1) drives the in-stream loop: same bytes as the plain encode"""
+    import torch
+    import cniic_amd
+    from cniic_amd.dist import ShardedClusterColors
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    img = make_img(0, 72, 88)
+    h, w = img.shape[:2]
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    enc = ShardedClusterColors(ctx, 16, None, dev, collectives="native")
+    assert enc.collectives == "native", "librccl could not be bound"
+    n, st2 = enc.encode(torch.from_numpy(img).to(dev), w, h, out)
+    # the communicator's all-reduce itself: in-place sum over one rank is the identity
+    t = torch.arange(1000, dtype=torch.int64, device=dev)
+    enc.be.comm_all_reduce(enc.comm, t)
+    torch.cuda.synchronize()
+    assert bool((t == torch.arange(1000, dtype=torch.int64, device=dev)).all())
+    enc.close()
+    got = out[:n].cpu().numpy().tobytes()
+    out2 = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    rc, n2, _ = ctx.encode("cluster-colors(16)", torch.from_numpy(img).to(dev), w=w, h=h, out=out2)
+    assert got == out2[:n2].cpu().numpy().tobytes()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_sharded_hip_world2_shared_gpu_matches_single_process():
     """two ranks (sharing the one GPU of the test box; collectives over gloo) = the oracle's union result"""
     K = 8
