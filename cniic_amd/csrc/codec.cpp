@@ -6,6 +6,7 @@
 //   ClusterColors   src/codec/clusterc.rs:17 dedup -> K-means -> remap -> Hufman
 //   VoronoiCluster  src/codec/clusterc.rs:147 5-D K-means, centroids only; Voronoi repaint on decode
 //   Delta           src/codec/hilbertc.rs:404 Hilbert gather -> neighbour delta -> huf::encode_all
+//   Hilbert{RLE(0)} src/codec/hilbertc.rs:12  Hilbert gather -> exact run-length records
 #include "codec.hpp"
 
 #include <algorithm>
@@ -41,6 +42,22 @@ static bool match_fun_u32(const std::string &s, const char *const *names, uint32
     return false;
 }
 
+// Hilbert::from_str (hilbertc.rs:341-397): fun_call named ^[Hh]ilbert$ with one argument, `rle` or `rle(<f64>)`.
+// Only the exact method (d == 0.0) is built; rle(d != 0) (a sequential running average) and zip are not.
+static bool match_hilbert_rle(const std::string &s) {
+    if (s.compare(0, 8, "hilbert(") != 0 && s.compare(0, 8, "Hilbert(") != 0) return false;
+    if (s.size() < 10 || s.back() != ')') return false;
+    const std::string arg = s.substr(8, s.size() - 9);
+    if (arg == "rle") return true;
+    if (arg.size() > 5 && arg.compare(0, 4, "rle(") == 0 && arg.back() == ')') {
+        const std::string num = arg.substr(4, arg.size() - 5);
+        char *end = nullptr;
+        const double d = strtod(num.c_str(), &end);
+        return end && *end == 0 && !num.empty() && d == 0.0;
+    }
+    return false;
+}
+
 bool parse_codec(const char *expr, CodecDesc *out) {
     if (!expr) return false;
     const std::string s(expr);
@@ -52,6 +69,7 @@ bool parse_codec(const char *expr, CodecDesc *out) {
     if (match_fun_u32(s, cc, &k)) { *out = {CODEC_CLUSTER_COLORS, k}; return true; }
     if (match_fun_u32(s, vo, &k)) { *out = {CODEC_VORONOI, k}; return true; }
     if (s == "delta") { *out = {CODEC_DELTA, 0}; return true; }  // prs::expect_name: ^delta$
+    if (match_hilbert_rle(s)) { *out = {CODEC_HILBERT_RLE, 0}; return true; }
     if (s.size() == 6) {                                         // hufc.rs:54-59 eq_ignore_ascii_case
         std::string t = s;
         std::transform(t.begin(), t.end(), t.begin(), [](unsigned char ch) { return (char)tolower(ch); });
@@ -66,11 +84,12 @@ std::string codec_name(const CodecDesc &d) {
     case CODEC_CLUSTER_COLORS: return "cluster-colors_" + std::to_string(d.arg);  // clusterc.rs:59-61
     case CODEC_VORONOI: return "voronoi_" + std::to_string(d.arg);        // clusterc.rs:191-193
     case CODEC_DELTA: return "delta";                                     // hilbertc.rs:433-435
+    case CODEC_HILBERT_RLE: return "hilbert-rle";                         // hilbertc.rs:83-85
     }
     return "";
 }
 
-bool codec_is_lossless(const CodecDesc &d) { return d.kind == CODEC_HUFMAN || d.kind == CODEC_DELTA; }
+bool codec_is_lossless(const CodecDesc &d) { return d.kind == CODEC_HUFMAN || d.kind == CODEC_DELTA || d.kind == CODEC_HILBERT_RLE; }
 
 // ------------------------------------------------------------------ output assembly
 // The encoded stream (host-built header + device-packed payload) is assembled in HBM: directly in
@@ -387,6 +406,27 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     return huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), true, n, table, true, header, out, cap, len);
 }
 
+// ------------------------------------------------------------------ Hilbert{RLE(0.0)}::encode (hilbertc.rs:26-39)
+static int encode_hilbert_rle(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len) {
+    const uint64_t n = (uint64_t)w * h;
+    std::vector<uint8_t> header;
+    put_u32(header, w);  // img.dimensions().serialize (:27)
+    put_u32(header, h);
+    StreamOut so(c, out, cap, len);
+    if (n == 0) {
+        CNIIC_TRY(so.begin(header, 0));
+        return so.finish();
+    }
+    DevBuf lin;
+    CNIIC_HIP_TRY(c, lin.alloc(n * 3));
+    CNIIC_TRY(hilbert_linearize(c, rgb_d, w, h, lin.as<uint8_t>()));  // hilbert::linearize (:29)
+    RlePlan plan;
+    CNIIC_TRY(rle_plan(c, lin.as<uint8_t>(), n, &plan));             // rle_exact (:34)
+    CNIIC_TRY(so.begin(header, plan.nruns * 12));                    // count.serialize + color.serialize per run (:35-36)
+    CNIIC_TRY(rle_emit(c, lin.as<uint8_t>(), &plan, reinterpret_cast<uint32_t *>(so.dev + 8)));
+    return so.finish();
+}
+
 int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, uint32_t h, const cniic_kmeans_opts *opts,
                  uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
@@ -401,6 +441,7 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
     case CODEC_CLUSTER_COLORS: return encode_cluster_colors(c, rgb_d, w, h, d.arg, opts, out, cap, len, stats);
     case CODEC_VORONOI: return encode_voronoi(c, rgb_d, w, h, d.arg, opts, out, cap, len, stats);
     case CODEC_DELTA: return encode_delta(c, rgb_d, w, h, out, cap, len);
+    case CODEC_HILBERT_RLE: return encode_hilbert_rle(c, rgb_d, w, h, out, cap, len);
     }
     return c->fail(CNIIC_ERR_BAD_ARG, "unknown codec");
 }
@@ -456,6 +497,29 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         const bool dst_dev = is_device_ptr(rgb_out);
         if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
         CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
+        return CNIIC_OK;
+    }
+    case CODEC_HILBERT_RLE: {  // hilbertc.rs:53-79: RleDecoder (:304-337) zipped with hilbert::iter
+        std::vector<uint8_t> lin(n * 3, 0);  // pixels the stream does not reach stay zero (ImageBuffer::new)
+        uint64_t i = 0;
+        while (i < n && pos < nbytes) {      // RepCount::deserialize(..)? ends the stream quietly
+            const uint32_t count = bytes[pos++];
+            uint64_t l;
+            if (count == 0 || !get_u64(bytes, nbytes, pos, l) || l != 3 || pos + 3 > nbytes)
+                return c->fail(CNIIC_ERR_DECODE, "hilbert-rle: bad run record (assert!(count > 0) / unwrap, hilbertc.rs:327-328)");
+            for (uint32_t k = 0; k < count && i < n; k++, i++) memcpy(&lin[3 * i], bytes + pos, 3);
+            pos += 3;
+        }
+        if (!n) return CNIIC_OK;
+        DevBuf lin_d, img_d;
+        CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(lin_d.p, lin.data(), n * 3, hipMemcpyHostToDevice, c->stream));
+        uint8_t *dst = rgb_out;
+        const bool dst_dev = is_device_ptr(rgb_out);
+        if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+        CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (:58-61)
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
         return CNIIC_OK;

@@ -7,7 +7,7 @@
 
 namespace cniic {
 
-enum CodecKind { CODEC_HUFMAN = 1, CODEC_CLUSTER_COLORS = 2, CODEC_VORONOI = 3, CODEC_DELTA = 4 };
+enum CodecKind { CODEC_HUFMAN = 1, CODEC_CLUSTER_COLORS = 2, CODEC_VORONOI = 3, CODEC_DELTA = 4, CODEC_HILBERT_RLE = 5 };
 
 struct CodecDesc {
     int      kind;

@@ -377,6 +377,11 @@ int mse_rgb(Ctx *c, const uint8_t *a_d, const uint8_t *b_d, uint64_t npx, double
 int synth_image(Ctx *c, int kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *out_d);
 int rgb_to_keys(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *keys_d);
 
+// ---- k_rle.hip: exact run-length coding of a linearised image (hilbertc.rs:100-196) ----
+struct RlePlan { uint64_t n = 0, nruns = 0; uint32_t nchunks = 0; DevBuf flags, run_off; };
+int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan);                       // counts the runs (syncs)
+int rle_emit(Ctx *c, const uint8_t *lin_d, const RlePlan *plan, uint32_t *out_words_d);      // 12-byte records
+
 // ---- k_hilbert.hip ----
 int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d);
 int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out_d);

@@ -1,0 +1,198 @@
+// k_rle.hip -- Hilbert { compress: RLE(0.0) } on gfx950: exact run-length coding along the Hilbert scan
+// (reference: src/codec/hilbertc.rs:12-98; rle_exact = AbstractRle + Exact, :100-196).
+//
+// A run is a colour and every following equal colour, up to RepCount::MAX = 255 elements; the element that
+// would be the 256th starts the next run (:128-137).  So inside a maximal segment of equal colours starting
+// at position s the runs start at s, s + 255, s + 510, ...: position i starts a run iff (i - s(i)) % 255 == 0
+// with s(i) = the last position <= i whose colour differs from its predecessor (position 0 counts).
+//
+//   k_rle_last      per 4096-position chunk: its last segment start                      reads 3 B/px
+//   k_rle_carry     exclusive max-scan over the chunks (single block)
+//   k_rle_flags     run-start flags (16 per thread, one u16) + runs per chunk            reads 3 B/px
+//   k_rle_offsets   exclusive sum-scan of the runs per chunk (single block) + total
+//   k_rle_starts    start position of every run, in order                                reads the flags
+//   k_rle_emit      (count:u8, colour: u64 len = 3 + 3 bytes) = three aligned words per run, behind the header
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace cniic {
+
+constexpr int kRleThreads = 256;
+constexpr int kRlePer = 16;
+constexpr uint32_t kRleChunk = kRleThreads * kRlePer;  // 4096
+constexpr uint32_t kRleMaxRun = 255;                    // RepCount::MAX (hilbertc.rs:23,130)
+
+// this thread's 16 positions: bit j of the result <=> position base + j differs from its predecessor (or is 0)
+__device__ __forceinline__ uint32_t segment_starts(const uint8_t *__restrict__ lin, uint64_t n, uint64_t base) {
+    uint32_t m = 0;
+    if (base >= n) return 0;
+    uint32_t prev = base ? rgb_key(lin + 3 * (base - 1)) : 0xffffffffu;  // no colour has this key
+#pragma unroll
+    for (int j = 0; j < kRlePer; j++) {
+        if (base + j < n) {
+            const uint32_t k = rgb_key(lin + 3 * (base + j));
+            if (k != prev) m |= 1u << j;
+            prev = k;
+        }
+    }
+    return m;
+}
+
+// inclusive max-scan over the 256 threads of a block, then exclusive (own value left out)
+__device__ __forceinline__ uint64_t block_exclusive_max(uint64_t v, uint64_t *wmax) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc = max(inc, t);
+    }
+    if (lane == 63) wmax[wid] = inc;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (int i = 0; i < wid; i++) pre = max(pre, wmax[i]);
+    uint64_t ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0;
+    __syncthreads();
+    return max(pre, ex);
+}
+
+// positions are stored + 1 so that 0 means "none"
+__global__ __launch_bounds__(kRleThreads) void k_rle_last(const uint8_t *__restrict__ lin, uint64_t n, uint64_t *__restrict__ chunk_last) {
+    __shared__ uint64_t wmax[kRleThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
+    const uint32_t m = segment_starts(lin, n, base);
+    uint64_t last = m ? base + (31 - __clz((int)m)) + 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) last = max(last, (uint64_t)__shfl_xor(last, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = last;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_last[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+}
+
+// single block: carry[c] = max over chunks before c (0 = none)
+__global__ __launch_bounds__(1024) void k_rle_carry(const uint64_t *__restrict__ chunk_last, uint32_t nchunks, uint64_t *__restrict__ carry) {
+    __shared__ uint64_t sh[1024];
+    const uint32_t per = (nchunks + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nchunks);
+    uint64_t m = 0;
+    for (uint32_t i = lo; i < hi; i++) m = max(m, chunk_last[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint64_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] = max(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    uint64_t run = threadIdx.x ? sh[threadIdx.x - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) { carry[i] = run; run = max(run, chunk_last[i]); }
+}
+
+__global__ __launch_bounds__(kRleThreads) void k_rle_flags(const uint8_t *__restrict__ lin, uint64_t n, const uint64_t *__restrict__ carry,
+                                                           uint16_t *__restrict__ flags, uint32_t *__restrict__ chunk_runs) {
+    __shared__ uint64_t wmax[kRleThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
+    const uint32_t m = segment_starts(lin, n, base);
+    const uint64_t mine = m ? base + (31 - __clz((int)m)) + 1 : 0;
+    uint64_t seg = max(block_exclusive_max(mine, wmax), carry[blockIdx.x]);  // (+1) start of the segment running into this thread
+    uint32_t f = 0;
+#pragma unroll
+    for (int j = 0; j < kRlePer; j++) {
+        if (base + j < n) {
+            if ((m >> j) & 1u) seg = base + j + 1;
+            if ((base + j + 1 - seg) % kRleMaxRun == 0) f |= 1u << j;
+        }
+    }
+    flags[(size_t)blockIdx.x * kRleThreads + threadIdx.x] = (uint16_t)f;
+    const uint32_t runs = block_reduce_sum<kRleThreads>((uint32_t)__popc(f));
+    if (threadIdx.x == 0) chunk_runs[blockIdx.x] = runs;
+}
+
+// single block: run_off[c] = runs in the chunks before c; *total = all runs
+__global__ __launch_bounds__(1024) void k_rle_offsets(const uint32_t *__restrict__ chunk_runs, uint32_t nchunks, uint64_t *__restrict__ run_off,
+                                                      uint64_t *__restrict__ total) {
+    __shared__ uint64_t sh[1024];
+    const uint32_t per = (nchunks + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nchunks);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += chunk_runs[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint64_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t run = sh[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i++) { run_off[i] = run; run += chunk_runs[i]; }
+    if (threadIdx.x == 1023) *total = sh[1023];
+}
+
+__global__ __launch_bounds__(kRleThreads) void k_rle_starts(const uint16_t *__restrict__ flags, const uint64_t *__restrict__ run_off,
+                                                            uint64_t *__restrict__ start_pos) {
+    __shared__ uint32_t wsum[kRleThreads / 64];
+    const uint32_t f = flags[(size_t)blockIdx.x * kRleThreads + threadIdx.x];
+    uint64_t r = run_off[blockIdx.x] + block_exclusive_scan<kRleThreads>((uint32_t)__popc(f), wsum);
+    const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
+    for (uint32_t m = f; m; m &= m - 1) start_pos[r++] = base + (uint32_t)(__ffs((int)m) - 1);
+}
+
+// record = count:u8 | len:u64 = 3 | r g b  = 12 bytes = words { count | 3 << 8, 0, r << 8 | g << 16 | b << 24 }
+__global__ __launch_bounds__(256) void k_rle_emit(const uint8_t *__restrict__ lin, uint64_t n, const uint64_t *__restrict__ start_pos,
+                                                  uint64_t nruns, uint32_t *__restrict__ out_words) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride) {
+        const uint64_t s = start_pos[r], e = r + 1 < nruns ? start_pos[r + 1] : n;
+        const uint8_t *p = lin + 3 * s;
+        out_words[3 * r + 0] = (uint32_t)(e - s) | (3u << 8);
+        out_words[3 * r + 1] = 0u;
+        out_words[3 * r + 2] = ((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24);
+    }
+}
+
+// lin_d: the image in Hilbert order (3 B/px).  Phase 1 counts the runs (host out-param, stream synced) and keeps
+// its scratch in `plan`; phase 2 writes the records at out_words (device, 4-byte aligned).
+int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan) {
+    plan->n = n;
+    plan->nruns = 0;
+    if (n == 0) return CNIIC_OK;
+    const uint64_t nchunks64 = ceil_div(n, kRleChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert-rle: image too large");
+    const uint32_t nchunks = (uint32_t)nchunks64;
+    plan->nchunks = nchunks;
+    DevBuf chunk_last, carry, chunk_runs, tot;
+    CNIIC_HIP_TRY(c, chunk_last.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, carry.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, chunk_runs.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    CNIIC_HIP_TRY(c, plan->flags.alloc((uint64_t)nchunks * kRleThreads * 2));
+    CNIIC_HIP_TRY(c, plan->run_off.alloc((uint64_t)nchunks * 8));
+    hipLaunchKernelGGL(k_rle_last, dim3(nchunks), dim3(kRleThreads), 0, c->stream, lin_d, n, chunk_last.as<uint64_t>());
+    hipLaunchKernelGGL(k_rle_carry, dim3(1), dim3(1024), 0, c->stream, chunk_last.as<uint64_t>(), nchunks, carry.as<uint64_t>());
+    hipLaunchKernelGGL(k_rle_flags, dim3(nchunks), dim3(kRleThreads), 0, c->stream, lin_d, n, carry.as<uint64_t>(),
+                       plan->flags.as<uint16_t>(), chunk_runs.as<uint32_t>());
+    hipLaunchKernelGGL(k_rle_offsets, dim3(1), dim3(1024), 0, c->stream, chunk_runs.as<uint32_t>(), nchunks, plan->run_off.as<uint64_t>(),
+                       tot.as<uint64_t>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    plan->nruns = total;
+    return CNIIC_OK;
+}
+
+int rle_emit(Ctx *c, const uint8_t *lin_d, const RlePlan *plan, uint32_t *out_words_d) {
+    if (plan->nruns == 0) return CNIIC_OK;
+    DevBuf start_pos;
+    CNIIC_HIP_TRY(c, start_pos.alloc(plan->nruns * 8));
+    hipLaunchKernelGGL(k_rle_starts, dim3(plan->nchunks), dim3(kRleThreads), 0, c->stream, plan->flags.as<uint16_t>(),
+                       plan->run_off.as<uint64_t>(), start_pos.as<uint64_t>());
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(plan->nruns, 256), 1), 4096);
+    hipLaunchKernelGGL(k_rle_emit, dim3(grid), dim3(256), 0, c->stream, lin_d, plan->n, start_pos.as<uint64_t>(), plan->nruns, out_words_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+}  // namespace cniic

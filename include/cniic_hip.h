@@ -241,7 +241,8 @@ int32_t cniic_huf_size(int32_t sym_kind, const uint64_t *counts, uint64_t n, uin
 
 /* ------------------------------------------------------------------ Codec trait (src/codec.rs:14-19) */
 /* expr is the reference's --codec= expression: "hufman", "cluster-colors(256)" / "ccol(256)",
- * "voronoi(2048)", "delta" (src/codec.rs:41-59, FromStr impls of each codec). */
+ * "voronoi(2048)", "delta", "hilbert(rle)" = "hilbert(rle(0))" (src/codec.rs:41-59, FromStr impls of each
+ * codec; hilbertc.rs:341-397 for the last one, whose name() is "hilbert-rle"; rle(d != 0) and zip are not built). */
 int32_t cniic_codec_parse(const char *expr, int32_t *kind, uint32_t *arg);
 int32_t cniic_codec_name(const char *expr, char *buf, uint64_t cap);   /* Codec::name()        */
 int32_t cniic_codec_is_lossless(const char *expr);                     /* 1 / 0 / negative err */

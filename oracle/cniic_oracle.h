@@ -190,6 +190,9 @@ int orc_voronoi_decode(const uint8_t *bytes, size_t n, uint8_t *rgb, size_t cap,
 double orc_mse(const uint8_t *a, const uint8_t *b, uint64_t npx);
 
 /* convenience wrappers for ctypes: encode into caller memory */
+/* Hilbert{RLE(0.0)}: exact run-length coding along the scan (hilbertc.rs:12-98, 100-196, 304-337) */
+int orc_hilbert_rle_encode(const uint8_t *rgb, uint32_t w, uint32_t h, orc_buf *out);
+int orc_hilbert_rle_decode(const uint8_t *bytes, size_t nb, uint8_t *rgb, size_t cap, uint32_t *w, uint32_t *h);
 int orc_encode(const char *codec, int mode, uint64_t seed, const uint8_t *rgb, uint32_t w,
                uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len, orc_km_stats *st);
 int orc_decode(const char *codec, const uint8_t *bytes, uint64_t n, uint8_t *rgb, uint64_t cap,

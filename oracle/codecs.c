@@ -200,6 +200,61 @@ int orc_voronoi_decode(const uint8_t *bytes, size_t nb, uint8_t *rgb, size_t cap
 }
 
 /* bench.rs:95-104: sum of dist(px,py).powi(2) in f64, divided by w*h */
+/* ---- Hilbert { compress: RLE(0.0) }  (hilbertc.rs:12-98): exact run-length coding along the scan ----
+ * rle_exact = AbstractRle with the Exact criteria (hilbertc.rs:100-196): a run takes the first colour and
+ * every following colour equal to it, up to RepCount::MAX = 255 elements (the element that would be the
+ * 256th starts the next run, :129-137); each run is serialised as count:u8 then the colour (:34-37). */
+int orc_hilbert_rle_encode(const uint8_t *rgb, uint32_t w, uint32_t h, orc_buf *out) {
+    uint64_t n = (uint64_t)w * h;
+    int rc = orc_ser_u32(out, w);                      /* img.dimensions().serialize :27 */
+    if (!rc) rc = orc_ser_u32(out, h);
+    if (rc || n == 0) return rc;
+    uint8_t *lin = (uint8_t *)malloc(3 * n);
+    if (!lin) return ORC_ERR_NOMEM;
+    rc = orc_hilbert_linearize(rgb, w, h, lin);        /* hilbert::linearize(img) :29 */
+    uint64_t i = 0;
+    while (!rc && i < n) {
+        const uint8_t *first = lin + 3 * i;            /* next_val :116-119, start_sequence :123 */
+        uint32_t count = 1;
+        i++;
+        while (i < n) {                                /* :125 */
+            if (memcmp(lin + 3 * i, first, 3) != 0) break;   /* not accepted: saved as self.last :139-142 */
+            count++;
+            i++;
+            if (count == 255) break;                   /* :128-137 */
+        }
+        rc = orc_ser_u8(out, (uint8_t)count);          /* :35 */
+        if (!rc) rc = orc_ser_rgb(out, first);         /* :36 */
+    }
+    free(lin);
+    return rc;
+}
+
+/* RleDecoder (hilbertc.rs:304-337) zipped with hilbert::iter (:58-61): pixels the stream does not reach stay
+ * zero (ImageBuffer::new); a zero count trips `assert!(self.count > 0)` and a cut colour the `unwrap()`,
+ * both reported as ORC_ERR_DECODE. */
+int orc_hilbert_rle_decode(const uint8_t *bytes, size_t nb, uint8_t *rgb, size_t cap, uint32_t *w, uint32_t *h) {
+    orc_rd r = { bytes, nb, 0 };
+    if (orc_de_u32(&r, w) || orc_de_u32(&r, h)) return ORC_ERR_DECODE;
+    uint64_t n = (uint64_t)*w * *h;
+    if (3 * n > cap) return ORC_ERR_CAPACITY;
+    memset(rgb, 0, 3 * n);
+    if (n == 0) return 0;
+    uint32_t *xy = (uint32_t *)malloc(8 * n);
+    if (!xy) return ORC_ERR_NOMEM;
+    int rc = orc_hilbert_iter(*w, *h, xy);
+    uint64_t i = 0;
+    while (!rc && i < n) {
+        uint8_t count, col[3];
+        if (orc_de_u8(&r, &count)) break;              /* stream ended: RepCount::deserialize(..)? */
+        if (count == 0 || orc_de_rgb(&r, col)) { rc = ORC_ERR_DECODE; break; }
+        for (uint32_t k = 0; k < count && i < n; k++, i++)
+            memcpy(rgb + 3 * ((uint64_t)xy[2 * i + 1] * *w + xy[2 * i]), col, 3);
+    }
+    free(xy);
+    return rc;
+}
+
 double orc_mse(const uint8_t *a, const uint8_t *b, uint64_t npx) {
     double tot = 0.0;
     for (uint64_t i = 0; i < npx; i++) {
@@ -233,7 +288,32 @@ static int parse_fun_u32(const char *s, const char *const *prefixes, uint32_t *a
     return 0;
 }
 
-enum { CODEC_NONE, CODEC_CLUSTER, CODEC_VORONOI, CODEC_DELTA, CODEC_HUFMAN };
+enum { CODEC_NONE, CODEC_CLUSTER, CODEC_VORONOI, CODEC_DELTA, CODEC_HUFMAN, CODEC_HILBERT_RLE };
+
+/* Hilbert::from_str (hilbertc.rs:341-397): fun_call with name ^[Hh]ilbert$ and one argument, `rle` or `rle(<f64>)`;
+ * only the exact method (d == 0.0) is on the path; rle(d != 0) and zip are not (sequential running average / zip-dict) */
+static int parse_hilbert_rle(const char *s) {
+    if (strncmp(s, "hilbert(", 8) != 0 && strncmp(s, "Hilbert(", 8) != 0) return 0;
+    const char *a = s + 8;
+    size_t l = strlen(a);
+    if (l < 1 || a[l - 1] != ')') return 0;
+    char arg[64];
+    if (l - 1 >= sizeof arg) return 0;
+    memcpy(arg, a, l - 1);
+    arg[l - 1] = 0;
+    if (strcmp(arg, "rle") == 0) return 1;
+    if (strncmp(arg, "rle(", 4) == 0 && arg[strlen(arg) - 1] == ')') {
+        char num[64];
+        size_t m = strlen(arg) - 5;
+        if (m == 0 || m >= sizeof num) return 0;
+        memcpy(num, arg + 4, m);
+        num[m] = 0;
+        char *end = NULL;
+        double d = strtod(num, &end);
+        return end && *end == 0 && d == 0.0;
+    }
+    return 0;
+}
 
 static int parse_codec(const char *s, uint32_t *K) {
     /* order of alternatives: codec.rs:120-127 */
@@ -243,6 +323,7 @@ static int parse_codec(const char *s, uint32_t *K) {
     if (parse_fun_u32(s, cc, K)) return CODEC_CLUSTER;       /* c(?:luster)?-?col(?:ors)?\((\d+)\) */
     if (parse_fun_u32(s, vo, K)) return CODEC_VORONOI;       /* voronoi\((\d+)\) */
     if (strcmp(s, "delta") == 0) return CODEC_DELTA;         /* hilbertc.rs:578-581 ^delta$ */
+    if (parse_hilbert_rle(s)) return CODEC_HILBERT_RLE;      /* after Delta, before Hufman: codec.rs:120-127 */
     size_t l = strlen(s);
     if (l == 6) {                                            /* hufc.rs:54-59 eq_ignore_ascii_case */
         char t[7];
@@ -264,6 +345,7 @@ int orc_encode(const char *codec, int mode, uint64_t seed, const uint8_t *rgb, u
     switch (c) {
     case CODEC_HUFMAN: rc = orc_hufman_encode(rgb, w, h, &b); break;
     case CODEC_DELTA: rc = orc_delta_encode(rgb, w, h, &b); break;
+    case CODEC_HILBERT_RLE: rc = orc_hilbert_rle_encode(rgb, w, h, &b); break;
     case CODEC_CLUSTER: rc = orc_cluster_colors_encode(rgb, w, h, K, mode, seed, &b, st); break;
     case CODEC_VORONOI: rc = orc_voronoi_encode(rgb, w, h, K, mode, seed, &b, st); break;
     default: rc = ORC_ERR_BAD_ARG;
@@ -284,6 +366,7 @@ int orc_decode(const char *codec, const uint8_t *bytes, uint64_t n, uint8_t *rgb
     case CODEC_HUFMAN: return orc_hufman_decode(bytes, n, rgb, cap, w, h);
     case CODEC_CLUSTER: return orc_hufman_decode(bytes, n, rgb, cap, w, h); /* clusterc.rs:55-57 */
     case CODEC_DELTA: return orc_delta_decode(bytes, n, rgb, cap, w, h);
+    case CODEC_HILBERT_RLE: return orc_hilbert_rle_decode(bytes, n, rgb, cap, w, h);
     case CODEC_VORONOI: return orc_voronoi_decode(bytes, n, rgb, cap, w, h);
     }
     return ORC_ERR_BAD_ARG;

@@ -33,7 +33,7 @@ def main():
             "photo_64x64": synth.photo(64, 64, synth.SEED0 + 3)}
     for name, img in imgs.items():
         out["img_" + name] = img
-        for expr in ("hufman", "delta", "cluster-colors(16)", "voronoi(8)"):
+        for expr in ("hufman", "delta", "hilbert(rle)", "cluster-colors(16)", "voronoi(8)"):
             rc, data, st = O.encode(expr, img, mode=O.MODE_L)
             assert rc == 0, (name, expr, rc)
             out["enc_%s_%s" % (name, expr)] = np.frombuffer(data, np.uint8)

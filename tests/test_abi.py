@@ -42,6 +42,8 @@ def test_no_oracle_in_product():
     ("c-colors(3)", "cluster-colors_3", False),                             # clusterc.rs:59-65,116-141
     ("voronoi(2048)", "voronoi_2048", False),                               # clusterc.rs:191-197
     ("delta", "delta", True),                                               # hilbertc.rs:433-439
+    ("hilbert(rle)", "hilbert-rle", True), ("Hilbert(rle(0))", "hilbert-rle", True),   # hilbertc.rs:81-97,341-383
+    ("hilbert(rle(0.0))", "hilbert-rle", True),
 ])
 def test_codec_names_and_flags(expr, name, lossless):
     from cniic_amd import _lib
@@ -49,7 +51,8 @@ def test_codec_names_and_flags(expr, name, lossless):
     assert _lib.codec_is_lossless(expr) == lossless
 
 
-@pytest.mark.parametrize("expr", ["", "huffman", "delta2", "Delta", "voronoi()", "cluster-colors(x)", "hilbert-rle", "zip-dict"])
+@pytest.mark.parametrize("expr", ["", "huffman", "delta2", "Delta", "voronoi()", "cluster-colors(x)", "hilbert-rle", "zip-dict",
+                                  "hilbert(zip)", "hilbert(rle(0.5))", "hilbert()", "HILBERT(rle)", "hilbert(rle)x"])
 def test_codec_parse_rejects(expr):
     from cniic_amd import _lib
     assert _lib.codec_parse(expr) is None

@@ -8,7 +8,7 @@ import pytest
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hotpath_golden.npz"))
 IMGS = ["photo_96x64", "uniform_40x33", "photo_64x64"]
-EXPRS = ["hufman", "delta", "cluster-colors(16)", "voronoi(8)"]
+EXPRS = ["hufman", "delta", "hilbert(rle)", "cluster-colors(16)", "voronoi(8)"]
 
 
 def keys_of(img):

@@ -149,3 +149,27 @@ def test_hufman_lossless_2048_uniform(env):
     assert rc == 0 and np.array_equal(back, img.cpu().numpy())
     k, c = ctx.hist_rgb24(img, npx=s * s)
     assert ctx.huf_size(_lib.SYM_RGB, c) + 8 == len(data)
+
+
+def test_hilbert_rle_4096_properties(env):
+    """Hilbert{RLE(0)} at 4096x4096: the run records expand to the linearised image, no run is empty or longer
+    than 255, neighbouring runs differ in colour unless the first is full, the decoder restores the image.
+    Two inputs: the photo-like image (runs of 1) and a posterised one (long runs, many at the cap)."""
+    ctx, torch, dev = env
+    size = 4096
+    photo = synth(ctx, torch, dev, 1, SEED + 2, size)
+    poster = (photo >> 6) << 6
+    for img in (photo, poster):
+        out = torch.empty(size * size * 12 + 64, dtype=torch.uint8, device=dev)
+        rc, n, _ = ctx.encode("hilbert(rle)", img, w=size, h=size, out=out)
+        assert rc == 0 and (n - 8) % 12 == 0
+        rec = out[8:n].cpu().numpy().reshape(-1, 12)
+        cnt = rec[:, 0].astype(np.int64)
+        assert cnt.min() >= 1 and cnt.max() <= 255 and int(cnt.sum()) == size * size
+        assert (rec[:, 1] == 3).all() and not rec[:, 2:9].any()
+        lin = ctx.hilbert_linearize(img.cpu().numpy()).reshape(-1, 3)
+        assert np.array_equal(np.repeat(rec[:, 9:12], cnt, axis=0), lin)
+        same = (rec[1:, 9:12] == rec[:-1, 9:12]).all(axis=1)
+        assert (cnt[:-1][same] == 255).all()
+        rc, back = ctx.decode("hilbert(rle)", out[:n].cpu().numpy().tobytes())
+        assert rc == 0 and np.array_equal(back, img.cpu().numpy())

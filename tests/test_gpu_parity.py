@@ -239,7 +239,7 @@ def test_huf_encode_all_long_codes(ctx):
 
 
 # ------------------------------------------------------------------ codecs end to end
-@pytest.mark.parametrize("expr", ["hufman", "delta", "cluster-colors(8)", "ccol(256)", "voronoi(6)", "voronoi(40)"])
+@pytest.mark.parametrize("expr", ["hufman", "delta", "hilbert(rle)", "cluster-colors(8)", "ccol(256)", "voronoi(6)", "voronoi(40)"])
 @pytest.mark.parametrize("shape", [(48, 40), (64, 64), (100, 75)])
 def test_codec_bytes_equal_oracle(ctx, expr, shape):
     img = synth_img(*shape, seed=21, levels=64)
@@ -252,7 +252,7 @@ def test_codec_bytes_equal_oracle(ctx, expr, shape):
     rc, back = ctx.decode(expr, data)
     rco, eback = O.decode(expr, edata)
     assert rc == rco == 0 and np.array_equal(back, eback)
-    if expr in ("hufman", "delta"):
+    if expr in ("hufman", "delta", "hilbert(rle)"):
         assert np.array_equal(back, img)
         assert ctx.mse(img, back) == 0.0
     else:
@@ -262,7 +262,7 @@ def test_codec_bytes_equal_oracle(ctx, expr, shape):
 def test_codec_edge_cases(ctx):
     from cniic_amd import _lib
     one = np.full((1, 1, 3), 9, np.uint8)
-    for expr in ("hufman", "delta"):
+    for expr in ("hufman", "delta", "hilbert(rle)"):
         rc, data, _ = ctx.encode(expr, one)
         assert rc == 0 and data == O.encode(expr, one)[1]
         rc, back = ctx.decode(expr, data)
@@ -274,6 +274,42 @@ def test_codec_edge_cases(ctx):
     assert rc == _lib.DECODE
 
 
+@pytest.mark.parametrize("case", ["flat", "stripes", "levels2", "long_runs", "wide", "tall"])
+def test_hilbert_rle_runs_equal_oracle(ctx, case):
+    """run boundaries, the 255 cap across chunk borders (4096 positions per block) and ragged sizes"""
+    rng = np.random.default_rng(5)
+    if case == "flat":
+        img = np.full((96, 80, 3), 200, np.uint8)                  # one segment of 7680: 30 full runs + 30
+    elif case == "stripes":
+        img = np.zeros((64, 64, 3), np.uint8); img[:, ::2] = 255
+    elif case == "levels2":
+        img = rng.integers(0, 2, (128, 128, 1)).astype(np.uint8).repeat(3, axis=2) * 255
+    elif case == "long_runs":
+        img = np.zeros((256, 256, 3), np.uint8); img[100:, :] = 7; img[5, 5] = 1
+    elif case == "wide":
+        img = (rng.integers(0, 3, (3, 700, 3)) * 100).astype(np.uint8)
+    else:
+        img = (rng.integers(0, 3, (513, 5, 3)) * 100).astype(np.uint8)
+    rc, data, _ = ctx.encode("hilbert(rle)", img)
+    rco, edata, _ = O.encode("hilbert(rle)", img)
+    assert rc == rco == 0 and data == edata
+    rc, back = ctx.decode("hilbert(rle)", data)
+    assert rc == 0 and np.array_equal(back, img)
+
+
+def test_hilbert_rle_decode_failure_points(ctx):
+    from cniic_amd import _lib
+    img = np.full((2, 2, 3), 9, np.uint8)
+    rc, data, _ = ctx.encode("hilbert(rle)", img)
+    rc, back = ctx.decode("hilbert(rle)", data[:8])
+    assert rc == 0 and not back.any()
+    bad = bytearray(data); bad[8] = 0
+    assert ctx.decode("hilbert(rle)", bytes(bad), allow=(_lib.DECODE,))[0] == _lib.DECODE
+    assert ctx.decode("hilbert(rle)", data[:15], allow=(_lib.DECODE,))[0] == _lib.DECODE
+    rc, back = ctx.decode("hilbert(rle)", data + b"\x07")
+    assert rc == 0 and np.array_equal(back, img)
+
+
 def test_codec_trait_surface(ctx):
     from cniic_amd import AnyCodec
     c = AnyCodec.from_str("cluster-colors(16)", ctx)
@@ -283,5 +319,8 @@ def test_codec_trait_surface(ctx):
     img = synth_img(32, 32, seed=2)
     assert np.array_equal(d.decode(d.encode(img)), img)
     assert d.decode(b"\x01\x00\x00\x00\x01\x00\x00\x00") is None
+    r = AnyCodec.from_str("hilbert(rle)", ctx)
+    assert r.name() == "hilbert-rle" and r.is_lossless()
+    assert np.array_equal(r.decode(r.encode(img)), img)
     with pytest.raises(ValueError):
         AnyCodec.from_str("hilbert-rle")

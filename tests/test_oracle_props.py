@@ -56,7 +56,7 @@ def synth(h, w, seed=0, levels=256):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("codec", ["hufman", "delta"])
+@pytest.mark.parametrize("codec", ["hufman", "delta", "hilbert(rle)"])
 @pytest.mark.parametrize("shape", [(1, 1), (3, 5), (16, 16), (33, 20)])
 def test_lossless_roundtrip(codec, shape):
     img = synth(*shape, seed=3)
@@ -65,6 +65,46 @@ def test_lossless_roundtrip(codec, shape):
     rc, back = O.decode(codec, data)
     assert rc == 0 and np.array_equal(back, img)
     assert O.mse(img, back) == 0.0
+
+
+def test_hilbert_rle_records_and_run_cap():
+    """Hilbert{RLE(0.0)} (hilbertc.rs:26-39, 100-196): dims, then (count:u8, colour = u64 len 3 + 3 bytes) per run;
+    a run stops at RepCount::MAX = 255 elements (:128-137) and the stream is the scan order of hilbert.rs"""
+    flat = np.full((32, 32, 3), 5, np.uint8)                       # 1024 equal pixels
+    rc, data, _ = O.encode("hilbert(rle)", flat)
+    assert rc == 0 and data[:8] == (32).to_bytes(4, "little") * 2
+    recs = [data[8 + 12 * i: 20 + 12 * i] for i in range((len(data) - 8) // 12)]
+    assert [r[0] for r in recs] == [255, 255, 255, 255, 4]
+    assert all(r[1:] == (3).to_bytes(8, "little") + bytes([5, 5, 5]) for r in recs)
+    # runs follow the scan: the sequence of decoded colours is the linearised image
+    img = synth(12, 20, seed=9, levels=3)
+    rc, data, _ = O.encode("Hilbert(rle(0))", img)
+    lin = O.hilbert_linearize(img).reshape(-1, 3)
+    out = []
+    for i in range((len(data) - 8) // 12):
+        r = data[8 + 12 * i: 20 + 12 * i]
+        out += [list(r[9:12])] * r[0]
+    assert np.array_equal(np.array(out, np.uint8), lin)
+    # no two consecutive runs share a colour unless the first one is full
+    for i in range((len(data) - 8) // 12 - 1):
+        a_, b_ = data[8 + 12 * i: 20 + 12 * i], data[20 + 12 * i: 32 + 12 * i]
+        assert a_[9:12] != b_[9:12] or a_[0] == 255
+
+
+def test_hilbert_rle_decoder_failure_points():
+    """RleDecoder (hilbertc.rs:304-337): a short stream leaves black pixels, a zero count or a cut colour fail"""
+    img = np.full((2, 2, 3), 9, np.uint8)
+    rc, data, _ = O.encode("hilbert(rle)", img)
+    assert data[8] == 4
+    rc, back = O.decode("hilbert(rle)", data[:8])                   # no runs at all: ImageBuffer::new zeros
+    assert rc == 0 and not back.any()
+    short = bytearray(data); short[8] = 3                           # three of the four pixels
+    rc, back = O.decode("hilbert(rle)", bytes(short))
+    assert rc == 0 and int((back == 9).all(axis=2).sum()) == 3
+    bad = bytearray(data); bad[8] = 0                               # assert!(self.count > 0)
+    assert O.decode("hilbert(rle)", bytes(bad))[0] != 0
+    assert O.decode("hilbert(rle)", data[:15])[0] != 0              # colour cut: unwrap()
+    assert O.decode("hilbert(rle)", data + b"\x07")[0] == 0          # bytes after the last needed run are never read
 
 
 def test_hufman_header_and_single_colour():

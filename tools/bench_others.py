@@ -15,7 +15,7 @@ from cniic_amd import _lib, synth
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-which = sys.argv[1:] or ["voronoi", "delta", "hufman", "delta16k"]
+which = sys.argv[1:] or ["voronoi", "delta", "hufman", "delta16k", "rle", "rle16k"]
 
 
 def image(size, seed):
@@ -46,10 +46,10 @@ if "voronoi" in which:
                       "GBps_algorithmic_7B_per_px": round(7.0 * size * size / (dt / max(1, st["iterations"])) / 1e9, 1),
                       "centroids_tested_per_px": round(st["pair_evals"] / max(1, st["iterations"]) / (size * size), 1), "rc": rc}))
 
-for name, size in (("delta", 4096), ("hufman", 4096), ("delta16k", 16384)):
+for name, size in (("delta", 4096), ("hufman", 4096), ("delta16k", 16384), ("rle", 4096), ("rle16k", 16384)):
     if name not in which:
         continue
-    expr = "delta" if name.startswith("delta") else "hufman"
+    expr = "delta" if name.startswith("delta") else "hilbert(rle)" if name.startswith("rle") else "hufman"
     img = image(size, synth.SEED0 + 5)
     out = torch.empty(size * size * 12 + (1 << 24), dtype=torch.uint8, device=dev)
     dt, (rc, ln, st) = timed(lambda: ctx.encode(expr, img, w=size, h=size, out=out), reps=2)
