@@ -59,7 +59,7 @@ static bool parse_synth(const std::string &s, Image &im) {  // synth:P:4096x4096
 
 int main(int argc, char **argv) {
     if (argc < 3 || strncmp(argv[1], "--codec=", 8) != 0) {
-        fprintf(stderr, "Usage: cniic_bench --codec=<codec> [<img file>..]\nAvailable codecs:\n  hufman\n  cluster-colors(<ncolors>)\n  voronoi(<k>)\n  delta\n");
+        fprintf(stderr, "Usage: cniic_bench --codec=<codec> [<img file>..]\nAvailable codecs:\n  hufman\n  cluster-colors(<ncolors>)\n  voronoi(<k>)\n  delta\n  hilbert(rle)\n");
         return 2;
     }
     const std::string expr = argv[1] + 8;
