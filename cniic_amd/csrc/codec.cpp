@@ -447,6 +447,12 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
 }
 
 // ------------------------------------------------------------------ decode
+// below this many symbols the parallel decoder's fixed cost is not worth it (CNIIC_GPU_DECODE_MIN overrides: tests)
+static uint64_t gpu_decode_min_symbols() {
+    const char *e = getenv("CNIIC_GPU_DECODE_MIN");
+    return e ? strtoull(e, nullptr, 10) : (1ull << 14);
+}
+
 static int put_image(Ctx *c, const uint8_t *src, bool src_dev, uint64_t bytes, uint8_t *dst) {
     if (!bytes) return CNIIC_OK;
     const bool dst_dev = is_device_ptr(dst);
@@ -468,35 +474,43 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
                                     (unsigned long long)(n * 3), (unsigned long long)cap);
     switch (d.kind) {
     case CODEC_HUFMAN:
-    case CODEC_CLUSTER_COLORS: {  // clusterc.rs:55-57 delegates to Hufman.decode (hufc.rs:19-40)
-        std::vector<uint32_t> keys(n);
-        if (!huff_decode_symbols(CNIIC_SYM_RGB, bytes, nbytes, pos, n, keys.data()))
-            return c->fail(CNIIC_ERR_DECODE, "Failed to decode symbol");
-        std::vector<uint8_t> img(n * 3);
-        for (uint64_t i = 0; i < n; i++) { img[3 * i] = (uint8_t)(keys[i] >> 16); img[3 * i + 1] = (uint8_t)(keys[i] >> 8); img[3 * i + 2] = (uint8_t)keys[i]; }
-        return put_image(c, img.data(), false, n * 3, rgb_out);
-    }
-    case CODEC_DELTA: {  // hilbertc.rs:417-431
-        std::vector<uint32_t> keys(n);
-        if (!huff_decode_symbols(CNIIC_SYM_SIGNED, bytes, nbytes, pos, n, keys.data()))
-            return c->fail(CNIIC_ERR_DECODE, "delta: cannot decode the difference stream");
-        std::vector<uint8_t> lin(n * 3);
-        int last[3] = {0, 0, 0};  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508)
-        for (uint64_t i = 0; i < n; i++)
-            for (int ch = 0; ch < 3; ch++) {
-                int v = last[ch] + (int)((keys[i] >> (18 - 9 * ch)) & 511) - 255;
-                if (v < 0 || v > 255) return c->fail(CNIIC_ERR_DECODE, "delta: colour out of range (hilbertc.rs:505)");
-                last[ch] = v;
-                lin[3 * i + ch] = (uint8_t)v;
-            }
+    case CODEC_CLUSTER_COLORS:   // clusterc.rs:55-57 delegates to Hufman.decode (hufc.rs:19-40)
+    case CODEC_DELTA: {          // hilbertc.rs:417-431
+        const bool delta = d.kind == CODEC_DELTA;
+        const int sym_kind = delta ? CNIIC_SYM_SIGNED : CNIIC_SYM_RGB;
+        std::vector<TrieNode> trie;
+        if (!huff_parse_trie(sym_kind, bytes, nbytes, pos, trie))
+            return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
         if (!n) return CNIIC_OK;
-        DevBuf lin_d, img_d;
-        CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(lin_d.p, lin.data(), n * 3, hipMemcpyHostToDevice, c->stream));
-        uint8_t *dst = rgb_out;
         const bool dst_dev = is_device_ptr(rgb_out);
+        DevBuf keys_d, lin_d, img_d;
+        CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
+        // symbols on the GPU (parallel, self-synchronising); small inputs and codes that do not settle go through the
+        // host walk (same trie, same answers)
+        int status = 2;
+        if (n >= gpu_decode_min_symbols()) CNIIC_TRY(huff_decode_dev(c, trie, bytes + pos, nbytes - pos, n, keys_d.as<uint32_t>(), &status));
+        if (status == 2) {
+            std::vector<uint32_t> keys(n);
+            if (!huff_decode_host(trie, bytes + pos, nbytes - pos, n, keys.data(), nullptr)) status = 1;
+            else {
+                status = 0;
+                CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_d.p, keys.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+                CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            }
+        }
+        if (status == 1)
+            return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
+        uint8_t *dst = rgb_out;
         if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
-        CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
+        if (!delta) {
+            CNIIC_TRY(keys_to_rgb(c, keys_d.as<uint32_t>(), n, dst));
+        } else {
+            CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
+            uint32_t bad = 0;  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508)
+            CNIIC_TRY(delta_undiff_dev(c, keys_d.as<uint32_t>(), n, lin_d.as<uint8_t>(), &bad));
+            if (bad) return c->fail(CNIIC_ERR_DECODE, "delta: colour out of range (hilbertc.rs:505)");
+            CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
+        }
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
         return CNIIC_OK;

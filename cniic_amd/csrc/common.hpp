@@ -377,6 +377,13 @@ int mse_rgb(Ctx *c, const uint8_t *a_d, const uint8_t *b_d, uint64_t npx, double
 int synth_image(Ctx *c, int kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *out_d);
 int rgb_to_keys(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *keys_d);
 
+// ---- k_hdecode.hip: parallel Huffman decode (self-synchronising subsequences), keys -> pixels, FromDiff as a scan ----
+struct TrieNode;
+int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t *payload, uint64_t payload_bytes, uint64_t nsyms,
+                    uint32_t *keys_d, int *status);  // status: 0 ok, 1 stream ends early, 2 did not settle (decode on the host)
+int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d);
+int delta_undiff_dev(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *lin_d, uint32_t *bad_h);
+
 // ---- k_rle.hip: exact run-length coding of a linearised image (hilbertc.rs:100-196) ----
 struct RlePlan { uint64_t n = 0, nruns = 0; uint32_t nchunks = 0; DevBuf flags, run_off; };
 int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan);                       // counts the runs (syncs)

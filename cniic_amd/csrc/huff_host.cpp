@@ -216,50 +216,90 @@ static bool get_symbol(const uint8_t *b, uint64_t n, uint64_t &pos, int kind, ui
     return true;
 }
 
-bool huff_decode_symbols(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, uint64_t nsyms,
-                         uint32_t *keys_out) {
-    // flat trie: child[2*i], child[2*i+1] for branches; leaves carry the key
-    struct Node { int64_t l = -1, r = -1; uint32_t key = 0; bool leaf = false; };
-    std::vector<Node> nodes;
+// Dec::deserialize (huf.rs:323-348): the pre-order trie at bytes[pos..] as flat nodes, root first
+bool huff_parse_trie(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, std::vector<TrieNode> &nodes) {
+    nodes.clear();
     struct Pending { size_t node; int filled; };
     std::vector<Pending> pend;
     bool have_root = false;
     for (;;) {
         if (pos >= nbytes) return false;
-        uint8_t tag = bytes[pos++];
-        Node nd;
+        const uint8_t tag = bytes[pos++];
+        TrieNode nd{0, 0};
         if (tag == 0) {
-            nd.leaf = true;
-            if (!get_symbol(bytes, nbytes, pos, sym_kind, nd.key)) return false;
+            nd.l = kTrieLeaf;
+            if (!get_symbol(bytes, nbytes, pos, sym_kind, nd.r)) return false;
         } else if (tag != 1) {
             return false;  // huf.rs:343-345
         }
-        size_t id = nodes.size();
+        const size_t id = nodes.size();
+        if (id >= 0xfffffffeull) return false;
         nodes.push_back(nd);
         if (have_root) {
             Pending &p = pend.back();
-            if (p.filled == 0) { nodes[p.node].l = (int64_t)id; p.filled = 1; }
-            else { nodes[p.node].r = (int64_t)id; pend.pop_back(); }
+            if (p.filled == 0) { nodes[p.node].l = (uint32_t)id; p.filled = 1; }
+            else { nodes[p.node].r = (uint32_t)id; pend.pop_back(); }
         }
         have_root = true;
         if (tag == 1) pend.push_back({id, 0});
         if (pend.empty()) break;
     }
-    // bit_reader MsbFirst (bit.rs:256-259) + BinTrie::lookup (huf.rs:187-206)
-    const uint8_t *p = bytes + pos;
-    const uint64_t nbits = (nbytes - pos) * 8;
+    return true;
+}
+
+// bit_reader MsbFirst (bit.rs:256-259) + BinTrie::lookup (huf.rs:187-206).  The walk is the reference's, taken
+// kLut bits at a time: lut[prefix] = the node reached from the root by those bits and how many of them were
+// used (a leaf may be reached early); a symbol longer than kLut bits goes on bit by bit from that node.
+bool huff_decode_host(const std::vector<TrieNode> &nodes, const uint8_t *p, uint64_t payload_bytes, uint64_t nsyms,
+                      uint32_t *keys_out, uint64_t *bytes_used) {
+    const uint64_t nbits = payload_bytes * 8;
     uint64_t bp = 0;
-    for (uint64_t i = 0; i < nsyms; i++) {
-        size_t nd = 0;
-        while (!nodes[nd].leaf) {
-            if (bp >= nbits) return false;  // EOF -> None
-            int bit = (p[bp >> 3] >> (7 - (bp & 7))) & 1;
-            bp++;
-            nd = (size_t)(bit ? nodes[nd].r : nodes[nd].l);
-        }
-        keys_out[i] = nodes[nd].key;
+    if (bytes_used) *bytes_used = 0;
+    if (nodes[0].l == kTrieLeaf) {  // single symbol: zero-length code, no payload (huf.rs:140-142)
+        for (uint64_t i = 0; i < nsyms; i++) keys_out[i] = nodes[0].r;
+        return true;
     }
-    pos += (bp + 7) / 8;
+    constexpr int kLut = 12;
+    struct Hop { uint32_t node; uint32_t used; };
+    std::vector<Hop> lut(1u << kLut);
+    for (uint32_t pre = 0; pre < (1u << kLut); pre++) {
+        uint32_t nd = 0, used = 0;
+        while (used < (uint32_t)kLut && nodes[nd].l != kTrieLeaf) {
+            nd = ((pre >> (kLut - 1 - used)) & 1) ? nodes[nd].r : nodes[nd].l;
+            used++;
+        }
+        lut[pre] = {nd, used};
+    }
+    auto peek = [&](uint64_t at) -> uint32_t {  // kLut bits from bit position `at`, zero-filled past the end
+        uint32_t v = 0;
+        const uint64_t byte = at >> 3;
+        for (int k = 0; k < 3; k++) v = (v << 8) | (byte + k < payload_bytes ? p[byte + k] : 0u);
+        return (v >> (24 - kLut - (at & 7))) & ((1u << kLut) - 1);
+    };
+    for (uint64_t i = 0; i < nsyms; i++) {
+        const Hop hp = lut[peek(bp)];
+        uint32_t nd = hp.node;
+        if (bp + hp.used > nbits) return false;  // EOF inside the symbol -> None
+        bp += hp.used;
+        while (nodes[nd].l != kTrieLeaf) {
+            if (bp >= nbits) return false;
+            const int bit = (p[bp >> 3] >> (7 - (bp & 7))) & 1;
+            bp++;
+            nd = bit ? nodes[nd].r : nodes[nd].l;
+        }
+        keys_out[i] = nodes[nd].r;
+    }
+    if (bytes_used) *bytes_used = (bp + 7) / 8;
+    return true;
+}
+
+bool huff_decode_symbols(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, uint64_t nsyms,
+                         uint32_t *keys_out) {
+    std::vector<TrieNode> nodes;
+    if (!huff_parse_trie(sym_kind, bytes, nbytes, pos, nodes)) return false;
+    uint64_t used = 0;
+    if (!huff_decode_host(nodes, bytes + pos, nbytes - pos, nsyms, keys_out, &used)) return false;
+    pos += used;
     return true;
 }
 

@@ -27,6 +27,13 @@ int  huff_symbol_size(int sym_kind);
 // total stream size of encode_all for this histogram
 uint64_t huff_stream_size(int sym_kind, const uint64_t *counts, const uint8_t *len, uint64_t n);
 
+// flat decoder trie: branch = (left, right) node indices, leaf = (kTrieLeaf, symbol key); node 0 is the root
+constexpr uint32_t kTrieLeaf = 0xffffffffu;
+struct TrieNode { uint32_t l, r; };
+bool huff_parse_trie(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, std::vector<TrieNode> &nodes);
+bool huff_decode_host(const std::vector<TrieNode> &nodes, const uint8_t *payload, uint64_t payload_bytes, uint64_t nsyms,
+                      uint32_t *keys_out, uint64_t *bytes_used);
+
 // Dec::deserialize + DecStream (huf.rs:323-348, 187-206, 366-374): read the trie at bytes[pos..],
 // then decode nsyms symbols into keys_out.  Returns false where the reference yields None.
 bool huff_decode_symbols(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, uint64_t nsyms,
