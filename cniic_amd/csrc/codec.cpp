@@ -134,6 +134,7 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
                        uint64_t *len) {
     if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "huf::encode_all on an empty stream (src/huf.rs:99 asserts)");
     const uint32_t bits = sym_kind == CNIIC_SYM_RGB ? 24 : 27;
+    host_trace().mark("huf: enter");
     // 1. utils::count_freqs (huf.rs:30)
     if (!have_hist) {
         if (rgb_d) CNIIC_TRY(hist_rgb_dense(c, rgb_d, n, table_d));
@@ -151,13 +152,16 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    host_trace().mark("huf: hist + compaction + D2H");
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
     HuffTree tree;
     std::vector<uint8_t> clen;
     std::vector<uint64_t> code;
     if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, clen, code))
         return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+    host_trace().mark("huf: tree + codes (host)");
     huff_serialize_tree(tree, sym_kind, keys.data(), header);
+    host_trace().mark("huf: serialise trie (host)");
     // 3. payload (huf.rs:37-41), packed in place behind the header
     uint64_t nbits = 0;
     for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
@@ -181,10 +185,14 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
                                  (uint64_t)header.size() * 8, &packed_bits));
     }
     timer.stop(1);
+    host_trace().mark("huf: pack");
     if (packed_bits != nbits)
         return c->fail(CNIIC_ERR_HIP, "huffman: packed %llu bits, histogram predicts %llu", (unsigned long long)packed_bits,
                        (unsigned long long)nbits);
-    return so.finish();
+    const int rc_fin = so.finish();
+    host_trace().mark("huf: finish");
+    host_trace().dump();
+    return rc_fin;
 }
 
 // ------------------------------------------------------------------ Hufman::encode (hufc.rs:12-17)
