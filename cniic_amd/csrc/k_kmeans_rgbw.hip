@@ -79,7 +79,7 @@ struct KmRgbwState {
     uint64_t res_cent = 0, res_members = 0, res_wsum = 0, res_bytes = 0;
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
-    DevBuf cell_piv, cell_mask, moved_list, queue;  // skip schedule state
+    DevBuf cell_piv, cell_mask, moved_list;  // skip schedule state
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -640,7 +640,6 @@ struct CellState {          // per non-empty cell, carried between iterations (s
     uint32_t *piv;          // [M] colour of the pivot of the last candidate build
     unsigned long long *mask;  // [M][MW]
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
-    uint32_t *queue;        // work queue cursor (zeroed by the update kernel)
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
 };
 
@@ -814,7 +813,7 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
                                                      uint64_t max_iters, uint2 *__restrict__ cconst,
                                                      uint32_t *__restrict__ cent, uint64_t *__restrict__ members_out,
                                                      uint64_t *__restrict__ wsum_out,
-                                                     uint32_t *__restrict__ moved_list, uint32_t *__restrict__ queue,
+                                                     uint32_t *__restrict__ moved_list,
                                                      KmDevState *__restrict__ st) {
     // everything this launch reads is requested before the `done` flag is looked at: one memory round trip
     const uint32_t done = st->done;
@@ -852,7 +851,7 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
         cconst[k] = make_cconst(ck, k, idbits);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && moved_list) { moved_list[0] = s_nmoved; *queue = 0; }
+    if (threadIdx.x == 0 && moved_list) moved_list[0] = s_nmoved;
     if (threadIdx.x == 0) {
         partials[5 * (size_t)K] = 0;
         partials[5 * (size_t)K + 1] = 0;
@@ -962,8 +961,6 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->cell_piv, (uint64_t)kNumCells * 4);
         KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
         KM_ALLOC(s->moved_list, ((uint64_t)K + 1) * 4);
-        KM_ALLOC(s->queue, 16);
-        (void)hipMemsetAsync(s->queue.p, 0, 16, c->stream);
         // before the first update every centroid counts as moved
         (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->moved_list.p), (int)K, 1, c->stream);
         KM_ALLOC(s->running, W * 8);
@@ -1034,7 +1031,7 @@ static int launch_update(KmRgbwState *s, int mode) {
     hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->running.as<uint64_t>(), mode, s->keys, s->U,
                        s->K, s->idbits, s->seed, s->max_iters, s->cconst.as<uint2>(), s->cent.as<uint32_t>(),
                        s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(), s->cells ? s->moved_list.as<uint32_t>() : nullptr,
-                       s->queue.as<uint32_t>(), s->dstate.as<KmDevState>());
+                       s->dstate.as<KmDevState>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -1071,7 +1068,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = reinterpret_cast<unsigned long long *>(s->partials);
-        CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(), s->queue.as<uint32_t>(),
+        CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
@@ -1231,7 +1228,6 @@ int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch) {
     Ctx *c = s->c;
     LaunchTimer lt;
     for (int i = 0; i <= reps; i++) {  // launch 0 is a warm-up
-        if (s->cells) CNIIC_HIP_TRY(c, hipMemsetAsync(s->queue.p, 0, 4, c->stream));  // skip schedule: rewind the work queue
         hipEvent_t a = lt.next(), b = lt.next();
         CNIIC_HIP_TRY(c, hipEventRecord(a, c->stream));
         launch_assign(s);
