@@ -80,6 +80,8 @@ struct KmRgbwState {
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     DevBuf cell_piv, cell_mask, moved_list;  // skip schedule state
+    DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
+    bool fused = false;
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -643,14 +645,38 @@ struct CellState {          // per non-empty cell, carried between iterations (s
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
 };
 
+// Centroid update folded into the next assign launch (km_rgbw_run, K <= 256): launch j first finishes iteration
+// j-1 -- every block redundantly turns (running sums + the sums of launch j-1) into the K centroids it needs in
+// LDS anyway (K divisions, 10 KiB of L2 reads), block 0 also writes the global state -- and then assigns.  That
+// removes one dependent kernel (4.8 us + the gap before it) per iteration.  The sums are triple-buffered: launch
+// j adds into buffer j % 3, reads (j - 1) % 3 and clears (j + 1) % 3; the running sums ping-pong.
+struct FusedUpdate {
+    uint32_t on;          // 0: an update kernel ran in between (centroids in cconst, moved list in CellState)
+    uint32_t launch_no;   // j
+    uint32_t idbits;
+    uint64_t max_iters, seed, U;
+    const uint32_t *keys;                        // canonical point list (empty-cluster reseed)
+    const unsigned long long *partials_prev;     // sums of launch j - 1 (all-reduced when there are several GPUs)
+    unsigned long long *partials_clear;          // the buffer launch j + 1 adds into
+    const unsigned long long *running_prev;
+    unsigned long long *running_new;
+    const uint32_t *cent_prev;                   // centroids of launch j - 1 (to tell which ones moved)
+    uint32_t *cent_new;                          // block 0 writes: this launch's centroids for launch j + 1 to compare with,
+    uint2 *cconst_g;                             // and the result block (centroids, members, weights, state)
+    uint32_t *cent_g;
+    uint64_t *members_out, *wsum_out;
+    KmDevState *st_rw;
+};
+
 template <typename LabelT, int IDBITS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
-    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs) {
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
-    __shared__ uint32_t s_moved, s_cell;
+    __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
+    __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
     constexpr int THREADS = WAVES * 64;
@@ -666,12 +692,86 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
     // iterations add/subtract only the points that moved.
-    const bool first = st->iter == 0;
-    const uint32_t nS = cs.moved[0];
-    const bool skip_mode = !first && nS <= cs.max_moved;
+    const bool first = fz.on ? fz.launch_no == 0 : st->iter == 0;
+    uint32_t nS = fz.on ? K : cs.moved[0];
+    const uint32_t *mlist = cs.moved + 1;  // ids of the centroids the last update changed
     const unsigned long long lt_mask = (1ull << lane) - 1;
     uint32_t moved = 0;
     unsigned long long evals = 0;
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+    if (!fz.on || first)
+        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; }
+    // fused update: one cluster per thread (K <= 256 <= THREADS); its ten sums and its old centroid are requested
+    // together with the set-up loads above, before anything is waited for
+    const bool upd = fz.on && !first;
+    const uint32_t uk = threadIdx.x;
+    unsigned long long v[5] = {0, 0, 0, 0, 0}, changed = 0, pev = 0;
+    uint32_t oldc = 0;
+    if (upd) {
+        changed = fz.partials_prev[5 * (size_t)K];
+        pev = fz.partials_prev[5 * (size_t)K + 1];
+        if (uk < K) {
+            const size_t at[5] = {3 * (size_t)uk, 3 * (size_t)uk + 1, 3 * (size_t)uk + 2, 3 * (size_t)K + uk, 4 * (size_t)K + uk};
+#pragma unroll
+            for (int i = 0; i < 5; i++) v[i] = fz.partials_prev[at[i]] + fz.running_prev[at[i]];
+            oldc = fz.cent_prev[uk];
+        }
+    }
+    if (done) return;
+    __syncthreads();
+    if (upd) {
+        // ---- finish iteration j - 1: Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137)
+        const uint32_t j = fz.launch_no;
+        if (uk < K) {
+            const uint32_t k = uk;
+            const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
+            uint32_t ck;
+            if (v[4] == 0) {
+                ck = fz.keys[reseed_index(fz.seed, j - 1, k, fz.U)];  // fake_clone of the stolen point
+                atomicAdd(&s_reseed, 1u);
+            } else {
+                const uint32_t r = (uint32_t)(v[0] / v[3]) & 255, g = (uint32_t)(v[1] / v[3]) & 255, b = (uint32_t)(v[2] / v[3]) & 255;
+                ck = (r << 16) | (g << 8) | b;
+                atomicAdd(&s_active, 1u);
+            }
+            const uint2 cc = make_cconst(ck, k, fz.idbits);
+            tab[k] = cc;
+            if (ck != oldc) {
+                const uint32_t pos = atomicAdd(&s_nmoved, 1u);
+                if (pos < kMaxMovedSkip) s_mlist[pos] = k;
+            }
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) fz.running_new[at[i]] = v[i];
+                fz.cent_new[k] = ck;
+                fz.cent_g[k] = ck;
+                fz.cconst_g[k] = cc;
+                fz.members_out[k] = v[4];
+                fz.wsum_out[k] = v[3];
+            }
+        }
+        if (blockIdx.x == 0)
+            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
+        __syncthreads();
+        const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            KmDevState *sw = fz.st_rw;
+            sw->changed_ring[(j - 1) % kHistRing] = changed;
+            sw->moved_last = changed;
+            sw->reseeds += s_reseed;
+            sw->active = s_active;
+            sw->pair_evals += pev;
+            sw->iter = j;
+            if (fin) sw->done = 1;
+        }
+        if (fin) return;  // converged (or the iteration cap): nothing to assign
+        nS = s_nmoved;
+        mlist = s_mlist;
+    } else if (fz.on && blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
+    }
+    const bool skip_mode = !first && nS <= cs.max_moved;
 
     if (!skip_mode) {
         // ================================================================= FULL schedule
@@ -680,10 +780,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         // static split predicts (with one fixed range per wave the slowest wave ran 2x the mean).
         const uint32_t bg = gw0 + blockIdx.x * WAVES;
         const uint32_t mb0 = wfirst[bg], mb1 = wfirst[bg + WAVES];
-        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_cell = mb0; }
-        if (done) return;
+        if (threadIdx.x == 0) s_cell = mb0;
         __syncthreads();
         auto draw = [&]() -> uint32_t {
             uint32_t v = 0;
@@ -735,15 +832,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         }
     } else {
         // ================================================================= SKIP schedule
-        for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-        if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
-        if (done) return;
-        __syncthreads();
         // this shard's cells: [m_lo, m_hi); the (up to 2 per lane) centroids that moved
         const uint32_t m_lo = wfirst[gw0], m_hi = wfirst[gw0 + gridDim.x * WAVES];
-        const uint32_t k1 = lane < nS ? cs.moved[1 + lane] : 0xffffffffu;
-        const uint32_t k2 = 64 + lane < nS ? cs.moved[1 + 64 + lane] : 0xffffffffu;
+        const uint32_t k1 = (uint32_t)lane < nS ? mlist[lane] : 0xffffffffu;
+        const uint32_t k2 = 64 + (uint32_t)lane < nS ? mlist[64 + lane] : 0xffffffffu;
         const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u, ck2 = k2 != 0xffffffffu ? tab[k2].x : 0u;
         // cells are dealt round-robin: what survives the skip test is clustered around the centroids that
         // moved, and striding spreads those clusters over all waves (a shared atomic queue would
@@ -964,6 +1056,15 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         // before the first update every centroid counts as moved
         (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->moved_list.p), (int)K, 1, c->stream);
         KM_ALLOC(s->running, W * 8);
+        s->fused = !s->wide && !(getenv("CNIIC_KM_UNFUSED") && atoi(getenv("CNIIC_KM_UNFUSED")));
+        if (s->fused) {
+            KM_ALLOC(s->fused_partials, 3 * W * 8);
+            KM_ALLOC(s->fused_running, 2 * W * 8);
+            KM_ALLOC(s->fused_cent, 2 * (uint64_t)K * 4);
+            (void)hipMemsetAsync(s->fused_partials.p, 0, 3 * W * 8, c->stream);
+            (void)hipMemsetAsync(s->fused_running.p, 0, 2 * W * 8, c->stream);
+            (void)hipMemcpyAsync(s->fused_cent.p, s->cent.p, (uint64_t)K * 4, hipMemcpyDeviceToDevice, c->stream);  // the initial centroids
+        }
         DevBuf count, cursor;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
         (void)hipMemsetAsync(s->running.p, 0, W * 8, c->stream);
@@ -1063,18 +1164,22 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
 
 // ev_start / ev_stop (profiling): events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's
 // own begin and end as a profiler sees them, not an event pair around it (which adds ~4 us of dispatch per launch)
-static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+// fused: the update of the previous iteration runs in this launch's prologue and the sums go to part_fused
+static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FusedUpdate *fused = nullptr,
+                          unsigned long long *part_fused = nullptr) {
     Ctx *c = s->c;
+    FusedUpdate fz{};
+    if (fused) fz = *fused;
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
-        auto *part = reinterpret_cast<unsigned long long *>(s->partials);
+        auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
                                (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
@@ -1083,11 +1188,12 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
                                       c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                       (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                       (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
-                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
+                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
+                                      part, st, cs, fz);
             else
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), lds, c->stream,
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs);
+                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs, fz);
         }
         return;
     }
@@ -1184,8 +1290,37 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
+    const uint64_t W = 5 * (uint64_t)s->K + 2;
+    uint32_t launch_no = 0;
     for (;;) {
         for (int b = 0; b < batch; b++) {
+            if (s->fused) {
+                // assign j with update j - 1 in its prologue; the sums are triple-buffered, running sums and the
+                // centroids to compare with ping-pong (see FusedUpdate)
+                const uint32_t j = launch_no++;
+                auto *P = s->fused_partials.as<unsigned long long>();
+                auto *Rn = s->fused_running.as<unsigned long long>();
+                auto *Cn = s->fused_cent.as<uint32_t>();
+                FusedUpdate fz{};
+                fz.on = 1; fz.launch_no = j; fz.idbits = s->idbits; fz.max_iters = s->max_iters; fz.seed = s->seed; fz.U = s->U;
+                fz.keys = s->keys;
+                fz.partials_prev = P + ((j + 2) % 3) * W;
+                fz.partials_clear = P + ((j + 1) % 3) * W;
+                fz.running_prev = Rn + ((j + 1) % 2) * W;
+                fz.running_new = Rn + (j % 2) * W;
+                fz.cent_prev = Cn + ((j + 1) % 2) * (size_t)s->K;
+                fz.cent_new = Cn + (j % 2) * (size_t)s->K;
+                fz.cconst_g = s->cconst.as<uint2>();
+                fz.cent_g = s->cent.as<uint32_t>();
+                fz.members_out = s->members_last.as<uint64_t>();
+                fz.wsum_out = s->wsum_last.as<uint64_t>();
+                fz.st_rw = s->dstate.as<KmDevState>();
+                unsigned long long *cur = P + (j % 3) * W;
+                if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur); }
+                else launch_assign(s, nullptr, nullptr, &fz, cur);
+                if (cm) CNIIC_TRY(comm_all_reduce(cm, cur, W, 2));  // the sums of all shards, before launch j + 1 reads them
+                continue;
+            }
             if (s->profile && s->cells && !s->wide) {
                 hipEvent_t a = lt.next(), b = lt.next();
                 launch_assign(s, a, b);
