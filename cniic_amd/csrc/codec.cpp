@@ -222,7 +222,10 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     auto s = std::make_unique<CcSession>();
     s->c = c; s->K = K; s->table = table_counts_d;
     CompactPlan plan;
-    CNIIC_TRY(hist_compact_count(c, table_counts_d, 24, &plan));
+    DevBuf cell_count;  // occupied bins per K-means colour cell, counted by the compaction on its way
+    CNIIC_HIP_TRY(c, cell_count.alloc((uint64_t)kNumCells * 4));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(cell_count.p, 0, (uint64_t)kNumCells * 4, c->stream));
+    CNIIC_TRY(hist_compact_count(c, table_counts_d, 24, &plan, cell_count.as<uint32_t>()));
     host_trace().mark("compact_count+sync");
     const uint64_t U = plan.n_unique;
     s->U = U;
@@ -234,7 +237,7 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     host_trace().mark("compact_write enq");
     // kmeans::cluster (clusterc.rs:28); the table now maps key -> rank + 1
     CNIIC_TRY(km_rgbw_create(c, s->keys_d.as<uint32_t>(), s->weight_d.as<uint32_t>(), U, shard, nshards, K, opts, partials_dev,
-                             table_counts_d, &s->km));
+                             table_counts_d, &s->km, cell_count.as<uint32_t>()));
     host_trace().mark("km_create");
     *out = s.release();
     return CNIIC_OK;

@@ -307,7 +307,8 @@ struct CompactPlan {
     uint64_t n_unique = 0;
     uint32_t bits = 0;
 };
-int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan);
+// cell_count_d (optional, 24-bit tables): zeroed u32[32768] receiving the occupied bins per K-means colour cell
+int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d = nullptr);
 // After this call the table holds, for every occupied bin, its RANK (index into the compacted
 // list) + 1; empty bins stay 0.  Outputs are optional device arrays of plan->n_unique entries.
 int hist_compact_write(Ctx *c, uint32_t *table_d, const CompactPlan *plan, uint32_t *keys_d, uint64_t *counts_d,
@@ -318,7 +319,8 @@ int dense_table(Ctx *c, uint32_t bits, uint32_t **table_d);  // zeroed scratch t
 struct KmRgbwState;  // opaque device state of one rgbw K-means problem
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
-                   const uint32_t *rank_table_d /* dense key -> rank+1 table, or null */, KmRgbwState **out);
+                   const uint32_t *rank_table_d /* dense key -> rank+1 table, or null */, KmRgbwState **out,
+                   const uint32_t *cell_count_d = nullptr /* with rank_table_d: points per cell, if already counted */);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
 int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials
@@ -376,6 +378,14 @@ int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, 
 int mse_rgb(Ctx *c, const uint8_t *a_d, const uint8_t *b_d, uint64_t npx, double *mse_h);
 int synth_image(Ctx *c, int kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *out_d);
 int rgb_to_keys(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *keys_d);
+
+// ---- colour-space cells of the cluster-colors K-means (numbering: cell_of in device_utils.hpp) ----
+#ifndef CNIIC_CELL_SHIFT
+#define CNIIC_CELL_SHIFT 3
+#endif
+constexpr int kCellShift = CNIIC_CELL_SHIFT;                    // 2^shift colours per cell side
+constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
+constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
 
 // ---- k_hdecode.hip: parallel Huffman decode (self-synchronising subsequences), keys -> pixels, FromDiff as a scan ----
 struct TrieNode;

@@ -86,6 +86,19 @@ template <int THREADS> __device__ __forceinline__ uint32_t block_exclusive_scan(
     return off + inc - v;
 }
 
+// ---- colour-space cells of the cluster-colors K-means (k_kmeans_rgbw.hip); the compaction counts them on its way
+// (kCellShift, kCellsPerDim, kNumCells: common.hpp)
+// Cell id = super-cell (4x4x4 cells = a 32^3 cube of colours; 9 bits, r-major) << 6 | cell within it (6 bits,
+// r-major): the 64 cells of a super-cell are consecutive, so a wave walking its cell range changes
+// super-cell rarely.
+constexpr int kSuperShift = 6;
+constexpr uint32_t kSupersPerDim = kCellsPerDim / 4;
+__device__ __forceinline__ uint32_t cell_of(uint32_t key) {
+    const uint32_t rc = ((key >> 16) & 255) >> kCellShift, gc = ((key >> 8) & 255) >> kCellShift, bc = (key & 255) >> kCellShift;
+    const uint32_t sup = ((rc >> 2) * kSupersPerDim + (gc >> 2)) * kSupersPerDim + (bc >> 2);
+    return (sup << kSuperShift) | ((rc & 3) << 4) | ((gc & 3) << 2) | (bc & 3);
+}
+
 __host__ __device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;

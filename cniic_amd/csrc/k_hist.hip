@@ -212,17 +212,33 @@ constexpr int kScanThreads = 256;
 constexpr int kScanPerThread = 16;
 constexpr int kScanChunk = kScanThreads * kScanPerThread;  // 4096 table entries per block
 
+// cell_count (24-bit RGB tables only, may be null): occupied bins per colour-space cell of the K-means that
+// follows.  A 4096-key chunk is one r, 16 g and all 256 b values: 2 x 32 cells, counted in LDS first.
 __global__ __launch_bounds__(kScanThreads) void k_compact_count(const uint32_t *__restrict__ table,
-                                                                uint32_t *__restrict__ blocksum) {
-    const uint4 *v = reinterpret_cast<const uint4 *>(table + (uint64_t)blockIdx.x * kScanChunk);
+                                                                uint32_t *__restrict__ blocksum,
+                                                                uint32_t *__restrict__ cell_count) {
+    __shared__ uint32_t s_cell[64];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
+    const uint4 *v = reinterpret_cast<const uint4 *>(table + base);
+    if (cell_count) {
+        if (threadIdx.x < 64) s_cell[threadIdx.x] = 0;
+        __syncthreads();
+    }
     uint32_t nz = 0;
 #pragma unroll
     for (int j = 0; j < kScanPerThread / 4; j++) {
-        uint4 q = v[j * kScanThreads + threadIdx.x];
-        nz += (q.x != 0) + (q.y != 0) + (q.z != 0) + (q.w != 0);
+        const uint32_t quad = j * kScanThreads + threadIdx.x;  // keys base + 4 quad .. + 3: one cell
+        const uint4 q = v[quad];
+        const uint32_t c4 = (q.x != 0) + (q.y != 0) + (q.z != 0) + (q.w != 0);
+        nz += c4;
+        if (cell_count && c4) atomicAdd(&s_cell[((quad >> 6) >> kCellShift) * 32 + (((4 * quad) & 255) >> kCellShift)], c4);
     }
-    nz = block_reduce_sum<kScanThreads>(nz);
+    nz = block_reduce_sum<kScanThreads>(nz);  // (its barriers also complete s_cell)
     if (threadIdx.x == 0) blocksum[blockIdx.x] = nz;
+    if (cell_count && threadIdx.x < 64 && s_cell[threadIdx.x]) {
+        const uint32_t g = (threadIdx.x >> 5) << kCellShift, b = (threadIdx.x & 31) << kCellShift;
+        atomicAdd(&cell_count[cell_of((uint32_t)base + (g << 8) + b)], s_cell[threadIdx.x]);
+    }
 }
 
 // single block: exclusive scan of nblocks sums in place; total -> *total
@@ -290,13 +306,14 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_write(uint32_t *__rest
 }
 
 // phase A+B: number of occupied bins (host out-param; stream synced) + per-block rank offsets
-int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan) {
+int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d) {
     const uint64_t entries = 1ull << bits;
     const uint32_t nblocks = (uint32_t)(entries / kScanChunk);
     DevBuf tot;
     CNIIC_HIP_TRY(c, plan->blockoff.alloc((uint64_t)nblocks * 4));
     CNIIC_HIP_TRY(c, tot.alloc(8));
-    hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>());
+    hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>(),
+                       bits == 24 ? cell_count_d : nullptr);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks, tot.as<uint64_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;

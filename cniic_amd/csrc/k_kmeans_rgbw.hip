@@ -38,9 +38,6 @@
 #include <memory>
 #include <vector>
 
-#ifndef CNIIC_CELL_SHIFT
-#define CNIIC_CELL_SHIFT 3
-#endif
 
 #include <hip/hip_ext.h>
 
@@ -53,9 +50,6 @@ constexpr uint32_t kBias = 1u << 18;  // > max |c|^2 = 195075
 constexpr int kPPT = 8;               // colours per thread per sweep (brute kernel)
 constexpr int kAssignThreads = 256;
 constexpr uint32_t kMaxBlocks = 512;
-constexpr int kCellShift = CNIIC_CELL_SHIFT;                    // 2^shift colours per cell side
-constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
-constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
 #ifndef CNIIC_CELL_WAVES
 #define CNIIC_CELL_WAVES 8
 #endif
@@ -97,16 +91,6 @@ __device__ __forceinline__ uint2 make_cconst(uint32_t ckey, uint32_t k, uint32_t
     return make_uint2(ckey, ((kBias - h) << idbits) | (idmask - k));
 }
 
-// Cell id = super-cell (4x4x4 cells = a 32^3 cube of colours; 9 bits, r-major) << 6 | cell within it (6 bits,
-// r-major): the 64 cells of a super-cell are consecutive, so a wave walking its cell range changes
-// super-cell rarely.
-constexpr int kSuperShift = 6;
-constexpr uint32_t kSupersPerDim = kCellsPerDim / 4;
-__device__ __forceinline__ uint32_t cell_of(uint32_t key) {
-    const uint32_t rc = ((key >> 16) & 255) >> kCellShift, gc = ((key >> 8) & 255) >> kCellShift, bc = (key & 255) >> kCellShift;
-    const uint32_t sup = ((rc >> 2) * kSupersPerDim + (gc >> 2)) * kSupersPerDim + (bc >> 2);
-    return (sup << kSuperShift) | ((rc & 3) << 4) | ((gc & 3) << 2) | (bc & 3);
-}
 struct CellBox { int32_t r0, g0, b0; };  // low corner of a cube of colours
 __device__ __forceinline__ CellBox super_box(uint32_t sup) {
     return CellBox{(int32_t)((sup / (kSupersPerDim * kSupersPerDim)) << (kCellShift + 2)),
@@ -999,7 +983,7 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
 
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
-                   const uint32_t *rank_table_d, KmRgbwState **out) {
+                   const uint32_t *rank_table_d, KmRgbwState **out, const uint32_t *cell_count_d) {
     if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
     const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
     if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
@@ -1072,8 +1056,12 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knob
         if (rank_table_d) {
             // codec path: the dense colour table (key -> canonical rank + 1) is walked cell by cell
-            hipLaunchKernelGGL(k_cells_count_tbl, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, count.as<uint32_t>());
-            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
+            const uint32_t *cnt = cell_count_d;  // counted by the compaction on its way, else one more walk of the table
+            if (!cnt) {
+                hipLaunchKernelGGL(k_cells_count_tbl, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, count.as<uint32_t>());
+                cnt = count.as<uint32_t>();
+            }
+            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, cnt, s->cell_start.as<uint32_t>(),
                                (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
                                s->ne_count.as<uint32_t>(), fixed_cost);
             if (s->wide)
