@@ -167,8 +167,8 @@ def main():
                        "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
                        "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2),
                        "bytes_per_px": round(nbytes / (W * H), 4),
-                       "parallelism": "1 GPU" if world == 1 else "pixels sharded over %d GPUs, shared palette, RCCL all-reduce "
-                                                                   "of histogram + K partial sums per iteration (%s)"
+                       "parallelism": "1 GPU" if world == 1 else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
+                                                                   "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
                                                                    % (world, "library communicator, in-stream" if enc.collectives == "native"
                                                                       else "torch.distributed")},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -468,6 +468,25 @@ int32_t cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done) {
     return CNIIC_OK;
 }
 
+int32_t cniic_occupancy_pack(cniic_ctx *c, const uint32_t *table_dev, uint32_t *occ_dev) {
+    LOCK(c);
+    if (!table_dev || !occ_dev || !is_device_ptr(table_dev) || !is_device_ptr(occ_dev))
+        return c->fail(CNIIC_ERR_BAD_ARG, "occupancy_pack: device buffers u32[2^24] and u32[2^21]");
+    return occupancy_pack(c, table_dev, occ_dev);
+}
+
+int32_t cniic_cc_create_local(cniic_ctx *c, uint32_t *table_dev, const uint32_t *occ_dev, uint32_t K, const cniic_kmeans_opts *opts,
+                              void *partials_dev, cniic_cc **out) {
+    LOCK(c);
+    if (!table_dev || !occ_dev || !out || !is_device_ptr(table_dev) || !is_device_ptr(occ_dev))
+        return c->fail(CNIIC_ERR_BAD_ARG, "cc_create_local: device table, device occupancy and an out pointer are needed");
+    if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_create_local: partials must be device memory");
+    CcSession *s = nullptr;
+    CNIIC_TRY(cc_prepare(c, table_dev, K, opts, 0, 1, partials_dev, &s, occ_dev));
+    *out = new cniic_cc{c, s};
+    return CNIIC_OK;
+}
+
 int32_t cniic_cc_poll_lagged(cniic_cc *cc, uint64_t *iterations, uint32_t *done, uint32_t *valid) {
     if (!cc || !done || !valid) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);

@@ -217,7 +217,7 @@ HostTrace &host_trace() { static thread_local HostTrace t; return t; }
 
 
 int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard, uint32_t nshards,
-               void *partials_dev, CcSession **out) {
+               void *partials_dev, CcSession **out, const uint32_t *occ_d) {
     if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
     auto s = std::make_unique<CcSession>();
     s->c = c; s->K = K; s->table = table_counts_d;
@@ -229,15 +229,22 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     host_trace().mark("compact_count+sync");
     const uint64_t U = plan.n_unique;
     s->U = U;
-    if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)",
-                                   (unsigned long long)U, K);
+    uint64_t Ug = 0;
+    if (occ_d) {  // the reference's point list is the union's; this rank holds its own share of it
+        CNIIC_TRY(gidx_build(c, occ_d, s->gbits, s->gprefix, &Ug));
+        s->local_points = true;
+    }
+    if ((occ_d ? Ug : U) / K == 0 || U == 0)
+        return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)",
+                       (unsigned long long)(occ_d ? Ug : U), K);
     CNIIC_HIP_TRY(c, s->keys_d.alloc(U * 4));
     CNIIC_HIP_TRY(c, s->weight_d.alloc(U * 4));
     CNIIC_TRY(hist_compact_write(c, table_counts_d, &plan, s->keys_d.as<uint32_t>(), nullptr, s->weight_d.as<uint32_t>()));
     host_trace().mark("compact_write enq");
     // kmeans::cluster (clusterc.rs:28); the table now maps key -> rank + 1
     CNIIC_TRY(km_rgbw_create(c, s->keys_d.as<uint32_t>(), s->weight_d.as<uint32_t>(), U, shard, nshards, K, opts, partials_dev,
-                             table_counts_d, &s->km, cell_count.as<uint32_t>()));
+                             table_counts_d, &s->km, cell_count.as<uint32_t>(), occ_d ? s->gbits.p : nullptr,
+                             occ_d ? s->gprefix.as<uint32_t>() : nullptr, Ug));
     host_trace().mark("km_create");
     *out = s.release();
     return CNIIC_OK;
@@ -274,13 +281,14 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     if (st.active < min_cc)
         return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
                        (unsigned long long)st.active, (unsigned long long)min_cc);
-    if (local_counts_d) {
+    if (local_counts_d || s->local_points) {
         // shared palette over several images: THIS image's pixels per cluster (its reduced image is
         // what Hufman.encode sees, clusterc.rs:52), from its own colour counts
         DevBuf lw;
         CNIIC_HIP_TRY(c, lw.alloc((uint64_t)K * 8));
         CNIIC_HIP_TRY(c, hipMemsetAsync(lw.p, 0, (uint64_t)K * 8, c->stream));
-        CNIIC_TRY(local_cluster_weights(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, local_counts_d, K, lw.as<uint64_t>()));
+        CNIIC_TRY(local_cluster_weights(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, local_counts_d, K, lw.as<uint64_t>(),
+                                        s->weight_d.as<uint32_t>()));
         CNIIC_HIP_TRY(c, hipMemcpyAsync(wsum.data(), lw.p, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (uint32_t k = 0; k < K; k++) members[k] = wsum[k] ? 1 : 0;

@@ -307,6 +307,9 @@ struct CompactPlan {
     uint64_t n_unique = 0;
     uint32_t bits = 0;
 };
+// occupancy across ranks: nibble per key (k_hist.hip), and the index of all occupied keys built from the summed nibbles
+int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d);  // u32[2^24] counts -> u32[2^21] nibble words
+int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h);
 // cell_count_d (optional, 24-bit tables): zeroed u32[32768] receiving the occupied bins per K-means colour cell
 int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d = nullptr);
 // After this call the table holds, for every occupied bin, its RANK (index into the compacted
@@ -320,7 +323,9 @@ struct KmRgbwState;  // opaque device state of one rgbw K-means problem
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
                    const uint32_t *rank_table_d /* dense key -> rank+1 table, or null */, KmRgbwState **out,
-                   const uint32_t *cell_count_d = nullptr /* with rank_table_d: points per cell, if already counted */);
+                   const uint32_t *cell_count_d = nullptr /* with rank_table_d: points per cell, if already counted */,
+                   const void *gbits_d = nullptr, const uint32_t *gprefix_d = nullptr, uint64_t Ug = 0
+                   /* the points are this rank's share of Ug colours: positions in the list of all occupied keys */);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
 int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials
@@ -370,8 +375,9 @@ int remap_rgb(Ctx *c, const uint8_t *rgb_d, uint64_t npx, const uint32_t *rank_t
               const uint32_t *lut_rgb_d /* packed centroid colour per unique colour rank */, uint8_t *out_d);
 int expand_codes_by_label(Ctx *c, const uint8_t *labels8_d, const uint16_t *labels16_d, uint64_t U, const uint8_t *clen_d,
                           const uint64_t *ccode_d, uint8_t *len_d, uint64_t *code_d);
+// (local_counts_d == nullptr: the weights come from weights_d[i] instead of local_counts_d[keys_d[i]])
 int local_cluster_weights(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U,
-                          const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d);
+                          const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d, const uint32_t *weights_d = nullptr);
 int label_lut(Ctx *c, const uint32_t *labels_d, uint64_t U, const uint32_t *cent_d, uint32_t *lut_d);
 int rank_from_keys(Ctx *c, const uint32_t *keys_d, uint64_t U, uint32_t *table_d);
 int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d);

@@ -99,6 +99,26 @@ __device__ __forceinline__ uint32_t cell_of(uint32_t key) {
     return (sup << kSuperShift) | ((rc & 3) << 4) | ((gc & 3) << 2) | (bc & 3);
 }
 
+// ---- index of the colours that occur anywhere (several GPUs, each holding only its own image's colours): the
+// "point list" of the reference is then the ascending list of ALL occupied keys, known only as a bitmap plus a
+// popcount prefix per 64-key word.  rank = position of a key in that list, select = the key at a position.
+struct GIdx {
+    const unsigned long long *bits;  // [2^18] occupancy, bit (key & 63) of word key >> 6; null: not in use
+    const uint32_t *wprefix;         // [2^18] occupied keys before each word
+    uint64_t U;                      // occupied keys in all
+};
+__device__ __forceinline__ uint32_t gidx_rank(const GIdx &g, uint32_t key) {
+    const uint32_t w = key >> 6;
+    return g.wprefix[w] + (uint32_t)__popcll(g.bits[w] & ((1ull << (key & 63)) - 1ull));
+}
+__device__ __forceinline__ uint32_t gidx_select(const GIdx &g, uint64_t idx) {
+    uint32_t a = 0, b = 1u << 18;  // the word holding the idx-th occupied key = the last one whose prefix is <= idx
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (g.wprefix[mid] <= idx) a = mid; else b = mid; }
+    unsigned long long word = g.bits[a];
+    for (uint32_t r = (uint32_t)(idx - g.wprefix[a]); r; r--) word &= word - 1;
+    return (a << 6) | (uint32_t)(__ffsll((long long)word) - 1);
+}
+
 __host__ __device__ __forceinline__ uint64_t splitmix_mix(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;

@@ -335,6 +335,51 @@ int hist_compact_write(Ctx *c, uint32_t *table_d, const CompactPlan *plan, uint3
     return CNIIC_OK;
 }
 
+// ---------------------------------------------------------------- occupancy across ranks (shared-palette cluster-colors)
+// occ: one nibble per 24-bit key (8 keys per u32 word, key k in bits 4 (k & 7) of word k >> 3), 1 where the key
+// occurs.  Summed over <= 15 ranks by an ordinary all-reduce the nibbles cannot carry; non-zero = occupied somewhere.
+__global__ __launch_bounds__(256) void k_occ_pack(const uint32_t *__restrict__ table, uint32_t *__restrict__ occ) {
+    const uint32_t wd = blockIdx.x * 256 + threadIdx.x;  // 2^21 words
+    const uint4 a = reinterpret_cast<const uint4 *>(table)[2 * (size_t)wd], b = reinterpret_cast<const uint4 *>(table)[2 * (size_t)wd + 1];
+    occ[wd] = (a.x != 0) | ((a.y != 0) << 4) | ((a.z != 0) << 8) | ((a.w != 0) << 12) | ((b.x != 0) << 16) | ((b.y != 0) << 20) |
+              ((b.z != 0) << 24) | ((uint32_t)(b.w != 0) << 28);
+}
+// bits[w] = occupancy of keys 64 w .. 64 w + 63 from 8 nibble words; cnt[w] = popcount
+__global__ __launch_bounds__(256) void k_gidx_words(const uint32_t *__restrict__ occ, unsigned long long *__restrict__ bits,
+                                                    uint32_t *__restrict__ cnt) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;  // 2^18 words
+    unsigned long long m = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t v = occ[8 * (size_t)w + j];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((v >> (4 * i)) & 15u) m |= 1ull << (8 * j + i);
+    }
+    bits[w] = m;
+    cnt[w] = (uint32_t)__popcll(m);
+}
+
+int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d) {
+    hipLaunchKernelGGL(k_occ_pack, dim3((1u << 21) / 256), dim3(256), 0, c->stream, table_d, occ_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// occ_d: the summed nibbles -> bitmap + popcount prefix per word; *U_h = occupied keys (stream synced)
+int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h) {
+    DevBuf tot;
+    CNIIC_HIP_TRY(c, bits.alloc((1ull << 18) * 8));
+    CNIIC_HIP_TRY(c, wprefix.alloc((1ull << 18) * 4));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    hipLaunchKernelGGL(k_gidx_words, dim3((1u << 18) / 256), dim3(256), 0, c->stream, occ_d, bits.as<unsigned long long>(), wprefix.as<uint32_t>());
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, wprefix.as<uint32_t>(), 1u << 18, tot.as<uint64_t>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(U_h, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
 int dense_table(Ctx *c, uint32_t bits, uint32_t **table_d) {
     const uint64_t bytes = (1ull << bits) * 4;
     if (c->dense.bytes < bytes) CNIIC_HIP_TRY(c, c->dense.alloc(bytes));

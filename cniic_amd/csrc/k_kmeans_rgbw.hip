@@ -74,6 +74,7 @@ struct KmRgbwState {
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     DevBuf cell_piv, cell_mask, moved_list;  // skip schedule state
+    GIdx gidx{nullptr, nullptr, 0};  // several GPUs: the points are this rank's share of gidx.U colours
     DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
     bool fused = false;
     uint32_t shard = 0, nshards = 1;
@@ -105,13 +106,13 @@ __device__ __forceinline__ CellBox cell_box(uint32_t c) {
 
 // ---------------------------------------------------------------- init (kmeans.rs:61-108)
 __global__ void k_rgbw_init_cent(const uint32_t *__restrict__ keys, uint64_t U, uint32_t K, uint32_t Kpad, uint32_t idbits,
-                                 uint2 *__restrict__ cconst, uint32_t *__restrict__ cent) {
+                                 uint2 *__restrict__ cconst, uint32_t *__restrict__ cent, GIdx gx) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) {
         // init_centroids (kmeans.rs:101-108): first element of chunk k
         uint64_t ppc = U / K;
         uint64_t first = (k < K - 1) ? U - ((uint64_t)k + 1) * ppc : 0;
-        uint32_t ck = keys[first];
+        uint32_t ck = gx.bits ? gidx_select(gx, first) : keys[first];
         cent[k] = ck;
         cconst[k] = make_cconst(ck, k, idbits);
     } else if (k < Kpad) {
@@ -311,7 +312,7 @@ template <typename LabelT>
 __global__ __launch_bounds__(512) void k_cells_write_tbl(const uint32_t *__restrict__ table, const uint32_t *__restrict__ weight,
                                                          const uint32_t *__restrict__ cell_start, uint64_t U, uint32_t K,
                                                          uint32_t *__restrict__ ckeys, uint32_t *__restrict__ cweight,
-                                                         uint32_t *__restrict__ crank, LabelT *__restrict__ labels) {
+                                                         uint32_t *__restrict__ crank, LabelT *__restrict__ labels, GIdx gx) {
     __shared__ uint32_t wsum[512 / 64];
     __shared__ uint32_t s_run;
     const uint32_t s = cell_start[blockIdx.x], e = cell_start[blockIdx.x + 1];
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(512) void k_cells_write_tbl(const uint32_t *__restr
             ckeys[pos] = key;
             cweight[pos] = weight[rank];
             crank[pos] = rank;
-            labels[pos] = (LabelT)init_label(rank, U, K);  // init_assignment kmeans.rs:61-78
+            labels[pos] = (LabelT)init_label(gx.bits ? gidx_rank(gx, key) : rank, U, K);  // init_assignment kmeans.rs:61-78
         }
         if (threadIdx.x == 511) s_run = pos + (v != 0);
         __syncthreads();
@@ -640,6 +641,7 @@ struct FusedUpdate {
     uint32_t idbits;
     uint64_t max_iters, seed, U;
     const uint32_t *keys;                        // canonical point list (empty-cluster reseed)
+    GIdx gx;                                     // ... or the index of all occupied colours (several GPUs)
     const unsigned long long *partials_prev;     // sums of launch j - 1 (all-reduced when there are several GPUs)
     unsigned long long *partials_clear;          // the buffer launch j + 1 adds into
     const unsigned long long *running_prev;
@@ -712,7 +714,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
             const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
             uint32_t ck;
             if (v[4] == 0) {
-                ck = fz.keys[reseed_index(fz.seed, j - 1, k, fz.U)];  // fake_clone of the stolen point
+                const uint64_t ri = reseed_index(fz.seed, j - 1, k, fz.U);  // fake_clone of the stolen point
+                ck = fz.gx.bits ? gidx_select(fz.gx, ri) : fz.keys[ri];
                 atomicAdd(&s_reseed, 1u);
             } else {
                 const uint32_t r = (uint32_t)(v[0] / v[3]) & 255, g = (uint32_t)(v[1] / v[3]) & 255, b = (uint32_t)(v[2] / v[3]) & 255;
@@ -890,7 +893,7 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
                                                      uint32_t *__restrict__ cent, uint64_t *__restrict__ members_out,
                                                      uint64_t *__restrict__ wsum_out,
                                                      uint32_t *__restrict__ moved_list,
-                                                     KmDevState *__restrict__ st) {
+                                                     KmDevState *__restrict__ st, GIdx gx) {
     // everything this launch reads is requested before the `done` flag is looked at: one memory round trip
     const uint32_t done = st->done;
     const uint64_t iter = st->iter;
@@ -915,7 +918,8 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
         wsum_out[k] = w;
         uint32_t ck;
         if (members == 0) {
-            ck = keys[reseed_index(seed, iter, k, U)];  // fake_clone of the stolen point
+            const uint64_t ri = reseed_index(seed, iter, k, U);  // fake_clone of the stolen point
+            ck = gx.bits ? gidx_select(gx, ri) : keys[ri];
             atomicAdd(&s_reseed, 1u);
         } else {
             const uint32_t r = (uint32_t)(v[0] / w) & 255, g = (uint32_t)(v[1] / w) & 255, b = (uint32_t)(v[2] / w) & 255;
@@ -983,11 +987,15 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
 
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
-                   const uint32_t *rank_table_d, KmRgbwState **out, const uint32_t *cell_count_d) {
+                   const uint32_t *rank_table_d, KmRgbwState **out, const uint32_t *cell_count_d, const void *gbits_d,
+                   const uint32_t *gprefix_d, uint64_t Ug) {
     if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
+    if (gbits_d && (!rank_table_d || nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
+        return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: a share of a larger point list needs the table-driven cells path, unsharded");
     const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
-    if (U / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
-                                   (unsigned long long)U, K);
+    const uint64_t Ulist = gbits_d ? Ug : U;  // length of the reference's point list (init chunks, reseed index)
+    if (Ulist / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
+                                       (unsigned long long)Ulist, K);
     if (K > 2048) return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 2048 not supported", K);
     if (U >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: too many points");
     auto *s = new KmRgbwState();
@@ -1001,6 +1009,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
     s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     s->keys = keys_d; s->weight = weight_d;
+    s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
     const uint64_t n = hi - lo;
     const uint64_t W = 5 * (uint64_t)K + 2;
     const uint64_t lab_bytes = s->wide ? 2 : 1;
@@ -1018,8 +1027,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     else { KM_ALLOC(s->partials_own, W * 8); s->partials = s->partials_own.as<uint64_t>(); }
     (void)hipMemsetAsync(s->partials, 0, W * 8, c->stream);
     (void)hipMemsetAsync(s->dstate.p, 0, sizeof(KmDevState), c->stream);
-    hipLaunchKernelGGL(k_rgbw_init_cent, dim3(ceil_div(s->Kpad, 256)), dim3(256), 0, c->stream, keys_d, U, K, s->Kpad, s->idbits,
-                       s->cconst.as<uint2>(), s->cent.as<uint32_t>());
+    hipLaunchKernelGGL(k_rgbw_init_cent, dim3(ceil_div(s->Kpad, 256)), dim3(256), 0, c->stream, keys_d, Ulist, K, s->Kpad, s->idbits,
+                       s->cconst.as<uint2>(), s->cent.as<uint32_t>(), s->gidx);
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, 1024), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
@@ -1066,12 +1075,12 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                                s->ne_count.as<uint32_t>(), fixed_cost);
             if (s->wide)
                 hipLaunchKernelGGL(k_cells_write_tbl<uint16_t>, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, weight_d,
-                                   s->cell_start.as<uint32_t>(), U, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
-                                   s->crank.as<uint32_t>(), s->labels.as<uint16_t>());
+                                   s->cell_start.as<uint32_t>(), Ulist, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
+                                   s->crank.as<uint32_t>(), s->labels.as<uint16_t>(), s->gidx);
             else
                 hipLaunchKernelGGL(k_cells_write_tbl<uint8_t>, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, weight_d,
-                                   s->cell_start.as<uint32_t>(), U, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
-                                   s->crank.as<uint32_t>(), s->labels.as<uint8_t>());
+                                   s->cell_start.as<uint32_t>(), Ulist, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
+                                   s->crank.as<uint32_t>(), s->labels.as<uint8_t>(), s->gidx);
         } else {
             // generic path (any point order): counting sort of the point list by cell
             KM_ALLOC(cursor, (uint64_t)kNumCells * 4);
@@ -1117,10 +1126,11 @@ void km_rgbw_destroy(KmRgbwState *s) { delete s; }
 
 static int launch_update(KmRgbwState *s, int mode) {
     Ctx *c = s->c;
-    hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->running.as<uint64_t>(), mode, s->keys, s->U,
+    hipLaunchKernelGGL(k_rgbw_update, dim3(1), dim3(256), 0, c->stream, s->partials, s->running.as<uint64_t>(), mode, s->keys,
+                       s->gidx.bits ? s->gidx.U : s->U,
                        s->K, s->idbits, s->seed, s->max_iters, s->cconst.as<uint2>(), s->cent.as<uint32_t>(),
                        s->members_last.as<uint64_t>(), s->wsum_last.as<uint64_t>(), s->cells ? s->moved_list.as<uint32_t>() : nullptr,
-                       s->dstate.as<KmDevState>());
+                       s->dstate.as<KmDevState>(), s->gidx);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -1290,7 +1300,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
                 auto *Rn = s->fused_running.as<unsigned long long>();
                 auto *Cn = s->fused_cent.as<uint32_t>();
                 FusedUpdate fz{};
-                fz.on = 1; fz.launch_no = j; fz.idbits = s->idbits; fz.max_iters = s->max_iters; fz.seed = s->seed; fz.U = s->U;
+                fz.on = 1; fz.launch_no = j; fz.idbits = s->idbits; fz.max_iters = s->max_iters; fz.seed = s->seed; fz.U = s->gidx.bits ? s->gidx.U : s->U; fz.gx = s->gidx;
                 fz.keys = s->keys;
                 fz.partials_prev = P + ((j + 2) % 3) * W;
                 fz.partials_clear = P + ((j + 1) % 3) * W;

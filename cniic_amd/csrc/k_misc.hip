@@ -133,17 +133,17 @@ int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, 
 }
 
 // pixels of ONE image per cluster, from that image's own dense colour counts:
-// out[label[i]] += local_counts[keys[i]]
+// out[label[i]] += local_counts[keys[i]]   (or weights[i] when there is no table)
 template <typename LabelT>
 __global__ __launch_bounds__(256) void k_local_weights(const uint32_t *__restrict__ keys, const LabelT *__restrict__ labels,
                                                        uint64_t U, const uint32_t *__restrict__ local_counts, uint32_t K,
-                                                       unsigned long long *__restrict__ out) {
+                                                       unsigned long long *__restrict__ out, const uint32_t *__restrict__ weights) {
     extern __shared__ unsigned long long bins[];
     for (uint32_t i = threadIdx.x; i < K; i += 256) bins[i] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride) {
-        const uint32_t cnt = local_counts[keys[i] & 0xffffff];
+        const uint32_t cnt = local_counts ? local_counts[keys[i] & 0xffffff] : weights[i];
         if (cnt) atomicAdd(&bins[labels[i]], (unsigned long long)cnt);
     }
     __syncthreads();
@@ -151,15 +151,15 @@ __global__ __launch_bounds__(256) void k_local_weights(const uint32_t *__restric
         if (bins[i]) atomicAdd(&out[i], bins[i]);
 }
 int local_cluster_weights(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U,
-                          const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d) {
+                          const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d, const uint32_t *weights_d) {
     if (!U) return CNIIC_OK;
     auto *o = reinterpret_cast<unsigned long long *>(out_d);
     if (wide)
         hipLaunchKernelGGL(k_local_weights<uint16_t>, dim3(grid_for(U, 256, 512)), dim3(256), (size_t)K * 8, c->stream, keys_d,
-                           reinterpret_cast<const uint16_t *>(labels_d), U, local_counts_d, K, o);
+                           reinterpret_cast<const uint16_t *>(labels_d), U, local_counts_d, K, o, weights_d);
     else
         hipLaunchKernelGGL(k_local_weights<uint8_t>, dim3(grid_for(U, 256, 512)), dim3(256), (size_t)K * 8, c->stream, keys_d,
-                           reinterpret_cast<const uint8_t *>(labels_d), U, local_counts_d, K, o);
+                           reinterpret_cast<const uint8_t *>(labels_d), U, local_counts_d, K, o, weights_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

@@ -1,15 +1,20 @@
 """Shared-palette `cluster-colors` over several GPUs (north_star config 4), one process per GPU.
 
 Every rank holds its own image; the ranks cluster the UNION of their pixels into one K-colour
-palette and each encodes its own image with it:
+palette and each encodes its own image with it.  A rank keeps only ITS OWN image's distinct colours:
 
-    local dense colour counts --all-reduce--> global counts -> distinct colours (same on all ranks)
-    K-means: every rank assigns its share of the colour-space cells, the K partial sums are
-             all-reduced (RCCL, sum of int64 words) each iteration, every rank updates identically
-    labels of the shards are merged (all-reduce of a byte array with one owner per element)
-    each rank Huffman-codes its own colour-reduced image (clusterc.rs:31-52)
+    local dense colour counts -> occupancy nibbles --all-reduce(sum, 8 MiB)--> which colours occur anywhere:
+        the reference's point list (ascending distinct colours of all pixels) as a bitmap + popcount prefix,
+        from which every rank initialises its own points (init_assignment / init_centroids, kmeans.rs:61-108)
+    K-means: every rank assigns its own colours, the K partial sums are all-reduced (RCCL, sum of
+             u64 words) each iteration, every rank updates identically
+    each rank Huffman-codes its own colour-reduced image (clusterc.rs:31-52) with its own cluster weights
 
-Sums are integers, so the palette is bit-identical for 1, 2, 4 or 8 ranks.
+A colour held by several ranks is several points at one position: each copy takes the same decisions and
+the integer sums equal those of the single merged point, so the palette is bit-identical for 1, 2, 4 or 8
+ranks and to clustering the union in one process.  Per-rank work does not grow with the rank count and no
+labels are exchanged.  (The first protocol all-reduced the 64 MiB count table and made every rank hold all
+the union's colours; its entry points -- cniic_cc_create, export / import labels -- remain in the ABI.)
 
 Collectives, two ways:
   * native (default on GPUs): the library's own RCCL communicator on the context's stream
@@ -44,11 +49,18 @@ class HipBackend:
     def new_partials(self, K):
         return self.torch.zeros(int(self.L.cniic_km_partial_words(K, 3)), dtype=self.torch.int64, device=self.dev)
 
-    def cc_create(self, table, K, rank, world, partials, max_iters=0, seed=0):
+    def occupancy(self, table):
+        """one nibble per colour, 1 where this image has it (u32[2^21]); summed over the ranks by an all-reduce"""
+        occ = self.torch.empty(1 << 21, dtype=self.torch.int32, device=self.dev)
+        self.ctx._check(self.L.cniic_occupancy_pack(self.ctx.h, C.c_void_p(table.data_ptr()), C.c_void_p(occ.data_ptr())))
+        return occ
+
+    def cc_create_local(self, table, occ, K, partials, max_iters=0, seed=0):
+        """K-means state over this rank's colours (table: its counts, overwritten), placed in the list of all occupied colours"""
         h = C.c_void_p()
         o = _lib.KmOpts(seed, max_iters, 0, 0)
-        self.ctx._check(self.L.cniic_cc_create(self.ctx.h, C.c_void_p(table.data_ptr()), C.c_uint32(K), C.byref(o), C.c_uint32(rank),
-                                               C.c_uint32(world), C.c_void_p(partials.data_ptr()), C.byref(h)))
+        self.ctx._check(self.L.cniic_cc_create_local(self.ctx.h, C.c_void_p(table.data_ptr()), C.c_void_p(occ.data_ptr()), C.c_uint32(K),
+                                                     C.byref(o), C.c_void_p(partials.data_ptr()), C.byref(h)))
         return h
 
     def assign(self, h):
@@ -151,6 +163,7 @@ class ShardedClusterColors:
         self.be = backend if backend is not None else HipBackend(ctx, device)
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
+        assert self.world <= 15, "the occupancy nibbles are summed over the ranks: at most 15"
         # "native": the library's RCCL communicator; "torch": torch.distributed per iteration
         want = collectives or os.environ.get("CNIIC_COLLECTIVES", "native")
         self.comm = None
@@ -172,10 +185,10 @@ class ShardedClusterColors:
     def encode(self, img, w, h, out):
         be = self.be
         local = be.hist_dense(img, w * h)           # utils::count_freqs of this rank's pixels
-        glob = local.clone()
-        self._all_reduce(glob)                      # colour counts of the union
+        occ = be.occupancy(local)
+        self._all_reduce(occ)                       # which colours occur on any rank (nibble sums, <= 15 ranks)
         partials = be.new_partials(self.K)
-        handle = be.cc_create(glob, self.K, self.rank, self.world, partials, self.max_iters)
+        handle = be.cc_create_local(local, occ, self.K, partials, self.max_iters)
         try:
             if self.comm is not None:               # one C call: assign -> ncclAllReduce -> update per iteration, in-stream
                 be.run(handle, self.comm)
@@ -193,15 +206,6 @@ class ShardedClusterColors:
                     it, done = be.poll(handle)
                 if done:
                     break
-            if self.world > 1:
-                lab = be.export_labels(handle)
-                if lab.element_size() == 2:         # K > 256: RCCL has no 16-bit integer type
-                    wide = lab.to(dtype=be.torch.int32)
-                    self._all_reduce(wide)
-                    lab = wide.to(dtype=lab.dtype)
-                else:
-                    self._all_reduce(lab)           # one owner per element, zeros elsewhere
-                be.import_labels(handle, lab)
-            return be.finish(handle, img, w, h, local if self.world > 1 else None, out)
+            return be.finish(handle, img, w, h, None, out)   # its own colours, labels and cluster weights: nothing to exchange
         finally:
             be.destroy(handle)

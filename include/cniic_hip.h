@@ -195,6 +195,23 @@ int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t 
                          uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
 void     cniic_cc_destroy(cniic_cc *cc);
 
+/* The same shared palette with every rank holding ONLY ITS OWN image's colours (per-rank work and memory do not
+ * grow with the number of ranks, no label exchange).  The reference's point list -- the ascending list of the
+ * distinct colours of all the pixels -- is then known to every rank as a bitmap:
+ *   cniic_hist_rgb24_dense(img)         -> this image's counts, u32[2^24]
+ *   cniic_occupancy_pack(counts, occ)   -> one nibble per colour (u32[2^21]), 1 where the colour occurs
+ *   all-reduce(sum) occ                 -> non-zero where ANY rank has the colour (<= 15 ranks: nibbles cannot carry)
+ *   cniic_cc_create_local(counts, occ)  -> this rank's points, initialised by their position in the list of all
+ *                                          occupied colours (init_assignment / init_centroids, kmeans.rs:61-108; the
+ *                                          empty-cluster reseed picks from the same list); counts is overwritten
+ *   the loop as above (cniic_cc_run, or assign / all-reduce / update); then cniic_cc_finish(img, NULL)
+ * A colour that occurs on several ranks is several points with one position: every copy takes the same decisions and
+ * the integer sums are those of the single merged point, so centroids, iteration count and palette are bit-identical to
+ * clustering the union (only the moved / member COUNTS, used for their zero-ness alone, see each copy). */
+int32_t  cniic_occupancy_pack(cniic_ctx *ctx, const uint32_t *table_dev, uint32_t *occ_dev);
+int32_t  cniic_cc_create_local(cniic_ctx *ctx, uint32_t *table_dev, const uint32_t *occ_dev, uint32_t K, const cniic_kmeans_opts *opts,
+                               void *partials_dev /* u64[5K+2] the caller all-reduces, or NULL with cniic_cc_run */, cniic_cc **out);
+
 /* ---- RCCL on the context's own stream (ncclAllReduce of the K partial sums between assign and
  * update, no host round trip).  librccl is bound at run time; without it these return CNIIC_ERR_UNSUPPORTED
  * and the caller all-reduces the buffers itself (cniic_cc_assign / cniic_cc_update above).

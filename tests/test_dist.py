@@ -1,8 +1,9 @@
 """The N>1 path: shared-palette cluster-colors driven by cniic_amd.dist.ShardedClusterColors.
 
-CPU (gloo, world_size 2): the driver's protocol (histogram all-reduce, per-iteration all-reduce of
-the K partial sums as SIGNED DELTAS, label merge, per-rank Huffman of the reduced image) is run
-with the oracle as the compute backend and must equal a single-process computation bit for bit.
+CPU (gloo, world_size 2): the driver's protocol (occupancy all-reduce, every rank clustering its own
+colours from their position in the list of all colours, per-iteration all-reduce of the K partial sums as
+SIGNED DELTAS, per-rank Huffman of the reduced image) is run with the oracle as the compute backend and
+must equal a single-process clustering of the union bit for bit.
 GPU: the same driver on the HIP backend (world_size 1, and 2 ranks sharing the GPU over gloo)."""
 import os
 import socket
@@ -40,17 +41,23 @@ class OracleBackend:
     def new_partials(self, K):
         return self.torch.zeros(5 * K + 2, dtype=self.torch.int64)
 
-    def cc_create(self, table, K, rank, world, partials, max_iters=0, seed=0):
+    def occupancy(self, table):
+        return self.torch.from_numpy((table.numpy() != 0).astype(np.int32))   # 0/1 per colour; the sum over ranks is > 0 where any has it
+
+    def cc_create_local(self, table, occ, K, partials, max_iters=0, seed=0):
+        """this rank's colours, placed in the ascending list of all occupied colours (the reference's point list)"""
         import oracle_lib as O
         cnt = table.numpy()
-        keys = np.nonzero(cnt)[0].astype(np.uint32)
-        U = keys.size
-        st = dict(K=K, keys=keys, w=cnt[keys].astype(np.uint32), U=U, lo=U * rank // world, hi=U * (rank + 1) // world,
-                  pts=np.stack([(keys >> 16) & 255, (keys >> 8) & 255, keys & 255], 1).astype(np.int32), partials=partials,
-                  labels=O.init_labels(U, K), running=np.zeros(5 * K, np.int64), prev=np.zeros(5 * K, np.int64), it=0,
+        keys = np.nonzero(cnt)[0].astype(np.uint32)                 # local points
+        gkeys = np.nonzero(occ.numpy())[0].astype(np.uint32)        # all occupied colours
+        U, Ug = keys.size, gkeys.size
+        grank = np.searchsorted(gkeys, keys)
+        unpack = lambda k: np.stack([(k >> 16) & 255, (k >> 8) & 255, k & 255], 1).astype(np.int32)
+        st = dict(K=K, keys=keys, w=cnt[keys].astype(np.uint32), U=U, lo=0, hi=U, pts=unpack(keys), gpts=unpack(gkeys), partials=partials,
+                  labels=O.init_labels(Ug, K)[grank], running=np.zeros(5 * K, np.int64), prev=np.zeros(5 * K, np.int64), it=0,
                   seed=seed or O.DEFAULT_SEED)
-        ppc = U // K
-        st["cent"] = np.stack([st["pts"][U - (c + 1) * ppc] if c < K - 1 else st["pts"][0] for c in range(K)]).astype(np.int32)
+        ppc = Ug // K
+        st["cent"] = np.stack([st["gpts"][Ug - (c + 1) * ppc] if c < K - 1 else st["gpts"][0] for c in range(K)]).astype(np.int32)
         return st
 
     def assign(self, st):
@@ -79,20 +86,12 @@ class OracleBackend:
             return
         st["running"] += p[:5 * K]
         run = st["running"].astype(np.uint64)
-        st["cent"], _ = O.kmeans_finalize(O.PT_RGBW, st["pts"], K, st["seed"], st["it"], run[:3 * K].reshape(K, 3), run[3 * K:4 * K],
-                                          run[4 * K:5 * K])
+        st["cent"], _ = O.kmeans_finalize(O.PT_RGBW, st["gpts"], K, st["seed"], st["it"], run[:3 * K].reshape(K, 3), run[3 * K:4 * K],
+                                          run[4 * K:5 * K])   # (an empty cluster is reseeded from the list of ALL colours)
         st["it"] += 1
         if int(p[5 * K]) == 0:
             st["done"] = True
         p[:] = 0
-
-    def export_labels(self, st):
-        out = np.zeros(st["U"], np.uint8)
-        out[st["lo"]:st["hi"]] = st["labels"][st["lo"]:st["hi"]]
-        return self.torch.from_numpy(out)
-
-    def import_labels(self, st, t):
-        st["labels"] = t.numpy().astype(np.uint32)
 
     def finish(self, st, img, w, h, local_table, out):
         import oracle_lib as O
