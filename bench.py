@@ -174,6 +174,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()  # rank 0 did the roofline encode on its own: tear down together
     if world > 1:
         enc.close()
     ctx.close()
