@@ -535,20 +535,17 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         return CNIIC_OK;
     }
     case CODEC_HILBERT_RLE: {  // hilbertc.rs:53-79: RleDecoder (:304-337) zipped with hilbert::iter
-        std::vector<uint8_t> lin(n * 3, 0);  // pixels the stream does not reach stay zero (ImageBuffer::new)
-        uint64_t i = 0;
-        while (i < n && pos < nbytes) {      // RepCount::deserialize(..)? ends the stream quietly
-            const uint32_t count = bytes[pos++];
-            uint64_t l;
-            if (count == 0 || !get_u64(bytes, nbytes, pos, l) || l != 3 || pos + 3 > nbytes)
-                return c->fail(CNIIC_ERR_DECODE, "hilbert-rle: bad run record (assert!(count > 0) / unwrap, hilbertc.rs:327-328)");
-            for (uint32_t k = 0; k < count && i < n; k++, i++) memcpy(&lin[3 * i], bytes + pos, 3);
-            pos += 3;
-        }
         if (!n) return CNIIC_OK;
-        DevBuf lin_d, img_d;
+        // pixels the stream does not reach stay zero (ImageBuffer::new); RepCount::deserialize(..)? ends it quietly
+        const uint64_t body = nbytes - pos, R = body / 12, tail = body % 12;
+        DevBuf rec_d, lin_d, img_d;
+        CNIIC_HIP_TRY(c, rec_d.alloc(std::max<uint64_t>(R * 12, 16)));
+        if (R) CNIIC_HIP_TRY(c, hipMemcpyAsync(rec_d.p, bytes + pos, R * 12, hipMemcpyHostToDevice, c->stream));
         CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(lin_d.p, lin.data(), n * 3, hipMemcpyHostToDevice, c->stream));
+        int status = 0;
+        CNIIC_TRY(rle_expand_dev(c, rec_d.as<uint8_t>(), R, tail, n, lin_d.as<uint8_t>(), &status));
+        if (status)
+            return c->fail(CNIIC_ERR_DECODE, "hilbert-rle: bad run record (assert!(count > 0) / unwrap, hilbertc.rs:327-328)");
         uint8_t *dst = rgb_out;
         const bool dst_dev = is_device_ptr(rgb_out);
         if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }

@@ -404,6 +404,7 @@ int delta_undiff_dev(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *lin_d,
 struct RlePlan { uint64_t n = 0, nruns = 0; uint32_t nchunks = 0; DevBuf flags, run_off; };
 int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan);                       // counts the runs (syncs)
 int rle_emit(Ctx *c, const uint8_t *lin_d, const RlePlan *plan, uint32_t *out_words_d);      // 12-byte records
+int rle_expand_dev(Ctx *c, const uint8_t *rec_d, uint64_t R, uint64_t tail_bytes, uint64_t n, uint8_t *lin_d, int *status);  // RleDecoder
 
 // ---- k_hilbert.hip ----
 int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d);

@@ -195,4 +195,74 @@ int rle_emit(Ctx *c, const uint8_t *lin_d, const RlePlan *plan, uint32_t *out_wo
     return CNIIC_OK;
 }
 
+// ---------------------------------------------------------------- RleDecoder (hilbertc.rs:304-337) as a scan + search
+// rec: the run records (12 bytes each) on the device.  The decoder reads records until w*h colours are out
+// (it is zipped with hilbert::iter, :58-61), so a record is READ iff it starts before colour n; a zero count
+// (assert!, :327) or a colour that is not 3 bytes long (unwrap, :328) in a record that is read is an error.
+__global__ void k_rle_counts(const uint8_t *__restrict__ rec, uint64_t R, uint32_t *__restrict__ cnt) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += stride) cnt[r] = rec[12 * r];
+}
+__global__ void k_rle_check(const uint8_t *__restrict__ rec, uint64_t R, const uint64_t *__restrict__ off, uint64_t n,
+                            uint32_t *__restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += stride) {
+        if (off[r] >= n) continue;  // never read
+        const uint8_t *p = rec + 12 * r;
+        bool ok = p[0] != 0 && p[1] == 3;
+        for (int i = 2; i < 9; i++) ok = ok && p[i] == 0;
+        if (!ok) *bad = 1u;
+    }
+}
+// colour i of the stream = colour of the last record whose first colour index is <= i; zeros past the stream
+__global__ void k_rle_expand(const uint8_t *__restrict__ rec, uint64_t R, const uint64_t *__restrict__ off, uint64_t total, uint64_t n,
+                             uint8_t *__restrict__ lin) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint8_t c0 = 0, c1 = 0, c2 = 0;
+        if (i < total) {
+            uint64_t a = 0, b = R;  // last r with off[r] <= i (records of count 0 share their successor's offset and are passed over)
+            while (b - a > 1) { const uint64_t mid = (a + b) >> 1; if (off[mid] <= i) a = mid; else b = mid; }
+            const uint8_t *p = rec + 12 * a + 9;
+            c0 = p[0]; c1 = p[1]; c2 = p[2];
+        }
+        lin[3 * i] = c0; lin[3 * i + 1] = c1; lin[3 * i + 2] = c2;
+    }
+}
+
+// rec_d: R complete records on the device -> lin_d: n colours in scan order.  *status: 0 ok, 1 a record that is read is bad
+// or (tail_bytes != 0 and the complete records do not reach n colours: the next record is cut)
+int rle_expand_dev(Ctx *c, const uint8_t *rec_d, uint64_t R, uint64_t tail_bytes, uint64_t n, uint8_t *lin_d, int *status) {
+    *status = 0;
+    if (n == 0) return CNIIC_OK;
+    uint64_t total = 0;
+    DevBuf cnt, off, tot, bad;
+    if (R) {
+        if (R > 0x7fffffffull * 1024) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert-rle: stream too long");
+        CNIIC_HIP_TRY(c, cnt.alloc(R * 4));
+        CNIIC_HIP_TRY(c, off.alloc(R * 8));
+        CNIIC_HIP_TRY(c, tot.alloc(8));
+        CNIIC_HIP_TRY(c, bad.alloc(4));
+        CNIIC_HIP_TRY(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(R, 256), 1), 8192);
+        hipLaunchKernelGGL(k_rle_counts, dim3(grid), dim3(256), 0, c->stream, rec_d, R, cnt.as<uint32_t>());
+        if (R > 0xffffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert-rle: stream too long");
+        hipLaunchKernelGGL(k_rle_offsets, dim3(1), dim3(1024), 0, c->stream, cnt.as<uint32_t>(), (uint32_t)R, off.as<uint64_t>(),
+                           tot.as<uint64_t>());
+        hipLaunchKernelGGL(k_rle_check, dim3(grid), dim3(256), 0, c->stream, rec_d, R, (const uint64_t *)off.as<uint64_t>(), n, bad.as<uint32_t>());
+        CNIIC_HIP_TRY(c, hipGetLastError());
+        uint32_t bad_h = 0;
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(&bad_h, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (bad_h) { *status = 1; return CNIIC_OK; }
+    }
+    if (total < n && tail_bytes) { *status = 1; return CNIIC_OK; }  // the decoder starts one more record and runs out of bytes
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(n, 256), 16384);
+    hipLaunchKernelGGL(k_rle_expand, dim3(grid), dim3(256), 0, c->stream, rec_d, R, (const uint64_t *)off.as<uint64_t>(), total, n, lin_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
 }  // namespace cniic
