@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -222,9 +223,20 @@ struct LaggedPoll {
     Ctx *c;
     const void *dstate;
     int slot = 0, pending = 0;
+    bool mapped = false;  // the kernels write the state into the third pinned slot themselves: no copy to enqueue
     LaggedPoll(Ctx *ctx, const void *dstate_d) : c(ctx), dstate(dstate_d) {}
+    // device address of the slot the kernels write in mapped mode (zeroed here)
+    int mapped_slot(KmDevState **dev_ptr) {
+        KmDevState *slots = static_cast<KmDevState *>(c->pinned);
+        memset(&slots[2], 0, sizeof(KmDevState));
+        void *d = nullptr;
+        CNIIC_HIP_TRY(c, hipHostGetDevicePointer(&d, &slots[2], 0));
+        *dev_ptr = static_cast<KmDevState *>(d);
+        mapped = true;
+        return CNIIC_OK;
+    }
     int prepare() {
-        static_assert(2 * sizeof(KmDevState) <= 4096, "two poll slots must fit the pinned page");
+        static_assert(3 * sizeof(KmDevState) <= 4096, "the poll slots must fit the pinned page");
         if (!c->pinned) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
         for (int i = 0; i < 2; i++)
             if (!c->poll_ev[i]) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
@@ -233,12 +245,21 @@ struct LaggedPoll {
     // call after enqueuing a batch; returns the state as of the batch BEFORE it in *h (valid when *have)
     int after_batch(KmDevState *h, bool *have) {
         KmDevState *slots = static_cast<KmDevState *>(c->pinned);
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(&slots[slot], dstate, sizeof(KmDevState), hipMemcpyDeviceToHost, c->stream));
+        if (!mapped) CNIIC_HIP_TRY(c, hipMemcpyAsync(&slots[slot], dstate, sizeof(KmDevState), hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipEventRecord(c->poll_ev[slot], c->stream));
         *have = pending > 0;
         if (pending) {
             CNIIC_HIP_TRY(c, hipEventSynchronize(c->poll_ev[slot ^ 1]));
-            *h = slots[slot ^ 1];
+            if (mapped) {  // at least as new as that batch; the flag is read first, the scalars it guards after it
+                volatile KmDevState *m = &slots[2];
+                KmDevState t{};
+                t.done = m->done;
+                std::atomic_thread_fence(std::memory_order_acquire);
+                t.iter = m->iter; t.moved_last = m->moved_last; t.reseeds = m->reseeds; t.active = m->active; t.pair_evals = m->pair_evals;
+                *h = t;
+            } else {
+                *h = slots[slot ^ 1];
+            }
         }
         slot ^= 1;
         pending = 1;

@@ -652,6 +652,7 @@ struct FusedUpdate {
     uint32_t *cent_g;
     uint64_t *members_out, *wsum_out;
     KmDevState *st_rw;
+    KmDevState *st_host;                         // pinned host copy of the scalar state (lagged polling without a copy kernel), or null
 };
 
 template <typename LabelT, int IDBITS, int WAVES>
@@ -751,6 +752,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
             sw->pair_evals += pev;
             sw->iter = j;
             if (fin) sw->done = 1;
+            if (fz.st_host) {  // the host polls this after the batch's event: scalars first, the flag last
+                KmDevState *hs = fz.st_host;
+                hs->moved_last = changed; hs->reseeds = sw->reseeds; hs->active = s_active; hs->pair_evals = sw->pair_evals; hs->iter = j;
+                __threadfence_system();
+                if (fin) hs->done = 1;
+            }
         }
         if (fin) return;  // converged (or the iteration cap): nothing to assign
         nS = s_nmoved;
@@ -1287,6 +1294,8 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     LaunchTimer lt;
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
+    KmDevState *st_host = nullptr;
+    if (s->fused) CNIIC_TRY(poll.mapped_slot(&st_host));
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     const uint64_t W = 5 * (uint64_t)s->K + 2;
     uint32_t launch_no = 0;
@@ -1313,6 +1322,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
                 fz.members_out = s->members_last.as<uint64_t>();
                 fz.wsum_out = s->wsum_last.as<uint64_t>();
                 fz.st_rw = s->dstate.as<KmDevState>();
+                fz.st_host = st_host;
                 unsigned long long *cur = P + (j % 3) * W;
                 if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur); }
                 else launch_assign(s, nullptr, nullptr, &fz, cur);
