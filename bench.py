@@ -47,7 +47,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # rehearsal knob: CNIIC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (process group, collectives) with one rank
+    sharded = world > 1 or os.environ.get("CNIIC_BENCH_FORCE_SHARDED") == "1"
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # rehearsal knobs for a 1-GPU box: CNIIC_BENCH_BACKEND=gloo CNIIC_BENCH_ONE_GPU=1 put every rank on cuda:0
@@ -79,9 +81,10 @@ def main():
     out = torch.empty(W * H * 4 + (1 << 20), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    if world > 1:
+    if sharded:
         from cniic_amd.dist import ShardedClusterColors
-        enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters)
+        enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters,
+                                   collectives="native" if world == 1 and os.environ.get("CNIIC_COLLECTIVES", "native") == "native" else None)
 
         def step():
             return enc.encode(img, W, H, out)
@@ -167,7 +170,7 @@ def main():
                        "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
                        "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2),
                        "bytes_per_px": round(nbytes / (W * H), 4),
-                       "parallelism": "1 GPU" if world == 1 else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
+                       "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
                                                                    "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
                                                                    % (world, "library communicator, in-stream" if enc.collectives == "native"
                                                                       else "torch.distributed")},
@@ -176,7 +179,7 @@ def main():
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()  # rank 0 did the roofline encode on its own: tear down together
-    if world > 1:
+    if sharded:
         enc.close()
     ctx.close()
     if dist is not None:
