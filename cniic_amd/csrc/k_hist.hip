@@ -344,20 +344,44 @@ __global__ __launch_bounds__(256) void k_occ_pack(const uint32_t *__restrict__ t
     occ[wd] = (a.x != 0) | ((a.y != 0) << 4) | ((a.z != 0) << 8) | ((a.w != 0) << 12) | ((b.x != 0) << 16) | ((b.y != 0) << 20) |
               ((b.z != 0) << 24) | ((uint32_t)(b.w != 0) << 28);
 }
-// bits[w] = occupancy of keys 64 w .. 64 w + 63 from 8 nibble words; cnt[w] = popcount
+// bits[w] = occupancy of keys 64 w .. 64 w + 63 from 8 nibble words; wprefix[w] = occupied keys before word w INSIDE
+// this block's 1024 words, blocktot[block] = occupied keys of the block (k_gidx_finish adds the blocks before)
 __global__ __launch_bounds__(256) void k_gidx_words(const uint32_t *__restrict__ occ, unsigned long long *__restrict__ bits,
-                                                    uint32_t *__restrict__ cnt) {
-    const uint32_t w = blockIdx.x * 256 + threadIdx.x;  // 2^18 words
-    unsigned long long m = 0;
+                                                    uint32_t *__restrict__ wprefix, uint32_t *__restrict__ blocktot) {
+    __shared__ uint32_t wsum[256 / 64];
+    const uint32_t w0 = (blockIdx.x * 256 + threadIdx.x) * 4;  // 4 consecutive words per thread
+    uint32_t cnt[4], mine = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t v = occ[8 * (size_t)w + j];
+    for (int q = 0; q < 4; q++) {
+        unsigned long long m = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            if ((v >> (4 * i)) & 15u) m |= 1ull << (8 * j + i);
+        for (int j = 0; j < 8; j++) {
+            const uint32_t v = occ[8 * (size_t)(w0 + q) + j];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if ((v >> (4 * i)) & 15u) m |= 1ull << (8 * j + i);
+        }
+        bits[w0 + q] = m;
+        cnt[q] = (uint32_t)__popcll(m);
+        mine += cnt[q];
     }
-    bits[w] = m;
-    cnt[w] = (uint32_t)__popcll(m);
+    uint32_t run = block_exclusive_scan<256>(mine, wsum);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { wprefix[w0 + q] = run; run += cnt[q]; }
+    if (threadIdx.x == 255) blocktot[blockIdx.x] = run;
+}
+// 256 blocks of k_gidx_words: every block's words get the occupied keys of the blocks before; *total = all of them
+__global__ __launch_bounds__(256) void k_gidx_finish(uint32_t *__restrict__ wprefix, const uint32_t *__restrict__ blocktot,
+                                                     uint64_t *__restrict__ total) {
+    __shared__ uint32_t wsum[256 / 64];
+    __shared__ uint32_t boff[256];
+    const uint32_t t = blocktot[threadIdx.x];
+    const uint32_t ex = block_exclusive_scan<256>(t, wsum);
+    boff[threadIdx.x] = ex;
+    if (blockIdx.x == 0 && threadIdx.x == 255) *total = (uint64_t)ex + t;
+    __syncthreads();
+    const uint32_t add = boff[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256) wprefix[blockIdx.x * 1024 + i] += add;
 }
 
 int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d) {
@@ -372,8 +396,12 @@ int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uin
     CNIIC_HIP_TRY(c, bits.alloc((1ull << 18) * 8));
     CNIIC_HIP_TRY(c, wprefix.alloc((1ull << 18) * 4));
     CNIIC_HIP_TRY(c, tot.alloc(8));
-    hipLaunchKernelGGL(k_gidx_words, dim3((1u << 18) / 256), dim3(256), 0, c->stream, occ_d, bits.as<unsigned long long>(), wprefix.as<uint32_t>());
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, wprefix.as<uint32_t>(), 1u << 18, tot.as<uint64_t>());
+    DevBuf blocktot;
+    CNIIC_HIP_TRY(c, blocktot.alloc(256 * 4));
+    hipLaunchKernelGGL(k_gidx_words, dim3(256), dim3(256), 0, c->stream, occ_d, bits.as<unsigned long long>(), wprefix.as<uint32_t>(),
+                       blocktot.as<uint32_t>());
+    hipLaunchKernelGGL(k_gidx_finish, dim3(256), dim3(256), 0, c->stream, wprefix.as<uint32_t>(), (const uint32_t *)blocktot.as<uint32_t>(),
+                       tot.as<uint64_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(U_h, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
