@@ -13,6 +13,18 @@ __device__ __forceinline__ uint32_t rgb_key(const uint8_t *p) {
 // v holds r in byte 0, g in byte 1, b in byte 2 (byte 3 ignored) -> r<<16|g<<8|b
 __device__ __forceinline__ uint32_t key_from_le24(uint32_t v) { return __builtin_bswap32(v) >> 8; }
 
+// pixel idx of an N-pixel interleaved RGB8 buffer as ONE (unaligned) dword load instead of three byte loads --
+// sub-dword loads go through the texture addresser several times slower; the last pixel, whose dword would
+// end one byte past the buffer, is read by bytes
+__device__ __forceinline__ uint32_t rgb_key_at(const uint8_t *rgb, uint64_t idx, uint64_t N) {
+    if (idx + 1 < N) {
+        uint32_t v;
+        __builtin_memcpy(&v, rgb + 3 * idx, 4);
+        return key_from_le24(v);
+    }
+    return rgb_key(rgb + 3 * idx);
+}
+
 // 16 interleaved RGB pixels (48 B, 16-B aligned) -> 16 packed keys
 __device__ __forceinline__ void load16px_keys(const uint4 *p, uint32_t key[16]) {
     uint4 q0 = p[0], q1 = p[1], q2 = p[2];

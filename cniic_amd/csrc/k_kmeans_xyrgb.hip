@@ -162,6 +162,12 @@ struct Dominance {
     }
 };
 
+// position of the i-th set bit of m (i < popcount(m)); wave-uniform arguments: scalar code
+__device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, uint32_t i) {
+    for (uint32_t t = 0; t < i; t++) m &= m - 1;
+    return (uint32_t)__ffs((int)m) - 1u;
+}
+
 // partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
 // [6K] moved ; [6K+1] pair evaluations.  At iteration 0 the partials are the full sums of the new
 // assignment; afterwards they are SIGNED deltas of the pixels that moved, added to running sums.
@@ -173,6 +179,16 @@ struct TileState {              // per tile, carried between iterations
     const uint32_t *moved;      // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;         // skip schedule when moved[0] <= max_moved (0 disables it)
 };
+
+// -DCNIIC_XY_PHASES: wave-clock totals per phase of k_xy_assign (a measuring build, never the shipped one)
+#ifdef CNIIC_XY_PHASES
+__device__ unsigned long long g_xy_phase[12];
+#define XY_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
+#define XY_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
+#else
+#define XY_PHASE(i) do {} while (0)
+#define XY_COUNT(i, v) do {} while (0)
+#endif
 
 __host__ __device__ constexpr uint32_t xy_acc_words(uint32_t K) { return (6 * K + 3) & ~3u; }  // keeps the int4 arrays aligned
 
@@ -198,10 +214,16 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     int4 *tab = reinterpret_cast<int4 *>(W_k + (size_t)kXWaves * wcap);
     __shared__ unsigned long long s_key;
     __shared__ uint32_t s_n;
-    __shared__ uint32_t wsum[kXWaves];
+    __shared__ uint32_t wsum[kXWaves], s_dirty[2][kXWaves], s_ncand[kXWaves];
     const uint32_t done = st->done;  // acted on once the set-up loads are out
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#ifdef CNIIC_XY_PHASES
+    long long t_ph = clock64();
+    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long s_ph[12];
+    if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
+#endif
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const bool first = st->iter == 0;
     const uint32_t nS = ts.moved[0];
@@ -232,8 +254,11 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     unsigned long long evals = 0;
     if (done) return;
     __syncthreads();
+    XY_PHASE(0);
 
-    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x) {
+    const uint64_t npix = (uint64_t)w * h;
+    uint32_t par = 0;
+    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x, par ^= 1) {
         const uint32_t stx = (sup % super_x) * kSTX, sty = (sup / super_x) * kSTY;
         const uint32_t tix = stx + (wv & (kSTX - 1)), tiy = sty + wv / kSTX;
         const bool has_tile = tix < tiles_x && tiy < tiles_y;
@@ -259,25 +284,34 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             }
             dirty = __ballot(d) != 0ull;
         }
-        // pixel (lane, row): x = tx0 + lane, y = ty0 + row; rows go in groups of kXRows.  The first group's
-        // pixels and labels are requested now and arrive while the block builds S.
-        const int32_t x = (int32_t)(tx0 + lane);
-        const bool okx = lane < tw;
+        // ---- the dirty tiles of the super-tile are evaluated by ALL 16 waves: the work unit is (tile, group of
+        // kXRows rows); wave v takes row group v & 3 of dirty tiles number (v >> 2), (v >> 2) + 4, ... so the wave of a
+        // clean tile works for its neighbours instead of waiting for them.
+        // (s_dirty alternates between two copies: with no dirty tile there is no second barrier before the next write)
+        if (lane == 0) s_dirty[par][wv] = dirty ? 1u : 0u;
+        XY_PHASE(1);
+        __syncthreads();  // (also frees S and the strips of the previous super-tile)
+        XY_PHASE(2);
+        const uint32_t dm16 = (uint32_t)__ballot(s_dirty[par][lane & (kXWaves - 1)] != 0u) & 0xffffu;  // wave-uniform
+        const uint32_t nd = (uint32_t)__popc(dm16);
+        if (nd == 0) continue;
+        const uint32_t g4 = (wv & 3) * kXRows;  // this wave's rows within a tile
         uint32_t px[2][kXRows], cur[2][kXRows];
-        auto load_rows = [&](int g, uint32_t (&p)[kXRows], uint32_t (&c)[kXRows]) {
+        // pixel (lane, row j) of the unit: x = first column of the tile + lane, y = first row of the tile + g4 + j
+        auto load_unit = [&](uint32_t slot, uint32_t (&p)[kXRows], uint32_t (&c)[kXRows]) {
+            const uint32_t ux = (stx + (slot & (kSTX - 1))) * kTW + lane, uy0 = (sty + slot / kSTX) * kTH + g4;
 #pragma unroll
             for (int j = 0; j < kXRows; j++) {
-                const uint32_t ly = g * kXRows + j;
                 p[j] = 0; c[j] = 0;
-                if (okx && ly < th) {
-                    const uint64_t idx = (uint64_t)(ty0 + ly) * w + (uint32_t)x;
-                    p[j] = rgb_key(rgb + 3 * idx);
+                if (ux < w && uy0 + j < h) {
+                    const uint64_t idx = (uint64_t)(uy0 + j) * w + ux;
+                    p[j] = rgb_key_at(rgb, idx, npix);
                     c[j] = labels[idx];
                 }
             }
         };
-        if (dirty) load_rows(0, px[0], cur[0]);
-        if (!__syncthreads_or(dirty)) continue;  // (also the barrier that frees S of the previous super-tile)
+        // the first unit's pixels and labels are requested now and arrive while the block builds S
+        if ((wv >> 2) < nd) load_unit(nth_set_bit(dm16, wv >> 2), px[0], cur[0]);
 
         // ---- super-tile list S (whole block): pivot = centroid nearest the super-tile's box centre
         bool s_over = brute != 0;
@@ -320,15 +354,11 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             nSl = s_n;
             s_over = nSl > kSCap;
         }
-        if (!dirty) continue;
-
-        // ================================================================= one wave, one tile
-
-        // ---- candidate strip: pivot = member of S nearest the tile's box centre, then the dominance test over S
-        const int4 *list_c = S_c;
-        const uint16_t *list_k = S_k;
-        uint32_t ncand = K;
-        if (!s_over) {
+        XY_PHASE(3);
+        // ---- candidate strip of this wave's own tile, if dirty: pivot = member of S nearest the tile's box centre,
+        // then the dominance test over S
+        if (dirty) XY_COUNT(7, 1);
+        if (dirty && !s_over) {
             uint32_t bd = 0xffffffffu, be = 0;
             for (uint32_t e = lane; e < nSl; e += 64) {
                 const uint32_t d = centre_dist(tb, S_c[e]);
@@ -357,22 +387,41 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 n += (uint32_t)__popcll(bm);
             }
             __builtin_amdgcn_wave_barrier();
-            if (n <= wcap) { list_c = my_c; list_k = my_k; ncand = n; } else ncand = nSl;  // S is a superset in the same order
+            if (lane == 0) s_ncand[wv] = n <= wcap ? n : (0x80000000u | nSl);  // (beyond the strip: S, a superset in the same order)
             pv.w = (int32_t)S_k[pe];
             if (lane == 0) ts.piv[tile] = pv;
             for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = my_mask[i];
-        } else {
+        } else if (dirty) {
             if (lane == 0) ts.piv[tile] = cent[0];                      // every centroid is a candidate:
             for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = ~0ull;  // any move makes the tile dirty
         }
 
-        // ---- assign, kXRows rows at a time; the next group's pixels and labels are in flight meanwhile
+        XY_PHASE(4);
+        __syncthreads();  // every dirty tile's strip is in LDS
+        XY_PHASE(2);
+
+        // ---- assign, one unit at a time; the next unit's pixels and labels are in flight meanwhile
 #pragma unroll
-        for (int g = 0; g < kTH / kXRows; g++) {
-            const uint32_t (&p)[kXRows] = px[g & 1];
-            const uint32_t (&c)[kXRows] = cur[g & 1];
-            if (g + 1 < kTH / kXRows) load_rows(g + 1, px[(g + 1) & 1], cur[(g + 1) & 1]);
-            if ((uint32_t)(g * kXRows) >= th) continue;  // wave-uniform
+        for (int r = 0; r < 4; r++) {
+            const uint32_t ui = (wv >> 2) + 4 * r;
+            if (ui >= nd) break;  // wave-uniform
+            const uint32_t (&p)[kXRows] = px[r & 1];
+            const uint32_t (&c)[kXRows] = cur[r & 1];
+            const uint32_t slot = nth_set_bit(dm16, ui);
+#ifdef CNIIC_XY_PHASES
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            XY_PHASE(8);
+#endif
+            if (ui + 4 < nd) load_unit(nth_set_bit(dm16, ui + 4), px[(r + 1) & 1], cur[(r + 1) & 1]);
+            const uint32_t ux0 = (stx + (slot & (kSTX - 1))) * kTW, uy0 = (sty + slot / kSTX) * kTH + g4;
+            if (uy0 >= h) continue;  // wave-uniform: the tile ends above this row group
+            const uint32_t nrows = min((uint32_t)kXRows, h - uy0), ucols = min((uint32_t)kTW, w - ux0);
+            const int32_t x = (int32_t)(ux0 + lane);
+            const bool okx = lane < ucols;
+            const uint32_t enc = s_ncand[slot];
+            const uint32_t ncand = s_over ? K : (enc & 0x7fffffffu);
+            const int4 *list_c = (enc >> 31) ? S_c : W_c + (size_t)slot * wcap;
+            const uint16_t *list_k = (enc >> 31) ? S_k : W_k + (size_t)slot * wcap;
             int4 own[kXRows];  // the centroid each pixel belongs to now
 #pragma unroll
             for (int j = 0; j < kXRows; j++) own[j] = use_tab ? tab[c[j]] : cent[c[j]];
@@ -387,7 +436,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
 #pragma unroll
                     for (int j = 0; j < kXRows; j++) {
-                        const int32_t y2 = 2 * (int32_t)(ty0 + g * kXRows + j);
+                        const int32_t y2 = 2 * (int32_t)(uy0 + j);
                         const int32_t gq = (int32_t)(xdot4(p[j], (uint32_t)cc.z) << 1) + xmad24(y2, cc.y, ax);
                         if (gq > best[j]) { best[j] = gq; bpos[j] = q; }
                     }
@@ -398,17 +447,20 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
 #pragma unroll
                     for (int j = 0; j < kXRows; j++) {
-                        const int32_t y2 = 2 * (int32_t)(ty0 + g * kXRows + j);
+                        const int32_t y2 = 2 * (int32_t)(uy0 + j);
                         const int32_t gq = (int32_t)(xdot4(p[j], (uint32_t)cc.z) << 1) + xmad24(y2, cc.y, ax);
                         if (gq > best[j]) { best[j] = gq; bpos[j] = q; }
                     }
                 }
             }
+#ifdef CNIIC_XY_PHASES
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            XY_PHASE(9);
+#endif
 #pragma unroll
             for (int j = 0; j < kXRows; j++) {
-                const uint32_t ly = g * kXRows + j;
-                const bool ok = okx && ly < th;
-                const int32_t y = (int32_t)(ty0 + ly);
+                const bool ok = okx && (uint32_t)j < nrows;
+                const int32_t y = (int32_t)(uy0 + j);
                 const int32_t gcur = (int32_t)(xdot4(p[j], (uint32_t)own[j].z) << 1) +
                                      xmad24(2 * y, own[j].y, xmad24(2 * x, own[j].x, -own[j].w));
                 const bool mv = ok && best[j] > gcur;  // strictly closer (kmeans.rs:375)
@@ -418,7 +470,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     labels[(uint64_t)y * w + (uint32_t)x] = (uint16_t)nl;
                     moved++;
                 }
-                const uint32_t r = (p[j] >> 16) & 255, gg = (p[j] >> 8) & 255, b = p[j] & 255;
+                const uint32_t r8 = (p[j] >> 16) & 255, gg = (p[j] >> 8) & 255, b = p[j] & 255;
                 if (first) {
                     // vector_add clusterc.rs:221-228 for every pixel.  A row of 64 pixels holds few distinct
                     // labels: one wave reduction per label instead of 64 colliding LDS atomics.
@@ -428,7 +480,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                         const bool in = ok && nl == lk;
                         const unsigned long long grp = __ballot(in);
                         const uint32_t cn = (uint32_t)__popcll(grp);
-                        const uint32_t sx = wave_reduce_sum(in ? (uint32_t)x : 0u), sr = wave_reduce_sum(in ? r : 0u);
+                        const uint32_t sx = wave_reduce_sum(in ? (uint32_t)x : 0u), sr = wave_reduce_sum(in ? r8 : 0u);
                         const uint32_t sg = wave_reduce_sum(in ? gg : 0u), sbb = wave_reduce_sum(in ? b : 0u);
                         if (lane == 0) {
                             uint32_t *a = acc + 6 * lk;
@@ -439,16 +491,18 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     }
                 } else if (mv) {  // +pixel to its new cluster, -pixel from its old one
                     uint32_t *a = acc + 6 * nl, *o = acc + 6 * c[j];
-                    atomicAdd(a + 0, (uint32_t)x); atomicAdd(a + 1, (uint32_t)y); atomicAdd(a + 2, r);
+                    atomicAdd(a + 0, (uint32_t)x); atomicAdd(a + 1, (uint32_t)y); atomicAdd(a + 2, r8);
                     atomicAdd(a + 3, gg); atomicAdd(a + 4, b); atomicAdd(a + 5, 1u);
-                    atomicAdd(o + 0, 0u - (uint32_t)x); atomicAdd(o + 1, 0u - (uint32_t)y); atomicAdd(o + 2, 0u - r);
+                    atomicAdd(o + 0, 0u - (uint32_t)x); atomicAdd(o + 1, 0u - (uint32_t)y); atomicAdd(o + 2, 0u - r8);
                     atomicAdd(o + 3, 0u - gg); atomicAdd(o + 4, 0u - b); atomicAdd(o + 5, 0u - 1u);
                 }
             }
+            if (lane == 0) evals += (unsigned long long)(ncand + 1) * ucols * nrows;
         }
-        if (lane == 0) evals += (unsigned long long)(ncand + 1) * tw * th;
+        XY_PHASE(5);
     }
     __syncthreads();
+    XY_PHASE(2);
     // the host sizes the grid so that one block's pixels * max coordinate stays below 2^31: one flush at the end
     for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) {
         const uint32_t v = acc[i];
@@ -460,6 +514,13 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     moved = block_reduce_sum<kXThreads>(moved);
     if (threadIdx.x == 0 && moved) atomicAdd(&partials[6 * (size_t)K], (unsigned long long)moved);
     if (lane == 0 && evals) atomicAdd(&partials[6 * (size_t)K + 1], evals);
+    XY_PHASE(6);
+#ifdef CNIIC_XY_PHASES
+    if (lane == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(&s_ph[i], ph_[i]);
+    __syncthreads();
+    if (threadIdx.x < 12) atomicAdd(&g_xy_phase[threadIdx.x], s_ph[threadIdx.x]);
+#endif
 }
 
 // Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137).
@@ -655,6 +716,15 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
         if (have && hst.done) break;
     }
     timer.stop(hst.iter);
+#ifdef CNIIC_XY_PHASES
+    {
+        unsigned long long ph[12], zero[12] = {0};
+        CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_xy_phase), sizeof ph));
+        CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_xy_phase), zero, sizeof zero));
+        fprintf(stderr, "xy phases (wave clocks): prologue %llu skiptest %llu barrier %llu S %llu tile %llu eval %llu epilogue %llu | dirty tiles %llu iters %llu | eval: loadwait %llu candloop %llu\n",
+                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], (unsigned long long)hst.iter, ph[8], ph[9]);
+    }
+#endif
     std::vector<int4> cent(K);
     CNIIC_HIP_TRY(c, hipMemcpy(cent.data(), s.cent.p, (size_t)K * 16, hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < K; k++) {

@@ -126,16 +126,25 @@ class HipBackend:
         idb = (C.c_uint8 * 128)(*raw[1:])
         h = C.c_void_p()
         rc = self.L.cniic_comm_create(self.ctx.h, idb, C.c_uint32(rank), C.c_uint32(world), C.byref(h))
-        mine = 1 if rc == _lib.OK else 0
-        if dist is not None and world > 1:  # all ranks or none
+        def agreed(mine):  # all ranks or none
+            if dist is None or world == 1:
+                return mine
             f = torch.tensor([mine], dtype=torch.int32, device=self.dev if backend == "nccl" else "cpu")
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
-            agreed = int(f.item())
-        else:
-            agreed = mine
-        if not agreed:
+            return int(f.item())
+
+        mine = 1 if rc == _lib.OK else 0
+        if not agreed(mine):
             if mine:
                 self.L.cniic_comm_destroy(h)
+            return None
+        # known-answer all-reduce before the K-means loop depends on it: rank r gives r + 1 in every word
+        probe = torch.full((5 * 256 + 2,), rank + 1, dtype=torch.int64, device=self.dev)
+        rc = self.L.cniic_comm_all_reduce(h, C.c_void_p(probe.data_ptr()), C.c_uint64(probe.numel()), C.c_int32(8))
+        torch.cuda.synchronize(self.dev)
+        good = 1 if rc == _lib.OK and bool((probe == world * (world + 1) // 2).all()) else 0
+        if not agreed(good):
+            self.L.cniic_comm_destroy(h)
             return None
         return h
 
