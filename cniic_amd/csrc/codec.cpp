@@ -250,6 +250,28 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
     return CNIIC_OK;
 }
 
+int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, const cniic_kmeans_opts *opts, CcSession **out) {
+    if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
+    auto s = std::make_unique<CcSession>();
+    s->c = c; s->K = K; s->sp_mode = true;
+    CNIIC_TRY(sp_build(c, rgb_d, npx, &s->sp));   // count_freqs (clusterc.rs:21): distinct colours per cell, occupancy bitmap
+    host_trace().mark("sp_build+sync");
+    const uint64_t U = s->sp.U;
+    s->U = U;
+    if (U / K == 0)
+        return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)U, K);
+    // kmeans::cluster (clusterc.rs:28): the point list is known as the bitmap; its cell-major copy is written below
+    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, U, 0, 1, K, opts, nullptr, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->sp.bits.p,
+                             s->sp.wprefix.as<uint32_t>(), U, true));
+    uint32_t *cell_start, *ckeys, *cweight;
+    km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
+    CNIIC_TRY(sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->sp.bits.p,
+                      s->sp.wprefix.as<uint32_t>(), U));
+    host_trace().mark("km_create + emit enq");
+    *out = s.release();
+    return CNIIC_OK;
+}
+
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
               uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats) {
     Ctx *c = s->c;
@@ -265,12 +287,18 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     CNIIC_TRY(km_rgbw_result_begin(km));
     const bool wide = km_rgbw_is_wide(km);
     DevBuf lab_d, key2label, pixlab;
-    CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
-    CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
-    CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
-    CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
     CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
-    CNIIC_TRY(pixel_labels(c, rgb_d, n, key2label.p, wide, pixlab.p));
+    if (s->sp_mode) {  // every pixel's label from the partition: no table of 2^24 entries, no random read
+        uint32_t *cell_start, *ckeys, *cweight;
+        km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
+        CNIIC_TRY(sp_pixel_labels(c, &s->sp, rgb_d, cell_start, ckeys, km_rgbw_labels_internal(km, nullptr), wide, pixlab.p));
+    } else {
+        CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
+        CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
+        CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * (wide ? 2 : 1)));
+        CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
+        CNIIC_TRY(pixel_labels(c, rgb_d, n, key2label.p, wide, pixlab.p));
+    }
     host_trace().mark("labels + pixel labels enq");
     CNIIC_TRY(km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st));
     host_trace().mark("km_result");
@@ -355,11 +383,27 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     return rc_fin;
 }
 
+// images of at least this many pixels take the super-cell partition (k_points.hip); CNIIC_SP_MIN_PIXELS overrides (tests: 0)
+static uint64_t sp_min_pixels() {
+    const char *e = getenv("CNIIC_SP_MIN_PIXELS");
+    return e ? strtoull(e, nullptr, 10) : (1ull << 20);
+}
+
 static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
                                  const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
                                  cniic_kmeans_stats *stats) {
     const uint64_t n = (uint64_t)w * h;
     host_trace().mark("enter");
+    if (n >= sp_min_pixels() && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))) {
+        CcSession *raw = nullptr;
+        CNIIC_TRY(cc_prepare_image(c, rgb_d, n, K, opts, &raw));
+        std::unique_ptr<CcSession> s(raw);
+        CNIIC_TRY(km_rgbw_run(s->km));
+        host_trace().mark("km_run");
+        const int rc_all = cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
+        host_trace().dump();
+        return rc_all;
+    }
     // count_freqs over the pixels (clusterc.rs:21)
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, 24, &table));

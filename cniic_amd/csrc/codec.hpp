@@ -34,12 +34,16 @@ struct CcSession {
     DevBuf keys_d, weight_d;
     DevBuf gbits, gprefix;       // shared palette over several images: index of the colours that occur in ANY of them
     bool local_points = false;   // ... and the points of this session are this image's colours only
+    SpPlan sp;                   // large images: the pixels partitioned by colour super-cell (k_points.hip) instead of the dense table
+    bool sp_mode = false;
     KmRgbwState *km = nullptr;
     ~CcSession();
 };
 // occ_d (optional): summed occupancy nibbles of all ranks (occupancy_pack); the table then holds THIS image's counts
 int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_opts *opts, uint32_t shard, uint32_t nshards,
                void *partials_dev, CcSession **out, const uint32_t *occ_d = nullptr);
+// the same from the image itself, through the super-cell partition (no dense table; 16-byte aligned rgb_d)
+int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, const cniic_kmeans_opts *opts, CcSession **out);
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
               uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
 

@@ -331,6 +331,24 @@ struct CompactPlan {
 // occupancy across ranks: nibble per key (k_hist.hip), and the index of all occupied keys built from the summed nibbles
 int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d);  // u32[2^24] counts -> u32[2^21] nibble words
 int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h);
+int gidx_finish(Ctx *c, uint32_t *wprefix_d, const uint32_t *blocktot_d, uint64_t *total_d);  // 256 blocks of 1024 words
+
+// ---- k_points.hip: pixels partitioned by colour super-cell (large cluster-colors encodes) ----
+struct SpPlan {
+    uint64_t npx = 0, U = 0;     // pixels, distinct colours
+    uint32_t nchunks = 0;
+    DevBuf cnt, pre, bstart;     // pixels per (chunk, bucket), those in earlier chunks, first entry of every bucket
+    DevBuf part, prank;          // u16 per pixel: colour inside its bucket (bucket order), position inside its run (pixel order)
+    DevBuf cell_count;           // distinct colours per K-means cell
+    DevBuf bits, wprefix;        // occupancy bitmap of the 2^24 colours + popcount prefix (GIdx)
+};
+int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan);  // syncs: plan->U
+// distinct colours, counts, initial labels -> the K-means state's cell-major arrays; (gbits, gprefix, Ug): index of the point list
+int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug);
+// final cell-major labels -> label of every pixel, image order
+int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint32_t *cell_start_d, const uint32_t *ckeys_d,
+                    const void *labels_d, bool wide, void *pixlab_d);
 // cell_count_d (optional, 24-bit tables): zeroed u32[32768] receiving the occupied bins per K-means colour cell
 int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d = nullptr);
 // After this call the table holds, for every occupied bin, its RANK (index into the compacted
@@ -346,7 +364,9 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                    const uint32_t *rank_table_d /* dense key -> rank+1 table, or null */, KmRgbwState **out,
                    const uint32_t *cell_count_d = nullptr /* with rank_table_d: points per cell, if already counted */,
                    const void *gbits_d = nullptr, const uint32_t *gprefix_d = nullptr, uint64_t Ug = 0
-                   /* the points are this rank's share of Ug colours: positions in the list of all occupied keys */);
+                   /* the points are this rank's share of Ug colours: positions in the list of all occupied keys */,
+                   bool points_follow = false /* keys_d / weight_d null: the caller writes the cell-major arrays (sp_emit) */);
+void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **ckeys_d, uint32_t **cweight_d);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);
 int km_rgbw_assign(KmRgbwState *s);                       // async: assign + partial sums -> partials

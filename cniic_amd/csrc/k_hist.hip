@@ -384,6 +384,12 @@ __global__ __launch_bounds__(256) void k_gidx_finish(uint32_t *__restrict__ wpre
     for (uint32_t i = threadIdx.x; i < 1024; i += 256) wprefix[blockIdx.x * 1024 + i] += add;
 }
 
+int gidx_finish(Ctx *c, uint32_t *wprefix_d, const uint32_t *blocktot_d, uint64_t *total_d) {
+    hipLaunchKernelGGL(k_gidx_finish, dim3(256), dim3(256), 0, c->stream, wprefix_d, blocktot_d, total_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
 int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d) {
     hipLaunchKernelGGL(k_occ_pack, dim3((1u << 21) / 256), dim3(256), 0, c->stream, table_d, occ_d);
     CNIIC_HIP_TRY(c, hipGetLastError());

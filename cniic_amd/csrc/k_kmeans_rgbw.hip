@@ -69,6 +69,7 @@ struct KmRgbwState {
     const uint32_t *keys = nullptr, *weight = nullptr;  // device, canonical order [0,U)
     DevBuf labels;       // canonical-order labels of [lo,hi) (brute path) / cell-major labels of [0,U) (cells path)
     DevBuf cconst, slabs, partials_own, dstate, cent, members_last, wsum_last;  // the last four are views into resblk
+    DevBuf arena;        // every zero-initialised buffer of the state in one allocation (resblk, partials_own, running, fused_*, moved_list are views)
     DevBuf resblk;       // [KmDevState | cent u32[K] | members u64[K] | wsum u64[K]]: one copy brings the result to the host
     uint64_t res_cent = 0, res_members = 0, res_wsum = 0, res_bytes = 0;
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
@@ -106,14 +107,17 @@ __device__ __forceinline__ CellBox cell_box(uint32_t c) {
 
 // ---------------------------------------------------------------- init (kmeans.rs:61-108)
 __global__ void k_rgbw_init_cent(const uint32_t *__restrict__ keys, uint64_t U, uint32_t K, uint32_t Kpad, uint32_t idbits,
-                                 uint2 *__restrict__ cconst, uint32_t *__restrict__ cent, GIdx gx) {
+                                 uint2 *__restrict__ cconst, uint32_t *__restrict__ cent, GIdx gx, uint32_t *__restrict__ cent_copy,
+                                 uint32_t *__restrict__ moved_list) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && moved_list) moved_list[0] = K;  // before the first update every centroid counts as moved
     if (k < K) {
         // init_centroids (kmeans.rs:101-108): first element of chunk k
         uint64_t ppc = U / K;
         uint64_t first = (k < K - 1) ? U - ((uint64_t)k + 1) * ppc : 0;
         uint32_t ck = gx.bits ? gidx_select(gx, first) : keys[first];
         cent[k] = ck;
+        if (cent_copy) cent_copy[k] = ck;
         cconst[k] = make_cconst(ck, k, idbits);
     } else if (k < Kpad) {
         cconst[k] = make_uint2(0u, 0u);  // padding: key 0 never wins
@@ -246,47 +250,41 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__
     }
 }
 
-// single block: exclusive scan of the cell counts -> cell_start[kNumCells + 1] (+ cursor copy), and
-// the compacted list of NON-EMPTY cells: ne_cell[m] = cell id, ne_start[m] = its first position,
+// Exclusive scan of the cell counts -> cell_start[kNumCells + 1] (+ cursor copy), and the compacted list of
+// NON-EMPTY cells: ne_cell[m] = cell id, ne_start[m] = its first position, ne_cost[m] = start + m * fixed_cost,
 // ne_start[M] = U, *ne_count = M.  Blocks walk the compacted list, never the empty cells.
-__global__ __launch_bounds__(1024) void k_cell_scan(const uint32_t *__restrict__ cell_count, uint32_t *__restrict__ cell_start,
-                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ ne_cell,
-                                                    uint32_t *__restrict__ ne_start, uint32_t *__restrict__ ne_cost,
-                                                    uint32_t *__restrict__ ne_count, uint32_t fixed_cost) {
-    __shared__ uint32_t sh[1024], sh2[1024];
-    constexpr uint32_t per = kNumCells / 1024;  // 32 consecutive cells per thread, held in registers
-    const uint32_t lo = threadIdx.x * per;
-    uint32_t v[per];
-    const uint4 *src = reinterpret_cast<const uint4 *>(cell_count + lo);
-#pragma unroll
-    for (uint32_t i = 0; i < per / 4; i++) { uint4 q = src[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
-    uint32_t s = 0, z = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < per; i++) { s += v[i]; z += v[i] != 0; }
-    // two block scans by wave shuffles (a Hillis-Steele loop over LDS took 20 barriers and 58 us)
-    uint32_t run = block_exclusive_scan<1024>(s, sh), m = block_exclusive_scan<1024>(z, sh2);
-    if (threadIdx.x == 1023) { sh[1023] = run + s; sh2[1023] = m + z; }
-    __syncthreads();
-    uint32_t st[per];
-#pragma unroll
-    for (uint32_t i = 0; i < per; i++) {
-        st[i] = run;
-        if (v[i]) { ne_cell[m] = lo + i; ne_start[m] = run; ne_cost[m] = run + m * fixed_cost; m++; }
-        run += v[i];
+// Two launches of kNumCells / 64 one-wave blocks (a single 1024-thread block took 57 us: ~10^5 scattered store
+// requests from one CU): per 64 cells (points, non-empty cells), then every wave adds up the groups before its own.
+constexpr uint32_t kCellGroups = kNumCells / 64;
+__global__ __launch_bounds__(64) void k_cell_totals(const uint32_t *__restrict__ cell_count, uint2 *__restrict__ tot) {
+    const uint32_t v = cell_count[blockIdx.x * 64 + threadIdx.x];
+    const uint32_t sum = wave_reduce_sum(v);
+    const uint32_t ne = (uint32_t)__popcll(__ballot(v != 0));
+    if (threadIdx.x == 0) tot[blockIdx.x] = make_uint2(sum, ne);
+}
+__global__ __launch_bounds__(64) void k_cell_scan(const uint32_t *__restrict__ cell_count, const uint2 *__restrict__ tot,
+                                                  uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cursor,
+                                                  uint32_t *__restrict__ ne_cell, uint32_t *__restrict__ ne_start,
+                                                  uint32_t *__restrict__ ne_cost, uint32_t *__restrict__ ne_count, uint32_t fixed_cost) {
+    const uint32_t lane = threadIdx.x, grp = blockIdx.x;
+    uint32_t ps = 0, pn = 0;
+    for (uint32_t g = lane; g < grp; g += 64) { const uint2 t = tot[g]; ps += t.x; pn += t.y; }
+    const uint32_t base = __shfl(wave_reduce_sum(ps), 0, 64), nbase = __shfl(wave_reduce_sum(pn), 0, 64);
+    const uint32_t cell = grp * 64 + lane, v = cell_count[cell];
+    const uint32_t start = base + wave_inclusive_scan(v) - v;
+    cell_start[cell] = start;
+    if (cursor) cursor[cell] = start;
+    const unsigned long long nzm = __ballot(v != 0);
+    if (v) {
+        const uint32_t m = nbase + (uint32_t)__popcll(nzm & ((1ull << lane) - 1ull));
+        ne_cell[m] = cell; ne_start[m] = start; ne_cost[m] = start + m * fixed_cost;
     }
-    uint4 *d1 = reinterpret_cast<uint4 *>(cell_start + lo);
-    uint4 *d2 = cursor ? reinterpret_cast<uint4 *>(cursor + lo) : nullptr;
-#pragma unroll
-    for (uint32_t i = 0; i < per / 4; i++) {
-        const uint4 q = make_uint4(st[4 * i], st[4 * i + 1], st[4 * i + 2], st[4 * i + 3]);
-        d1[i] = q;
-        if (d2) d2[i] = q;
-    }
-    if (threadIdx.x == 1023) {
-        cell_start[kNumCells] = sh[1023];
-        ne_start[sh2[1023]] = sh[1023];
-        ne_cost[sh2[1023]] = sh[1023] + sh2[1023] * fixed_cost;
-        *ne_count = sh2[1023];
+    if (grp == kCellGroups - 1 && lane == 63) {
+        const uint32_t U = start + v, M = nbase + (uint32_t)__popcll(nzm);
+        cell_start[kNumCells] = U;
+        ne_start[M] = U;
+        ne_cost[M] = U + M * fixed_cost;
+        *ne_count = M;
     }
 }
 
@@ -995,9 +993,11 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
                    const uint32_t *rank_table_d, KmRgbwState **out, const uint32_t *cell_count_d, const void *gbits_d,
-                   const uint32_t *gprefix_d, uint64_t Ug) {
+                   const uint32_t *gprefix_d, uint64_t Ug, bool points_follow) {
     if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
-    if (gbits_d && (!rank_table_d || nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
+    if (points_follow && (!gbits_d || !cell_count_d || nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
+        return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: points written by the caller need the cell counts and the colour index");
+    if (!points_follow && gbits_d && (!rank_table_d || nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
         return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: a share of a larger point list needs the table-driven cells path, unsharded");
     const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
     const uint64_t Ulist = gbits_d ? Ug : U;  // length of the reference's point list (init chunks, reseed index)
@@ -1025,24 +1025,49 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->res_members = s->res_cent + (((uint64_t)K * 4 + 7) & ~7ull);
     s->res_wsum = s->res_members + (uint64_t)K * 8;
     s->res_bytes = s->res_wsum + (uint64_t)K * 8;
-    KM_ALLOC(s->resblk, s->res_bytes);
+    // one zeroed arena (one fill instead of seven): result block | own partials | running sums | the fused loop's
+    // buffers | moved list; the centroid kernel below writes the non-zero parts
+    s->fused = s->cells && !s->wide && !(getenv("CNIIC_KM_UNFUSED") && atoi(getenv("CNIIC_KM_UNFUSED")));
+    {
+        auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
+        const uint64_t o_part = up(s->res_bytes), o_run = o_part + up(partials_dev ? 0 : W * 8), o_fp = o_run + up(s->cells ? W * 8 : 0);
+        const uint64_t o_fr = o_fp + up(s->fused ? 3 * W * 8 : 0), o_fc = o_fr + up(s->fused ? 2 * W * 8 : 0);
+        const uint64_t o_mv = o_fc + up(s->fused ? 2 * (uint64_t)K * 4 : 0), total = o_mv + up(s->cells ? ((uint64_t)K + 1) * 4 : 0);
+        KM_ALLOC(s->arena, total);
+        (void)hipMemsetAsync(s->arena.p, 0, total, c->stream);
+        uint8_t *a = s->arena.as<uint8_t>();
+        s->resblk.view(a, s->res_bytes);
+        if (partials_dev) {
+            s->partials = reinterpret_cast<uint64_t *>(partials_dev);
+            (void)hipMemsetAsync(s->partials, 0, W * 8, c->stream);
+        } else {
+            s->partials_own.view(a + o_part, W * 8);
+            s->partials = s->partials_own.as<uint64_t>();
+        }
+        if (s->cells) {
+            s->running.view(a + o_run, W * 8);
+            s->moved_list.view(a + o_mv, ((uint64_t)K + 1) * 4);
+        }
+        if (s->fused) {
+            s->fused_partials.view(a + o_fp, 3 * W * 8);
+            s->fused_running.view(a + o_fr, 2 * W * 8);
+            s->fused_cent.view(a + o_fc, 2 * (uint64_t)K * 4);
+        }
+    }
     s->dstate.view(s->resblk.p, sizeof(KmDevState));
     s->cent.view(static_cast<uint8_t *>(s->resblk.p) + s->res_cent, (uint64_t)K * 4);
     s->members_last.view(static_cast<uint8_t *>(s->resblk.p) + s->res_members, (uint64_t)K * 8);
     s->wsum_last.view(static_cast<uint8_t *>(s->resblk.p) + s->res_wsum, (uint64_t)K * 8);
-    if (partials_dev) s->partials = reinterpret_cast<uint64_t *>(partials_dev);
-    else { KM_ALLOC(s->partials_own, W * 8); s->partials = s->partials_own.as<uint64_t>(); }
-    (void)hipMemsetAsync(s->partials, 0, W * 8, c->stream);
-    (void)hipMemsetAsync(s->dstate.p, 0, sizeof(KmDevState), c->stream);
     hipLaunchKernelGGL(k_rgbw_init_cent, dim3(ceil_div(s->Kpad, 256)), dim3(256), 0, c->stream, keys_d, Ulist, K, s->Kpad, s->idbits,
-                       s->cconst.as<uint2>(), s->cent.as<uint32_t>(), s->gidx);
+                       s->cconst.as<uint2>(), s->cent.as<uint32_t>(), s->gidx, s->fused ? s->fused_cent.as<uint32_t>() : (uint32_t *)nullptr,
+                       s->cells ? s->moved_list.as<uint32_t>() : (uint32_t *)nullptr);
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, 1024), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
-        KM_ALLOC(s->crank, U * 4);
+        if (!points_follow) KM_ALLOC(s->crank, U * 4);
         KM_ALLOC(s->cell_start, ((uint64_t)kNumCells + 1) * 4);
         KM_ALLOC(s->ne_cell, (uint64_t)kNumCells * 4);
         KM_ALLOC(s->ne_start, ((uint64_t)kNumCells + 1) * 4);
@@ -1052,32 +1077,26 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->cell_piv, (uint64_t)kNumCells * 4);
         KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
-        KM_ALLOC(s->moved_list, ((uint64_t)K + 1) * 4);
-        // before the first update every centroid counts as moved
-        (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s->moved_list.p), (int)K, 1, c->stream);
-        KM_ALLOC(s->running, W * 8);
-        s->fused = !s->wide && !(getenv("CNIIC_KM_UNFUSED") && atoi(getenv("CNIIC_KM_UNFUSED")));
-        if (s->fused) {
-            KM_ALLOC(s->fused_partials, 3 * W * 8);
-            KM_ALLOC(s->fused_running, 2 * W * 8);
-            KM_ALLOC(s->fused_cent, 2 * (uint64_t)K * 4);
-            (void)hipMemsetAsync(s->fused_partials.p, 0, 3 * W * 8, c->stream);
-            (void)hipMemsetAsync(s->fused_running.p, 0, 2 * W * 8, c->stream);
-            (void)hipMemcpyAsync(s->fused_cent.p, s->cent.p, (uint64_t)K * 4, hipMemcpyDeviceToDevice, c->stream);  // the initial centroids
-        }
-        DevBuf count, cursor;
+        DevBuf count, cursor, cell_tot;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
-        (void)hipMemsetAsync(s->running.p, 0, W * 8, c->stream);
+        KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8);
         uint32_t fixed_cost = kCellFixedCost;
         if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knob
-        if (rank_table_d) {
+        if (points_follow) {
+            // the caller's partition (k_points.hip) writes ckeys / cweight / labels itself, from cell_start
+            hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, cell_count_d, cell_tot.as<uint2>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, cell_count_d, (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
+                               (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
+                               s->ne_count.as<uint32_t>(), fixed_cost);
+        } else if (rank_table_d) {
             // codec path: the dense colour table (key -> canonical rank + 1) is walked cell by cell
             const uint32_t *cnt = cell_count_d;  // counted by the compaction on its way, else one more walk of the table
             if (!cnt) {
                 hipLaunchKernelGGL(k_cells_count_tbl, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, count.as<uint32_t>());
                 cnt = count.as<uint32_t>();
             }
-            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, cnt, s->cell_start.as<uint32_t>(),
+            hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, cnt, cell_tot.as<uint2>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, cnt, (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
                                (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
                                s->ne_count.as<uint32_t>(), fixed_cost);
             if (s->wide)
@@ -1094,7 +1113,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
             (void)hipMemsetAsync(count.p, 0, (uint64_t)kNumCells * 4, c->stream);
             const uint32_t g = grid_1d(U);
             hipLaunchKernelGGL(k_cell_count, dim3(g), dim3(256), 0, c->stream, keys_d, U, count.as<uint32_t>());
-            hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), s->cell_start.as<uint32_t>(),
+            hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, count.as<uint32_t>(), cell_tot.as<uint2>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, count.as<uint32_t>(), (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
                                cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
                                s->ne_count.as<uint32_t>(), fixed_cost);
             hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
@@ -1451,6 +1471,13 @@ int km_rgbw_import_labels(KmRgbwState *s, const void *src_d) {
 }
 
 uint64_t km_rgbw_points(KmRgbwState *s) { return s->U; }
+
+// the cell-major arrays (cells path): first position of every cell, colours, pixel counts
+void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **ckeys_d, uint32_t **cweight_d) {
+    *cell_start_d = s->cell_start.as<uint32_t>();
+    *ckeys_d = s->ckeys.as<uint32_t>();
+    *cweight_d = s->cweight.as<uint32_t>();
+}
 
 // cell-major label array of all U points (cells path): the buffer ranks all-gather over
 void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes) {

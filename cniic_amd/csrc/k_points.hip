@@ -1,0 +1,441 @@
+// k_points.hip -- the front and back end of ClusterColors::encode around the K-means, for large images
+// (reference: count_freqs of the pixels, src/utils.rs:4-16 called at src/codec/clusterc.rs:21-24, and the
+// colour -> centroid-colour remap of every pixel, clusterc.rs:31-47).
+//
+// What the K-means (k_kmeans_rgbw.hip) wants is the list of DISTINCT colours with their pixel counts in
+// cell-major order (cell_of: 32^3 colour cells, the 4^3 cells of a 32^3-colour "super-cell" consecutive), and
+// what Huffman wants afterwards is the cluster label of every pixel.  Both are a histogram / a lookup over
+// 2^24 colours, far beyond LDS, and scattered 2- or 4-byte accesses to HBM-resident tables are bound by the
+// number of L2 requests (one per lane), not by bytes.  So the pixels are partitioned ONCE by super-cell
+// (512 buckets), staged through LDS so that every global access is a run of consecutive addresses:
+//
+//   k_sp_count     per 64 Ki-pixel chunk: pixels per bucket (LDS histogram)                     read 3 B/px
+//   k_sp_colscan / k_sp_bstart   where each (chunk, bucket) run starts
+//   k_sp_scatter   per chunk: 15-bit colour-in-bucket of every pixel, sorted by bucket in LDS and written as
+//                  512 runs; the pixel's position inside its run goes to prank[pixel]          read 3, write 2 + 2 B/px
+//   k_sp_hist<0>   per bucket: LDS histogram of its 2^15 colours -> occupied colours per cell, occupancy bitmap
+//   (bitmap -> popcount prefix = GIdx: rank of a colour in the ascending list of all colours = the
+//    reference's point order, used for init_assignment / init_centroids / the reseed index)
+//   k_sp_hist<1>   per bucket again: the distinct colours, counts and initial labels, written cell-major
+//   ... K-means ...
+//   k_sp_partlab   per bucket: label of every partitioned pixel from an LDS table of the bucket's colours
+//   k_sp_pixlab    per chunk: its 512 label runs into LDS, each pixel picks run[prank]  -> label stream
+//
+// No atomics on global memory, no table of 2^24 entries, and every pixel's label is found without a random
+// read.  Results are identical to the dense-table path (k_hist.hip + k_cells_write_tbl + k_pixel_labels): the
+// point set, weights, initial labels and cell order are the same.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace cniic {
+
+constexpr uint32_t kSpBuckets = 512;           // super-cells: r[7:5] g[7:5] b[7:5]
+constexpr uint32_t kSpBins = 1u << 15;         // colours of a super-cell
+constexpr uint32_t kSpChunk = 1u << 16;        // pixels per chunk: a position inside a run fits 16 bits
+constexpr int kSpThreads = 1024;
+constexpr uint32_t kSpWaves = kSpThreads / 64;
+
+__device__ __forceinline__ uint32_t sp_bucket(uint32_t key) {
+    return (((key >> 21) & 7u) << 6) | (((key >> 13) & 7u) << 3) | ((key >> 5) & 7u);
+}
+// colour inside its super-cell, cell-major: cell within the super-cell (cell_of's low 6 bits) << 9 | colour within the cell
+__device__ __forceinline__ uint32_t sp_bin(uint32_t key) {
+    const uint32_t r = (key >> 16) & 31u, g = (key >> 8) & 31u, b = key & 31u;
+    return ((r >> 3) << 13) | ((g >> 3) << 11) | ((b >> 3) << 9) | ((r & 7u) << 6) | ((g & 7u) << 3) | (b & 7u);
+}
+__device__ __forceinline__ uint32_t sp_key(uint32_t bucket, uint32_t bin) {
+    const uint32_t r = (((bucket >> 6) & 7u) << 5) | (((bin >> 13) & 3u) << 3) | ((bin >> 6) & 7u);
+    const uint32_t g = (((bucket >> 3) & 7u) << 5) | (((bin >> 11) & 3u) << 3) | ((bin >> 3) & 7u);
+    const uint32_t b = ((bucket & 7u) << 5) | (((bin >> 9) & 3u) << 3) | (bin & 7u);
+    return (r << 16) | (g << 8) | b;
+}
+
+// exclusive scan of 512 values held one per thread by threads 0..511 of a 1024-thread block; all threads call
+__device__ __forceinline__ uint32_t scan512(uint32_t v, uint32_t *wsum) { return block_exclusive_scan<kSpThreads>(v, wsum); }
+
+// pixels of chunk c: [c * kSpChunk, min(npx, (c + 1) * kSpChunk)); thread t takes the 16-pixel groups t, t + 1024, ...
+template <typename F> __device__ __forceinline__ void sp_for_pixels(const uint8_t *__restrict__ rgb, uint64_t npx, F &&f) {
+    const uint64_t p0 = (uint64_t)blockIdx.x * kSpChunk, p1 = min(npx, p0 + kSpChunk);
+    const uint4 *v = reinterpret_cast<const uint4 *>(rgb);
+    for (uint64_t g = p0 / 16 + threadIdx.x; g * 16 < p1; g += kSpThreads) {
+        uint32_t key[16];
+        if (g * 16 + 16 <= p1) {
+            load16px_keys(v + 3 * g, key);
+            f(g * 16, key, 16u);
+        } else {  // the image's last, partial group
+            const uint32_t m = (uint32_t)(p1 - g * 16);
+            for (uint32_t i = 0; i < 16; i++) key[i] = i < m ? rgb_key(rgb + 3 * (g * 16 + i)) : 0u;
+            f(g * 16, key, m);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSpThreads) void k_sp_count(const uint8_t *__restrict__ rgb, uint64_t npx, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t h[kSpBuckets];
+    if (threadIdx.x < kSpBuckets) h[threadIdx.x] = 0;
+    __syncthreads();
+    sp_for_pixels(rgb, npx, [&](uint64_t, const uint32_t (&key)[16], uint32_t m) {
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++)
+            if (i < m) atomicAdd(&h[sp_bucket(key[i])], 1u);
+    });
+    __syncthreads();
+    if (threadIdx.x < kSpBuckets) cnt[(size_t)blockIdx.x * kSpBuckets + threadIdx.x] = h[threadIdx.x];
+}
+
+// one block per bucket: pre[c][b] = pixels of bucket b in the chunks before c; total[b]
+__global__ __launch_bounds__(256) void k_sp_colscan(const uint32_t *__restrict__ cnt, uint32_t nchunks, uint32_t *__restrict__ pre,
+                                                    uint32_t *__restrict__ total) {
+    __shared__ uint32_t wsum[256 / 64];
+    const uint32_t b = blockIdx.x, per = (nchunks + 255) / 256;
+    const uint32_t c0 = threadIdx.x * per, c1 = min(c0 + per, nchunks);
+    uint32_t s = 0;
+    for (uint32_t c = c0; c < c1; c++) s += cnt[(size_t)c * kSpBuckets + b];
+    uint32_t run = block_exclusive_scan<256>(s, wsum);
+    for (uint32_t c = c0; c < c1; c++) {
+        pre[(size_t)c * kSpBuckets + b] = run;
+        run += cnt[(size_t)c * kSpBuckets + b];
+    }
+    if (threadIdx.x == 255) total[b] = run;  // (the last thread's range ends the column, or is empty and holds the sum)
+}
+
+__global__ __launch_bounds__(kSpBuckets) void k_sp_bstart(const uint32_t *__restrict__ total, uint32_t *__restrict__ bstart) {
+    __shared__ uint32_t wsum[kSpBuckets / 64];
+    const uint32_t t = total[threadIdx.x];
+    const uint32_t ex = block_exclusive_scan<kSpBuckets>(t, wsum);
+    bstart[threadIdx.x] = ex;
+    if (threadIdx.x == kSpBuckets - 1) bstart[kSpBuckets] = ex + t;
+}
+
+// LDS (dynamic): stage u16[kSpChunk] | off u32[kSpBuckets] | cur u32[kSpBuckets]
+__global__ __launch_bounds__(kSpThreads) void k_sp_scatter(const uint8_t *__restrict__ rgb, uint64_t npx, const uint32_t *__restrict__ cnt,
+                                                           const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bstart,
+                                                           uint16_t *__restrict__ part, uint16_t *__restrict__ prank) {
+    extern __shared__ __align__(16) uint8_t sp_lds[];
+    uint16_t *stage = reinterpret_cast<uint16_t *>(sp_lds);
+    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * 2);
+    uint32_t *cur = off + kSpBuckets;
+    __shared__ uint32_t wsum[kSpWaves];
+    const uint32_t *mycnt = cnt + (size_t)blockIdx.x * kSpBuckets;
+    const uint32_t n_b = threadIdx.x < kSpBuckets ? mycnt[threadIdx.x] : 0u;
+    const uint32_t ex = scan512(n_b, wsum);
+    if (threadIdx.x < kSpBuckets) { off[threadIdx.x] = ex; cur[threadIdx.x] = 0; }
+    __syncthreads();
+    sp_for_pixels(rgb, npx, [&](uint64_t first, const uint32_t (&key)[16], uint32_t m) {
+        uint32_t rk[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            rk[i] = 0;
+            if (i < m) {
+                const uint32_t b = sp_bucket(key[i]);
+                rk[i] = atomicAdd(&cur[b], 1u);  // position inside the (chunk, bucket) run: any order, remembered per pixel
+                stage[off[b] + rk[i]] = (uint16_t)sp_bin(key[i]);
+            }
+        }
+        if (m == 16) {
+            uint4 *d = reinterpret_cast<uint4 *>(prank + first);
+            d[0] = make_uint4(rk[0] | (rk[1] << 16), rk[2] | (rk[3] << 16), rk[4] | (rk[5] << 16), rk[6] | (rk[7] << 16));
+            d[1] = make_uint4(rk[8] | (rk[9] << 16), rk[10] | (rk[11] << 16), rk[12] | (rk[13] << 16), rk[14] | (rk[15] << 16));
+        } else {
+            for (uint32_t i = 0; i < m; i++) prank[first + i] = (uint16_t)rk[i];
+        }
+    });
+    __syncthreads();
+    // the chunk's 512 runs go out, each to consecutive addresses
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t *mypre = pre + (size_t)blockIdx.x * kSpBuckets;
+    for (uint32_t b = wv; b < kSpBuckets; b += kSpWaves) {
+        const uint32_t n = mycnt[b];
+        if (n == 0) continue;
+        const uint16_t *src = stage + off[b];
+        uint16_t *dst = part + (size_t)bstart[b] + mypre[b];
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
+// entries [s, e) of a u16 stream, four per step where the address allows (8-byte aligned), else one by one
+template <typename F> __device__ __forceinline__ void sp_for_entries(const uint16_t *__restrict__ part, uint64_t s, uint64_t e, F &&f) {
+    const uint64_t a = min(e, (s + 3) & ~3ull), z = a + ((e - a) & ~3ull);
+    for (uint64_t i = s + threadIdx.x; i < a; i += kSpThreads) { const uint32_t v = part[i]; f(i, v, v, v, v, 1u); }
+    for (uint64_t i = a + 4 * (uint64_t)threadIdx.x; i < z; i += 4 * kSpThreads) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(part + i);
+        f(i, q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, 4u);
+    }
+    for (uint64_t i = z + threadIdx.x; i < e; i += kSpThreads) { const uint32_t v = part[i]; f(i, v, v, v, v, 1u); }
+}
+
+// LDS histogram of one bucket's colours.  A flat image puts every pixel of a wave into one bin: equal
+// neighbours are added together, and a wave whose 256 entries are all the same colour adds once.
+__device__ __forceinline__ void sp_bucket_hist(const uint16_t *__restrict__ part, uint64_t s, uint64_t e, uint32_t *hist) {
+    for (uint32_t i = threadIdx.x; i < kSpBins; i += kSpThreads) hist[i] = 0;
+    __syncthreads();
+    sp_for_entries(part, s, e, [&](uint64_t, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t m) {
+        if (m == 1) { atomicAdd(&hist[a], 1u); return; }
+        const bool same = a == b && b == c && c == d;
+        const uint32_t first = __builtin_amdgcn_readfirstlane(a);
+        if (__all(same && a == first) && __popcll(__ballot(1)) == 64) {
+            if ((threadIdx.x & 63) == 0) atomicAdd(&hist[a], 256u);
+        } else if (same) {
+            atomicAdd(&hist[a], 4u);
+        } else {
+            atomicAdd(&hist[a], 1u); atomicAdd(&hist[b], 1u); atomicAdd(&hist[c], 1u); atomicAdd(&hist[d], 1u);
+        }
+    });
+    __syncthreads();
+}
+
+struct SpEmit {             // k_sp_hist<true>: where the distinct colours go (the K-means state's cell-major arrays)
+    const uint32_t *cell_start;
+    uint32_t *ckeys, *cweight;
+    void *labels;
+    uint32_t K, wide;
+    GIdx gx;
+};
+
+// One block per bucket.  EMIT = false: occupied colours per cell -> cell_count[bucket * 64 + cell], occupancy bitmap
+// words of the bucket.  EMIT = true: the distinct colours, counts and initial labels, in cell-major order.
+template <bool EMIT>
+__global__ __launch_bounds__(kSpThreads) void k_sp_hist(const uint16_t *__restrict__ part, const uint32_t *__restrict__ bstart,
+                                                        uint32_t *__restrict__ cell_count, uint32_t *__restrict__ bits32, SpEmit em) {
+    extern __shared__ __align__(16) uint8_t sp_lds[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sp_lds);
+    __shared__ uint32_t wsum[kSpWaves];
+    const uint32_t bucket = blockIdx.x;
+    const uint64_t s = bstart[bucket], e = bstart[bucket + 1];
+    if (s == e) {  // no pixel here: no colours (the K-means never looks at an empty cell), but the bitmap words are ours
+        if (!EMIT) {
+            if (threadIdx.x < 64) cell_count[bucket * 64 + threadIdx.x] = 0;
+            const uint32_t r5 = threadIdx.x >> 5, g5 = threadIdx.x & 31;
+            const uint32_t R = (((bucket >> 6) & 7u) << 5) | r5, G = (((bucket >> 3) & 7u) << 5) | g5;
+            bits32[(R << 11) | (G << 3) | (bucket & 7u)] = 0;
+        }
+        return;
+    }
+    sp_bucket_hist(part, s, e, hist);
+    // thread t owns bins [32 t, 32 t + 32): half a row of one cell (16 threads per cell)
+    uint32_t nz = 0;
+    const uint32_t b0 = threadIdx.x * 32;
+    if (!EMIT) {
+#pragma unroll
+        for (uint32_t i = 0; i < 32; i++) nz += hist[b0 + i] != 0;
+        uint32_t cell_nz = nz;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) cell_nz += __shfl_xor(cell_nz, o, 64);
+        if ((threadIdx.x & 15) == 0) cell_count[bucket * 64 + (threadIdx.x >> 4)] = cell_nz;
+        // bitmap: thread (r5, g5) gathers the 32 b values of its colour row
+        const uint32_t r5 = threadIdx.x >> 5, g5 = threadIdx.x & 31;
+        uint32_t word = 0;
+#pragma unroll
+        for (uint32_t bq = 0; bq < 4; bq++) {
+            const uint32_t base = ((r5 >> 3) << 13) | ((g5 >> 3) << 11) | (bq << 9) | ((r5 & 7u) << 6) | ((g5 & 7u) << 3);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) word |= (hist[base + j] != 0 ? 1u : 0u) << (bq * 8 + j);
+        }
+        const uint32_t R = (((bucket >> 6) & 7u) << 5) | r5, G = (((bucket >> 3) & 7u) << 5) | g5;
+        bits32[(R << 11) | (G << 3) | (bucket & 7u)] = word;
+    } else {
+        // wave w owns bins [2048 w, 2048 w + 2048) = 4 cells, 64 at a time with lane <-> bin: the occupied lanes of one
+        // step write consecutive positions (one or two lines per store), and share 8 bitmap words for the rank
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        uint32_t mine = 0;
+        for (uint32_t st = 0; st < 32; st++) mine += (uint32_t)__popcll(__ballot(hist[wv * 2048 + st * 64 + lane] != 0));
+        if (lane == 0) wsum[wv] = mine;
+        __syncthreads();
+        uint32_t pos0 = em.cell_start[bucket * 64];
+        for (uint32_t i = 0; i < wv; i++) pos0 += wsum[i];
+        const uint32_t U = (uint32_t)em.gx.U, ppc = U / em.K;
+        const float rcp = 1.0f / (float)ppc;
+        for (uint32_t st = 0; st < 32; st++) {
+            const uint32_t bin = wv * 2048 + st * 64 + lane, v = hist[bin];
+            const unsigned long long bm = __ballot(v != 0);
+            if (v) {
+                const uint32_t pos = pos0 + (uint32_t)__popcll(bm & lt_mask);
+                const uint32_t key = sp_key(bucket, bin);
+                em.ckeys[pos] = key;
+                em.cweight[pos] = v;
+                const uint32_t lab = init_label24(gidx_rank(em.gx, key), U, em.K, ppc, rcp);  // init_assignment kmeans.rs:61-78
+                if (em.wide) static_cast<uint16_t *>(em.labels)[pos] = (uint16_t)lab;
+                else static_cast<uint8_t *>(em.labels)[pos] = (uint8_t)lab;
+            }
+            pos0 += (uint32_t)__popcll(bm);
+        }
+    }
+}
+
+// bits (u64[2^18]) -> wprefix inside blocks of 1024 words + blocktot; k_gidx_finish (k_hist.hip) completes it
+__global__ __launch_bounds__(256) void k_bits_prefix(const unsigned long long *__restrict__ bits, uint32_t *__restrict__ wprefix,
+                                                     uint32_t *__restrict__ blocktot) {
+    __shared__ uint32_t wsum[256 / 64];
+    const uint32_t w0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t cnt[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { cnt[q] = (uint32_t)__popcll(bits[w0 + q]); mine += cnt[q]; }
+    uint32_t run = block_exclusive_scan<256>(mine, wsum);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { wprefix[w0 + q] = run; run += cnt[q]; }
+    if (threadIdx.x == 255) blocktot[blockIdx.x] = run;
+}
+
+// ---- back end.  One block per bucket: LDS table bin -> final label from the bucket's points, then the label of
+// every partitioned pixel, in partition order.
+template <typename LabelT>
+__global__ __launch_bounds__(kSpThreads) void k_sp_partlab(const uint16_t *__restrict__ part, const uint32_t *__restrict__ bstart,
+                                                           const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ ckeys,
+                                                           const LabelT *__restrict__ labels, LabelT *__restrict__ partlab) {
+    extern __shared__ __align__(16) uint8_t sp_lds[];
+    LabelT *lut = reinterpret_cast<LabelT *>(sp_lds);
+    const uint32_t bucket = blockIdx.x;
+    const uint64_t s = bstart[bucket], e = bstart[bucket + 1];
+    if (s == e) return;
+    const uint32_t q0 = cell_start[bucket * 64], q1 = cell_start[bucket * 64 + 64];
+    for (uint32_t i = q0 + threadIdx.x; i < q1; i += kSpThreads) lut[sp_bin(ckeys[i])] = labels[i];
+    __syncthreads();
+    sp_for_entries(part, s, e, [&](uint64_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t m) {
+        if (m == 1) { partlab[i] = lut[a]; return; }
+        if (sizeof(LabelT) == 1) {  // i is a multiple of 4
+            *reinterpret_cast<uint32_t *>(partlab + i) = (uint32_t)lut[a] | ((uint32_t)lut[b] << 8) | ((uint32_t)lut[c] << 16) | ((uint32_t)lut[d] << 24);
+        } else {
+            *reinterpret_cast<uint2 *>(partlab + i) = make_uint2((uint32_t)lut[a] | ((uint32_t)lut[b] << 16), (uint32_t)lut[c] | ((uint32_t)lut[d] << 16));
+        }
+    });
+}
+
+// One block per chunk: its 512 label runs into LDS, then every pixel picks run(bucket)[prank].
+// LDS (dynamic): stage LabelT[kSpChunk] | off u32[kSpBuckets]
+template <typename LabelT>
+__global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restrict__ rgb, uint64_t npx, const uint32_t *__restrict__ cnt,
+                                                          const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bstart,
+                                                          const LabelT *__restrict__ partlab, const uint16_t *__restrict__ prank,
+                                                          LabelT *__restrict__ pixlab) {
+    extern __shared__ __align__(16) uint8_t sp_lds[];
+    LabelT *stage = reinterpret_cast<LabelT *>(sp_lds);
+    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * sizeof(LabelT));
+    __shared__ uint32_t wsum[kSpWaves];
+    const uint32_t *mycnt = cnt + (size_t)blockIdx.x * kSpBuckets, *mypre = pre + (size_t)blockIdx.x * kSpBuckets;
+    const uint32_t n_b = threadIdx.x < kSpBuckets ? mycnt[threadIdx.x] : 0u;
+    const uint32_t ex = scan512(n_b, wsum);
+    if (threadIdx.x < kSpBuckets) off[threadIdx.x] = ex;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t b = wv; b < kSpBuckets; b += kSpWaves) {
+        const uint32_t n = mycnt[b];
+        if (n == 0) continue;
+        const LabelT *src = partlab + (size_t)bstart[b] + mypre[b];
+        LabelT *dst = stage + off[b];
+        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    sp_for_pixels(rgb, npx, [&](uint64_t first, const uint32_t (&key)[16], uint32_t m) {
+        uint32_t lab[16];
+        if (m == 16) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(prank + first);
+            const uint4 r0 = rp[0], r1 = rp[1];
+            const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) lab[i] = stage[off[sp_bucket(key[i])] + ((rw[i >> 1] >> (16 * (i & 1))) & 0xffffu)];
+            if (sizeof(LabelT) == 1) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) w[j] = lab[4 * j] | (lab[4 * j + 1] << 8) | (lab[4 * j + 2] << 16) | (lab[4 * j + 3] << 24);
+                *reinterpret_cast<uint4 *>(pixlab + first) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                uint4 *d = reinterpret_cast<uint4 *>(pixlab + first);
+                d[0] = make_uint4(lab[0] | (lab[1] << 16), lab[2] | (lab[3] << 16), lab[4] | (lab[5] << 16), lab[6] | (lab[7] << 16));
+                d[1] = make_uint4(lab[8] | (lab[9] << 16), lab[10] | (lab[11] << 16), lab[12] | (lab[13] << 16), lab[14] | (lab[15] << 16));
+            }
+        } else {
+            for (uint32_t i = 0; i < m; i++) pixlab[first + i] = stage[off[sp_bucket(key[i])] + prank[first + i]];
+        }
+    });
+}
+
+// =========================================================================== host
+static int sp_set_lds(Ctx *c) {
+    static bool done = false;  // (function attributes are per process)
+    if (done) return CNIIC_OK;
+    const int big = 140 * 1024;
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_partlab<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_partlab<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_pixlab<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_pixlab<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    done = true;
+    return CNIIC_OK;
+}
+
+// pixels -> partition + occupied colours per cell + occupancy bitmap with its prefix; plan->U on the host (syncs)
+int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
+    if (npx == 0 || (reinterpret_cast<uintptr_t>(rgb_d) & 15)) return c->fail(CNIIC_ERR_BAD_ARG, "sp_build: empty or unaligned image");
+    CNIIC_TRY(sp_set_lds(c));
+    plan->npx = npx;
+    plan->nchunks = (uint32_t)ceil_div(npx, kSpChunk);
+    const uint64_t nc = plan->nchunks;
+    CNIIC_HIP_TRY(c, plan->cnt.alloc(nc * kSpBuckets * 4));
+    CNIIC_HIP_TRY(c, plan->pre.alloc(nc * kSpBuckets * 4));
+    CNIIC_HIP_TRY(c, plan->bstart.alloc(((uint64_t)kSpBuckets + 1) * 4));
+    CNIIC_HIP_TRY(c, plan->part.alloc(npx * 2 + 16));
+    CNIIC_HIP_TRY(c, plan->prank.alloc((npx + 16) * 2));
+    CNIIC_HIP_TRY(c, plan->cell_count.alloc((uint64_t)kNumCells * 4));
+    CNIIC_HIP_TRY(c, plan->bits.alloc((1ull << 18) * 8));
+    CNIIC_HIP_TRY(c, plan->wprefix.alloc((1ull << 18) * 4));
+    DevBuf total, blocktot, tot;
+    CNIIC_HIP_TRY(c, total.alloc((uint64_t)kSpBuckets * 4));
+    CNIIC_HIP_TRY(c, blocktot.alloc(256 * 4));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    hipLaunchKernelGGL(k_sp_count, dim3(plan->nchunks), dim3(kSpThreads), 0, c->stream, rgb_d, npx, plan->cnt.as<uint32_t>());
+    hipLaunchKernelGGL(k_sp_colscan, dim3(kSpBuckets), dim3(256), 0, c->stream, plan->cnt.as<uint32_t>(), plan->nchunks,
+                       plan->pre.as<uint32_t>(), total.as<uint32_t>());
+    hipLaunchKernelGGL(k_sp_bstart, dim3(1), dim3(kSpBuckets), 0, c->stream, total.as<uint32_t>(), plan->bstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_sp_scatter, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8, c->stream, rgb_d, npx,
+                       plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), plan->part.as<uint16_t>(),
+                       plan->prank.as<uint16_t>());
+    hipLaunchKernelGGL(k_sp_hist<false>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
+                       plan->bstart.as<uint32_t>(), plan->cell_count.as<uint32_t>(), plan->bits.as<uint32_t>(), SpEmit{});
+    hipLaunchKernelGGL(k_bits_prefix, dim3(256), dim3(256), 0, c->stream, plan->bits.as<unsigned long long>(), plan->wprefix.as<uint32_t>(),
+                       blocktot.as<uint32_t>());
+    CNIIC_TRY(gidx_finish(c, plan->wprefix.as<uint32_t>(), blocktot.as<uint32_t>(), tot.as<uint64_t>()));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&plan->U, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
+// the distinct colours, counts and initial labels into the K-means state's cell-major arrays (cell_start: its scan of
+// plan->cell_count); gx: the index of the reference's point list (this image's own bitmap, or the union's)
+int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug) {
+    const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
+    hipLaunchKernelGGL(k_sp_hist<true>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
+                       plan->bstart.as<uint32_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr,
+                       SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx});
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// labels_d: the K-means' final cell-major labels -> pixlab_d: label of every pixel in image order
+int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint32_t *cell_start_d, const uint32_t *ckeys_d,
+                    const void *labels_d, bool wide, void *pixlab_d) {
+    DevBuf partlab;
+    const uint64_t lb = wide ? 2 : 1;
+    CNIIC_HIP_TRY(c, partlab.alloc(plan->npx * lb + 16));
+    if (wide) {
+        hipLaunchKernelGGL(k_sp_partlab<uint16_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 2, c->stream, plan->part.as<uint16_t>(),
+                           plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint16_t *>(labels_d), partlab.as<uint16_t>());
+        hipLaunchKernelGGL(k_sp_pixlab<uint16_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 4, c->stream, rgb_d,
+                           plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint16_t>(),
+                           plan->prank.as<uint16_t>(), static_cast<uint16_t *>(pixlab_d));
+    } else {
+        hipLaunchKernelGGL(k_sp_partlab<uint8_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins, c->stream, plan->part.as<uint16_t>(),
+                           plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint8_t *>(labels_d), partlab.as<uint8_t>());
+        hipLaunchKernelGGL(k_sp_pixlab<uint8_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk + kSpBuckets * 4, c->stream, rgb_d,
+                           plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint8_t>(),
+                           plan->prank.as<uint16_t>(), static_cast<uint8_t *>(pixlab_d));
+    }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+}  // namespace cniic

@@ -310,6 +310,50 @@ def test_hilbert_rle_decode_failure_points(ctx):
     assert rc == 0 and np.array_equal(back, img)
 
 
+# ------------------------------------------------------------------ cluster-colors through the super-cell partition
+@pytest.fixture()
+def sp_path(monkeypatch):
+    """route every cluster-colors encode through the pixel partition of k_points.hip, whatever the size"""
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "0")
+
+
+@pytest.mark.parametrize("expr", ["cluster-colors(8)", "ccol(256)", "cluster-colors(300)"])
+@pytest.mark.parametrize("shape", [(7, 5), (48, 40), (100, 75), (301, 299)])
+def test_partition_path_equals_oracle(ctx, sp_path, expr, shape):
+    """odd pixel counts (the 16-pixel groups end in a partial one), more than one 64 Ki-pixel chunk, u16 labels"""
+    from cniic_amd import _lib
+    img = synth_img(*shape, seed=23, levels=200, noise=3)
+    rc, data, st = ctx.encode(expr, img, allow=(_lib.TOO_FEW_POINTS,))
+    rco, edata, est = O.encode(expr, img, mode=O.MODE_L)
+    assert rc == rco
+    if rc == 0:
+        assert data == edata and st["iterations"] == est["iterations"]
+
+
+@pytest.mark.parametrize("kind", ["flat2", "dark", "noise"])
+def test_partition_path_skewed_colour_distributions(ctx, sp_path, monkeypatch, kind):
+    """every pixel in one or two super-cells (one LDS bin takes a whole wave), or spread over all 512"""
+    h, w = 260, 300
+    rng = np.random.default_rng(5)
+    if kind == "flat2":      # two colours: long runs of equal entries in one bucket
+        img = np.zeros((h, w, 3), np.uint8)
+        img[:, w // 3:] = (200, 10, 77)
+        K = 2
+    elif kind == "dark":     # all colours below 32: a single super-cell
+        img = rng.integers(0, 32, (h, w, 3)).astype(np.uint8)
+        K = 16
+    else:
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        K = 64
+    expr = "cluster-colors(%d)" % K
+    rc, data, st = ctx.encode(expr, img)
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", str(1 << 40))   # the dense-table path (checked against the oracle above and elsewhere)
+    rc2, data2, st2 = ctx.encode(expr, img)
+    assert rc == rc2 == 0 and data == data2 and st["iterations"] == st2["iterations"]
+    rco, edata, _ = O.encode(expr, img, mode=O.MODE_L)
+    assert rco == 0 and data == edata
+
+
 @pytest.fixture()
 def gpu_decode(monkeypatch):
     """route every Huffman decode through the parallel GPU decoder, whatever the size"""
