@@ -255,18 +255,22 @@ int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, con
     auto s = std::make_unique<CcSession>();
     s->c = c; s->K = K; s->sp_mode = true;
     CNIIC_TRY(sp_build(c, rgb_d, npx, &s->sp));   // count_freqs (clusterc.rs:21): distinct colours per cell, occupancy bitmap
-    host_trace().mark("sp_build+sync");
-    const uint64_t U = s->sp.U;
-    s->U = U;
-    if (U / K == 0)
-        return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)U, K);
-    // kmeans::cluster (clusterc.rs:28): the point list is known as the bitmap; its cell-major copy is written below
-    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, U, 0, 1, K, opts, nullptr, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->sp.bits.p,
-                             s->sp.wprefix.as<uint32_t>(), U, true));
+    // kmeans::cluster (clusterc.rs:28): the point list is known as the bitmap and its cell-major copy is written below.
+    // The number of distinct colours is still on the device: the state is sized for the most there can be, its
+    // set-up kernels read the count there, and the host only waits for it after all of them are enqueued.
+    const uint64_t Umax = std::min<uint64_t>(npx, 1ull << 24);
+    const uint64_t *U_dev = s->sp.total.as<uint64_t>();
+    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, Umax, 0, 1, K, opts, nullptr, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->sp.bits.p,
+                             s->sp.wprefix.as<uint32_t>(), Umax, true, U_dev));
     uint32_t *cell_start, *ckeys, *cweight;
     km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
     CNIIC_TRY(sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->sp.bits.p,
-                      s->sp.wprefix.as<uint32_t>(), U));
+                      s->sp.wprefix.as<uint32_t>(), U_dev));
+    CNIIC_TRY(sp_wait_count(c, &s->sp));
+    s->U = s->sp.U;
+    if (s->U / K == 0)
+        return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)s->U, K);
+    CNIIC_TRY(km_rgbw_set_points(s->km, s->U));
     host_trace().mark("km_create + emit enq");
     *out = s.release();
     return CNIIC_OK;

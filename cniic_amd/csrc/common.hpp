@@ -126,6 +126,8 @@ struct Ctx {
     void  *pinned_res = nullptr;  // pinned landing area of K-means result blocks (grown on demand)
     uint64_t pinned_res_bytes = 0;
     hipEvent_t res_ev = nullptr;
+    uint64_t *pinned_u = nullptr;  // pinned landing slot of sp_build's distinct-colour count, and the event behind its copy
+    hipEvent_t u_ev = nullptr;
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -341,11 +343,13 @@ struct SpPlan {
     DevBuf part, prank;          // u16 per pixel: colour inside its bucket (bucket order), position inside its run (pixel order)
     DevBuf cell_count;           // distinct colours per K-means cell
     DevBuf bits, wprefix;        // occupancy bitmap of the 2^24 colours + popcount prefix (GIdx)
+    DevBuf total;                // u64 on the device: distinct colours (the kernels of the set-up read it there)
 };
-int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan);  // syncs: plan->U
+int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan);  // asynchronous: the count arrives with sp_wait_count
+int sp_wait_count(Ctx *c, SpPlan *plan);                                  // plan->U on the host (waits for its copy only)
 // distinct colours, counts, initial labels -> the K-means state's cell-major arrays; (gbits, gprefix, Ug): index of the point list
 int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
-            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug);
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, const uint64_t *Ug_dev);
 // final cell-major labels -> label of every pixel, image order
 int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint32_t *cell_start_d, const uint32_t *ckeys_d,
                     const void *labels_d, bool wide, void *pixlab_d);
@@ -365,7 +369,10 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                    const uint32_t *cell_count_d = nullptr /* with rank_table_d: points per cell, if already counted */,
                    const void *gbits_d = nullptr, const uint32_t *gprefix_d = nullptr, uint64_t Ug = 0
                    /* the points are this rank's share of Ug colours: positions in the list of all occupied keys */,
-                   bool points_follow = false /* keys_d / weight_d null: the caller writes the cell-major arrays (sp_emit) */);
+                   bool points_follow = false /* keys_d / weight_d null: the caller writes the cell-major arrays (sp_emit) */,
+                   const uint64_t *points_dev = nullptr /* with points_follow: U and Ug are upper bounds, the count is here
+                                                           on the device; km_rgbw_set_points before anything else */);
+int km_rgbw_set_points(KmRgbwState *s, uint64_t U);
 void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **ckeys_d, uint32_t **cweight_d);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);

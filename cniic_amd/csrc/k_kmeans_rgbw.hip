@@ -108,8 +108,9 @@ __device__ __forceinline__ CellBox cell_box(uint32_t c) {
 // ---------------------------------------------------------------- init (kmeans.rs:61-108)
 __global__ void k_rgbw_init_cent(const uint32_t *__restrict__ keys, uint64_t U, uint32_t K, uint32_t Kpad, uint32_t idbits,
                                  uint2 *__restrict__ cconst, uint32_t *__restrict__ cent, GIdx gx, uint32_t *__restrict__ cent_copy,
-                                 uint32_t *__restrict__ moved_list) {
+                                 uint32_t *__restrict__ moved_list, const uint64_t *__restrict__ U_dev) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (U_dev) U = max(*U_dev, (uint64_t)K);  // the count is still on its way to the host (fewer points than clusters: refused there)
     if (k == 0 && moved_list) moved_list[0] = K;  // before the first update every centroid counts as moved
     if (k < K) {
         // init_centroids (kmeans.rs:101-108): first element of chunk k
@@ -993,7 +994,7 @@ static inline uint32_t grid_1d(uint64_t n, uint32_t cap = 2048) {
 int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uint64_t U, uint32_t shard,
                    uint32_t nshards, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev,
                    const uint32_t *rank_table_d, KmRgbwState **out, const uint32_t *cell_count_d, const void *gbits_d,
-                   const uint32_t *gprefix_d, uint64_t Ug, bool points_follow) {
+                   const uint32_t *gprefix_d, uint64_t Ug, bool points_follow, const uint64_t *points_dev) {
     if (K == 0 || U == 0 || nshards == 0 || shard >= nshards) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: bad sizes");
     if (points_follow && (!gbits_d || !cell_count_d || nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
         return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: points written by the caller need the cell counts and the colour index");
@@ -1001,7 +1002,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: a share of a larger point list needs the table-driven cells path, unsharded");
     const uint64_t lo = U * shard / nshards, hi = U * (shard + 1) / nshards;  // brute path: equal point slices
     const uint64_t Ulist = gbits_d ? Ug : U;  // length of the reference's point list (init chunks, reseed index)
-    if (Ulist / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
+    if (points_dev && !points_follow) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: a device-side point count needs points_follow");
+    if (!points_dev && Ulist / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
                                        (unsigned long long)Ulist, K);
     if (K > 2048) return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 2048 not supported", K);
     if (U >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: too many points");
@@ -1060,7 +1062,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->wsum_last.view(static_cast<uint8_t *>(s->resblk.p) + s->res_wsum, (uint64_t)K * 8);
     hipLaunchKernelGGL(k_rgbw_init_cent, dim3(ceil_div(s->Kpad, 256)), dim3(256), 0, c->stream, keys_d, Ulist, K, s->Kpad, s->idbits,
                        s->cconst.as<uint2>(), s->cent.as<uint32_t>(), s->gidx, s->fused ? s->fused_cent.as<uint32_t>() : (uint32_t *)nullptr,
-                       s->cells ? s->moved_list.as<uint32_t>() : (uint32_t *)nullptr);
+                       s->cells ? s->moved_list.as<uint32_t>() : (uint32_t *)nullptr, points_dev);
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, 1024), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
@@ -1471,6 +1473,15 @@ int km_rgbw_import_labels(KmRgbwState *s, const void *src_d) {
 }
 
 uint64_t km_rgbw_points(KmRgbwState *s) { return s->U; }
+
+// a state created with an upper bound (points_dev): the number of points, now that the host knows it
+int km_rgbw_set_points(KmRgbwState *s, uint64_t U) {
+    if (U == 0 || U > s->U || U / s->K == 0)
+        return s->c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)", (unsigned long long)U, s->K);
+    s->U = U; s->hi = U;
+    if (s->gidx.bits) s->gidx.U = U;
+    return CNIIC_OK;
+}
 
 // the cell-major arrays (cells path): first position of every cell, colours, pixel counts
 void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **ckeys_d, uint32_t **cweight_d) {

@@ -107,19 +107,52 @@ __global__ __launch_bounds__(kSpBuckets) void k_sp_bstart(const uint32_t *__rest
     if (threadIdx.x == kSpBuckets - 1) bstart[kSpBuckets] = ex + t;
 }
 
-// LDS (dynamic): stage u16[kSpChunk] | off u32[kSpBuckets] | cur u32[kSpBuckets]
+// The chunk's pixels sorted by bucket occupy positions [0, n) of the LDS stage; off[b] .. off[b + 1] is bucket b's run
+// (off[kSpBuckets] = n).  Wave w walks the positions [w per, (w + 1) per) 64 at a time, lane <-> position, each lane
+// keeping the bucket of its position (runs are short: the bucket advances about every other step).  STEPS positions
+// per lane are handed over together so that their loads can be in flight at once.  A walk by runs instead costs a
+// dependent round trip to memory per run, and one by rounds over all runs is quadratic when a run is long.
+template <int STEPS, typename F> __device__ __forceinline__ void sp_walk_sorted(const uint32_t *off, uint32_t n, F &&f) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t per = (n + kSpThreads - 1) / kSpThreads * 64;
+    const uint32_t j0 = wv * per, j1 = min(n, j0 + per);
+    if (j0 >= j1) return;
+    const uint32_t jj = min(j0 + lane, j1 - 1);
+    uint32_t lo = 0, hi = kSpBuckets;  // off[lo] <= jj < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= jj) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo, end = off[b + 1];
+    for (uint32_t j = j0 + lane; j < j1; j += 64 * STEPS) {
+        uint32_t jb[STEPS];
+#pragma unroll
+        for (int t = 0; t < STEPS; t++) {
+            const uint32_t q = j + 64 * t;
+            jb[t] = 0xffffffffu;
+            if (q < j1) {
+                while (q >= end) { b++; end = off[b + 1]; }
+                jb[t] = b;
+            }
+        }
+        f(j, jb);
+    }
+}
+
+// LDS (dynamic): stage u16[kSpChunk] | off u32[kSpBuckets + 1] | cur u32[kSpBuckets]
 __global__ __launch_bounds__(kSpThreads) void k_sp_scatter(const uint8_t *__restrict__ rgb, uint64_t npx, const uint32_t *__restrict__ cnt,
                                                            const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bstart,
                                                            uint16_t *__restrict__ part, uint16_t *__restrict__ prank) {
     extern __shared__ __align__(16) uint8_t sp_lds[];
     uint16_t *stage = reinterpret_cast<uint16_t *>(sp_lds);
-    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * 2);
-    uint32_t *cur = off + kSpBuckets;
+    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * 2);  // [kSpBuckets + 1]
+    uint32_t *cur = off + kSpBuckets + 1;
     __shared__ uint32_t wsum[kSpWaves];
     const uint32_t *mycnt = cnt + (size_t)blockIdx.x * kSpBuckets;
     const uint32_t n_b = threadIdx.x < kSpBuckets ? mycnt[threadIdx.x] : 0u;
     const uint32_t ex = scan512(n_b, wsum);
     if (threadIdx.x < kSpBuckets) { off[threadIdx.x] = ex; cur[threadIdx.x] = 0; }
+    if (threadIdx.x == kSpBuckets - 1) off[kSpBuckets] = ex + n_b;
     __syncthreads();
     sp_for_pixels(rgb, npx, [&](uint64_t first, const uint32_t (&key)[16], uint32_t m) {
         uint32_t rk[16];
@@ -141,15 +174,15 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_scatter(const uint8_t *__rest
         }
     });
     __syncthreads();
-    // the chunk's 512 runs go out, each to consecutive addresses
+    // the chunk's 512 runs go out, each to consecutive addresses.  Wave w owns buckets w, w + 16, ...: their sizes and
+    // places are fetched by 32 lanes at once (fetched per bucket they are 32 dependent round trips to memory)
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t *mypre = pre + (size_t)blockIdx.x * kSpBuckets;
-    for (uint32_t b = wv; b < kSpBuckets; b += kSpWaves) {
-        const uint32_t n = mycnt[b];
-        if (n == 0) continue;
-        const uint16_t *src = stage + off[b];
-        uint16_t *dst = part + (size_t)bstart[b] + mypre[b];
-        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
+    const uint32_t mb = wv + kSpWaves * (lane & 31);
+    const uint32_t m_n = mycnt[mb], m_dst = bstart[mb] + mypre[mb], m_off = off[mb];
+    for (uint32_t k = 0; k < kSpBuckets / kSpWaves; k++) {
+        const uint32_t n = __shfl(m_n, k, 64), d0 = __shfl(m_dst, k, 64), o = __shfl(m_off, k, 64);
+        for (uint32_t i = lane; i < n; i += 64) part[(size_t)d0 + i] = stage[o + i];
     }
 }
 
@@ -189,7 +222,8 @@ struct SpEmit {             // k_sp_hist<true>: where the distinct colours go (t
     uint32_t *ckeys, *cweight;
     void *labels;
     uint32_t K, wide;
-    GIdx gx;
+    GIdx gx;                    // (U: read from U_dev)
+    const uint64_t *U_dev;
 };
 
 // One block per bucket.  EMIT = false: occupied colours per cell -> cell_count[bucket * 64 + cell], occupancy bitmap
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_hist(const uint16_t *__restri
         __syncthreads();
         uint32_t pos0 = em.cell_start[bucket * 64];
         for (uint32_t i = 0; i < wv; i++) pos0 += wsum[i];
-        const uint32_t U = (uint32_t)em.gx.U, ppc = U / em.K;
+        const uint32_t U = (uint32_t)*em.U_dev, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
         const float rcp = 1.0f / (float)ppc;
         for (uint32_t st = 0; st < 32; st++) {
             const uint32_t bin = wv * 2048 + st * 64 + lane, v = hist[bin];
@@ -302,7 +336,7 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_partlab(const uint16_t *__res
 }
 
 // One block per chunk: its 512 label runs into LDS, then every pixel picks run(bucket)[prank].
-// LDS (dynamic): stage LabelT[kSpChunk] | off u32[kSpBuckets]
+// LDS (dynamic): stage LabelT[kSpChunk] | off u32[kSpBuckets + 1] | gsrc u32[kSpBuckets]
 template <typename LabelT>
 __global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restrict__ rgb, uint64_t npx, const uint32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ pre, const uint32_t *__restrict__ bstart,
@@ -310,21 +344,26 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restr
                                                           LabelT *__restrict__ pixlab) {
     extern __shared__ __align__(16) uint8_t sp_lds[];
     LabelT *stage = reinterpret_cast<LabelT *>(sp_lds);
-    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * sizeof(LabelT));
+    uint32_t *off = reinterpret_cast<uint32_t *>(sp_lds + (size_t)kSpChunk * sizeof(LabelT));  // [kSpBuckets + 1]
+    uint32_t *gsrc = off + kSpBuckets + 1;
     __shared__ uint32_t wsum[kSpWaves];
     const uint32_t *mycnt = cnt + (size_t)blockIdx.x * kSpBuckets, *mypre = pre + (size_t)blockIdx.x * kSpBuckets;
     const uint32_t n_b = threadIdx.x < kSpBuckets ? mycnt[threadIdx.x] : 0u;
     const uint32_t ex = scan512(n_b, wsum);
     if (threadIdx.x < kSpBuckets) off[threadIdx.x] = ex;
+    if (threadIdx.x == kSpBuckets - 1) off[kSpBuckets] = ex + n_b;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t b = wv; b < kSpBuckets; b += kSpWaves) {
-        const uint32_t n = mycnt[b];
-        if (n == 0) continue;
-        const LabelT *src = partlab + (size_t)bstart[b] + mypre[b];
-        LabelT *dst = stage + off[b];
-        for (uint32_t i = lane; i < n; i += 64) dst[i] = src[i];
-    }
+    // the chunk's 512 label runs come in: gsrc[b] = where bucket b's run of this chunk starts, minus its place in the stage
+    if (threadIdx.x < kSpBuckets) gsrc[threadIdx.x] = bstart[threadIdx.x] + mypre[threadIdx.x] - off[threadIdx.x];
+    __syncthreads();
+    sp_walk_sorted<8>(off, off[kSpBuckets], [&](uint32_t j, const uint32_t (&jb)[8]) {
+        LabelT got[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) got[t] = jb[t] != 0xffffffffu ? partlab[(size_t)(gsrc[jb[t]] + (j + 64 * t))] : (LabelT)0;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (jb[t] != 0xffffffffu) stage[j + 64 * t] = got[t];
+    });
     __syncthreads();
     sp_for_pixels(rgb, npx, [&](uint64_t first, const uint32_t (&key)[16], uint32_t m) {
         uint32_t lab[16];
@@ -366,7 +405,8 @@ static int sp_set_lds(Ctx *c) {
     return CNIIC_OK;
 }
 
-// pixels -> partition + occupied colours per cell + occupancy bitmap with its prefix; plan->U on the host (syncs)
+// pixels -> partition + occupied colours per cell + occupancy bitmap with its prefix.  Nothing waits: the number of
+// distinct colours stays on the device (plan->total) for the set-up kernels that follow, and sp_wait_count fetches it
 int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
     if (npx == 0 || (reinterpret_cast<uintptr_t>(rgb_d) & 15)) return c->fail(CNIIC_ERR_BAD_ARG, "sp_build: empty or unaligned image");
     CNIIC_TRY(sp_set_lds(c));
@@ -381,36 +421,44 @@ int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
     CNIIC_HIP_TRY(c, plan->cell_count.alloc((uint64_t)kNumCells * 4));
     CNIIC_HIP_TRY(c, plan->bits.alloc((1ull << 18) * 8));
     CNIIC_HIP_TRY(c, plan->wprefix.alloc((1ull << 18) * 4));
-    DevBuf total, blocktot, tot;
+    DevBuf total, blocktot;
     CNIIC_HIP_TRY(c, total.alloc((uint64_t)kSpBuckets * 4));
     CNIIC_HIP_TRY(c, blocktot.alloc(256 * 4));
-    CNIIC_HIP_TRY(c, tot.alloc(8));
+    CNIIC_HIP_TRY(c, plan->total.alloc(8));
+    if (!c->pinned_u) CNIIC_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->pinned_u), 64, hipHostMallocDefault));
+    if (!c->u_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->u_ev, hipEventDisableTiming));
     hipLaunchKernelGGL(k_sp_count, dim3(plan->nchunks), dim3(kSpThreads), 0, c->stream, rgb_d, npx, plan->cnt.as<uint32_t>());
     hipLaunchKernelGGL(k_sp_colscan, dim3(kSpBuckets), dim3(256), 0, c->stream, plan->cnt.as<uint32_t>(), plan->nchunks,
                        plan->pre.as<uint32_t>(), total.as<uint32_t>());
     hipLaunchKernelGGL(k_sp_bstart, dim3(1), dim3(kSpBuckets), 0, c->stream, total.as<uint32_t>(), plan->bstart.as<uint32_t>());
-    hipLaunchKernelGGL(k_sp_scatter, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8, c->stream, rgb_d, npx,
+    hipLaunchKernelGGL(k_sp_scatter, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8 + 16, c->stream, rgb_d, npx,
                        plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), plan->part.as<uint16_t>(),
                        plan->prank.as<uint16_t>());
     hipLaunchKernelGGL(k_sp_hist<false>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
                        plan->bstart.as<uint32_t>(), plan->cell_count.as<uint32_t>(), plan->bits.as<uint32_t>(), SpEmit{});
     hipLaunchKernelGGL(k_bits_prefix, dim3(256), dim3(256), 0, c->stream, plan->bits.as<unsigned long long>(), plan->wprefix.as<uint32_t>(),
                        blocktot.as<uint32_t>());
-    CNIIC_TRY(gidx_finish(c, plan->wprefix.as<uint32_t>(), blocktot.as<uint32_t>(), tot.as<uint64_t>()));
+    CNIIC_TRY(gidx_finish(c, plan->wprefix.as<uint32_t>(), blocktot.as<uint32_t>(), plan->total.as<uint64_t>()));
     CNIIC_HIP_TRY(c, hipGetLastError());
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(&plan->U, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(c->pinned_u, plan->total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipEventRecord(c->u_ev, c->stream));
+    return CNIIC_OK;
+}
+
+int sp_wait_count(Ctx *c, SpPlan *plan) {
+    CNIIC_HIP_TRY(c, hipEventSynchronize(c->u_ev));
+    plan->U = *c->pinned_u;
     return CNIIC_OK;
 }
 
 // the distinct colours, counts and initial labels into the K-means state's cell-major arrays (cell_start: its scan of
 // plan->cell_count); gx: the index of the reference's point list (this image's own bitmap, or the union's)
 int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
-            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug) {
-    const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, const uint64_t *Ug_dev) {
+    const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, 0};
     hipLaunchKernelGGL(k_sp_hist<true>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
                        plan->bstart.as<uint32_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr,
-                       SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx});
+                       SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx, Ug_dev});
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -424,13 +472,13 @@ int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint
     if (wide) {
         hipLaunchKernelGGL(k_sp_partlab<uint16_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 2, c->stream, plan->part.as<uint16_t>(),
                            plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint16_t *>(labels_d), partlab.as<uint16_t>());
-        hipLaunchKernelGGL(k_sp_pixlab<uint16_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 4, c->stream, rgb_d,
+        hipLaunchKernelGGL(k_sp_pixlab<uint16_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8 + 16, c->stream, rgb_d,
                            plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint16_t>(),
                            plan->prank.as<uint16_t>(), static_cast<uint16_t *>(pixlab_d));
     } else {
         hipLaunchKernelGGL(k_sp_partlab<uint8_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins, c->stream, plan->part.as<uint16_t>(),
                            plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint8_t *>(labels_d), partlab.as<uint8_t>());
-        hipLaunchKernelGGL(k_sp_pixlab<uint8_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk + kSpBuckets * 4, c->stream, rgb_d,
+        hipLaunchKernelGGL(k_sp_pixlab<uint8_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk + kSpBuckets * 8 + 16, c->stream, rgb_d,
                            plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint8_t>(),
                            plan->prank.as<uint16_t>(), static_cast<uint8_t *>(pixlab_d));
     }
