@@ -437,12 +437,13 @@ int32_t cniic_cc_create(cniic_ctx *c, uint32_t *table_dev, uint32_t K, const cni
 }
 
 uint64_t cniic_cc_unique(cniic_cc *cc) { return cc && cc->s ? cc->s->U : 0; }
-uint32_t cniic_cc_label_bytes(cniic_cc *cc) { return cc && cc->s && km_rgbw_is_wide(cc->s->km) ? 2 : 1; }
+uint32_t cniic_cc_label_bytes(cniic_cc *cc) { return cc && cc->s && cc->s->km && km_rgbw_is_wide(cc->s->km) ? 2 : 1; }
 
 int32_t cniic_cc_assign(cniic_cc *cc) {
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     return km_rgbw_assign(cc->s->km);
 }
 
@@ -450,6 +451,7 @@ int32_t cniic_cc_update(cniic_cc *cc, uint64_t *changed) {
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     CNIIC_TRY(km_rgbw_update(cc->s->km));
     if (!changed) return CNIIC_OK;  // asynchronous: the caller polls later with cniic_cc_poll
     uint64_t ch = 0;
@@ -462,6 +464,7 @@ int32_t cniic_cc_poll(cniic_cc *cc, uint64_t *iterations, uint32_t *done) {
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     cniic_kmeans_stats st{};
     uint32_t d = 0;
     CNIIC_TRY(km_rgbw_poll(cc->s->km, &st, &d));
@@ -489,10 +492,38 @@ int32_t cniic_cc_create_local(cniic_ctx *c, uint32_t *table_dev, const uint32_t 
     return CNIIC_OK;
 }
 
+int32_t cniic_cc_image_begin(cniic_ctx *c, const uint8_t *rgb_dev, uint64_t npx, cniic_cc **out) {
+    LOCK(c);
+    if (!rgb_dev || !out || npx == 0 || !is_device_ptr(rgb_dev) || (reinterpret_cast<uintptr_t>(rgb_dev) & 15))
+        return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_begin: a non-empty, 16-byte aligned device image and an out pointer are needed");
+    CcSession *s = nullptr;
+    CNIIC_TRY(cc_image_begin(c, rgb_dev, npx, &s));
+    *out = new cniic_cc{c, s};
+    return CNIIC_OK;
+}
+
+int32_t cniic_cc_image_occupancy(cniic_cc *cc, uint32_t *occ_dev) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    if (!cc->s->sp_mode || !occ_dev || !is_device_ptr(occ_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_occupancy: image session and device buffer needed");
+    return sp_occupancy(c, &cc->s->sp, occ_dev);
+}
+
+int32_t cniic_cc_image_create(cniic_cc *cc, const uint32_t *occ_dev, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    if (!occ_dev || !is_device_ptr(occ_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_create: device occupancy needed");
+    if (partials_dev && !is_device_ptr(partials_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_create: partials must be device memory");
+    return cc_image_create(cc->s, occ_dev, K, opts, partials_dev);
+}
+
 int32_t cniic_cc_poll_lagged(cniic_cc *cc, uint64_t *iterations, uint32_t *done, uint32_t *valid) {
     if (!cc || !done || !valid) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     cniic_kmeans_stats st{};
     CNIIC_TRY(km_rgbw_poll_lagged(cc->s->km, &st, done, valid));
     if (iterations) *iterations = st.iterations;
@@ -541,6 +572,7 @@ int32_t cniic_cc_run(cniic_cc *cc, cniic_comm *cm, cniic_kmeans_stats *stats) {
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     if (cm && cm->m && comm_ctx(cm->m) != cc->c) return c->fail(CNIIC_ERR_BAD_ARG, "cc_run: communicator of another context");
     CNIIC_TRY(km_rgbw_run(cc->s->km, cm ? cm->m : nullptr));
     if (stats) {
@@ -551,7 +583,7 @@ int32_t cniic_cc_run(cniic_cc *cc, cniic_comm *cm, cniic_kmeans_stats *stats) {
 }
 
 int32_t cniic_cc_partials(cniic_cc *cc, void **dev_ptr) {
-    if (!cc || !dev_ptr) return CNIIC_ERR_BAD_ARG;
+    if (!cc || !dev_ptr || !cc->s->km) return CNIIC_ERR_BAD_ARG;
     *dev_ptr = km_rgbw_partials_dev(cc->s->km);
     return CNIIC_OK;
 }
@@ -560,6 +592,7 @@ int32_t cniic_cc_export_labels(cniic_cc *cc, void *dst_dev) {
     if (!cc || !dst_dev) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     return km_rgbw_export_labels(cc->s->km, dst_dev);
 }
 
@@ -567,6 +600,7 @@ int32_t cniic_cc_import_labels(cniic_cc *cc, const void *src_dev) {
     if (!cc || !src_dev) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     return km_rgbw_import_labels(cc->s->km, src_dev);
 }
 
@@ -575,6 +609,7 @@ int32_t cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
     LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     if (!rgb || !out || !len) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish: null argument");
     if (local_table_dev && !is_device_ptr(local_table_dev)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish: local table must be device memory");
     In<uint8_t> in;

@@ -265,7 +265,7 @@ int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, con
     uint32_t *cell_start, *ckeys, *cweight;
     km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
     CNIIC_TRY(sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->sp.bits.p,
-                      s->sp.wprefix.as<uint32_t>(), U_dev));
+                      s->sp.wprefix.as<uint32_t>(), 0, U_dev));
     CNIIC_TRY(sp_wait_count(c, &s->sp));
     s->U = s->sp.U;
     if (s->U / K == 0)
@@ -274,6 +274,33 @@ int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, con
     host_trace().mark("km_create + emit enq");
     *out = s.release();
     return CNIIC_OK;
+}
+
+int cc_image_begin(Ctx *c, const uint8_t *rgb_d, uint64_t npx, CcSession **out) {
+    auto s = std::make_unique<CcSession>();
+    s->c = c; s->sp_mode = true; s->local_points = true;
+    CNIIC_TRY(sp_build(c, rgb_d, npx, &s->sp));
+    *out = s.release();
+    return CNIIC_OK;
+}
+
+int cc_image_create(CcSession *s, const uint32_t *occ_d, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev) {
+    Ctx *c = s->c;
+    if (!s->sp_mode || s->km) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_create: needs a session from cc_image_begin, once");
+    if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
+    s->K = K;
+    uint64_t Ug = 0;
+    CNIIC_TRY(gidx_build(c, occ_d, s->gbits, s->gprefix, &Ug));  // the reference's point list: the colours of all images (syncs)
+    CNIIC_TRY(sp_wait_count(c, &s->sp));
+    s->U = s->sp.U;
+    if (Ug / K == 0 || s->U == 0)
+        return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)Ug, K);
+    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, s->U, 0, 1, K, opts, partials_dev, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->gbits.p,
+                             s->gprefix.as<uint32_t>(), Ug, true));
+    uint32_t *cell_start, *ckeys, *cweight;
+    km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
+    return sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->gbits.p,
+                   s->gprefix.as<uint32_t>(), Ug, nullptr);
 }
 
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
@@ -319,8 +346,14 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
         DevBuf lw;
         CNIIC_HIP_TRY(c, lw.alloc((uint64_t)K * 8));
         CNIIC_HIP_TRY(c, hipMemsetAsync(lw.p, 0, (uint64_t)K * 8, c->stream));
-        CNIIC_TRY(local_cluster_weights(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, local_counts_d, K, lw.as<uint64_t>(),
-                                        s->weight_d.as<uint32_t>()));
+        if (s->sp_mode) {  // cell-major colours, labels and pixel counts of this image: any common order will do
+            uint32_t *cell_start, *ckeys, *cweight;
+            km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
+            CNIIC_TRY(local_cluster_weights(c, ckeys, km_rgbw_labels_internal(km, nullptr), wide, U, nullptr, K, lw.as<uint64_t>(), cweight));
+        } else {
+            CNIIC_TRY(local_cluster_weights(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, local_counts_d, K, lw.as<uint64_t>(),
+                                            s->weight_d.as<uint32_t>()));
+        }
         CNIIC_HIP_TRY(c, hipMemcpyAsync(wsum.data(), lw.p, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (uint32_t k = 0; k < K; k++) members[k] = wsum[k] ? 1 : 0;

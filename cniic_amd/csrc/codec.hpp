@@ -44,6 +44,10 @@ int cc_prepare(Ctx *c, uint32_t *table_counts_d, uint32_t K, const cniic_kmeans_
                void *partials_dev, CcSession **out, const uint32_t *occ_d = nullptr);
 // the same from the image itself, through the super-cell partition (no dense table; 16-byte aligned rgb_d)
 int cc_prepare_image(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t K, const cniic_kmeans_opts *opts, CcSession **out);
+// shared palette over several images, through the partition: begin (this image's pixels), the caller sums the occupancy of
+// all ranks (sp_occupancy), create (K-means state over this image's colours placed in the list of all colours)
+int cc_image_begin(Ctx *c, const uint8_t *rgb_d, uint64_t npx, CcSession **out);
+int cc_image_create(CcSession *s, const uint32_t *occ_d, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev);
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
               uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
 

@@ -349,7 +349,8 @@ int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan);  // asyn
 int sp_wait_count(Ctx *c, SpPlan *plan);                                  // plan->U on the host (waits for its copy only)
 // distinct colours, counts, initial labels -> the K-means state's cell-major arrays; (gbits, gprefix, Ug): index of the point list
 int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
-            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, const uint64_t *Ug_dev);
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug, const uint64_t *Ug_dev /* overrides Ug when set */);
+int sp_occupancy(Ctx *c, const SpPlan *plan, uint32_t *occ_d);  // this image's colours as summable nibbles, u32[2^21]
 // final cell-major labels -> label of every pixel, image order
 int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint32_t *cell_start_d, const uint32_t *ckeys_d,
                     const void *labels_d, bool wide, void *pixlab_d);

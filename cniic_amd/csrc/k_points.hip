@@ -222,8 +222,8 @@ struct SpEmit {             // k_sp_hist<true>: where the distinct colours go (t
     uint32_t *ckeys, *cweight;
     void *labels;
     uint32_t K, wide;
-    GIdx gx;                    // (U: read from U_dev)
-    const uint64_t *U_dev;
+    GIdx gx;
+    const uint64_t *U_dev;      // when set: the length of the point list is here, not yet in gx.U
 };
 
 // One block per bucket.  EMIT = false: occupied colours per cell -> cell_count[bucket * 64 + cell], occupancy bitmap
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_hist(const uint16_t *__restri
         __syncthreads();
         uint32_t pos0 = em.cell_start[bucket * 64];
         for (uint32_t i = 0; i < wv; i++) pos0 += wsum[i];
-        const uint32_t U = (uint32_t)*em.U_dev, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
+        const uint32_t U = em.U_dev ? (uint32_t)*em.U_dev : (uint32_t)em.gx.U, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
         const float rcp = 1.0f / (float)ppc;
         for (uint32_t st = 0; st < 32; st++) {
             const uint32_t bin = wv * 2048 + st * 64 + lane, v = hist[bin];
@@ -454,11 +454,26 @@ int sp_wait_count(Ctx *c, SpPlan *plan) {
 // the distinct colours, counts and initial labels into the K-means state's cell-major arrays (cell_start: its scan of
 // plan->cell_count); gx: the index of the reference's point list (this image's own bitmap, or the union's)
 int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
-            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, const uint64_t *Ug_dev) {
-    const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, 0};
+            uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug, const uint64_t *Ug_dev) {
+    const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
     hipLaunchKernelGGL(k_sp_hist<true>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
                        plan->bstart.as<uint32_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr,
                        SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx, Ug_dev});
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// occupancy of this image's colours as one nibble per colour (u32[2^21]), the form the ranks sum (k_hist.hip: k_occ_pack)
+__global__ __launch_bounds__(256) void k_occ_from_bits(const uint32_t *__restrict__ bits32, uint32_t *__restrict__ occ) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // occ word i = colours 8 i .. 8 i + 7
+    const uint32_t byte = (bits32[i >> 2] >> (8 * (i & 3))) & 255u;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v |= ((byte >> j) & 1u) << (4 * j);
+    occ[i] = v;
+}
+int sp_occupancy(Ctx *c, const SpPlan *plan, uint32_t *occ_d) {
+    hipLaunchKernelGGL(k_occ_from_bits, dim3((1u << 21) / 256), dim3(256), 0, c->stream, plan->bits.as<uint32_t>(), occ_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

@@ -63,6 +63,24 @@ class HipBackend:
                                                      C.byref(o), C.c_void_p(partials.data_ptr()), C.byref(h)))
         return h
 
+    # ---- large images: the pixel partition instead of the dense table (same session handle afterwards)
+    def image_begin(self, img, npx):
+        """None when the image does not qualify (small, or not 16-byte aligned): the dense-table calls above apply"""
+        if npx < int(os.environ.get("CNIIC_SP_MIN_PIXELS", 1 << 20)) or img.data_ptr() % 16:  # (the library's own threshold and knob)
+            return None
+        h = C.c_void_p()
+        self.ctx._check(self.L.cniic_cc_image_begin(self.ctx.h, C.c_void_p(img.data_ptr()), C.c_uint64(npx), C.byref(h)))
+        return h
+
+    def image_occupancy(self, h):
+        occ = self.torch.empty(1 << 21, dtype=self.torch.int32, device=self.dev)
+        self.ctx._check(self.L.cniic_cc_image_occupancy(h, C.c_void_p(occ.data_ptr())))
+        return occ
+
+    def image_create(self, h, occ, K, partials, max_iters=0, seed=0):
+        o = _lib.KmOpts(seed, max_iters, 0, 0)
+        self.ctx._check(self.L.cniic_cc_image_create(h, C.c_void_p(occ.data_ptr()), C.c_uint32(K), C.byref(o), C.c_void_p(partials.data_ptr())))
+
     def assign(self, h):
         self.ctx._check(self.L.cniic_cc_assign(h))
 
@@ -193,11 +211,21 @@ class ShardedClusterColors:
 
     def encode(self, img, w, h, out):
         be = self.be
-        local = be.hist_dense(img, w * h)           # utils::count_freqs of this rank's pixels
-        occ = be.occupancy(local)
-        self._all_reduce(occ)                       # which colours occur on any rank (nibble sums, <= 15 ranks)
         partials = be.new_partials(self.K)
-        handle = be.cc_create_local(local, occ, self.K, partials, self.max_iters)
+        handle = be.image_begin(img, w * h) if hasattr(be, "image_begin") else None
+        if handle is not None:                      # large image: utils::count_freqs through the pixel partition (k_points.hip)
+            try:
+                occ = be.image_occupancy(handle)
+                self._all_reduce(occ)               # which colours occur on any rank (nibble sums, <= 15 ranks)
+                be.image_create(handle, occ, self.K, partials, self.max_iters)
+            except Exception:
+                be.destroy(handle)
+                raise
+        else:
+            local = be.hist_dense(img, w * h)       # utils::count_freqs of this rank's pixels, dense table
+            occ = be.occupancy(local)
+            self._all_reduce(occ)
+            handle = be.cc_create_local(local, occ, self.K, partials, self.max_iters)
         try:
             if self.comm is not None:               # one C call: assign -> ncclAllReduce -> update per iteration, in-stream
                 be.run(handle, self.comm)

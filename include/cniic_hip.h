@@ -211,6 +211,17 @@ void     cniic_cc_destroy(cniic_cc *cc);
 int32_t  cniic_occupancy_pack(cniic_ctx *ctx, const uint32_t *table_dev, uint32_t *occ_dev);
 int32_t  cniic_cc_create_local(cniic_ctx *ctx, uint32_t *table_dev, const uint32_t *occ_dev, uint32_t K, const cniic_kmeans_opts *opts,
                                void *partials_dev /* u64[5K+2] the caller all-reduces, or NULL with cniic_cc_run */, cniic_cc **out);
+/* The same without the dense table, for large images (16-byte aligned device image): the pixels are partitioned by colour
+ * super-cell once (what ClusterColors::encode of a single image does here above 2^20 pixels), which gives this image's
+ * colours, their occupancy and, after the K-means, every pixel's label without a random read.
+ *   cniic_cc_image_begin(img)           -> session holding the partition (no K-means state yet)
+ *   cniic_cc_image_occupancy(cc, occ)   -> the nibbles of this image's colours, u32[2^21]; all-reduce(sum) as above
+ *   cniic_cc_image_create(cc, occ, K)   -> the K-means state, as cniic_cc_create_local
+ *   the loop, then cniic_cc_finish(cc, img, NULL) with the same image */
+int32_t  cniic_cc_image_begin(cniic_ctx *ctx, const uint8_t *rgb_dev, uint64_t npx, cniic_cc **out);
+int32_t  cniic_cc_image_occupancy(cniic_cc *cc, uint32_t *occ_dev);
+int32_t  cniic_cc_image_create(cniic_cc *cc, const uint32_t *occ_dev, uint32_t K, const cniic_kmeans_opts *opts,
+                               void *partials_dev /* as cniic_cc_create_local */);
 
 /* ---- RCCL on the context's own stream (ncclAllReduce of the K partial sums between assign and
  * update, no host round trip).  librccl is bound at run time; without it these return CNIIC_ERR_UNSUPPORTED

@@ -134,10 +134,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, K, use_hip, q):
+def _worker(rank, world, port, K, use_hip, q, env=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cniic_amd.dist import ShardedClusterColors
@@ -162,12 +163,12 @@ def _worker(rank, world, port, K, use_hip, q):
         dist.destroy_process_group()
 
 
-def _run(world, K, use_hip):
+def _run(world, K, use_hip, env=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, K, use_hip, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, use_hip, q, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -244,3 +245,36 @@ def test_sharded_hip_world2_shared_gpu_matches_single_process():
     for r in (0, 1):
         assert res[r][0] == exp[r], "rank %d stream differs" % r
         assert res[r][1] == iters
+
+
+@pytest.mark.gpu
+def test_sharded_hip_world2_through_the_pixel_partition(monkeypatch):
+    """the same two ranks with every image taking the large-image route (cniic_cc_image_*): still the union's result"""
+    K = 8
+    res = _run(2, K, use_hip=True, env={"CNIIC_SP_MIN_PIXELS": "0"})
+    exp, iters = expected_streams([make_img(0), make_img(1)], K)
+    for r in (0, 1):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
+
+
+@pytest.mark.gpu
+def test_image_session_world1_equals_plain_encode(monkeypatch):
+    """cniic_cc_image_begin / _occupancy / _create on one rank = ClusterColors::encode, both through the partition"""
+    import torch
+    import cniic_amd
+    from cniic_amd.dist import ShardedClusterColors
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "0")
+    img = make_img(5, 130, 517)
+    h, w = img.shape[:2]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    rc, exp, st = ctx.encode("cluster-colors(16)", img)
+    out = torch.zeros(w * h * 16, dtype=torch.uint8, device=dev)
+    n, st2 = ShardedClusterColors(ctx, 16, None, dev).encode(torch.from_numpy(img).to(dev), w, h, out)
+    assert bytes(out[:n].cpu().numpy().tobytes()) == exp and st2["iterations"] == st["iterations"]
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", str(1 << 40))   # and both equal the dense-table route
+    rc, exp2, st3 = ctx.encode("cluster-colors(16)", img)
+    assert exp2 == exp and st3["iterations"] == st["iterations"]
+    ctx.close()
