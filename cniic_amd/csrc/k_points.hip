@@ -13,10 +13,11 @@
 //   k_sp_colscan / k_sp_bstart   where each (chunk, bucket) run starts
 //   k_sp_scatter   per chunk: 15-bit colour-in-bucket of every pixel, sorted by bucket in LDS and written as
 //                  512 runs; the pixel's position inside its run goes to prank[pixel]          read 3, write 2 + 2 B/px
-//   k_sp_hist<0>   per bucket: LDS histogram of its 2^15 colours -> occupied colours per cell, occupancy bitmap
+//   k_sp_hist      per bucket: LDS histogram of its 2^15 colours -> occupied colours per cell, occupancy bitmap,
+//                  and the bucket's distinct colours with their counts, staged in cell-major order
 //   (bitmap -> popcount prefix = GIdx: rank of a colour in the ascending list of all colours = the
 //    reference's point order, used for init_assignment / init_centroids / the reseed index)
-//   k_sp_hist<1>   per bucket again: the distinct colours, counts and initial labels, written cell-major
+//   k_sp_emit      the staged colours, counts and their initial labels to their places in the K-means arrays
 //   ... K-means ...
 //   k_sp_partlab   per bucket: label of every partitioned pixel from an LDS table of the bucket's colours
 //   k_sp_pixlab    per chunk: its 512 label runs into LDS, each pixel picks run[prank]  -> label stream
@@ -99,12 +100,16 @@ __global__ __launch_bounds__(256) void k_sp_colscan(const uint32_t *__restrict__
     if (threadIdx.x == 255) total[b] = run;  // (the last thread's range ends the column, or is empty and holds the sum)
 }
 
-__global__ __launch_bounds__(kSpBuckets) void k_sp_bstart(const uint32_t *__restrict__ total, uint32_t *__restrict__ bstart) {
+// bstart: first entry of every bucket in the partition; sstart: first slot of its staged distinct colours (a bucket
+// of n pixels has at most min(n, 2^15) of them)
+__global__ __launch_bounds__(kSpBuckets) void k_sp_bstart(const uint32_t *__restrict__ total, uint32_t *__restrict__ bstart,
+                                                          uint32_t *__restrict__ sstart) {
     __shared__ uint32_t wsum[kSpBuckets / 64];
     const uint32_t t = total[threadIdx.x];
     const uint32_t ex = block_exclusive_scan<kSpBuckets>(t, wsum);
     bstart[threadIdx.x] = ex;
     if (threadIdx.x == kSpBuckets - 1) bstart[kSpBuckets] = ex + t;
+    sstart[threadIdx.x] = block_exclusive_scan<kSpBuckets>(min(t, kSpBins), wsum);
 }
 
 // The chunk's pixels sorted by bucket occupy positions [0, n) of the LDS stage; off[b] .. off[b + 1] is bucket b's run
@@ -217,7 +222,63 @@ __device__ __forceinline__ void sp_bucket_hist(const uint16_t *__restrict__ part
     __syncthreads();
 }
 
-struct SpEmit {             // k_sp_hist<true>: where the distinct colours go (the K-means state's cell-major arrays)
+
+// One block per bucket: LDS histogram of its colours -> occupied colours per cell (cell_count[bucket * 64 + cell]), the
+// bucket's words of the occupancy bitmap, and the bucket's distinct colours as (bin, count) pairs in bin order = cell-major
+// order, staged at sstart[bucket] (where they go in the K-means arrays is only known when every bucket has counted).
+__global__ __launch_bounds__(kSpThreads) void k_sp_hist(const uint16_t *__restrict__ part, const uint32_t *__restrict__ bstart,
+                                                        const uint32_t *__restrict__ sstart, uint32_t *__restrict__ cell_count,
+                                                        uint32_t *__restrict__ bits32, uint16_t *__restrict__ sbin,
+                                                        uint32_t *__restrict__ scnt) {
+    extern __shared__ __align__(16) uint8_t sp_lds[];
+    uint32_t *hist = reinterpret_cast<uint32_t *>(sp_lds);
+    __shared__ uint32_t wsum[kSpWaves];
+    const uint32_t bucket = blockIdx.x;
+    const uint64_t s = bstart[bucket], e = bstart[bucket + 1];
+    const uint32_t r5 = threadIdx.x >> 5, g5 = threadIdx.x & 31;  // thread (r5, g5) owns one colour row of the bitmap
+    const uint32_t word_at = ((((bucket >> 6) & 7u) << 5 | r5) << 11) | ((((bucket >> 3) & 7u) << 5 | g5) << 3) | (bucket & 7u);
+    if (s == e) {  // no pixel here: no colours (the K-means never looks at an empty cell), but the bitmap words are ours
+        if (threadIdx.x < 64) cell_count[bucket * 64 + threadIdx.x] = 0;
+        bits32[word_at] = 0;
+        return;
+    }
+    sp_bucket_hist(part, s, e, hist);
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t bq = 0; bq < 4; bq++) {
+        const uint32_t base = ((r5 >> 3) << 13) | ((g5 >> 3) << 11) | (bq << 9) | ((r5 & 7u) << 6) | ((g5 & 7u) << 3);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) word |= (hist[base + j] != 0 ? 1u : 0u) << (bq * 8 + j);
+    }
+    bits32[word_at] = word;
+    // wave w owns bins [2048 w, 2048 w + 2048) = 4 cells, 64 at a time with lane <-> bin: the occupied lanes of one
+    // step write consecutive positions (one or two lines per store)
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t mine = 0;
+    for (uint32_t c4 = 0; c4 < 4; c4++) {
+        uint32_t in_cell = 0;
+        for (uint32_t st = 0; st < 8; st++) in_cell += (uint32_t)__popcll(__ballot(hist[wv * 2048 + c4 * 512 + st * 64 + lane] != 0));
+        if (lane == 0) cell_count[bucket * 64 + wv * 4 + c4] = in_cell;
+        mine += in_cell;
+    }
+    if (lane == 0) wsum[wv] = mine;
+    __syncthreads();
+    uint32_t pos0 = sstart[bucket];
+    for (uint32_t i = 0; i < wv; i++) pos0 += wsum[i];
+    for (uint32_t st = 0; st < 32; st++) {
+        const uint32_t bin = wv * 2048 + st * 64 + lane, v = hist[bin];
+        const unsigned long long bm = __ballot(v != 0);
+        if (v) {
+            const uint32_t pos = pos0 + (uint32_t)__popcll(bm & lt_mask);
+            sbin[pos] = (uint16_t)bin;
+            scnt[pos] = v;
+        }
+        pos0 += (uint32_t)__popcll(bm);
+    }
+}
+
+struct SpEmit {             // where the distinct colours go: the K-means state's cell-major arrays
     const uint32_t *cell_start;
     uint32_t *ckeys, *cweight;
     void *labels;
@@ -226,74 +287,22 @@ struct SpEmit {             // k_sp_hist<true>: where the distinct colours go (t
     const uint64_t *U_dev;      // when set: the length of the point list is here, not yet in gx.U
 };
 
-// One block per bucket.  EMIT = false: occupied colours per cell -> cell_count[bucket * 64 + cell], occupancy bitmap
-// words of the bucket.  EMIT = true: the distinct colours, counts and initial labels, in cell-major order.
-template <bool EMIT>
-__global__ __launch_bounds__(kSpThreads) void k_sp_hist(const uint16_t *__restrict__ part, const uint32_t *__restrict__ bstart,
-                                                        uint32_t *__restrict__ cell_count, uint32_t *__restrict__ bits32, SpEmit em) {
-    extern __shared__ __align__(16) uint8_t sp_lds[];
-    uint32_t *hist = reinterpret_cast<uint32_t *>(sp_lds);
-    __shared__ uint32_t wsum[kSpWaves];
-    const uint32_t bucket = blockIdx.x;
-    const uint64_t s = bstart[bucket], e = bstart[bucket + 1];
-    if (s == e) {  // no pixel here: no colours (the K-means never looks at an empty cell), but the bitmap words are ours
-        if (!EMIT) {
-            if (threadIdx.x < 64) cell_count[bucket * 64 + threadIdx.x] = 0;
-            const uint32_t r5 = threadIdx.x >> 5, g5 = threadIdx.x & 31;
-            const uint32_t R = (((bucket >> 6) & 7u) << 5) | r5, G = (((bucket >> 3) & 7u) << 5) | g5;
-            bits32[(R << 11) | (G << 3) | (bucket & 7u)] = 0;
-        }
-        return;
-    }
-    sp_bucket_hist(part, s, e, hist);
-    // thread t owns bins [32 t, 32 t + 32): half a row of one cell (16 threads per cell)
-    uint32_t nz = 0;
-    const uint32_t b0 = threadIdx.x * 32;
-    if (!EMIT) {
-#pragma unroll
-        for (uint32_t i = 0; i < 32; i++) nz += hist[b0 + i] != 0;
-        uint32_t cell_nz = nz;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) cell_nz += __shfl_xor(cell_nz, o, 64);
-        if ((threadIdx.x & 15) == 0) cell_count[bucket * 64 + (threadIdx.x >> 4)] = cell_nz;
-        // bitmap: thread (r5, g5) gathers the 32 b values of its colour row
-        const uint32_t r5 = threadIdx.x >> 5, g5 = threadIdx.x & 31;
-        uint32_t word = 0;
-#pragma unroll
-        for (uint32_t bq = 0; bq < 4; bq++) {
-            const uint32_t base = ((r5 >> 3) << 13) | ((g5 >> 3) << 11) | (bq << 9) | ((r5 & 7u) << 6) | ((g5 & 7u) << 3);
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) word |= (hist[base + j] != 0 ? 1u : 0u) << (bq * 8 + j);
-        }
-        const uint32_t R = (((bucket >> 6) & 7u) << 5) | r5, G = (((bucket >> 3) & 7u) << 5) | g5;
-        bits32[(R << 11) | (G << 3) | (bucket & 7u)] = word;
-    } else {
-        // wave w owns bins [2048 w, 2048 w + 2048) = 4 cells, 64 at a time with lane <-> bin: the occupied lanes of one
-        // step write consecutive positions (one or two lines per store), and share 8 bitmap words for the rank
-        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        uint32_t mine = 0;
-        for (uint32_t st = 0; st < 32; st++) mine += (uint32_t)__popcll(__ballot(hist[wv * 2048 + st * 64 + lane] != 0));
-        if (lane == 0) wsum[wv] = mine;
-        __syncthreads();
-        uint32_t pos0 = em.cell_start[bucket * 64];
-        for (uint32_t i = 0; i < wv; i++) pos0 += wsum[i];
-        const uint32_t U = em.U_dev ? (uint32_t)*em.U_dev : (uint32_t)em.gx.U, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
-        const float rcp = 1.0f / (float)ppc;
-        for (uint32_t st = 0; st < 32; st++) {
-            const uint32_t bin = wv * 2048 + st * 64 + lane, v = hist[bin];
-            const unsigned long long bm = __ballot(v != 0);
-            if (v) {
-                const uint32_t pos = pos0 + (uint32_t)__popcll(bm & lt_mask);
-                const uint32_t key = sp_key(bucket, bin);
-                em.ckeys[pos] = key;
-                em.cweight[pos] = v;
-                const uint32_t lab = init_label24(gidx_rank(em.gx, key), U, em.K, ppc, rcp);  // init_assignment kmeans.rs:61-78
-                if (em.wide) static_cast<uint16_t *>(em.labels)[pos] = (uint16_t)lab;
-                else static_cast<uint8_t *>(em.labels)[pos] = (uint8_t)lab;
-            }
-            pos0 += (uint32_t)__popcll(bm);
-        }
+// the staged colours of every bucket -> keys, counts and initial labels at their cell-major positions: a copy, the bucket's
+// place being cell_start of its first cell.  kSpEmitSplit blocks per bucket.
+constexpr uint32_t kSpEmitSplit = 4;
+__global__ __launch_bounds__(256) void k_sp_emit(const uint32_t *__restrict__ sstart, const uint16_t *__restrict__ sbin,
+                                                 const uint32_t *__restrict__ scnt, SpEmit em) {
+    const uint32_t bucket = blockIdx.x / kSpEmitSplit, part_no = blockIdx.x % kSpEmitSplit;
+    const uint32_t q0 = em.cell_start[bucket * 64], n = em.cell_start[bucket * 64 + 64] - q0, s0 = sstart[bucket];
+    const uint32_t U = em.U_dev ? (uint32_t)*em.U_dev : (uint32_t)em.gx.U, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
+    const float rcp = 1.0f / (float)ppc;
+    for (uint32_t i = part_no * 256 + threadIdx.x; i < n; i += 256 * kSpEmitSplit) {
+        const uint32_t key = sp_key(bucket, sbin[s0 + i]);
+        em.ckeys[q0 + i] = key;
+        em.cweight[q0 + i] = scnt[s0 + i];
+        const uint32_t lab = init_label24(gidx_rank(em.gx, key), U, em.K, ppc, rcp);  // init_assignment kmeans.rs:61-78
+        if (em.wide) static_cast<uint16_t *>(em.labels)[q0 + i] = (uint16_t)lab;
+        else static_cast<uint8_t *>(em.labels)[q0 + i] = (uint8_t)lab;
     }
 }
 
@@ -395,8 +404,7 @@ static int sp_set_lds(Ctx *c) {
     if (done) return CNIIC_OK;
     const int big = 140 * 1024;
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_hist), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_partlab<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_partlab<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sp_pixlab<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -419,6 +427,10 @@ int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
     CNIIC_HIP_TRY(c, plan->part.alloc(npx * 2 + 16));
     CNIIC_HIP_TRY(c, plan->prank.alloc((npx + 16) * 2));
     CNIIC_HIP_TRY(c, plan->cell_count.alloc((uint64_t)kNumCells * 4));
+    const uint64_t smax = std::min<uint64_t>(npx, 1ull << 24);  // distinct colours at most
+    CNIIC_HIP_TRY(c, plan->sstart.alloc((uint64_t)kSpBuckets * 4));
+    CNIIC_HIP_TRY(c, plan->sbin.alloc(smax * 2));
+    CNIIC_HIP_TRY(c, plan->scnt.alloc(smax * 4));
     CNIIC_HIP_TRY(c, plan->bits.alloc((1ull << 18) * 8));
     CNIIC_HIP_TRY(c, plan->wprefix.alloc((1ull << 18) * 4));
     DevBuf total, blocktot;
@@ -430,12 +442,14 @@ int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
     hipLaunchKernelGGL(k_sp_count, dim3(plan->nchunks), dim3(kSpThreads), 0, c->stream, rgb_d, npx, plan->cnt.as<uint32_t>());
     hipLaunchKernelGGL(k_sp_colscan, dim3(kSpBuckets), dim3(256), 0, c->stream, plan->cnt.as<uint32_t>(), plan->nchunks,
                        plan->pre.as<uint32_t>(), total.as<uint32_t>());
-    hipLaunchKernelGGL(k_sp_bstart, dim3(1), dim3(kSpBuckets), 0, c->stream, total.as<uint32_t>(), plan->bstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_sp_bstart, dim3(1), dim3(kSpBuckets), 0, c->stream, total.as<uint32_t>(), plan->bstart.as<uint32_t>(),
+                       plan->sstart.as<uint32_t>());
     hipLaunchKernelGGL(k_sp_scatter, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8 + 16, c->stream, rgb_d, npx,
                        plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), plan->part.as<uint16_t>(),
                        plan->prank.as<uint16_t>());
-    hipLaunchKernelGGL(k_sp_hist<false>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
-                       plan->bstart.as<uint32_t>(), plan->cell_count.as<uint32_t>(), plan->bits.as<uint32_t>(), SpEmit{});
+    hipLaunchKernelGGL(k_sp_hist, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
+                       plan->bstart.as<uint32_t>(), plan->sstart.as<uint32_t>(), plan->cell_count.as<uint32_t>(), plan->bits.as<uint32_t>(),
+                       plan->sbin.as<uint16_t>(), plan->scnt.as<uint32_t>());
     hipLaunchKernelGGL(k_bits_prefix, dim3(256), dim3(256), 0, c->stream, plan->bits.as<unsigned long long>(), plan->wprefix.as<uint32_t>(),
                        blocktot.as<uint32_t>());
     CNIIC_TRY(gidx_finish(c, plan->wprefix.as<uint32_t>(), blocktot.as<uint32_t>(), plan->total.as<uint64_t>()));
@@ -456,9 +470,8 @@ int sp_wait_count(Ctx *c, SpPlan *plan) {
 int sp_emit(Ctx *c, const SpPlan *plan, const uint32_t *cell_start_d, uint32_t *ckeys_d, uint32_t *cweight_d, void *labels_d, bool wide,
             uint32_t K, const void *gbits_d, const uint32_t *gprefix_d, uint64_t Ug, const uint64_t *Ug_dev) {
     const GIdx gx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
-    hipLaunchKernelGGL(k_sp_hist<true>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 4, c->stream, plan->part.as<uint16_t>(),
-                       plan->bstart.as<uint32_t>(), (uint32_t *)nullptr, (uint32_t *)nullptr,
-                       SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx, Ug_dev});
+    hipLaunchKernelGGL(k_sp_emit, dim3(kSpBuckets * kSpEmitSplit), dim3(256), 0, c->stream, plan->sstart.as<uint32_t>(), plan->sbin.as<uint16_t>(),
+                       plan->scnt.as<uint32_t>(), SpEmit{cell_start_d, ckeys_d, cweight_d, labels_d, K, wide ? 1u : 0u, gx, Ug_dev});
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
