@@ -181,6 +181,17 @@ __global__ __launch_bounds__(256) void k_hilbert_xy(uint32_t w, uint32_t h, uint
     }
 }
 
+// pixel idx as r | g << 8 | b << 16 (bits 24..31 unspecified) with one load; the buffer's last pixel by bytes
+__device__ __forceinline__ uint32_t px_le24(const uint8_t *__restrict__ rgb, uint64_t idx, uint64_t n) {
+    if (idx + 1 < n) {
+        uint32_t v;
+        __builtin_memcpy(&v, rgb + 3 * idx, 4);
+        return v;
+    }
+    const uint8_t *p = rgb + 3 * idx;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
 // hilbert::linearize (hilbert.rs:10-12, 34-38): out[d] = pixel(scan(d)); SCATTER = inverse
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict__ src, uint32_t w, uint32_t h, uint32_t order,
@@ -194,9 +205,9 @@ __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict_
         uint32_t x, y;
         sc.xy(d, x, y);
         const uint64_t p = (uint64_t)y * w + x;
-        const uint8_t *s = src + 3 * (SCATTER ? d : p);
+        const uint32_t v = px_le24(src, SCATTER ? d : p, n);
         uint8_t *o = dst + 3 * (SCATTER ? p : d);
-        o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+        o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
     }
 }
 
@@ -224,22 +235,34 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t run = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; run < nruns; run += stride) {
         const uint64_t d0 = run * kDeltaRun;
-        int32_t pr = 0, pg = 0, pb = 0;
-        if (d0 > 0) {
-            uint32_t x, y;
-            sc.xy(d0 - 1, x, y);
-            const uint8_t *p = rgb + 3 * ((uint64_t)y * w + x);
-            pr = p[0]; pg = p[1]; pb = p[2];
+        // the run's pixels: one (unaligned) dword each -- three byte loads per pixel were 15 load instructions per thread
+        uint32_t px[kDeltaRun];
+#pragma unroll
+        for (int i = 0; i < kDeltaRun; i++) {
+            px[i] = 0;
+            if (d0 + i < n) {
+                uint32_t x, y;
+                sc.xy(d0 + i, x, y);
+                px[i] = px_le24(rgb, (uint64_t)y * w + x, n);
+            }
         }
+        // the pixel before the run is the neighbouring lane's last one (runs are consecutive across the lanes of a wave)
+        uint32_t prev = __shfl_up(px[kDeltaRun - 1], 1, 64);
+        if ((threadIdx.x & 63) == 0) {
+            prev = 0;  // START = (0, 0, 0) hilbertc.rs:445
+            if (d0 > 0) {
+                uint32_t x, y;
+                sc.xy(d0 - 1, x, y);
+                prev = px_le24(rgb, (uint64_t)y * w + x, n);
+            }
+        }
+        int32_t pr = prev & 255, pg = (prev >> 8) & 255, pb = (prev >> 16) & 255;
         uint32_t key[kDeltaRun];
 #pragma unroll
         for (int i = 0; i < kDeltaRun; i++) {
             key[i] = 0;
             if (d0 + i < n) {
-                uint32_t x, y;
-                sc.xy(d0 + i, x, y);
-                const uint8_t *p = rgb + 3 * ((uint64_t)y * w + x);
-                const int32_t r = p[0], g = p[1], b = p[2];
+                const int32_t r = px[i] & 255, g = (px[i] >> 8) & 255, b = (px[i] >> 16) & 255;
                 const int32_t dr = r - pr, dg = g - pg, db = b - pb;
                 key[i] = ((uint32_t)(dr + 255) << 18) | ((uint32_t)(dg + 255) << 9) | (uint32_t)(db + 255);
                 pr = r; pg = g; pb = b;
