@@ -74,7 +74,7 @@ struct KmRgbwState {
     uint64_t res_cent = 0, res_members = 0, res_wsum = 0, res_bytes = 0;
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
-    DevBuf cell_piv, cell_mask, moved_list;  // skip schedule state
+    DevBuf cell_rec, moved_list;  // skip schedule state
     GIdx gidx{nullptr, nullptr, 0};  // several GPUs: the points are this rank's share of gidx.U colours
     DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
     bool fused = false;
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict_
     wfirst[g] = g == G ? M : a;
 }
 
+__host__ __device__ constexpr uint32_t cell_rec_words(uint32_t MW) { return (2 + 2 * MW + 15) & ~15u; }  // u32 words of a cell's skip record (CellState below)
 constexpr uint32_t kMaxMovedSkip = 128;  // skip schedule when at most this many centroids moved (2 per lane)
 
 // squared distance from colour key ck to the centre of the cube with low corner bx and side ext + 1
@@ -475,8 +476,8 @@ __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, ui
 // stored for the skip test.
 template <int IDBITS>
 __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t n, uint32_t c, int lane, unsigned long long lt_mask,
-                                                     uint2 *cand, unsigned long long *wmask, uint32_t *cell_piv,
-                                                     unsigned long long *cell_mask, uint32_t m, uint32_t MW) {
+                                                     uint2 *cand, unsigned long long *wmask, uint32_t *cell_rec, uint32_t m,
+                                                     uint32_t MW) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     constexpr int32_t ext = (1 << kCellShift) - 1;
     const CellBox bx = cell_box(c);
@@ -500,8 +501,9 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
         ncand += (uint32_t)__popcll(bm);
     }
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < MW; i += 64) cell_mask[(size_t)m * MW + i] = wmask[i];
-    if (lane == 0) cell_piv[m] = pv;
+    uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
+    for (uint32_t i = lane; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
+    if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c);
     return ncand;
 }
 
@@ -622,9 +624,13 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
     }
 }
 
-struct CellState {          // per non-empty cell, carried between iterations (skip schedule)
-    uint32_t *piv;          // [M] colour of the pivot of the last candidate build
-    unsigned long long *mask;  // [M][MW]
+// Per non-empty cell, carried between iterations for the skip schedule: ONE record of cell_rec_words(MW) u32 --
+// [0] colour of the pivot of the last candidate build, [1] the cell's id, [2 + w] word w of the candidate bitmask --
+// 64 bytes for K <= 256, so that the skip test of a cell is one coalesced load (lane <-> word) that can be
+// requested several cells ahead; pivot, cell id and mask words then come out of the register by lane reads.
+// (Three separate arrays cost the test two dependent round trips to memory per cell: 16 % of the encode.)
+struct CellState {
+    uint32_t *rec;          // [M][cell_rec_words(MW)]
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
 };
@@ -654,8 +660,18 @@ struct FusedUpdate {
     KmDevState *st_host;                         // pinned host copy of the scalar state (lagged polling without a copy kernel), or null
 };
 
+// -DCNIIC_RGBW_PHASES: wave-clock totals per phase of k_rgbw_assign_cells (a measuring build, never the shipped one)
+#ifdef CNIIC_RGBW_PHASES
+__device__ unsigned long long g_rgbw_phase[12];
+#define RG_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
+#define RG_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
+#else
+#define RG_PHASE(i) do {} while (0)
+#define RG_COUNT(i, v) do {} while (0)
+#endif
+
 template <typename LabelT, int IDBITS, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
@@ -682,6 +698,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
     uint32_t nS = fz.on ? K : cs.moved[0];
     const uint32_t *mlist = cs.moved + 1;  // ids of the centroids the last update changed
     const unsigned long long lt_mask = (1ull << lane) - 1;
+#ifdef CNIIC_RGBW_PHASES
+    long long t_ph = clock64();
+    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long s_ph[12];
+    if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
+#endif
     uint32_t moved = 0;
     unsigned long long evals = 0;
     for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
@@ -718,7 +740,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                 ck = fz.gx.bits ? gidx_select(fz.gx, ri) : fz.keys[ri];
                 atomicAdd(&s_reseed, 1u);
             } else {
-                const uint32_t r = (uint32_t)(v[0] / v[3]) & 255, g = (uint32_t)(v[1] / v[3]) & 255, b = (uint32_t)(v[2] / v[3]) & 255;
+                // (sums of channel * weight over at most 2^32 pixels: exact through a double quotient)
+                const uint32_t r = div_floor_small(v[0], v[3]) & 255, g = div_floor_small(v[1], v[3]) & 255, b = div_floor_small(v[2], v[3]) & 255;
                 ck = (r << 16) | (g << 8) | b;
                 atomicAdd(&s_active, 1u);
             }
@@ -765,6 +788,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
     }
     const bool skip_mode = !first && nS <= cs.max_moved;
+    RG_PHASE(0);
 
     if (!skip_mode) {
         // ================================================================= FULL schedule
@@ -780,6 +804,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
             if (lane == 0) v = atomicAdd(&s_cell, 1u);
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         };
+        RG_PHASE(10);
         uint32_t m = draw();
         uint32_t s = 0, e = 0, c = 0;
         uint32_t p[kSweep], cur[kSweep], wt[kSweep];
@@ -799,9 +824,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
             const uint32_t mn = draw();
             uint32_t s_next = 0, e_next = 0, c_next = 0;
             if (mn < mb1) { s_next = ne_start[mn]; e_next = ne_start[mn + 1]; c_next = ne_cell[mn]; }
-            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); }
-            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW)
-                                                : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
+            RG_PHASE(1);
+            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); }
+            RG_PHASE(2);
+            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
+                                                : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+            RG_PHASE(3);
+            RG_COUNT(9, 1);
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
                 const uint32_t nts = more ? base + 64 * kSweep : s_next;
@@ -820,6 +849,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
             evals += (unsigned long long)(e - s) * (ncand + 1);
+            RG_PHASE(4);
             __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
             m = mn; s = s_next; e = e_next; c = c_next;
         }
@@ -835,15 +865,53 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         // saturate: one word serves ~90 dequeues/us)
         const uint32_t nwaves = gridDim.x * WAVES;
         {
-            for (uint32_t m = m_lo + blockIdx.x * WAVES + wid; m < m_hi; m += nwaves) {
-                const uint32_t c = ne_cell[m];
+            // The records of this wave's next kRecBatch cells are requested together -- lanes 16 i .. 16 i + 15 of one
+            // register hold cell i's record (K <= 256: 16 words), four cells per load instruction -- and read out lane
+            // by lane: one round trip to memory per batch, not per cell (most cells turn out clean and cost nothing else).
+            constexpr uint32_t kRecBatch = IDBITS == 8 ? 8 : 1;
+            const uint32_t RW = cell_rec_words(MW);
+            const uint32_t m_first = m_lo + blockIdx.x * WAVES + wid;
+            for (uint32_t mb = m_first; mb < m_hi; mb += kRecBatch * nwaves) {
+              uint32_t rA = 0, rB = 0;
+              if (IDBITS == 8) {
+                  const uint32_t ma = mb + ((uint32_t)lane >> 4) * nwaves, mc = ma + 4 * nwaves;
+                  if (ma < m_hi) rA = cs.rec[(size_t)ma * 16 + (lane & 15)];
+                  if (mc < m_hi) rB = cs.rec[(size_t)mc * 16 + (lane & 15)];
+              } else {  // a record of up to 80 words (K <= 2048): one cell at a time
+                  const uint32_t *rec = cs.rec + (size_t)mb * RW;
+                  if ((uint32_t)lane < RW) rA = rec[lane];
+                  if (64 + (uint32_t)lane < RW) rB = rec[64 + lane];
+              }
+              for (uint32_t bi = 0; bi < kRecBatch; bi++) {
+                const uint32_t m = mb + bi * nwaves;
+                if (m >= m_hi) break;
+                uint32_t pvt, c;
+                bool in1, in2;
+                if (IDBITS == 8) {
+                    const uint32_t r = bi < 4 ? rA : rB;
+                    const int l0 = (int)((bi & 3) * 16);
+                    pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)r, l0 + 1);
+                    in1 = (((uint32_t)__shfl((int)r, l0 + 2 + (int)((k1 >> 5) & 7), 64) >> (k1 & 31)) & 1u) != 0;
+                    in2 = (((uint32_t)__shfl((int)r, l0 + 2 + (int)((k2 >> 5) & 7), 64) >> (k2 & 31)) & 1u) != 0;
+                } else {
+                    pvt = (uint32_t)__builtin_amdgcn_readlane((int)rA, 0);
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)rA, 1);
+                    const uint32_t i1 = 2 + ((k1 & 0x7ffu) >> 5), i2 = 2 + ((k2 & 0x7ffu) >> 5);
+                    // (all four shuffles by every lane: a lane that sits out a shuffle is read as nothing by the others)
+                    const uint32_t a1 = (uint32_t)__shfl((int)rA, (int)(i1 & 63), 64), b1 = (uint32_t)__shfl((int)rB, (int)(i1 & 63), 64);
+                    const uint32_t a2 = (uint32_t)__shfl((int)rA, (int)(i2 & 63), 64), b2 = (uint32_t)__shfl((int)rB, (int)(i2 & 63), 64);
+                    const uint32_t w1 = i1 < 64 ? a1 : b1, w2 = i2 < 64 ? a2 : b2;
+                    in1 = ((w1 >> (k1 & 31)) & 1u) != 0;
+                    in2 = ((w2 >> (k2 & 31)) & 1u) != 0;
+                }
                 Dominance dm;
-                dm.set(cell_box(c), (1 << kCellShift) - 1, cs.piv[m]);
-                bool dirty = false;  // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
-                if (k1 != 0xffffffffu)
-                    dirty = dm.worst(ck1) >= 0 || ((cs.mask[(size_t)m * MW + (k1 >> 6)] >> (k1 & 63)) & 1ull);
-                if (k2 != 0xffffffffu)
-                    dirty = dirty || dm.worst(ck2) >= 0 || ((cs.mask[(size_t)m * MW + (k2 >> 6)] >> (k2 & 63)) & 1ull);
+                dm.set(cell_box(c), (1 << kCellShift) - 1, pvt);
+                // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                bool dirty = false;
+                if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
+                if (k2 != 0xffffffffu) dirty = dirty || in2 || dm.worst(ck2) >= 0;
+                RG_PHASE(6);
                 if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
@@ -855,7 +923,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                     wt[u] = q < e ? cweight[q] : 0u;
                 }
                 // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
-                const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.piv, cs.mask, m, MW);
+                const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
 #pragma unroll
@@ -870,10 +938,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
                     for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                 }
                 evals += (unsigned long long)(e - s) * (ncand + 1);
+                RG_PHASE(7);
                 __builtin_amdgcn_wave_barrier();
+              }
             }
         }
     }
+    RG_PHASE(11);
     moved = wave_reduce_sum(moved);
     if (lane == 0) {
         if (moved) atomicAdd(&s_moved, moved);
@@ -886,6 +957,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_rgbw_assign_cells(
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
         if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
     }
+    RG_PHASE(5);
+#ifdef CNIIC_RGBW_PHASES
+    if (lane == 0)
+        for (int i = 0; i < 12; i++)
+            if (ph_[i]) atomicAdd(&s_ph[i], ph_[i]);
+    __syncthreads();
+    if (threadIdx.x < 12 && s_ph[threadIdx.x]) atomicAdd(&g_rgbw_phase[threadIdx.x], s_ph[threadIdx.x]);
+#endif
 }
 
 // ---------------------------------------------------------------- centroid update
@@ -928,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
             ck = gx.bits ? gidx_select(gx, ri) : keys[ri];
             atomicAdd(&s_reseed, 1u);
         } else {
-            const uint32_t r = (uint32_t)(v[0] / w) & 255, g = (uint32_t)(v[1] / w) & 255, b = (uint32_t)(v[2] / w) & 255;
+            const uint32_t r = div_floor_small(v[0], w) & 255, g = div_floor_small(v[1], w) & 255, b = div_floor_small(v[2], w) & 255;
             ck = (r << 16) | (g << 8) | b;
             atomicAdd(&s_active, 1u);
         }
@@ -1077,8 +1156,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_count, 4);
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
-        KM_ALLOC(s->cell_piv, (uint64_t)kNumCells * 4);
-        KM_ALLOC(s->cell_mask, (uint64_t)kNumCells * ((K + 63) / 64) * 8);
+        KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
         DevBuf count, cursor, cell_tot;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
         KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8);
@@ -1200,7 +1278,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
-        CellState cs{s->cell_piv.as<uint32_t>(), s->cell_mask.as<unsigned long long>(), s->moved_list.as<uint32_t>(),
+        CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : kMaxMovedSkip};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
@@ -1383,6 +1461,17 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
         kt.ms += lt.total_ms();
         kt.launches += lt.used / 2;
     }
+#ifdef CNIIC_RGBW_PHASES
+    {
+        unsigned long long ph[12], zero[12] = {0};
+        CNIIC_HIP_TRY(c, hipDeviceSynchronize());
+        CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_rgbw_phase), sizeof ph));
+        CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_phase), zero, sizeof zero));
+        fprintf(stderr, "rgbw phases (wave clocks): prologue %llu draw %llu super %llu cell-build %llu sweep %llu epilogue %llu skip-test %llu "
+                        "skip-build+sweep %llu | super builds %llu cells %llu iters %llu | first barrier+draw %llu tail %llu\n",
+                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], (unsigned long long)h.iter, ph[10], ph[11]);
+    }
+#endif
     return CNIIC_OK;
 }
 
