@@ -173,3 +173,41 @@ def test_hilbert_rle_4096_properties(env):
         assert (cnt[:-1][same] == 255).all()
         rc, back = ctx.decode("hilbert(rle)", out[:n].cpu().numpy().tobytes())
         assert rc == 0 and np.array_equal(back, img.cpu().numpy())
+
+
+def test_cluster_colors_partition_equals_dense_table_at_odd_sizes(env, monkeypatch):
+    """above the 2^20-pixel threshold the encode goes through the pixel partition (k_points.hip): same bytes as the
+    dense-table route, for sizes that leave a partial 64 Ki-pixel chunk and a partial 16-pixel group, u8 and u16 labels"""
+    ctx, torch, dev = env
+    for (h, w, K, kind) in ((1031, 1021, 64, 1), (1100, 1000, 300, 1), (1024, 1024, 16, 0)):
+        img = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(kind, SEED + 11, w, h, out=img)
+        out = torch.empty(h * w * 4 + 4096, dtype=torch.uint8, device=dev)
+        monkeypatch.delenv("CNIIC_SP_MIN_PIXELS", raising=False)
+        rc, n1, st1 = ctx.encode("cluster-colors(%d)" % K, img, w=w, h=h, out=out)
+        a = out[:n1].cpu().numpy().tobytes()
+        monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", str(1 << 40))
+        rc2, n2, st2 = ctx.encode("cluster-colors(%d)" % K, img, w=w, h=h, out=out)
+        b = out[:n2].cpu().numpy().tobytes()
+        assert rc == rc2 == 0 and a == b and st1["iterations"] == st2["iterations"], (h, w, K)
+
+
+def test_cluster_colors_16384_roundtrip_properties(env):
+    """the partition at 2^28 pixels (4096 chunks, every bucket split over thousands of runs): at most K colours come
+    back, the decoded image keeps the dimensions, and a second encode gives the same bytes"""
+    ctx, torch, dev = env
+    size, K = 16384, 256
+    img = synth(ctx, torch, dev, 1, SEED + 5, size)
+    out = torch.empty(size * size + (1 << 20), dtype=torch.uint8, device=dev)
+    rc, n1, st = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out)
+    assert rc == 0 and st["iterations"] > 1
+    data = out[:n1].cpu().numpy().tobytes()
+    rc, n2, _ = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out)
+    assert rc == 0 and out[:n2].cpu().numpy().tobytes() == data
+    rc, back_h = ctx.decode("cluster-colors(%d)" % K, data)
+    assert rc == 0 and back_h.shape == (size, size, 3)
+    back = torch.from_numpy(back_h).to(dev)
+    keys = (back[..., 0].to(torch.int32) << 16) | (back[..., 1].to(torch.int32) << 8) | back[..., 2].to(torch.int32)
+    assert int(torch.unique(keys).numel()) <= K
+    err = (back[::64, ::64].to(torch.float32) - img[::64, ::64].to(torch.float32)).pow(2).mean().item()
+    assert err < 400.0   # 256 colours for the whole cube: cells ~40 levels wide, i.e. ~12-16 levels rms per channel, not noise
