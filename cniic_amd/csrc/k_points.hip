@@ -191,13 +191,20 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_scatter(const uint8_t *__rest
     }
 }
 
-// entries [s, e) of a u16 stream, four per step where the address allows (8-byte aligned), else one by one
+// entries [s, e) of a u16 stream, four per load where the address allows (8-byte aligned), else one by one; four
+// loads are in flight per thread (a crowded bucket is one block's work: with one load at a time its 220 K entries at
+// C2 were 54 dependent round trips to memory and set the kernel's time)
 template <typename F> __device__ __forceinline__ void sp_for_entries(const uint16_t *__restrict__ part, uint64_t s, uint64_t e, F &&f) {
     const uint64_t a = min(e, (s + 3) & ~3ull), z = a + ((e - a) & ~3ull);
     for (uint64_t i = s + threadIdx.x; i < a; i += kSpThreads) { const uint32_t v = part[i]; f(i, v, v, v, v, 1u); }
-    for (uint64_t i = a + 4 * (uint64_t)threadIdx.x; i < z; i += 4 * kSpThreads) {
-        const uint2 q = *reinterpret_cast<const uint2 *>(part + i);
-        f(i, q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16, 4u);
+    constexpr uint64_t kStep = 4 * (uint64_t)kSpThreads;
+    for (uint64_t i = a + 4 * (uint64_t)threadIdx.x; i < z; i += 4 * kStep) {
+        uint2 q[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) q[t] = i + t * kStep < z ? *reinterpret_cast<const uint2 *>(part + i + t * kStep) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (i + t * kStep < z) f(i + t * kStep, q[t].x & 0xffffu, q[t].x >> 16, q[t].y & 0xffffu, q[t].y >> 16, 4u);
     }
     for (uint64_t i = z + threadIdx.x; i < e; i += kSpThreads) { const uint32_t v = part[i]; f(i, v, v, v, v, 1u); }
 }
@@ -296,13 +303,29 @@ __global__ __launch_bounds__(256) void k_sp_emit(const uint32_t *__restrict__ ss
     const uint32_t q0 = em.cell_start[bucket * 64], n = em.cell_start[bucket * 64 + 64] - q0, s0 = sstart[bucket];
     const uint32_t U = em.U_dev ? (uint32_t)*em.U_dev : (uint32_t)em.gx.U, ppc = max(U / em.K, 1u);  // (fewer colours than clusters: the host refuses later)
     const float rcp = 1.0f / (float)ppc;
-    for (uint32_t i = part_no * 256 + threadIdx.x; i < n; i += 256 * kSpEmitSplit) {
-        const uint32_t key = sp_key(bucket, sbin[s0 + i]);
-        em.ckeys[q0 + i] = key;
-        em.cweight[q0 + i] = scnt[s0 + i];
-        const uint32_t lab = init_label24(gidx_rank(em.gx, key), U, em.K, ppc, rcp);  // init_assignment kmeans.rs:61-78
-        if (em.wide) static_cast<uint16_t *>(em.labels)[q0 + i] = (uint16_t)lab;
-        else static_cast<uint8_t *>(em.labels)[q0 + i] = (uint8_t)lab;
+    // four entries per thread and step, each a chain of two loads (the staged colour, then its two index words): the
+    // chains travel together
+    constexpr uint32_t kStride = 256 * kSpEmitSplit;
+    for (uint32_t i0 = part_no * 256 + threadIdx.x; i0 < n; i0 += 4 * kStride) {
+        uint32_t key[4], cnt[4], rank[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t i = i0 + t * kStride;
+            key[t] = i < n ? sp_key(bucket, sbin[s0 + i]) : 0u;
+            cnt[t] = i < n ? scnt[s0 + i] : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) rank[t] = i0 + t * kStride < n ? gidx_rank(em.gx, key[t]) : 0u;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t i = i0 + t * kStride;
+            if (i >= n) continue;
+            em.ckeys[q0 + i] = key[t];
+            em.cweight[q0 + i] = cnt[t];
+            const uint32_t lab = init_label24(rank[t], U, em.K, ppc, rcp);  // init_assignment kmeans.rs:61-78
+            if (em.wide) static_cast<uint16_t *>(em.labels)[q0 + i] = (uint16_t)lab;
+            else static_cast<uint8_t *>(em.labels)[q0 + i] = (uint8_t)lab;
+        }
     }
 }
 
