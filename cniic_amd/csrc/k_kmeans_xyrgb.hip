@@ -3,7 +3,7 @@
 //
 // Layout: the RGB8 image stays as given (3 B/px, x and y are implicit in the pixel index) plus one
 // u16 label per pixel: 3 + 2 read, 2 written = 7 B/px/iteration.  The centroid table is
-// an array of int4 (cx, cy, r<<16|g<<8|b, |c|^2): one 16-byte load per centroid.
+// an array of int4 (cx, cy, r<<16|g<<8|b, -|c|^2): one 16-byte load per centroid.
 //
 // Exactness: assign is exact Lloyd under the reference's rules (stay unless STRICTLY closer,
 // kmeans.rs:375; lowest id among equidistant minima) on integer squared distances.
@@ -60,7 +60,7 @@ struct KmXyState {
 __device__ __forceinline__ uint32_t xdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
 __device__ __forceinline__ int32_t xmad24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
 __device__ __forceinline__ int4 make_cent(int32_t x, int32_t y, uint32_t col) {
-    return make_int4(x, y, (int32_t)col, xmad24(x, x, xmad24(y, y, (int32_t)xdot4(col, col))));
+    return make_int4(x, y, (int32_t)col, -xmad24(x, x, xmad24(y, y, (int32_t)xdot4(col, col))));
 }
 
 __global__ void k_xy_init(const uint8_t *__restrict__ rgb, uint32_t w, uint64_t N, uint32_t K,
@@ -431,20 +431,23 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             for (int j = 0; j < kXRows; j++) { best[j] = INT32_MIN; bpos[j] = 0; }
             // maximise 2 p.c - |c|^2; ascending k and a strict compare: first maximum = lowest id
             if (!s_over) {
+                const int32_t x2 = 2 * x, y20 = 2 * (int32_t)uy0;
                 for (uint32_t q = 0; q < ncand; q++) {
                     const int4 cc = list_c[q];  // LDS broadcast
-                    const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
+                    // 2 (x cx + y cy) - |c|^2 for the unit's first row; each further row adds 2 cy
+                    int32_t t = xmad24(x2, cc.x, xmad24(y20, cc.y, cc.w));
+                    const int32_t cy2 = cc.y << 1;
 #pragma unroll
                     for (int j = 0; j < kXRows; j++) {
-                        const int32_t y2 = 2 * (int32_t)(uy0 + j);
-                        const int32_t gq = (int32_t)(xdot4(p[j], (uint32_t)cc.z) << 1) + xmad24(y2, cc.y, ax);
+                        const int32_t gq = (int32_t)((xdot4(p[j], (uint32_t)cc.z) << 1) + (uint32_t)t);
                         if (gq > best[j]) { best[j] = gq; bpos[j] = q; }
+                        t += cy2;
                     }
                 }
             } else {
                 for (uint32_t q = 0; q < K; q++) {  // q wave-uniform: scalar loads
                     const int4 cc = cent[q];
-                    const int32_t ax = xmad24(2 * x, cc.x, -cc.w);
+                    const int32_t ax = xmad24(2 * x, cc.x, cc.w);
 #pragma unroll
                     for (int j = 0; j < kXRows; j++) {
                         const int32_t y2 = 2 * (int32_t)(uy0 + j);
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 const bool ok = okx && (uint32_t)j < nrows;
                 const int32_t y = (int32_t)(uy0 + j);
                 const int32_t gcur = (int32_t)(xdot4(p[j], (uint32_t)own[j].z) << 1) +
-                                     xmad24(2 * y, own[j].y, xmad24(2 * x, own[j].x, -own[j].w));
+                                     xmad24(2 * y, own[j].y, xmad24(2 * x, own[j].x, own[j].w));
                 const bool mv = ok && best[j] > gcur;  // strictly closer (kmeans.rs:375)
                 uint32_t nl = c[j];
                 if (mv) {
@@ -759,7 +762,7 @@ int km_xyrgb_step(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
         const int32_t cx = (int32_t)centroids_h[k].x, cy = (int32_t)centroids_h[k].y;
         const uint8_t *q = centroids_h[k].rgb;
         cent[k] = make_int4(cx, cy, (int32_t)(((uint32_t)q[0] << 16) | ((uint32_t)q[1] << 8) | q[2]),
-                            cx * cx + cy * cy + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                            -(cx * cx + cy * cy + q[0] * q[0] + q[1] * q[1] + q[2] * q[2]));
     }
     CNIIC_HIP_TRY(c, hipMemcpyAsync(s.cent.p, cent.data(), (size_t)K * 16, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_xy_narrow, dim3(xy_grid(s.N)), dim3(256), 0, c->stream, labels_d_u32, s.labels.as<uint16_t>(), s.N);

@@ -9,4 +9,4 @@ img=torch.empty((size,size,3),dtype=torch.uint8,device=dev); ctx.synth_image(_li
 out=torch.empty(1<<20,dtype=torch.uint8,device=dev)
 ctx.encode("voronoi(%d)"%K,img,w=size,h=size,out=out,max_iters=2,allow=(_lib.FEW_ACTIVE,)); torch.cuda.synchronize()
 t=time.perf_counter(); rc,ln,st=ctx.encode("voronoi(%d)"%K,img,w=size,h=size,out=out,max_iters=cap,allow=(_lib.FEW_ACTIVE,)); torch.cuda.synchronize(); dt=time.perf_counter()-t
-print(json.dumps(dict(size=size,K=K,rc=rc,iters=st["iterations"],moved_last=st["moved_last"],sec=round(dt,3),ms_per_iter=round(dt*1e3/max(1,st["iterations"]),3),cand_per_px=round(st["pair_evals"]/max(1,st["iterations"])/(size*size),1),reseeds=st["empty_reseeds"],active=st["active"])))
+print(json.dumps(dict(size=size,K=K,rc=rc,iters=st["iterations"],moved_last=st["moved_last"],sec=round(dt,5),ms_per_iter=round(dt*1e3/max(1,st["iterations"]),3),cand_per_px=round(st["pair_evals"]/max(1,st["iterations"])/(size*size),1),reseeds=st["empty_reseeds"],active=st["active"])))
