@@ -416,3 +416,18 @@ def test_codec_trait_surface(ctx):
     assert np.array_equal(r.decode(r.encode(img)), img)
     with pytest.raises(ValueError):
         AnyCodec.from_str("hilbert-rle")
+
+
+@pytest.mark.parametrize("n_colours,K", [(8, 8), (9, 8), (8, 1), (300, 299), (40, 7)])
+def test_partition_path_few_colours(ctx, sp_path, n_colours, K):
+    """as many colours as clusters (every chunk of the initial assignment is one point), one more, a single cluster"""
+    rng = np.random.default_rng(n_colours * 131 + K)
+    pal = rng.choice(1 << 24, n_colours, replace=False).astype(np.uint32)
+    idx = np.concatenate([np.arange(n_colours), rng.integers(0, n_colours, 2000 - n_colours)])
+    rng.shuffle(idx)
+    k = pal[idx]
+    img = np.stack([(k >> 16) & 255, (k >> 8) & 255, k & 255], 1).astype(np.uint8).reshape(40, 50, 3)
+    expr = "cluster-colors(%d)" % K
+    rc, data, st = ctx.encode(expr, img)
+    rco, edata, est = O.encode(expr, img, mode=O.MODE_L)
+    assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
