@@ -1,6 +1,8 @@
 // huff_host.cpp -- see huff_host.hpp.  Reference: src/huf.rs, src/ser.rs, src/bit.rs:256-259.
 #include "huff_host.hpp"
 
+#include <cstddef>
+#include <cstdlib>
 #include <utility>
 
 #include "../../include/cniic_hip.h"
@@ -11,16 +13,18 @@ namespace {
 
 // One heap entry: huf.rs:63-66 `Suffix { freq, tree }` with Ord reversed on freq (huf.rs:80-85),
 // so "greater" means "smaller frequency" and the max-heap pops the rarest subtree first.
-struct Suffix {
-    uint64_t freq;
+// FreqT = u32 whenever the total fits (every image this library takes: < 2^32 pixels): 8-byte entries, half the
+// memory the sift loops walk; u64 otherwise.
+template <typename FreqT> struct SuffixT {
+    FreqT freq;
     uint32_t node;
 };
-inline bool le(const Suffix &a, const Suffix &b) { return a.freq >= b.freq; }  // a <= b in reversed order
-inline bool lt(const Suffix &a, const Suffix &b) { return a.freq > b.freq; }
+template <typename S> inline bool le(const S &a, const S &b) { return a.freq >= b.freq; }  // a <= b in reversed order
+template <typename S> inline bool lt(const S &a, const S &b) { return a.freq > b.freq; }
 
 // std::collections::BinaryHeap restated: the exact sift routines decide how equal frequencies are
 // ordered, hence the tree shape.
-class RustMaxHeap {
+template <typename Suffix> class RustMaxHeap {
   public:
     explicit RustMaxHeap(std::vector<Suffix> v) : d_(std::move(v)) {  // From<Vec<T>> -> rebuild()
         for (size_t n = d_.size() / 2; n > 0;) sift_down_range(--n, d_.size());
@@ -73,41 +77,56 @@ class RustMaxHeap {
         size_t pos = 0;
         Suffix hole = d_[0];
         size_t child = 1;
+        Suffix *d = d_.data();
+        // every level's address depends on the compare of the level above: the walk is a chain of cache misses once
+        // the array outgrows L1.  The four grandchildren of (child, child + 1) are one contiguous run, and so are
+        // their eight children: both are requested before the compare that picks one of them.
         while (end >= 2 && child <= end - 2) {
-            if (le(d_[child], d_[child + 1])) child++;
-            d_[pos] = d_[child];
+            __builtin_prefetch(d + 4 * child + 3);
+            __builtin_prefetch(d + 4 * child + 3 + 64 / sizeof(Suffix) - 1);
+            child += le(d[child], d[child + 1]) ? 1 : 0;
+            d[pos] = d[child];
             pos = child;
             child = 2 * pos + 1;
         }
         if (end >= 1 && child == end - 1) {
-            d_[pos] = d_[child];
+            d[pos] = d[child];
             pos = child;
         }
-        d_[pos] = hole;
+        d[pos] = hole;
         sift_up(0, pos);
     }
 };
 
 }  // namespace
 
-bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
-    if (n == 0 || n > 0x7fffffffull) return false;  // huf.rs:99 assert!(min_heap.len() > 0)
-    t.nleaf = n;
-    t.left.assign(n > 1 ? n - 1 : 0, 0);
-    t.right.assign(n > 1 ? n - 1 : 0, 0);
+template <typename FreqT> static void build_tree_with(const uint64_t *counts, uint64_t n, HuffTree &t) {
+    using Suffix = SuffixT<FreqT>;
     std::vector<Suffix> items(n);
-    for (uint64_t i = 0; i < n; i++) items[i] = Suffix{counts[i], (uint32_t)i};
-    RustMaxHeap heap(std::move(items));
+    for (uint64_t i = 0; i < n; i++) items[i] = Suffix{(FreqT)counts[i], (uint32_t)i};
+    RustMaxHeap<Suffix> heap(std::move(items));
     uint32_t next = (uint32_t)n;
     while (heap.size() > 1) {  // huf.rs:100-110
         Suffix l = heap.pop();
         Suffix r = heap.pop();
         t.left[next - n] = l.node;
         t.right[next - n] = r.node;
-        heap.push(Suffix{l.freq + r.freq, next});
+        heap.push(Suffix{(FreqT)(l.freq + r.freq), next});
         next++;
     }
     t.root = heap.pop().node;
+}
+
+bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
+    if (n == 0 || n > 0x7fffffffull) return false;  // huf.rs:99 assert!(min_heap.len() > 0)
+    t.nleaf = n;
+    t.left.assign(n > 1 ? n - 1 : 0, 0);
+    t.right.assign(n > 1 ? n - 1 : 0, 0);
+    uint64_t total = 0;
+    bool small = true;
+    for (uint64_t i = 0; i < n && small; i++) { total += counts[i]; small = total < (1ull << 32) && counts[i] < (1ull << 32); }
+    if (small) build_tree_with<uint32_t>(counts, n, t);
+    else build_tree_with<uint64_t>(counts, n, t);
     return true;
 }
 
@@ -115,20 +134,27 @@ bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64
     const uint64_t n = t.nleaf;
     len.assign(n, 0);
     code.assign(n, 0);
-    struct Fr { uint32_t node; uint32_t depth; uint64_t bits; };
-    std::vector<Fr> st;
-    st.push_back({t.root, 0, 0});
+    if (n == 1) return true;  // a single symbol: the zero-length code (huf.rs:140-142)
+    // An inner node is made after its two children, so it has the larger id and the root the largest: walking the
+    // ids downwards meets every parent before its children (Bit::Zero = left, Bit::One = right).  No stack.
+    const uint64_t ninner = n - 1;
+    std::vector<uint8_t> idepth(ninner, 0);
+    std::vector<uint64_t> ibits(ninner, 0);
     bool ok = true;
-    while (!st.empty()) {
-        Fr f = st.back();
-        st.pop_back();
-        if (f.node < n) {
-            if (f.depth > 64) { ok = false; continue; }
-            len[f.node] = (uint8_t)f.depth;
-            code[f.node] = f.bits;
-        } else {
-            st.push_back({t.right[f.node - n], f.depth + 1, (f.bits << 1) | 1});  // Bit::One  = right
-            st.push_back({t.left[f.node - n], f.depth + 1, f.bits << 1});         // Bit::Zero = left
+    for (uint64_t i = ninner; i-- > 0;) {
+        const uint32_t d = (uint32_t)idepth[i] + 1;
+        const uint64_t b = ibits[i];
+        const uint32_t kid[2] = {t.left[i], t.right[i]};
+        for (int s = 0; s < 2; s++) {
+            const uint64_t cb = (d <= 64 ? (b << 1) : 0) | (uint64_t)s;
+            if (kid[s] < n) {
+                if (d > 64) { ok = false; continue; }
+                len[kid[s]] = (uint8_t)d;
+                code[kid[s]] = cb;
+            } else {
+                idepth[kid[s] - n] = (uint8_t)(d > 255 ? 255 : d);
+                ibits[kid[s] - n] = cb;
+            }
         }
     }
     return ok;
@@ -174,16 +200,31 @@ static void put_symbol(std::vector<uint8_t> &o, int kind, uint32_t key) {
 
 void huff_serialize_tree(const HuffTree &t, int sym_kind, const uint32_t *keys, std::vector<uint8_t> &out) {
     const uint64_t n = t.nleaf;
+    // the size is known (n leaves of 1 + S bytes, n - 1 branch tags): written through a pointer, not byte by byte
+    const uint64_t S = (uint64_t)huff_symbol_size(sym_kind), base = out.size();
+    out.resize(base + n * (1 + S) + (n - 1));
+    uint8_t *o = out.data() + base;
     std::vector<uint32_t> st;
+    st.reserve(128);
     st.push_back(t.root);
     while (!st.empty()) {
-        uint32_t nd = st.back();
+        const uint32_t nd = st.back();
         st.pop_back();
         if (nd < n) {
-            out.push_back(0);  // SER_ENUM_LEAF huf.rs:296
-            put_symbol(out, sym_kind, keys[nd]);
+            *o++ = 0;  // SER_ENUM_LEAF huf.rs:296
+            const uint32_t key = keys[nd];
+            if (sym_kind == CNIIC_SYM_RGB) {  // ser.rs:210-214: u64 length (3) + 3 bytes
+                o[0] = 3; o[1] = o[2] = o[3] = o[4] = o[5] = o[6] = o[7] = 0;
+                o[8] = (uint8_t)(key >> 16); o[9] = (uint8_t)(key >> 8); o[10] = (uint8_t)key;
+                o += 11;
+            } else {                          // hilbertc.rs:561-565 -> ser.rs:188-195: three i16 LE
+                for (int i = 0; i < 3; i++) {
+                    const uint16_t u = (uint16_t)(int16_t)((int)((key >> (18 - 9 * i)) & 511) - 255);
+                    *o++ = (uint8_t)u; *o++ = (uint8_t)(u >> 8);
+                }
+            }
         } else {
-            out.push_back(1);  // SER_ENUM_BRANCH huf.rs:297
+            *o++ = 1;  // SER_ENUM_BRANCH huf.rs:297
             st.push_back(t.right[nd - n]);
             st.push_back(t.left[nd - n]);
         }
