@@ -241,31 +241,34 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_count(const uint32_t *
     }
 }
 
-// single block: exclusive scan of nblocks sums in place; total -> *total
-__global__ __launch_bounds__(1024) void k_compact_scan(uint32_t *__restrict__ blocksum, uint32_t nblocks,
-                                                       uint64_t *__restrict__ total) {
-    __shared__ uint32_t sh[1024];
-    const uint32_t per = (nblocks + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per;
-    const uint32_t hi = min(lo + per, nblocks);
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += blocksum[i];
-    sh[threadIdx.x] = s;
+// exclusive scan of nblocks sums in place; total -> *total.  Blocks of 1024 sums scan their own part and leave their
+// total, then every block adds the totals before it (one block over the 32768 sums of a 2^27-bin table took 54 us).
+__global__ __launch_bounds__(1024) void k_compact_scan_local(uint32_t *__restrict__ blocksum, uint32_t nblocks,
+                                                             uint32_t *__restrict__ parttot, uint64_t *__restrict__ total) {
+    __shared__ uint32_t wsum[1024 / 64];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < nblocks ? blocksum[i] : 0u;
+    const uint32_t ex = block_exclusive_scan<1024>(v, wsum);
+    if (i < nblocks) blocksum[i] = ex;
+    if (threadIdx.x == 1023) {
+        parttot[blockIdx.x] = ex + v;
+        if (gridDim.x == 1) *total = (uint64_t)ex + v;
+    }
+}
+__global__ __launch_bounds__(1024) void k_compact_scan_add(uint32_t *__restrict__ blocksum, uint32_t nblocks,
+                                                           const uint32_t *__restrict__ parttot, uint64_t *__restrict__ total) {
+    __shared__ uint32_t s_before;
+    uint32_t mine = 0;  // (a table's occupied bins fit 32 bits)
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024) mine += parttot[b];
+    if (threadIdx.x == 0) s_before = 0;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += add;
-        __syncthreads();
-    }
-    uint32_t run = sh[threadIdx.x] - s;  // exclusive prefix of this thread's range
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t v = blocksum[i];
-        blocksum[i] = run;
-        run += v;
-    }
-    if (threadIdx.x == 1023) *total = sh[1023];
+    mine = wave_reduce_sum(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_before, mine);
+    __syncthreads();
+    const uint32_t before = s_before;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nblocks) blocksum[i] += before;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = (uint64_t)before + parttot[blockIdx.x];
 }
 
 __global__ __launch_bounds__(kScanThreads) void k_compact_write(uint32_t *__restrict__ table,
@@ -314,7 +317,16 @@ int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPl
     CNIIC_HIP_TRY(c, tot.alloc(8));
     hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>(),
                        bits == 24 ? cell_count_d : nullptr);
-    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks, tot.as<uint64_t>());
+    {
+        const uint32_t nparts = (nblocks + 1023) / 1024;
+        DevBuf parttot;
+        CNIIC_HIP_TRY(c, parttot.alloc((uint64_t)nparts * 4));
+        hipLaunchKernelGGL(k_compact_scan_local, dim3(nparts), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks,
+                           parttot.as<uint32_t>(), tot.as<uint64_t>());
+        if (nparts > 1)
+            hipLaunchKernelGGL(k_compact_scan_add, dim3(nparts), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks,
+                               (const uint32_t *)parttot.as<uint32_t>(), tot.as<uint64_t>());
+    }
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));

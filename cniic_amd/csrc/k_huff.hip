@@ -65,25 +65,46 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count(const void *__restr
     if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
 }
 
-// single block: chunk_off[i] = exclusive prefix (u64) of chunk_bits; total -> *total_bits
-__global__ __launch_bounds__(1024) void k_pack_scan(const uint32_t *__restrict__ chunk_bits, uint32_t nchunks,
-                                                    uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ total_bits) {
-    __shared__ unsigned long long sh[1024];
-    const uint32_t per = (nchunks + 1023) / 1024;
-    const uint32_t lo = min(threadIdx.x * per, nchunks), hi = min(lo + per, nchunks);
-    unsigned long long s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += chunk_bits[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        unsigned long long add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += add;
-        __syncthreads();
+// chunk_off[i] = exclusive prefix (u64) of chunk_bits; total -> *total_bits.  Up to 1024 chunks: one block.  More
+// (a 16384^2 image has 65536): every 1024-chunk block scans its own part and leaves its sum, then every block adds the
+// sums before it (a single block walking 64 values per thread took 115 us there).
+__global__ __launch_bounds__(1024) void k_pack_scan_local(const uint32_t *__restrict__ chunk_bits, uint32_t nchunks,
+                                                          uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ blocktot,
+                                                          uint64_t *__restrict__ total_bits) {
+    __shared__ uint32_t wsum[1024 / 64];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < nchunks ? chunk_bits[i] : 0u;  // <= 4096 symbols x 64 bits: a block's sum fits 32 bits
+    const uint32_t ex = block_exclusive_scan<1024>(v, wsum);
+    if (i < nchunks) chunk_off[i] = ex;
+    if (threadIdx.x == 1023) {
+        blocktot[blockIdx.x] = (uint64_t)ex + v;
+        if (gridDim.x == 1) *total_bits = (uint64_t)ex + v;
     }
-    unsigned long long run = sh[threadIdx.x] - s;
-    for (uint32_t i = lo; i < hi; i++) { chunk_off[i] = run; run += chunk_bits[i]; }
-    if (threadIdx.x == 1023) *total_bits = sh[1023];
+}
+__global__ __launch_bounds__(1024) void k_pack_scan_add(uint32_t nchunks, uint64_t *__restrict__ chunk_off,
+                                                        const uint64_t *__restrict__ blocktot, uint64_t *__restrict__ total_bits) {
+    __shared__ unsigned long long s_before;
+    unsigned long long mine = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024) mine += blocktot[b];
+    if (threadIdx.x == 0) s_before = 0;
+    __syncthreads();
+    mine = wave_reduce_sum64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_before, mine);
+    __syncthreads();
+    const unsigned long long before = s_before;
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nchunks) chunk_off[i] += before;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_bits = before + blocktot[blockIdx.x];
+}
+static int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *chunk_off_d, uint64_t *total_d) {
+    const uint32_t nb = (nchunks + 1023) / 1024;
+    DevBuf blocktot;
+    CNIIC_HIP_TRY(c, blocktot.alloc((uint64_t)nb * 8));
+    hipLaunchKernelGGL(k_pack_scan_local, dim3(nb), dim3(1024), 0, c->stream, chunk_bits_d, nchunks, chunk_off_d, blocktot.as<uint64_t>(), total_d);
+    if (nb > 1)
+        hipLaunchKernelGGL(k_pack_scan_add, dim3(nb), dim3(1024), 0, c->stream, nchunks, chunk_off_d, (const uint64_t *)blocktot.as<uint64_t>(), total_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
 }
 
 template <int SRC>
@@ -295,7 +316,7 @@ int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32
     else
         hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream,
                            reinterpret_cast<const uint8_t *>(pixlab_d), n, K, clen_d, cb.as<uint32_t>());
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     if (wide)
         hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
                            reinterpret_cast<const uint16_t *>(pixlab_d), n, K, clen_d, ccode_d, co.as<uint64_t>(),
@@ -328,7 +349,7 @@ static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank
     CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
     CNIIC_HIP_TRY(c, tot.alloc(8));
     hipLaunchKernelGGL(k_pack_count<SRC>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, src_d, n, rank_table_d, len_d, cb.as<uint32_t>());
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -480,7 +501,7 @@ int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_
         hipLaunchKernelGGL(k_pack_count32<SRC_RGB>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, rgb_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_pack_count32<SRC_KEYS>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, syms_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
-    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, c->stream, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
                        reinterpret_cast<uint32_t *>(out_d), bit_base);
     CNIIC_HIP_TRY(c, hipGetLastError());
