@@ -86,6 +86,7 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     if (c->res_ev) (void)hipEventDestroy(c->res_ev);
     if (c->pinned_u) (void)hipHostFree(c->pinned_u);
     if (c->u_ev) (void)hipEventDestroy(c->u_ev);
+    if (c->huf_ev) (void)hipEventDestroy(c->huf_ev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -151,7 +151,17 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     std::vector<uint64_t> counts(U);
     CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->huf_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->huf_ev, hipEventDisableTiming));
+    CNIIC_HIP_TRY(c, hipEventRecord(c->huf_ev, c->stream));
+    // While the host builds the tree the GPU turns every symbol into its rank in the compacted list -- the one random
+    // read per symbol into the dense table (it now holds rank + 1), which needs no code -- in place over the symbol
+    // stream when it is ours.  The pack then reads that stream and the small per-rank length / code tables.
+    DevBuf ranks_own;
+    uint32_t *ranks = syms_d;
+    if (!syms_d || !syms_scratch) { CNIIC_HIP_TRY(c, ranks_own.alloc(n * 4 + 16)); ranks = ranks_own.as<uint32_t>(); }
+    const bool inline_codes = U < (1ull << 26);  // (len, code) of a symbol in one u32 looked up by rank; else per-rank tables
+    CNIIC_TRY(huff_rank_stream(c, syms_d, rgb_d, n, table_d, ranks, !inline_codes));
+    CNIIC_HIP_TRY(c, hipEventSynchronize(c->huf_ev));
     host_trace().mark("huf: hist + compaction + D2H");
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
     HuffTree tree;
@@ -174,15 +184,13 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
     uint64_t packed_bits = 0;
     ScopedKernelTimer timer(c, "huff_pack");
-    if (U < (1ull << 26)) {
-        DevBuf packed_own;
-        uint32_t *packed = syms_d;  // in place over our own symbol stream
-        if (!syms_d || !syms_scratch) { CNIIC_HIP_TRY(c, packed_own.alloc(n * 4 + 16)); packed = packed_own.as<uint32_t>(); }
-        CNIIC_TRY(huff_pack_code32(c, syms_d, rgb_d, n, table_d, keys_d.as<uint32_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>(), U,
-                                   packed, so.dev, (uint64_t)header.size() * 8, &packed_bits));
+    if (inline_codes) {
+        DevBuf code32;
+        CNIIC_HIP_TRY(c, code32.alloc(U * 4));
+        CNIIC_TRY(huff_pack_code32(c, ranks, nullptr, n, code32.as<uint32_t>(), nullptr, len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, ranks,
+                                   so.dev, (uint64_t)header.size() * 8, &packed_bits));
     } else {
-        CNIIC_TRY(huff_pack_keys(c, syms_d, rgb_d, n, table_d, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev,
-                                 (uint64_t)header.size() * 8, &packed_bits));
+        CNIIC_TRY(huff_pack_ranks(c, ranks, n, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev, (uint64_t)header.size() * 8, &packed_bits));
     }
     timer.stop(1);
     host_trace().mark("huf: pack");

@@ -128,6 +128,7 @@ struct Ctx {
     hipEvent_t res_ev = nullptr;
     uint64_t *pinned_u = nullptr;  // pinned landing slot of sp_build's distinct-colour count, and the event behind its copy
     hipEvent_t u_ev = nullptr;
+    hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -470,6 +471,11 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
 int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n,
                    const uint32_t *rank_table_d, const uint8_t *len_d, const uint64_t *code_d,
                    uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+// the same in two steps: the symbols' ranks as a stream (needs no code: runs while the host builds the tree), then the pack
+int huff_rank_stream(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, const uint32_t *rank_table_d,
+                     uint32_t *ranks_d, bool one_based);
+int huff_pack_ranks(Ctx *c, const uint32_t *ranks_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
+                    uint64_t bit_base, uint64_t *nbits_h);
 // same result with one random read per symbol (needs every code length <= 26): the dense table is
 // overwritten with len<<26|code per key; packed_d = n u32 of scratch (may alias syms)
 int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, uint32_t *table_d,

@@ -20,7 +20,7 @@ constexpr int kPackPer = 16;
 constexpr int kPackChunk = kPackThreads * kPackPer;  // symbols per block
 constexpr int kPackWords = kPackChunk * 2 + 2;       // LDS words: 64 bits per symbol worst case
 
-enum { SRC_RGB = 0, SRC_KEYS = 1, SRC_SYM16 = 2 };
+enum { SRC_RGB = 0, SRC_KEYS = 1, SRC_SYM16 = 2, SRC_RANKS = 3 };
 
 // fetch the ranks of this thread's 16 consecutive symbols (0xffffffff past the end)
 template <int SRC>
@@ -42,10 +42,39 @@ __device__ __forceinline__ void fetch_ranks(const void *__restrict__ src, uint64
         const uint32_t *keys = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
         for (int i = 0; i < kPackPer; i++) rank[i] = (first + i < n) ? rank_table[keys[first + i]] - 1 : 0xffffffffu;
+    } else if (SRC == SRC_RANKS) {  // the stream of rank + 1 left by k_rank_stream
+        const uint32_t *rk = reinterpret_cast<const uint32_t *>(src);
+        if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(rk) & 15) == 0)) {
+            const uint4 *v = reinterpret_cast<const uint4 *>(rk + first);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const uint4 q = v[j]; rank[4 * j] = q.x - 1; rank[4 * j + 1] = q.y - 1; rank[4 * j + 2] = q.z - 1; rank[4 * j + 3] = q.w - 1; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kPackPer; i++) rank[i] = (first + i < n) ? rk[first + i] - 1 : 0xffffffffu;
+        }
     } else {
         const uint16_t *sym = reinterpret_cast<const uint16_t *>(src);
 #pragma unroll
         for (int i = 0; i < kPackPer; i++) rank[i] = (first + i < n) ? (uint32_t)sym[first + i] : 0xffffffffu;
+    }
+}
+
+// rank + 1 of every symbol as a linear stream: the one random read per symbol into the dense table, done while the
+// host builds the tree (it needs no code); the pack passes then read the stream and the small per-rank tables
+template <int SRC>
+__global__ __launch_bounds__(kPackThreads) void k_rank_stream(const void *__restrict__ src, uint64_t n,
+                                                              const uint32_t *__restrict__ rank_table, uint32_t *__restrict__ out,
+                                                              uint32_t plus) {
+    const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
+    uint32_t rank[kPackPer];
+    fetch_ranks<SRC>(src, n, first, rank_table, rank);
+    if (first + kPackPer <= n && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        uint4 *o = reinterpret_cast<uint4 *>(out + first);
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = make_uint4(rank[4 * j] + plus, rank[4 * j + 1] + plus, rank[4 * j + 2] + plus, rank[4 * j + 3] + plus);
+    } else {
+        for (int i = 0; i < kPackPer; i++)
+            if (first + i < n) out[first + i] = rank[i] + plus;
     }
 }
 
@@ -372,7 +401,7 @@ __global__ __launch_bounds__(256) void k_fill_code32(const uint32_t *__restrict_
                                                      const uint64_t *__restrict__ code, uint64_t U, uint32_t *__restrict__ table) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride)
-        table[keys[i]] = len[i] <= 26 ? ((uint32_t)len[i] << 26) | (uint32_t)code[i]
+        table[keys ? keys[i] : (uint32_t)i] = len[i] <= 26 ? ((uint32_t)len[i] << 26) | (uint32_t)code[i]
                                       : (kEscape << 26) | (uint32_t)i;  // long (rare) code: escape to len[rank] / code[rank]
 }
 
@@ -480,7 +509,8 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write32(const uint32_t *_
 }
 
 // table_d: dense symbol table (any content; overwritten).  keys_d/len_d/code_d: the U distinct symbols
-// and their codes (U < 2^26; codes longer than 26 bits escape to the per-rank tables).  src: pixels (rgb) or symbol keys; packed_d: n u32 of scratch,
+// and their codes (U < 2^26; codes longer than 26 bits escape to the per-rank tables).  src: pixels (rgb) or symbol keys (keys_d null: the
+// symbols ARE ranks and table_d has U entries); packed_d: n u32 of scratch,
 // may alias the symbol stream when that buffer is not needed afterwards.
 int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, uint32_t *table_d,
                      const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint32_t *packed_d,
@@ -519,6 +549,27 @@ int huff_pack_keys(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or
                    uint64_t bit_base, uint64_t *nbits_h) {
     if (rgb_or_null_d) return pack_impl<SRC_RGB>(c, rgb_or_null_d, n, rank_table_d, len_d, code_d, out_d, bit_base, nbits_h);
     return pack_impl<SRC_KEYS>(c, keys_or_null_d, n, rank_table_d, len_d, code_d, out_d, bit_base, nbits_h);
+}
+
+// ranks_d[i] = rank (+ 1 when one_based) of symbol i (may alias keys_or_null_d: every thread reads its symbols before it writes)
+int huff_rank_stream(Ctx *c, const uint32_t *keys_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, const uint32_t *rank_table_d,
+                     uint32_t *ranks_d, bool one_based) {
+    if (n == 0) return CNIIC_OK;
+    const uint64_t nchunks64 = ceil_div(n, kPackChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: too many symbols");
+    if (rgb_or_null_d)
+        hipLaunchKernelGGL(k_rank_stream<SRC_RGB>, dim3((uint32_t)nchunks64), dim3(kPackThreads), 0, c->stream, rgb_or_null_d, n, rank_table_d, ranks_d,
+                           one_based ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(k_rank_stream<SRC_KEYS>, dim3((uint32_t)nchunks64), dim3(kPackThreads), 0, c->stream, keys_or_null_d, n, rank_table_d, ranks_d,
+                           one_based ? 1u : 0u);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+int huff_pack_ranks(Ctx *c, const uint32_t *ranks_d, uint64_t n, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
+                    uint64_t bit_base, uint64_t *nbits_h) {
+    return pack_impl<SRC_RANKS>(c, ranks_d, n, nullptr, len_d, code_d, out_d, bit_base, nbits_h);
 }
 
 }  // namespace cniic
