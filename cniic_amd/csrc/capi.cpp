@@ -497,6 +497,7 @@ int32_t cniic_cc_image_begin(cniic_ctx *c, const uint8_t *rgb_dev, uint64_t npx,
     LOCK(c);
     if (!rgb_dev || !out || npx == 0 || !is_device_ptr(rgb_dev) || (reinterpret_cast<uintptr_t>(rgb_dev) & 15))
         return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_begin: a non-empty, 16-byte aligned device image and an out pointer are needed");
+    if (npx >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_begin: too many pixels");
     CcSession *s = nullptr;
     CNIIC_TRY(cc_image_begin(c, rgb_dev, npx, &s));
     *out = new cniic_cc{c, s};
