@@ -431,3 +431,27 @@ def test_partition_path_few_colours(ctx, sp_path, n_colours, K):
     rc, data, st = ctx.encode(expr, img)
     rco, edata, est = O.encode(expr, img, mode=O.MODE_L)
     assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+
+
+# ------------------------------------------------------------------ the reference's own known answers, through the HIP path
+def _key(r, g, b):
+    return (r << 16) | (g << 8) | b
+
+
+def test_reference_kats_on_the_gpu(ctx):
+    """clusterc.rs:304-312 rgb_mean ([0,0,0], [2,2,2] -> [1,1,1]); kmeans.rs:491-500 all_clusters (as many points as
+    clusters: each is its own centroid); kmeans.rs:525-539 squares2 (two far squares, K = 2 -> exactly their centres),
+    here as 3x3x3 cubes of colours; kmeans.rs:516-523 square1 (K = 1 -> the centre, all members)"""
+    rc, r = ctx.kmeans_rgbw([_key(0, 0, 0), _key(2, 2, 2)], [1, 1], 1)
+    assert rc == 0 and r["centroids"].tolist() == [[1, 1, 1]] and r["members"].tolist() == [2]
+    rc, r = ctx.kmeans_rgbw([_key(0, 0, 0), _key(1, 1, 1)], [1, 1], 2)
+    assert rc == 0 and sorted(r["centroids"].tolist()) == [[0, 0, 0], [1, 1, 1]] and sorted(r["labels"].tolist()) == [0, 1]
+    cube = lambda c: [_key(c + dr, c + dg, c + db) for dr in (-1, 0, 1) for dg in (-1, 0, 1) for db in (-1, 0, 1)]
+    keys = np.array(sorted(cube(50) + cube(200)), np.uint32)
+    rc, r = ctx.kmeans_rgbw(keys, np.ones(keys.size, np.uint32), 2)
+    assert rc == 0 and sorted(r["centroids"].tolist()) == [[50, 50, 50], [200, 200, 200]] and sorted(r["members"].tolist()) == [27, 27]
+    rc, r = ctx.kmeans_rgbw(np.array(sorted(cube(100)), np.uint32), np.ones(27, np.uint32), 1)
+    assert rc == 0 and r["centroids"].tolist() == [[100, 100, 100]] and r["members"].tolist() == [27]
+    # the weighted mean truncates (clusterc.rs:96-112): (0*3 + 10*1) / 4 = 2
+    rc, r = ctx.kmeans_rgbw([_key(0, 0, 0), _key(10, 10, 10)], [3, 1], 1)
+    assert rc == 0 and r["centroids"].tolist() == [[2, 2, 2]]
