@@ -666,7 +666,9 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         uint8_t *dst = rgb_out;
         const bool dst_dev = is_device_ptr(rgb_out);
         if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
-        CNIIC_TRY(voronoi_paint(c, cent_d.as<cniic_colorpos>(), (uint32_t)K, *w, *h, dst));
+        bool small_coords = *w <= (1u << 14) && *h <= (1u << 14);  // then the pruned repaint is exact (k_misc.hip)
+        for (uint64_t k = 0; k < K && small_coords; k++) small_coords = cent[k].x < (1u << 14) && cent[k].y < (1u << 14);
+        CNIIC_TRY(voronoi_paint(c, cent_d.as<cniic_colorpos>(), (uint32_t)K, *w, *h, dst, small_coords));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
         return CNIIC_OK;

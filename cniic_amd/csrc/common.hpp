@@ -431,7 +431,7 @@ int local_cluster_weights(Ctx *c, const uint32_t *keys_d, const void *labels_d, 
                           const uint32_t *local_counts_d, uint32_t K, uint64_t *out_d, const uint32_t *weights_d = nullptr);
 int label_lut(Ctx *c, const uint32_t *labels_d, uint64_t U, const uint32_t *cent_d, uint32_t *lut_d);
 int rank_from_keys(Ctx *c, const uint32_t *keys_d, uint64_t U, uint32_t *table_d);
-int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d);
+int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d, bool small_coords = false);
 int mse_rgb(Ctx *c, const uint8_t *a_d, const uint8_t *b_d, uint64_t npx, double *mse_h);
 int synth_image(Ctx *c, int kind, uint64_t seed, uint32_t w, uint32_t h, uint8_t *out_d);
 int rgb_to_keys(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *keys_d);

@@ -209,10 +209,91 @@ __global__ __launch_bounds__(256) void k_voronoi_paint(const cniic_colorpos *__r
     }
 }
 
-int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d) {
+// The same with the centroids pruned per 64x32-pixel tile (one 256-thread block): pivot = centroid nearest the tile centre;
+// centroid k is kept iff max over the tile of d(p, pivot) - d(p, c_k) >= 0 (linear in p: taken at the corners, as in
+// k_kmeans_xyrgb.hip), i.e. unless the pivot is STRICTLY nearer everywhere -- so every minimum and every tie survives,
+// in ascending id, and the first minimum among the kept ones is the first minimum among all.  Needs true (not
+// wrapping) arithmetic: coordinates below 2^14 (the host checks; any other stream takes the brute-force kernel).
+constexpr int kVTW = 64, kVTH = 32, kVCap = 256;  // (K <= 4096: at most 16 consecutive ids per thread, a bit each in `keep`)
+__global__ __launch_bounds__(256) void k_voronoi_paint_tiles(const cniic_colorpos *__restrict__ cent, uint32_t K, uint32_t w, uint32_t h,
+                                                             uint32_t tiles_x, uint8_t *__restrict__ out) {
+    __shared__ int2 s_c[kVCap];
+    __shared__ uint16_t s_k[kVCap];
+    __shared__ unsigned long long s_key;
+    __shared__ uint32_t wsum[256 / 64], s_n;
+    const uint32_t tx0 = (blockIdx.x % tiles_x) * kVTW, ty0 = (blockIdx.x / tiles_x) * kVTH;
+    const int32_t x0 = (int32_t)tx0, x1 = (int32_t)min(w, tx0 + kVTW) - 1, y0 = (int32_t)ty0, y1 = (int32_t)min(h, ty0 + kVTH) - 1;
+    const int32_t cx2 = x0 + x1, cy2 = y0 + y1;  // twice the tile centre
+    const uint32_t per = (K + 255) / 256, k_lo = threadIdx.x * per;
+    if (threadIdx.x == 0) s_key = ~0ull;
+    __syncthreads();
+    unsigned long long key = ~0ull;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t k = k_lo + i;
+        if (k >= K) break;
+        const int32_t dx = 2 * (int32_t)cent[k].x - cx2, dy = 2 * (int32_t)cent[k].y - cy2;
+        key = min(key, ((unsigned long long)(uint32_t)(dx * dx + dy * dy) << 12) | k);  // (< 2^31: coordinates < 2^14)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_xor(key, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(&s_key, key);
+    __syncthreads();
+    const uint32_t pk = (uint32_t)(s_key & 4095ull);
+    const int32_t px = (int32_t)cent[pk].x, py = (int32_t)cent[pk].y;
+    const int32_t ax0 = px - 2 * x0, ax1 = px - 2 * x1, ay0 = py - 2 * y0, ay1 = py - 2 * y1;
+    uint32_t keep = 0, cnt = 0;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t k = k_lo + i;
+        if (k >= K) break;
+        const int32_t kx = (int32_t)cent[k].x, ky = (int32_t)cent[k].y, dx = px - kx, dy = py - ky;
+        const int32_t f = max(dx * (kx + ax0), dx * (kx + ax1)) + max(dy * (ky + ay0), dy * (ky + ay1));  // |terms| < 2^30
+        if (f >= 0) { keep |= 1u << i; cnt++; }
+    }
+    uint32_t off = block_exclusive_scan<256>(cnt, wsum);
+    if (threadIdx.x == 255) s_n = off + cnt;
+    for (uint32_t i = 0; i < per; i++)
+        if ((keep >> i) & 1u) {
+            if (off < kVCap) { s_c[off] = make_int2((int32_t)cent[k_lo + i].x, (int32_t)cent[k_lo + i].y); s_k[off] = (uint16_t)(k_lo + i); }
+            off++;
+        }
+    __syncthreads();
+    const uint32_t n = s_n;
+    const uint32_t x = tx0 + (threadIdx.x & 63);
+    for (uint32_t j = 0; j < kVTH / 4; j++) {
+        const uint32_t y = ty0 + (threadIdx.x >> 6) + 4 * j;
+        if (x >= w || y >= h) continue;
+        uint32_t best = 0xffffffffu, bk = 0;
+        if (n <= kVCap) {
+            uint32_t bq = 0;
+            for (uint32_t q = 0; q < n; q++) {
+                const int2 cc = s_c[q];  // LDS broadcast
+                const int32_t dx = cc.x - (int32_t)x, dy = cc.y - (int32_t)y;
+                const uint32_t d = (uint32_t)(dx * dx + dy * dy);
+                if (d < best) { best = d; bq = q; }
+            }
+            bk = s_k[bq];
+        } else {
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t dx = cent[k].x - x, dy = cent[k].y - y, d = dx * dx + dy * dy;
+                if (d < best || k == 0) { best = d; bk = k; }
+            }
+        }
+        const uint8_t *col = cent[bk].rgb;
+        uint8_t *o = out + 3 * ((uint64_t)y * w + x);
+        o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
+    }
+}
+
+// small_coords: every centroid coordinate and both image sides are below 2^14 (true arithmetic = the reference's wrapping one)
+int voronoi_paint(Ctx *c, const cniic_colorpos *cent_d, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d, bool small_coords) {
     uint64_t npx = (uint64_t)w * h;
     if (!npx) return CNIIC_OK;
-    hipLaunchKernelGGL(k_voronoi_paint, dim3(grid_for(npx, 256, 256 * 16)), dim3(256), 0, c->stream, cent_d, K, w, h, out_d);
+    if (small_coords && K >= 1 && K <= 4096) {
+        const uint32_t tiles_x = (w + kVTW - 1) / kVTW, tiles_y = (h + kVTH - 1) / kVTH;
+        hipLaunchKernelGGL(k_voronoi_paint_tiles, dim3(tiles_x * tiles_y), dim3(256), 0, c->stream, cent_d, K, w, h, tiles_x, out_d);
+    } else {
+        hipLaunchKernelGGL(k_voronoi_paint, dim3(grid_for(npx, 256, 256 * 16)), dim3(256), 0, c->stream, cent_d, K, w, h, out_d);
+    }
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

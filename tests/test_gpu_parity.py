@@ -455,3 +455,35 @@ def test_reference_kats_on_the_gpu(ctx):
     # the weighted mean truncates (clusterc.rs:96-112): (0*3 + 10*1) / 4 = 2
     rc, r = ctx.kmeans_rgbw([_key(0, 0, 0), _key(10, 10, 10)], [3, 1], 1)
     assert rc == 0 and r["centroids"].tolist() == [[2, 2, 2]]
+
+
+def _voronoi_stream(w, h, cents):
+    import struct
+    b = struct.pack("<IIQ", w, h, len(cents))
+    for (x, y, col) in cents:
+        b += struct.pack("<IIQ", x, y, 3) + bytes(col)
+    return b
+
+
+@pytest.mark.parametrize("case", ["dense", "ties", "outside", "huge_coords", "many"])
+def test_voronoi_repaint_pruned_equals_brute_force(ctx, case):
+    """VoronoiCluster::decode (clusterc.rs:180-186): first minimum of the wrapping u32 key.  The tile-pruned repaint must
+    agree with the oracle's brute force, including exact ties (duplicated and mirrored centroids) and centroids outside the
+    image; coordinates of 2^14 and more take the brute-force kernel"""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    w, h = 333, 217
+    K = {"dense": 500, "ties": 64, "outside": 40, "huge_coords": 30, "many": 3000}[case]
+    xs, ys = rng.integers(0, w, K), rng.integers(0, h, K)
+    if case == "ties":
+        xs[K // 2:], ys[K // 2:] = xs[:K - K // 2], ys[:K - K // 2]          # every site twice: the lower id must win
+        xs[::7] = w - 1 - xs[::7]                                             # and mirrored pairs: equidistant columns
+    if case == "outside":
+        xs, ys = rng.integers(0, 3 * w, K), rng.integers(0, 3 * h, K)
+    if case == "huge_coords":
+        xs = rng.integers(0, 1 << 32, K, dtype=np.uint64)
+        ys = rng.integers(0, 1 << 32, K, dtype=np.uint64)
+    cents = [(int(xs[i]), int(ys[i]), rng.integers(0, 256, 3).astype(np.uint8).tolist()) for i in range(K)]
+    data = _voronoi_stream(w, h, cents)
+    rc, got = ctx.decode("voronoi(%d)" % K, data)
+    rco, exp = O.decode("voronoi(%d)" % K, data)
+    assert rc == rco == 0 and np.array_equal(got, exp)
