@@ -1144,7 +1144,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                        s->cells ? s->moved_list.as<uint32_t>() : (uint32_t *)nullptr, points_dev);
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
-        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, 1024), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
+        s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, s->wide ? 1024 : 64), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
