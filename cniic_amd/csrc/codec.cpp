@@ -297,18 +297,27 @@ int cc_image_create(CcSession *s, const uint32_t *occ_d, uint32_t K, const cniic
     if (!s->sp_mode || s->km) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_create: needs a session from cc_image_begin, once");
     if (K == 0) return c->fail(CNIIC_ERR_BAD_ARG, "cluster-colors(0)");
     s->K = K;
-    uint64_t Ug = 0;
-    CNIIC_TRY(gidx_build(c, occ_d, s->gbits, s->gprefix, &Ug));  // the reference's point list: the colours of all images (syncs)
-    CNIIC_TRY(sp_wait_count(c, &s->sp));
+    // The reference's point list is the colours of ALL images: the summed occupancy as a bitmap + prefix.  Its length (and
+    // this image's own colour count) stay on the device while the state is set up -- sized for the most there can be, the
+    // set-up kernels read the counts where they are -- and the host fetches both once everything is enqueued.
+    CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+    uint64_t *Ug_h = c->pinned_u + 1;
+    CNIIC_TRY(gidx_build(c, occ_d, s->gbits, s->gprefix, Ug_h, &s->gtotal));
+    const uint64_t Umax = std::min<uint64_t>(s->sp.npx, 1ull << 24);
+    const uint64_t *Ug_dev = s->gtotal.as<uint64_t>();
+    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, Umax, 0, 1, K, opts, partials_dev, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->gbits.p,
+                             s->gprefix.as<uint32_t>(), 1ull << 24, true, Ug_dev));
+    uint32_t *cell_start, *ckeys, *cweight;
+    km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
+    CNIIC_TRY(sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->gbits.p,
+                      s->gprefix.as<uint32_t>(), 0, Ug_dev));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the all-reduced occupancy had to arrive anyway)
+    const uint64_t Ug = *Ug_h;
+    s->sp.U = *c->pinned_u;  // sp_build's copy, ordered before the one above
     s->U = s->sp.U;
     if (Ug / K == 0 || s->U == 0)
         return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)Ug, K);
-    CNIIC_TRY(km_rgbw_create(c, nullptr, nullptr, s->U, 0, 1, K, opts, partials_dev, nullptr, &s->km, s->sp.cell_count.as<uint32_t>(), s->gbits.p,
-                             s->gprefix.as<uint32_t>(), Ug, true));
-    uint32_t *cell_start, *ckeys, *cweight;
-    km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
-    return sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->gbits.p,
-                   s->gprefix.as<uint32_t>(), Ug, nullptr);
+    return km_rgbw_set_points(s->km, s->U, Ug);
 }
 
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
@@ -327,9 +336,23 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     const bool wide = km_rgbw_is_wide(km);
     DevBuf lab_d, key2label, pixlab;
     CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
+    DevBuf lw;
+    bool lw_early = false;
     if (s->sp_mode) {  // every pixel's label from the partition: no table of 2^24 entries, no random read
         uint32_t *cell_start, *ckeys, *cweight;
         km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
+        if (s->local_points && K <= 4096) {
+            // shared palette: THIS image's pixels per cluster (below) -- asked for first, so that the answer travels while
+            // the pixel labels are computed instead of stalling the stream after them
+            CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+            CNIIC_HIP_TRY(c, lw.alloc((uint64_t)K * 8));
+            CNIIC_HIP_TRY(c, hipMemsetAsync(lw.p, 0, (uint64_t)K * 8, c->stream));
+            CNIIC_TRY(local_cluster_weights(c, ckeys, km_rgbw_labels_internal(km, nullptr), wide, U, nullptr, K, lw.as<uint64_t>(), cweight));
+            CNIIC_HIP_TRY(c, hipMemcpyAsync(c->pinned_u + 8, lw.p, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+            if (!c->u_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->u_ev, hipEventDisableTiming));
+            CNIIC_HIP_TRY(c, hipEventRecord(c->u_ev, c->stream));
+            lw_early = true;
+        }
         CNIIC_TRY(sp_pixel_labels(c, &s->sp, rgb_d, cell_start, ckeys, km_rgbw_labels_internal(km, nullptr), wide, pixlab.p));
     } else {
         CNIIC_HIP_TRY(c, lab_d.alloc(U * (wide ? 2 : 1)));
@@ -348,10 +371,12 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     if (st.active < min_cc)
         return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
                        (unsigned long long)st.active, (unsigned long long)min_cc);
-    if (local_counts_d || s->local_points) {
+    if (lw_early) {
+        CNIIC_HIP_TRY(c, hipEventSynchronize(c->u_ev));
+        for (uint32_t k = 0; k < K; k++) { wsum[k] = c->pinned_u[8 + k]; members[k] = wsum[k] ? 1 : 0; }
+    } else if (local_counts_d || s->local_points) {
         // shared palette over several images: THIS image's pixels per cluster (its reduced image is
         // what Hufman.encode sees, clusterc.rs:52), from its own colour counts
-        DevBuf lw;
         CNIIC_HIP_TRY(c, lw.alloc((uint64_t)K * 8));
         CNIIC_HIP_TRY(c, hipMemsetAsync(lw.p, 0, (uint64_t)K * 8, c->stream));
         if (s->sp_mode) {  // cell-major colours, labels and pixel counts of this image: any common order will do

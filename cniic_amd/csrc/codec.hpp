@@ -32,7 +32,7 @@ struct CcSession {
     uint32_t *table = nullptr;   // dense colour table: counts on entry of cc_prepare, key -> rank + 1 afterwards
     uint64_t U = 0;
     DevBuf keys_d, weight_d;
-    DevBuf gbits, gprefix;       // shared palette over several images: index of the colours that occur in ANY of them
+    DevBuf gbits, gprefix, gtotal;  // shared palette over several images: index of the colours that occur in ANY of them (+ their number, on the device)
     bool local_points = false;   // ... and the points of this session are this image's colours only
     SpPlan sp;                   // large images: the pixels partitioned by colour super-cell (k_points.hip) instead of the dense table
     bool sp_mode = false;

@@ -126,7 +126,8 @@ struct Ctx {
     void  *pinned_res = nullptr;  // pinned landing area of K-means result blocks (grown on demand)
     uint64_t pinned_res_bytes = 0;
     hipEvent_t res_ev = nullptr;
-    uint64_t *pinned_u = nullptr;  // pinned landing slot of sp_build's distinct-colour count, and the event behind its copy
+    uint64_t *pinned_u = nullptr;  // 64 KiB of pinned host memory: [0] sp_build's distinct-colour count, [1] the point list's length,
+                                   // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
 
@@ -148,6 +149,11 @@ struct Ctx {
             return (ctx)->fail(CNIIC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, \
                                hipGetErrorString(_e));                                    \
     } while (0)
+
+inline hipError_t ctx_pinned_u(Ctx *c) {
+    if (c->pinned_u) return hipSuccess;
+    return hipHostMalloc(reinterpret_cast<void **>(&c->pinned_u), 64 * 1024, hipHostMallocDefault);
+}
 
 #define CNIIC_TRY(expr)              \
     do {                             \
@@ -333,7 +339,7 @@ struct CompactPlan {
 };
 // occupancy across ranks: nibble per key (k_hist.hip), and the index of all occupied keys built from the summed nibbles
 int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d);  // u32[2^24] counts -> u32[2^21] nibble words
-int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h);
+int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h, DevBuf *total_keep = nullptr);
 int gidx_finish(Ctx *c, uint32_t *wprefix_d, const uint32_t *blocktot_d, uint64_t *total_d);  // 256 blocks of 1024 words
 
 // ---- k_points.hip: pixels partitioned by colour super-cell (large cluster-colors encodes) ----
@@ -375,7 +381,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                    bool points_follow = false /* keys_d / weight_d null: the caller writes the cell-major arrays (sp_emit) */,
                    const uint64_t *points_dev = nullptr /* with points_follow: U and Ug are upper bounds, the count is here
                                                            on the device; km_rgbw_set_points before anything else */);
-int km_rgbw_set_points(KmRgbwState *s, uint64_t U);
+int km_rgbw_set_points(KmRgbwState *s, uint64_t U, uint64_t Ulist = 0 /* 0: the points are the whole list */);
 void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **ckeys_d, uint32_t **cweight_d);
 void km_rgbw_destroy(KmRgbwState *s);
 int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t *labels_d_u32);

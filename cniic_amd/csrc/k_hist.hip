@@ -409,8 +409,11 @@ int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d) {
 }
 
 // occ_d: the summed nibbles -> bitmap + popcount prefix per word; *U_h = occupied keys (stream synced)
-int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h) {
-    DevBuf tot;
+// total_keep (optional): the count also stays on the device there, and nothing waits -- the caller takes it from *U_h after
+// synchronising the stream or an event of its own
+int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uint64_t *U_h, DevBuf *total_keep) {
+    DevBuf tot_own;
+    DevBuf &tot = total_keep ? *total_keep : tot_own;
     CNIIC_HIP_TRY(c, bits.alloc((1ull << 18) * 8));
     CNIIC_HIP_TRY(c, wprefix.alloc((1ull << 18) * 4));
     CNIIC_HIP_TRY(c, tot.alloc(8));
@@ -422,7 +425,7 @@ int gidx_build(Ctx *c, const uint32_t *occ_d, DevBuf &bits, DevBuf &wprefix, uin
                        tot.as<uint64_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(U_h, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!total_keep) CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
 

@@ -1564,11 +1564,12 @@ int km_rgbw_import_labels(KmRgbwState *s, const void *src_d) {
 uint64_t km_rgbw_points(KmRgbwState *s) { return s->U; }
 
 // a state created with an upper bound (points_dev): the number of points, now that the host knows it
-int km_rgbw_set_points(KmRgbwState *s, uint64_t U) {
-    if (U == 0 || U > s->U || U / s->K == 0)
-        return s->c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)", (unsigned long long)U, s->K);
+int km_rgbw_set_points(KmRgbwState *s, uint64_t U, uint64_t Ulist) {
+    if (Ulist == 0) Ulist = U;
+    if (U == 0 || U > s->U || Ulist / s->K == 0)
+        return s->c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)", (unsigned long long)Ulist, s->K);
     s->U = U; s->hi = U;
-    if (s->gidx.bits) s->gidx.U = U;
+    if (s->gidx.bits) s->gidx.U = Ulist;
     return CNIIC_OK;
 }
 

@@ -460,7 +460,7 @@ int sp_build(Ctx *c, const uint8_t *rgb_d, uint64_t npx, SpPlan *plan) {
     CNIIC_HIP_TRY(c, total.alloc((uint64_t)kSpBuckets * 4));
     CNIIC_HIP_TRY(c, blocktot.alloc(256 * 4));
     CNIIC_HIP_TRY(c, plan->total.alloc(8));
-    if (!c->pinned_u) CNIIC_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->pinned_u), 64, hipHostMallocDefault));
+    CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     if (!c->u_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->u_ev, hipEventDisableTiming));
     hipLaunchKernelGGL(k_sp_count, dim3(plan->nchunks), dim3(kSpThreads), 0, c->stream, rgb_d, npx, plan->cnt.as<uint32_t>());
     hipLaunchKernelGGL(k_sp_colscan, dim3(kSpBuckets), dim3(256), 0, c->stream, plan->cnt.as<uint32_t>(), plan->nchunks,
