@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096, help="image side (default: configs[1], 4096)")
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--max-iters", type=int, default=0, help="0 = to convergence, like the reference")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="side of the crop timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2560, help="side of the crop timed on the CPU (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
