@@ -47,7 +47,8 @@ class HipBackend:
         return t
 
     def new_partials(self, K):
-        return self.torch.zeros(int(self.L.cniic_km_partial_words(K, 3)), dtype=self.torch.int64, device=self.dev)
+        # (uninitialised: the session zeroes it on the context's stream when it is created -- torch's stream may be another)
+        return self.torch.empty(int(self.L.cniic_km_partial_words(K, 3)), dtype=self.torch.int64, device=self.dev)
 
     def occupancy(self, table):
         """one nibble per colour, 1 where this image has it (u32[2^21]); summed over the ranks by an all-reduce"""
@@ -158,6 +159,7 @@ class HipBackend:
             return None
         # known-answer all-reduce before the K-means loop depends on it: rank r gives r + 1 in every word
         probe = torch.full((5 * 256 + 2,), rank + 1, dtype=torch.int64, device=self.dev)
+        torch.cuda.synchronize(self.dev)  # (filled on torch's stream, reduced on the context's)
         rc = self.L.cniic_comm_all_reduce(h, C.c_void_p(probe.data_ptr()), C.c_uint64(probe.numel()), C.c_int32(8))
         torch.cuda.synchronize(self.dev)
         good = 1 if rc == _lib.OK and bool((probe == world * (world + 1) // 2).all()) else 0
@@ -180,7 +182,10 @@ class HipBackend:
 
 
 class ShardedClusterColors:
-    """encode(img, w, h, out) -> (stream bytes written to out, K-means stats), collectively on all ranks."""
+    """encode(img, w, h, out) -> (stream bytes written to out, K-means stats), collectively on all ranks.
+
+    The context must run on torch's current stream (Context(dev, stream=torch.cuda.current_stream().cuda_stream)): the
+    torch.distributed fallback reduces the library's buffers on torch's stream, between kernels of the context's."""
 
     def __init__(self, ctx, K, dist, device, max_iters=0, backend=None, poll_every=4, collectives=None):
         self.K = K
