@@ -1389,7 +1389,8 @@ struct LaunchTimer {
 // summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
 int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
-    const int batch = 4;
+    const int batch = cm ? 2 : 4;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
+                                   // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
     KmDevState h;
     LaunchTimer lt;
     LaggedPoll poll(c, s->dstate.p);
