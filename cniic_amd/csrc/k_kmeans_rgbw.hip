@@ -1396,7 +1396,11 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
     KmDevState *st_host = nullptr;
-    if (s->fused) CNIIC_TRY(poll.mapped_slot(&st_host));
+    // The mapped slot shows the host a state AT LEAST as new as the batch it asks about -- how much newer depends on timing.
+    // Alone that only ends the loop a little earlier; with collectives every rank must leave after the SAME batch (a rank
+    // that enqueues one more all-reduce than its peers waits for them forever), so there the state is the in-stream copy
+    // taken at a fixed place of the sequence, identical on all ranks.
+    if (s->fused && !cm) CNIIC_TRY(poll.mapped_slot(&st_host));
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     const uint64_t W = 5 * (uint64_t)s->K + 2;
     uint32_t launch_no = 0;
