@@ -549,6 +549,15 @@ int32_t cniic_comm_create(cniic_ctx *c, const uint8_t id[128], uint32_t rank, ui
     return CNIIC_OK;
 }
 
+int32_t cniic_comm_create_host(cniic_ctx *c, uint32_t rank, uint32_t nranks, cniic_host_sum_fn fn, void *user, cniic_comm **out) {
+    if (!c || !out) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    Comm *m = nullptr;
+    CNIIC_TRY(comm_create_host(c, rank, nranks, fn, user, &m));
+    *out = new cniic_comm{m};
+    return CNIIC_OK;
+}
+
 void cniic_comm_destroy(cniic_comm *cm) {
     if (!cm) return;
     if (cm->m) {

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -48,6 +49,11 @@ struct Comm {
     Ctx *c = nullptr;
     ncclComm_t comm = nullptr;
     uint32_t rank = 0, nranks = 1;
+    // a host's own transport instead of RCCL (MPI, a socket, gloo ...): called with the stream drained, must leave the
+    // in-place unsigned sum over all ranks in the host buffer when it returns (cniic_comm_create_host)
+    int32_t (*host_sum)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes) = nullptr;
+    void *user = nullptr;
+    std::vector<uint8_t> bounce;
 };
 
 int comm_unique_id(uint8_t *id128) {
@@ -73,6 +79,15 @@ int comm_create(Ctx *c, const uint8_t *id128, uint32_t rank, uint32_t nranks, Co
     return CNIIC_OK;
 }
 
+int comm_create_host(Ctx *c, uint32_t rank, uint32_t nranks, int32_t (*fn)(void *, void *, uint64_t, int32_t), void *user, Comm **out) {
+    if (!fn || nranks == 0 || rank >= nranks) return c->fail(CNIIC_ERR_BAD_ARG, "comm_create_host: rank %u of %u, callback %p", rank, nranks, (void *)fn);
+    Comm *m = new Comm{c, nullptr, rank, nranks};
+    m->host_sum = fn;
+    m->user = user;
+    *out = m;
+    return CNIIC_OK;
+}
+
 void comm_destroy(Comm *cm) {
     if (!cm) return;
     if (cm->comm) (void)rccl().CommDestroy(cm->comm);
@@ -87,6 +102,16 @@ int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind) {
     Ctx *c = cm->c;
     const ncclDataType_t dt = kind == 0 ? ncclUint8 : kind == 1 ? ncclUint32 : ncclUint64;
     if (kind < 0 || kind > 2) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce: unknown element kind %d", kind);
+    if (cm->host_sum) {  // through the host: drain the stream, bounce, let the caller's transport sum, put it back
+        const int eb = kind == 0 ? 1 : kind == 1 ? 4 : 8;
+        cm->bounce.resize((size_t)count * eb);
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(cm->bounce.data(), buf_d, cm->bounce.size(), hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (cm->host_sum(cm->user, cm->bounce.data(), count, eb) != 0) return c->fail(CNIIC_ERR_HIP, "all_reduce: the host transport failed");
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(buf_d, cm->bounce.data(), cm->bounce.size(), hipMemcpyHostToDevice, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return CNIIC_OK;
+    }
     const ncclResult_t e = rccl().AllReduce(buf_d, buf_d, (size_t)count, dt, ncclSum, cm->comm, c->stream);
     if (e != ncclSuccess) return c->fail(CNIIC_ERR_HIP, "ncclAllReduce: %s", rccl().GetErrorString(e));
     return CNIIC_OK;

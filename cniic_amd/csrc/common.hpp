@@ -391,6 +391,7 @@ int km_rgbw_update(KmRgbwState *s);                       // async: centroids fr
 struct Comm;
 int comm_unique_id(uint8_t *id128);
 int comm_create(Ctx *c, const uint8_t *id128, uint32_t rank, uint32_t nranks, Comm **out);
+int comm_create_host(Ctx *c, uint32_t rank, uint32_t nranks, int32_t (*fn)(void *, void *, uint64_t, int32_t), void *user, Comm **out);
 void comm_destroy(Comm *cm);
 Ctx *comm_ctx(Comm *cm);
 uint32_t comm_size(const Comm *cm);

@@ -168,6 +168,33 @@ class HipBackend:
             return None
         return h
 
+    def comm_create_host(self, dist, rank, world):
+        """the same communicator over torch.distributed's CPU path (gloo): the library's C loop runs unchanged, every
+        all-reduce goes through host memory.  For hosts without RCCL, and for exercising the C loop with several ranks
+        on one GPU (tests)."""
+        torch = self.torch
+        import numpy as np
+
+        def host_sum(user, buf, count, elem_bytes):
+            try:
+                dt = {1: np.uint8, 4: np.int32, 8: np.int64}[elem_bytes]   # (two's complement: the sum is the unsigned one)
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(count * elem_bytes,)).view(dt)
+                t = torch.from_numpy(a)
+                if elem_bytes == 1:
+                    w = t.to(torch.int32)
+                    dist.all_reduce(w)
+                    t.copy_(w.to(torch.uint8))
+                else:
+                    dist.all_reduce(t)
+                return 0
+            except Exception:  # never unwind through the C frames
+                return 1
+
+        self._host_sum_cb = _lib.HOST_SUM_FN(host_sum)   # kept alive as long as the backend
+        h = C.c_void_p()
+        self.ctx._check(self.L.cniic_comm_create_host(self.ctx.h, C.c_uint32(rank), C.c_uint32(world), self._host_sum_cb, None, C.byref(h)))
+        return h
+
     def comm_destroy(self, comm):
         if comm is not None:
             self.L.cniic_comm_destroy(comm)
@@ -201,7 +228,9 @@ class ShardedClusterColors:
         self.comm = None
         if want == "native" and hasattr(self.be, "comm_create") and (self.world > 1 or collectives == "native"):
             self.comm = self.be.comm_create(dist, self.rank, self.world)
-        self.collectives = "native" if self.comm is not None else "torch"
+        elif want == "host" and hasattr(self.be, "comm_create_host") and dist is not None:
+            self.comm = self.be.comm_create_host(dist, self.rank, self.world)   # "host": the C loop over the caller's transport
+        self.collectives = want if self.comm is not None else "torch"
 
     def close(self):
         if self.comm is not None:

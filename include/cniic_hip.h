@@ -235,6 +235,12 @@ int32_t  cniic_comm_unique_id(uint8_t id[128]);
 int32_t  cniic_comm_create(cniic_ctx *ctx, const uint8_t id[128], uint32_t rank, uint32_t nranks, cniic_comm **out);
 void     cniic_comm_destroy(cniic_comm *comm);
 int32_t  cniic_comm_all_reduce(cniic_comm *comm, void *buf_dev, uint64_t count, int32_t elem_bytes);
+/* The same communicator over the caller's own transport (MPI, sockets, gloo ...) where RCCL is not wanted: every
+ * all-reduce drains the stream, hands `count` elements of `elem_bytes` bytes to fn in HOST memory and expects the
+ * in-place unsigned sum over all ranks there when fn returns 0.  Slower (a host round trip per iteration), same
+ * results; cniic_cc_run / cniic_comm_all_reduce take it like the RCCL one. */
+typedef int32_t (*cniic_host_sum_fn)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes);
+int32_t  cniic_comm_create_host(cniic_ctx *ctx, uint32_t rank, uint32_t nranks, cniic_host_sum_fn fn, void *user, cniic_comm **out);
 int32_t  cniic_cc_run(cniic_cc *cc, cniic_comm *comm /* NULL: one rank */, cniic_kmeans_stats *stats);
 
 /* ------------------------------------------------------------------ cluster-colors remap */

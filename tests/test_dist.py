@@ -150,7 +150,9 @@ def _worker(rank, world, port, K, use_hip, q, env=None):
             torch.cuda.set_device(0)
             torch.cuda.set_stream(torch.cuda.Stream(device=dev))
             ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-            enc = ShardedClusterColors(ctx, K, dist, dev)
+            enc = ShardedClusterColors(ctx, K, dist, dev, collectives=(env or {}).get("TEST_COLLECTIVES"))
+            if env and env.get("TEST_COLLECTIVES"):
+                assert enc.collectives == env["TEST_COLLECTIVES"]
             timg = torch.from_numpy(img).to(dev)
             out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8, device=dev)
         else:
@@ -278,3 +280,18 @@ def test_image_session_world1_equals_plain_encode(monkeypatch):
     rc, exp2, st3 = ctx.encode("cluster-colors(16)", img)
     assert exp2 == exp and st3["iterations"] == st["iterations"]
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["dense", "partition"])
+def test_native_loop_world2_over_a_host_transport(route):
+    """cniic_cc_run -- the library's own K-means loop, all-reduce between the assign launches, convergence read at a fixed
+    place of the sequence -- with TWO ranks (sharing the test box's GPU): the communicator is the host-transport one
+    (cniic_comm_create_host, here gloo), so the C loop sees real sums of two ranks.  Result = the oracle's union result."""
+    K = 8
+    env = {"TEST_COLLECTIVES": "host", "CNIIC_SP_MIN_PIXELS": "0" if route == "partition" else str(1 << 40)}
+    res = _run(2, K, use_hip=True, env=env)
+    exp, iters = expected_streams([make_img(0), make_img(1)], K)
+    for r in (0, 1):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
