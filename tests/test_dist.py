@@ -295,3 +295,14 @@ def test_native_loop_world2_over_a_host_transport(route):
     for r in (0, 1):
         assert res[r][0] == exp[r], "rank %d stream differs" % r
         assert res[r][1] == iters
+
+
+@pytest.mark.gpu
+def test_native_loop_world4_over_a_host_transport():
+    """four ranks (occupancy nibbles summed over four images, four-way partial sums) through the library's own loop"""
+    K = 16
+    res = _run(4, K, use_hip=True, env={"TEST_COLLECTIVES": "host", "CNIIC_SP_MIN_PIXELS": "0"})
+    exp, iters = expected_streams([make_img(r) for r in range(4)], K)
+    for r in range(4):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
