@@ -24,6 +24,8 @@ def keys_of(img):
 
 def make_img(rank, h=40, w=56):
     from cniic_amd import synth
+    if "FUZZ_SEED0" in os.environ:  # tools/fuzz_dist.py: other sizes and seeds, the same in the spawned workers
+        return synth.photo(int(os.environ["FUZZ_W"]), int(os.environ["FUZZ_H"]), 12345 + int(os.environ["FUZZ_SEED0"]) + rank)
     return synth.photo(w, h, synth.SEED0 + 40 + rank)
 
 
