@@ -224,6 +224,12 @@ struct KmDevState {
     uint64_t changed_ring[kHistRing];
 };
 
+// One launch's view of the scalar state, written by that launch into slot (launch number % kPollRing) of a pinned ring:
+// what the host reads for launch L is then the same on every rank, whatever the timing (multi-GPU loops must all leave
+// after the same batch), without a copy kernel in the stream.
+struct PollRec { uint64_t iter; uint32_t done; uint32_t seq; uint64_t moved_last, reseeds, active, pair_evals; };
+constexpr uint32_t kPollRing = 16;
+
 // Lagged convergence polling.  The K-means loops enqueue batches of (assign, update) launches; every
 // kernel exits at once when the device-side `done` flag is set.  After each batch the state is copied to
 // a pinned slot and an event recorded, but the host only waits for the copy of the PREVIOUS batch, so the
@@ -233,7 +239,20 @@ struct LaggedPoll {
     const void *dstate;
     int slot = 0, pending = 0;
     bool mapped = false;  // the kernels write the state into the third pinned slot themselves: no copy to enqueue
+    bool ring = false;    // ... or every launch into its own slot of the ring behind the three slots (deterministic per launch)
+    uint32_t last_prev = 0;
     LaggedPoll(Ctx *ctx, const void *dstate_d) : c(ctx), dstate(dstate_d) {}
+    static constexpr size_t ring_offset() { return (3 * sizeof(KmDevState) + 63) & ~size_t(63); }
+    int ring_slot(PollRec **dev_ptr) {
+        static_assert(ring_offset() + kPollRing * sizeof(PollRec) <= 4096, "the poll ring must fit the pinned page");
+        PollRec *r = reinterpret_cast<PollRec *>(static_cast<uint8_t *>(c->pinned) + ring_offset());
+        memset(r, 0xff, kPollRing * sizeof(PollRec));  // no slot carries a valid launch number yet
+        void *d = nullptr;
+        CNIIC_HIP_TRY(c, hipHostGetDevicePointer(&d, r, 0));
+        *dev_ptr = static_cast<PollRec *>(d);
+        ring = true;
+        return CNIIC_OK;
+    }
     // device address of the slot the kernels write in mapped mode (zeroed here)
     int mapped_slot(KmDevState **dev_ptr) {
         KmDevState *slots = static_cast<KmDevState *>(c->pinned);
@@ -251,15 +270,22 @@ struct LaggedPoll {
             if (!c->poll_ev[i]) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
         return CNIIC_OK;
     }
-    // call after enqueuing a batch; returns the state as of the batch BEFORE it in *h (valid when *have)
-    int after_batch(KmDevState *h, bool *have) {
+    // call after enqueuing a batch; returns the state as of the batch BEFORE it in *h (valid when *have).
+    // last_launch: number of the batch's last launch (ring mode)
+    int after_batch(KmDevState *h, bool *have, uint32_t last_launch = 0) {
         KmDevState *slots = static_cast<KmDevState *>(c->pinned);
-        if (!mapped) CNIIC_HIP_TRY(c, hipMemcpyAsync(&slots[slot], dstate, sizeof(KmDevState), hipMemcpyDeviceToHost, c->stream));
+        if (!mapped && !ring) CNIIC_HIP_TRY(c, hipMemcpyAsync(&slots[slot], dstate, sizeof(KmDevState), hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipEventRecord(c->poll_ev[slot], c->stream));
         *have = pending > 0;
         if (pending) {
             CNIIC_HIP_TRY(c, hipEventSynchronize(c->poll_ev[slot ^ 1]));
-            if (mapped) {  // at least as new as that batch; the flag is read first, the scalars it guards after it
+            if (ring) {  // the record the previous batch's last launch wrote: complete before its event, untouched for kPollRing launches
+                const volatile PollRec *r = reinterpret_cast<const volatile PollRec *>(static_cast<uint8_t *>(c->pinned) + ring_offset()) + last_prev % kPollRing;
+                if (r->seq != last_prev) return c->fail(CNIIC_ERR_HIP, "kmeans: launch %u left no state record (found %u)", last_prev, r->seq);
+                KmDevState t{};
+                t.done = r->done; t.iter = r->iter; t.moved_last = r->moved_last; t.reseeds = r->reseeds; t.active = r->active; t.pair_evals = r->pair_evals;
+                *h = t;
+            } else if (mapped) {  // at least as new as that batch; the flag is read first, the scalars it guards after it
                 volatile KmDevState *m = &slots[2];
                 KmDevState t{};
                 t.done = m->done;
@@ -272,6 +298,7 @@ struct LaggedPoll {
         }
         slot ^= 1;
         pending = 1;
+        last_prev = last_launch;
         return CNIIC_OK;
     }
     // state after everything enqueued so far

@@ -658,7 +658,16 @@ struct FusedUpdate {
     uint64_t *members_out, *wsum_out;
     KmDevState *st_rw;
     KmDevState *st_host;                         // pinned host copy of the scalar state (lagged polling without a copy kernel), or null
+    PollRec *st_ring;                            // ... or the ring of per-launch records (loops with collectives), or null
 };
+
+// this launch's record of the scalar state (block 0, thread 0): fields first, the launch number last
+__device__ __forceinline__ void poll_record(PollRec *ring, uint32_t launch_no, const KmDevState *sw) {
+    PollRec *r = ring + launch_no % kPollRing;
+    r->iter = sw->iter; r->done = sw->done; r->moved_last = sw->moved_last; r->reseeds = sw->reseeds; r->active = sw->active; r->pair_evals = sw->pair_evals;
+    __threadfence_system();
+    r->seq = launch_no;
+}
 
 // -DCNIIC_RGBW_PHASES: wave-clock totals per phase of k_rgbw_assign_cells (a measuring build, never the shipped one)
 #ifdef CNIIC_RGBW_PHASES
@@ -726,7 +735,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             oldc = fz.cent_prev[uk];
         }
     }
-    if (done) return;
+    if (done) {  // a launch past convergence: nothing but its state record (the host may ask for exactly this launch)
+        if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
+        return;
+    }
     __syncthreads();
     if (upd) {
         // ---- finish iteration j - 1: Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137)
@@ -780,12 +792,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 __threadfence_system();
                 if (fin) hs->done = 1;
             }
+            if (fz.st_ring) poll_record(fz.st_ring, j, sw);
         }
         if (fin) return;  // converged (or the iteration cap): nothing to assign
         nS = s_nmoved;
         mlist = s_mlist;
     } else if (fz.on && blockIdx.x == 0) {
         for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
+        if (fz.st_ring && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);  // (launch 0: nothing finished yet)
     }
     const bool skip_mode = !first && nS <= cs.max_moved;
     RG_PHASE(0);
@@ -1401,6 +1415,8 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     // that enqueues one more all-reduce than its peers waits for them forever), so there the state is the in-stream copy
     // taken at a fixed place of the sequence, identical on all ranks.
     if (s->fused && !cm) CNIIC_TRY(poll.mapped_slot(&st_host));
+    PollRec *st_ring = nullptr;
+    if (s->fused && cm) CNIIC_TRY(poll.ring_slot(&st_ring));  // (unfused loops with collectives: the in-stream copy)
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     const uint64_t W = 5 * (uint64_t)s->K + 2;
     uint32_t launch_no = 0;
@@ -1428,6 +1444,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
                 fz.wsum_out = s->wsum_last.as<uint64_t>();
                 fz.st_rw = s->dstate.as<KmDevState>();
                 fz.st_host = st_host;
+                fz.st_ring = st_ring;
                 unsigned long long *cur = P + (j % 3) * W;
                 if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur); }
                 else launch_assign(s, nullptr, nullptr, &fz, cur);
@@ -1455,7 +1472,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
         }
         CNIIC_HIP_TRY(c, hipGetLastError());
         bool have = false;
-        CNIIC_TRY(poll.after_batch(&h, &have));
+        CNIIC_TRY(poll.after_batch(&h, &have, launch_no ? launch_no - 1 : 0));
         if (have && h.done) break;
     }
     timer.stop(h.iter);
