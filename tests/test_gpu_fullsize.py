@@ -94,6 +94,47 @@ def test_config5_delta_lossless_4096_and_hilbert_bijection(env):
     assert tuple(xy[0]) == (0, 0) and tuple(xy[-1]) == (size - 1, 0)
 
 
+def test_config5_delta_16384(env):
+    """configs[4] at its full size: `delta` + Huffman histogram on one 16384 x 16384 image.  Lossless round trip,
+    histogram total = N, stream length = what the histogram predicts + the 8 header bytes, and the
+    scan positions of 10^5 sampled d (plus both ends) equal the oracle's random-access d -> (x, y)."""
+    import oracle_lib as O
+    ctx, torch, dev = env
+    from cniic_amd import _lib
+    size = 16384
+    N = size * size
+    img = synth(ctx, torch, dev, 1, SEED + 5, size)
+    out = torch.empty(N * 4 + (1 << 26), dtype=torch.uint8, device=dev)
+    rc, n, _ = ctx.encode("delta", img, w=size, h=size, out=out)
+    assert rc == 0
+    keys, counts, _ = ctx.hilbert_delta_hist(img, w=size, h=size)
+    assert int(counts.sum()) == N and np.all(np.diff(keys.astype(np.int64)) > 0)
+    assert ctx.huf_size(_lib.SYM_SIGNED, counts) + 8 == n
+    data = out[:n].cpu().numpy().tobytes()
+    del out
+    rc, back = ctx.decode("delta", data)
+    assert rc == 0 and back.shape == (size, size, 3)
+    src = img.cpu().numpy()
+    assert np.array_equal(back, src)
+    del back, data
+    # the delta symbols along the scan are those of the linearised image (P2, hilbertc.rs:463-477), checked on a window
+    xy = ctx.hilbert_xy(size, size)
+    rng = np.random.default_rng(16384)
+    ds = np.concatenate([[0, 1, N - 2, N - 1], rng.integers(0, N, 100000)])
+    for d in ds.tolist():
+        assert tuple(xy[d]) == O.hilbert_d2xy(size, size, d), d
+    lin = xy[:, 1].astype(np.int64) * size + xy[:, 0]
+    seen = np.zeros(N, np.bool_)
+    seen[lin] = True
+    assert seen.all()                                                            # bijection at order 14
+    d0 = int(rng.integers(1, N - 70000))
+    win = src[xy[d0 - 1:d0 + 65536, 1], xy[d0 - 1:d0 + 65536, 0]].astype(np.int32)
+    dsym = win[1:] - win[:-1] + 255
+    exp = (dsym[:, 0] << 18) | (dsym[:, 1] << 9) | dsym[:, 2]
+    syms = ctx.hilbert_delta_hist(img, want_syms=True, w=size, h=size)[2]
+    assert np.array_equal(syms[d0:d0 + 65536], exp.astype(np.uint32))
+
+
 def test_hilbert_non_pow2_large_bijection(env):
     ctx, torch, dev = env
     w, h = 1920, 1080                                                            # config 4 frame size
