@@ -78,11 +78,11 @@ struct KmRgbwState {
     GIdx gidx{nullptr, nullptr, 0};  // several GPUs: the points are this rank's share of gidx.U colours
     DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
     bool fused = false;
-    bool sup = false;            // classify + sweep pair (k_rgbw_classify, k_rgbw_sweep): K <= 256, one shard
+    bool sup = false;            // super-cell-major assign (k_rgbw_assign_sup): K <= 256, one shard
     bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
-    DevBuf sup_rec, sup_agg, sup_wl, sup_wln;  // per cell: candidate mask + state word; aggregate of its points; work items and their count per super-cell
+    DevBuf sup_rec, sup_agg;     // per cell: candidate mask + state word; aggregate of its points
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -678,6 +678,7 @@ __device__ __forceinline__ void poll_record(PollRec *ring, uint32_t launch_no, c
 // -DCNIIC_RGBW_PHASES: wave-clock totals per phase of k_rgbw_assign_cells (a measuring build, never the shipped one)
 #ifdef CNIIC_RGBW_PHASES
 __device__ unsigned long long g_rgbw_phase[12];
+__device__ unsigned long long g_rgbw_blk[512][4];  // census of one launch (CNIIC_DBG_LAUNCH): per block start, end (100 MHz clock), HW id, items
 __device__ unsigned int g_rgbw_launch[128][8];  // per launch of the super-cell kernel: swept cells, swept points, bulk cells, single-candidate cells, longest list, non-empty cells, sum |S|
 #define RG_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
 #define RG_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
@@ -988,24 +989,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 #endif
 }
 
-// ---------------------------------------------------------------- classify + sweep (K <= 256, one shard)
-// The same exact pruning, turned inside out: the per-cell work is done ONE LANE PER CELL instead of one wave per cell,
-// and an iteration is two launches.
-//   k_rgbw_classify (one wave per super-cell = a 32^3 cube of colours, 64 cells; its prologue finishes the previous
-//   iteration, as k_rgbw_assign_cells does):
-//     1. S = the centroids that can win anywhere in the super-cell (build_super);
-//     2. lane l = cell l of the super-cell: pivot = member of S nearest the cell's centre, candidates = members of S the
-//        pivot does not dominate over the cell's cube, as a 256-bit mask of cluster ids in registers (|S| x ~30
-//        instructions for 64 cells; the wave-per-cell build cost ~170 per cell and was most of the old kernel);
-//     3. per cell, from its record (the mask and a state word kept from the last launch):
-//          one candidate b, cell uniformly labelled a   -> a != b: the whole cell moves at once -- its aggregate (sum r w,
-//                                                          sum g w, sum b w, sum w; written at iteration 0) is subtracted
-//                                                          from a and added to b; not one point is read;
-//          no centroid of (old mask | new mask) moved   -> every point repeats its decision (see below): nothing to do;
-//          otherwise                                    -> a work item {cell, state, extent, mask} goes on the super-cell's list.
-//   k_rgbw_sweep: the items of all 512 lists, dealt round-robin to every wave of the chip (the lists are uneven: a
-//   super-cell crossed by the boundaries of the centroids that moved holds 30-50 items late in a run, most hold none),
-//   each wave sweeping its cells' points against their candidates.
+// ---------------------------------------------------------------- super-cell-major assign (K <= 256, one shard)
+// The same exact pruning, turned inside out: ONE BLOCK PER SUPER-CELL (a 32^3 cube of colours, 64 cells), the per-cell
+// work done ONE LANE PER CELL instead of one wave per cell, and whole cells handled as aggregates where possible.
+//   1. the first four waves build S, the centroids that can win anywhere in the super-cell (thread = centroid);
+//   2. the same waves, lane l = cell l of the super-cell, wave w = every fourth member of S: pivot = member of S nearest
+//      the cell's centre, candidates = members of S the pivot does not dominate over the cell's cube, as a 256-bit mask
+//      of cluster ids (|S| x ~30 instructions for 64 cells; the wave-per-cell build cost ~170 per cell and was most of
+//      the old kernel);
+//   3. wave 0, per cell, from its record (the mask and a state word kept from the last launch):
+//        one candidate b, cell uniformly labelled a   -> a != b: the whole cell moves at once -- its aggregate (sum r w,
+//                                                        sum g w, sum b w, sum w; written at iteration 0) is subtracted
+//                                                        from a and added to b; not one point is read;
+//        no centroid of (old mask | new mask) moved   -> every point repeats its decision (see below): nothing to do;
+//        otherwise                                    -> the cell goes on the block's work list;
+//   4. all waves of the block draw cells from the list and sweep their points against the candidates.
 // A cell whose points all carry label a is remembered as "uniform a"; its labels in memory are then not maintained
 // (k_rgbw_materialize writes them when somebody asks for the labels).
 //
@@ -1018,234 +1016,25 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 // colour would survive the test with margin 0), so a cell uniformly labelled a != b moves to b whole.
 constexpr uint32_t kNumSupers = kNumCells >> kSuperShift;
 constexpr uint32_t kSupRecWords = 12;  // u32 per cell: [0..7] candidate mask of the last launch, [8] 0 = labels in memory are current, 1 + a = uniform a
-constexpr uint32_t kItemWords = 12;    // work item: [0] cell within the super-cell | state << 16, [1] first point, [2] end, [3] super-cell, [4..11] candidate mask
-constexpr int kClassifyWaves = 4;      // one super-cell per wave
-constexpr int kSweepWaves = 8;
-constexpr uint32_t kSweepBlocks = 768; // every block resident at once (6 waves per SIMD)
+#ifndef CNIIC_SUP_WAVES
+#define CNIIC_SUP_WAVES 12
+#endif
+constexpr int kSupWaves = CNIIC_SUP_WAVES;  // waves per block; two blocks per CU, so that all 512 are resident at once
+constexpr int kSupMinW = kSupWaves / 2;     // ... i.e. this many waves per SIMD (the register budget: 96 VGPRs at 5, 80 at 6)
+constexpr int kSupCW = 4;                   // waves that build S and classify (thread = centroid: K <= 256)
 
 struct SupState {
     uint32_t *rec;                 // [kNumCells][kSupRecWords]
     unsigned long long *cagg;      // [kNumCells][4] aggregates of the cell's points: sum r w, sum g w, sum b w, sum w
     const uint32_t *cell_start;    // [kNumCells + 1]
-    uint32_t *wl;                  // [kNumSupers][64][kItemWords] work items of this launch
-    uint32_t *wl_n;                // [kNumSupers] items per super-cell
     uint32_t no_skip;              // every cell with more than one candidate or mixed labels is swept in every launch (A/B)
 };
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_rgbw_classify(
-    uint32_t K, const uint2 *__restrict__ cconst, unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st,
-    const uint32_t *__restrict__ moved_g, SupState ss, FusedUpdate fz) {
-    constexpr uint32_t IDMASK = 255;
-    constexpr int THREADS = WAVES * 64;
-    static_assert(THREADS >= 256, "one thread per cluster in the folded-in update");
-    extern __shared__ __align__(16) unsigned long long lds[];  // uint2 tab[K] | WAVES x uint2 S[K]
-    __shared__ uint32_t s_nmoved, s_reseed, s_active;
-    __shared__ uint32_t s_mm[8];      // bit k: centroid k changed in the last update
-    const uint32_t done = st->done;
-    uint2 *tab = reinterpret_cast<uint2 *>(lds);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint2 *S = tab + K + (size_t)wid * K;
-    const uint32_t sup = blockIdx.x * WAVES + wid;
-    const bool first = fz.on ? fz.launch_no == 0 : st->iter == 0;
-    const unsigned long long lt_mask = (1ull << lane) - 1;
-#ifdef CNIIC_RGBW_PHASES
-    long long t_ph = clock64();
-    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    // ---- set-up loads, all requested before anything is waited for: extent, record and aggregate of this lane's cell
-    const uint32_t cell = (sup << kSuperShift) | (uint32_t)lane;
-    const uint32_t c_s = ss.cell_start[cell], c_e = ss.cell_start[cell + 1];
-    const uint4 *rp_in = reinterpret_cast<const uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
-    const uint4 r0 = rp_in[0], r1 = rp_in[1], r2 = rp_in[2];
-    const ulonglong2 *ap = reinterpret_cast<const ulonglong2 *>(ss.cagg + (size_t)cell * 4);
-    const ulonglong2 ag0 = ap[0], ag1 = ap[1];
-    if (!fz.on || first)
-        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-    if (threadIdx.x == 0) { s_nmoved = 0; s_reseed = 0; s_active = 0; }
-    if (threadIdx.x < 8) s_mm[threadIdx.x] = (first || ss.no_skip) ? 0xffffffffu : 0u;
-    const bool upd = fz.on && !first;
-    const uint32_t uk = threadIdx.x;
-    unsigned long long v[5] = {0, 0, 0, 0, 0}, changed = 0, pev = 0;
-    uint32_t oldc = 0;
-    if (upd) {
-        changed = fz.partials_prev[5 * (size_t)K];
-        pev = fz.partials_prev[5 * (size_t)K + 1];
-        if (uk < K) {
-            const size_t at[5] = {3 * (size_t)uk, 3 * (size_t)uk + 1, 3 * (size_t)uk + 2, 3 * (size_t)K + uk, 4 * (size_t)K + uk};
-#pragma unroll
-            for (int i = 0; i < 5; i++) v[i] = fz.partials_prev[at[i]] + fz.running_prev[at[i]];
-            oldc = fz.cent_prev[uk];
-        }
-    }
-    if (done) {  // a launch past convergence: nothing but its state record
-        if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
-        return;
-    }
-    __syncthreads();
-    if (upd) {
-        // ---- finish iteration j - 1 (as k_rgbw_assign_cells): Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137)
-        const uint32_t j = fz.launch_no;
-        if (uk < K) {
-            const uint32_t k = uk;
-            const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
-            uint32_t ck;
-            if (v[4] == 0) {
-                const uint64_t ri = reseed_index(fz.seed, j - 1, k, fz.U);  // fake_clone of the stolen point
-                ck = fz.gx.bits ? gidx_select(fz.gx, ri) : fz.keys[ri];
-                atomicAdd(&s_reseed, 1u);
-            } else {
-                const uint32_t r = div_floor_small(v[0], v[3]) & 255, g = div_floor_small(v[1], v[3]) & 255, b = div_floor_small(v[2], v[3]) & 255;
-                ck = (r << 16) | (g << 8) | b;
-                atomicAdd(&s_active, 1u);
-            }
-            const uint2 cc = make_cconst(ck, k, fz.idbits);
-            tab[k] = cc;
-            if (ck != oldc) {
-                atomicAdd(&s_nmoved, 1u);
-                atomicOr(&s_mm[k >> 5], 1u << (k & 31));
-            }
-            if (blockIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 5; i++) fz.running_new[at[i]] = v[i];
-                fz.cent_new[k] = ck;
-                fz.cent_g[k] = ck;
-                fz.cconst_g[k] = cc;   // (the sweep launch reads its table from here)
-                fz.members_out[k] = v[4];
-                fz.wsum_out[k] = v[3];
-            }
-        }
-        if (blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
-        __syncthreads();
-        const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            KmDevState *sw = fz.st_rw;
-            sw->changed_ring[(j - 1) % kHistRing] = changed;
-            sw->moved_last = changed;
-            sw->reseeds += s_reseed;
-            sw->active = s_active;
-            sw->pair_evals += pev;
-            sw->iter = j;
-            if (fin) sw->done = 1;
-            if (fz.st_host) {
-                KmDevState *hs = fz.st_host;
-                hs->moved_last = changed; hs->reseeds = sw->reseeds; hs->active = s_active; hs->pair_evals = sw->pair_evals; hs->iter = j;
-                __threadfence_system();
-                if (fin) hs->done = 1;
-            }
-            if (fz.st_ring) poll_record(fz.st_ring, j, sw);
-        }
-        if (fin) return;  // (the sweep launch behind this one sees `done`)
-    } else {
-        if (fz.on && blockIdx.x == 0) {
-            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
-            if (fz.st_ring && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
-        }
-        if (!fz.on && !first && !ss.no_skip) {  // an update kernel ran in between: its list of the centroids it changed
-            const uint32_t nmv = moved_g[0];
-            if (nmv >= K) { if (threadIdx.x < 8) s_mm[threadIdx.x] = 0xffffffffu; }
-            else for (uint32_t i = threadIdx.x; i < nmv; i += THREADS) { const uint32_t k = moved_g[1 + i]; atomicOr(&s_mm[k >> 5], 1u << (k & 31)); }
-            __syncthreads();
-        }
-    }
-    RG_PHASE(6);
-    // ================================================================= classification (lane = cell)
-    const uint32_t n = c_e - c_s;
-    if (__ballot(n != 0) == 0ull) {  // nothing in this super-cell
-        if (lane == 0) ss.wl_n[sup] = 0;
-        return;
-    }
-    const uint32_t nS = build_super(tab, K, sup, lane, lt_mask, S, K);
-    RG_PHASE(7);
-    constexpr int32_t ext = (1 << kCellShift) - 1;
-    const CellBox bx = cell_box(cell);
-    uint32_t bd = 0xffffffffu, pv = 0;
-    for (uint32_t jx = 0; jx < nS; jx++) {
-        const uint32_t ck = S[jx].x;  // same address in every lane: LDS broadcast
-        const uint32_t d = centre_dist(ck, bx, ext);
-        if (d < bd) { bd = d; pv = ck; }
-    }
-    Dominance dm;
-    dm.set(bx, ext, pv);
-    uint32_t nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t ncand = 0, lastid = 0;
-    for (uint32_t jx = 0; jx < nS; jx++) {
-        const uint2 cc = S[jx];
-        const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(IDMASK - (cc.y & IDMASK)));
-        const bool keep = dm.worst(cc.x) >= 0;
-        const uint32_t bit = keep ? (1u << (id & 31)) : 0u;
-        switch (id >> 5) {  // (uniform)
-        case 0: nm[0] |= bit; break; case 1: nm[1] |= bit; break; case 2: nm[2] |= bit; break; case 3: nm[3] |= bit; break;
-        case 4: nm[4] |= bit; break; case 5: nm[5] |= bit; break; case 6: nm[6] |= bit; break; default: nm[7] |= bit; break;
-        }
-        ncand += keep ? 1u : 0u;
-        lastid = keep ? id : lastid;
-    }
-    const uint32_t om[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    uint32_t hitw = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) hitw |= (om[i] | nm[i]) & s_mm[i];
-    const bool hit = hitw != 0;
-    const uint32_t state = r2.x;  // 0: labels in memory, 1 + a: uniform a
-    uint32_t nstate = state;
-    bool sweep = false, bulk = false;
-    if (n) {
-        if (ncand == 1) {
-            if (state) bulk = state != 1 + lastid;
-            else sweep = hit;  // (not hit: the labels in memory are all `lastid` already)
-            nstate = 1 + lastid;
-        } else if (hit) {
-            sweep = true;
-            nstate = 0;
-        }
-        uint4 *rp = reinterpret_cast<uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
-        rp[0] = make_uint4(nm[0], nm[1], nm[2], nm[3]);
-        rp[1] = make_uint4(nm[4], nm[5], nm[6], nm[7]);
-        if (nstate != state) rp[2] = make_uint4(nstate, 0, 0, 0);
-    }
-    if (bulk) {  // the whole cell changes cluster: its aggregate moves, no point is read
-        const unsigned long long rw = ag0.x, gw = ag0.y, bw = ag1.x, ww = ag1.y;
-        const uint32_t a = state - 1, b = lastid;
-        atomicAdd(&partials[3 * b + 0], rw); atomicAdd(&partials[3 * b + 1], gw); atomicAdd(&partials[3 * b + 2], bw);
-        atomicAdd(&partials[3 * K + b], ww); atomicAdd(&partials[4 * K + b], (unsigned long long)n);
-        atomicAdd(&partials[3 * a + 0], 0ull - rw); atomicAdd(&partials[3 * a + 1], 0ull - gw); atomicAdd(&partials[3 * a + 2], 0ull - bw);
-        atomicAdd(&partials[3 * K + a], 0ull - ww); atomicAdd(&partials[4 * K + a], 0ull - (unsigned long long)n);
-        atomicAdd(&partials[5 * (size_t)K], (unsigned long long)n);
-    }
-    const unsigned long long sm = __ballot(sweep);
-    if (sweep) {
-        uint4 *ip = reinterpret_cast<uint4 *>(ss.wl + ((size_t)sup * 64 + (uint32_t)__popcll(sm & lt_mask)) * kItemWords);
-        ip[0] = make_uint4((uint32_t)lane | (state << 16), c_s, c_e, sup);
-        ip[1] = make_uint4(nm[0], nm[1], nm[2], nm[3]);
-        ip[2] = make_uint4(nm[4], nm[5], nm[6], nm[7]);
-    }
-    if (lane == 0) {
-        ss.wl_n[sup] = (uint32_t)__popcll(sm);
-        atomicAdd(&partials[5 * (size_t)K + 1], (unsigned long long)nS * (uint32_t)__popcll(__ballot(n != 0)));
-    }
-#ifdef CNIIC_RGBW_PHASES
-    {
-        unsigned int *L = g_rgbw_launch[(fz.on ? fz.launch_no : 0) & 127];
-        const uint32_t nsw = (uint32_t)__popcll(sm), psw = wave_reduce_sum(sweep ? n : 0u), nb = (uint32_t)__popcll(__ballot(bulk)),
-                       n1 = (uint32_t)__popcll(__ballot(n && ncand == 1)), nne = (uint32_t)__popcll(__ballot(n != 0));
-        if (lane == 0) { atomicAdd(&L[0], nsw); atomicAdd(&L[1], psw); atomicAdd(&L[2], nb); atomicAdd(&L[3], n1); atomicMax(&L[4], nsw); atomicAdd(&L[5], nne); atomicAdd(&L[6], nS); }
-    }
-#endif
-    RG_PHASE(8);
-#ifdef CNIIC_RGBW_PHASES
-    if (lane == 0)
-        for (int i = 0; i < 12; i++)
-            if (ph_[i]) atomicAdd(&g_rgbw_phase[i], ph_[i]);
-#endif
-}
-
-// one sweep of the classify + sweep pair: 64 x kSweep points starting at `base` (those < e) against the candidates of the
-// item held in `itw` (lane t = word t of the item).  The mask words are wave-uniform: walking their set bits is scalar
-// work, and a candidate costs one LDS broadcast read + 3 VALU per point slot.
+// one sweep: 64 x kSweep points starting at `base` (those < e) against the candidates of the mask mw[0..7] (LDS, the same
+// for the whole wave: walking its set bits is scalar work, and a candidate costs one LDS broadcast read + 3 VALU per point slot)
 template <bool FIRST>
 __device__ __forceinline__ void sweep_masked(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep], uint32_t base,
-                                             uint32_t e, int lane, uint32_t itw, bool allwrite, const uint2 *tab, uint32_t K, uint8_t *__restrict__ labels,
+                                             uint32_t e, int lane, const uint32_t *mw, bool allwrite, const uint2 *tab, uint32_t K, uint8_t *__restrict__ labels,
                                              unsigned long long *acc, uint32_t &moved, uint32_t &ncand) {
     constexpr uint32_t IDMASK = 255;
     uint32_t best[kSweep];
@@ -1253,7 +1042,7 @@ __device__ __forceinline__ void sweep_masked(const uint32_t (&p)[kSweep], const 
     for (int u = 0; u < kSweep; u++) best[u] = 0;
     ncand = 0;
     for (int wi = 0; wi < 8; wi++) {
-        uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)itw, 4 + wi);
+        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)mw[wi * 64]);  // (word-major: s_mask[word][cell])
         while (m) {
             const uint32_t id = (uint32_t)wi * 32 + (uint32_t)__builtin_ctz(m);
             m &= m - 1;
@@ -1326,105 +1115,331 @@ __device__ __forceinline__ void sweep_masked(const uint32_t (&p)[kSweep], const 
     }
 }
 
-template <int WAVES, bool FIRST>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_sweep(
+#ifdef CNIIC_RGBW_PHASES
+#undef RG_PHASE
+#define RG_PHASE(i) do {} while (0)
+#endif
+template <int WAVES, bool FIRST, int MINW>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_rgbw_assign_sup(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, uint32_t K, const uint2 *__restrict__ cconst,
-    uint8_t *__restrict__ labels, unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, SupState ss) {
+    uint8_t *__restrict__ labels, unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, const uint32_t *__restrict__ moved_g,
+    SupState ss, FusedUpdate fz) {
+    constexpr uint32_t IDMASK = 255;
     constexpr int THREADS = WAVES * 64;
-    static_assert(THREADS == (int)kNumSupers, "one thread per super-cell list in the scan");
-    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K]
-    __shared__ __align__(16) uint32_t s_pre[kNumSupers + 8];  // items in the lists before each super-cell; [kNumSupers] = all
-    __shared__ uint32_t s_wsum[WAVES];
-    __shared__ uint32_t s_moved;
+    static_assert(WAVES >= kSupCW && kSupCW * 64 >= 256, "thread = centroid in the S build and the folded-in update");
+    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | uint2 S[K]
+    __shared__ uint32_t s_moved, s_nmoved, s_reseed, s_active, s_nlist, s_draw, s_pmin;
+    __shared__ uint32_t s_wcnt[kSupCW];
+    __shared__ uint32_t s_mm[8];        // bit k: centroid k changed in the last update
+    __shared__ uint32_t s_cmin[64];     // per cell: (distance of the nearest member of S to the cell's centre) << 8 | its position in S
+    __shared__ uint32_t s_mask[8 * 64]; // [word][cell]: candidate mask of this launch
+    __shared__ uint32_t s_list[64];     // work list: cell within the super-cell | (state word) << 8
+    __shared__ uint32_t s_cs[65];       // cell_start of the 64 cells (+ end)
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;
-    const uint32_t cnt = ss.wl_n[threadIdx.x];
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
+    uint2 *S = tab + K;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-    for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; }
-    if (done) return;
+    const uint32_t sup = blockIdx.x;
+    const unsigned long long lt_mask = (1ull << lane) - 1;
 #ifdef CNIIC_RGBW_PHASES
-    long long t_ph = clock64();
-    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    __shared__ unsigned long long s_ph[12];
-    if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
+    const bool census = fz.on && fz.launch_no == (ss.no_skip >> 16) && (ss.no_skip >> 16) != 0;
+    if (census && threadIdx.x == 0) { g_rgbw_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); g_rgbw_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
 #endif
-    {
-        const uint32_t ex = block_exclusive_scan<THREADS>(cnt, s_wsum);
-        s_pre[threadIdx.x] = ex;
-        if (threadIdx.x == THREADS - 1) { for (int i = 0; i < 8; i++) s_pre[kNumSupers + i] = ex + cnt; }
+    // ---- set-up loads, all requested before anything is waited for
+    // wave 0, lane = cell: extent, record and aggregate of the cell
+    const uint32_t cell = (sup << kSuperShift) | (uint32_t)lane;
+    uint32_t c_s = 0, c_e = 0;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
+    ulonglong2 ag0 = make_ulonglong2(0, 0), ag1 = ag0;
+    if (wid == 0) {
+        c_s = ss.cell_start[cell]; c_e = ss.cell_start[cell + 1];
+        const uint4 *rp = reinterpret_cast<const uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
+        r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+        const ulonglong2 *ap = reinterpret_cast<const ulonglong2 *>(ss.cagg + (size_t)cell * 4);
+        ag0 = ap[0]; ag1 = ap[1];
+    }
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
+    if (!fz.on || FIRST)
+        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
+    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_nlist = 0; s_draw = 0; s_pmin = 0xffffffffu; }
+    if (threadIdx.x < 8) s_mm[threadIdx.x] = (FIRST || (ss.no_skip & 1u)) ? 0xffffffffu : 0u;
+    if (threadIdx.x < 64) s_cmin[threadIdx.x] = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < 64 * 8; i += THREADS) s_mask[i] = 0u;
+    const bool upd = fz.on && !FIRST;
+    const uint32_t uk = threadIdx.x;
+    unsigned long long v[5] = {0, 0, 0, 0, 0}, changed = 0, pev = 0;
+    uint32_t oldc = 0;
+    if (upd) {
+        changed = fz.partials_prev[5 * (size_t)K];
+        pev = fz.partials_prev[5 * (size_t)K + 1];
+        if (uk < K) {
+            const size_t at[5] = {3 * (size_t)uk, 3 * (size_t)uk + 1, 3 * (size_t)uk + 2, 3 * (size_t)K + uk, 4 * (size_t)K + uk};
+#pragma unroll
+            for (int i = 0; i < 5; i++) v[i] = fz.partials_prev[at[i]] + fz.running_prev[at[i]];
+            oldc = fz.cent_prev[uk];
+        }
+    }
+    if (done) {  // a launch past convergence: nothing but its state record
+        if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
+        return;
     }
     __syncthreads();
-    const uint32_t total = s_pre[kNumSupers];
-    const uint32_t nwaves = gridDim.x * WAVES;
+    if (upd) {
+        // ---- finish iteration j - 1 (as k_rgbw_assign_cells): Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137)
+        const uint32_t j = fz.launch_no;
+        if (uk < K) {
+            const uint32_t k = uk;
+            const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
+            uint32_t ck;
+            if (v[4] == 0) {
+                const uint64_t ri = reseed_index(fz.seed, j - 1, k, fz.U);  // fake_clone of the stolen point
+                ck = fz.gx.bits ? gidx_select(fz.gx, ri) : fz.keys[ri];
+                atomicAdd(&s_reseed, 1u);
+            } else {
+                const uint32_t r = div_floor_small(v[0], v[3]) & 255, g = div_floor_small(v[1], v[3]) & 255, b = div_floor_small(v[2], v[3]) & 255;
+                ck = (r << 16) | (g << 8) | b;
+                atomicAdd(&s_active, 1u);
+            }
+            const uint2 cc = make_cconst(ck, k, fz.idbits);
+            tab[k] = cc;
+            if (ck != oldc) {
+                atomicAdd(&s_nmoved, 1u);
+                atomicOr(&s_mm[k >> 5], 1u << (k & 31));
+            }
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int i = 0; i < 5; i++) fz.running_new[at[i]] = v[i];
+                fz.cent_new[k] = ck;
+                fz.cent_g[k] = ck;
+                fz.cconst_g[k] = cc;
+                fz.members_out[k] = v[4];
+                fz.wsum_out[k] = v[3];
+            }
+        }
+        if (blockIdx.x == 0)
+            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
+        __syncthreads();
+        const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            KmDevState *sw = fz.st_rw;
+            sw->changed_ring[(j - 1) % kHistRing] = changed;
+            sw->moved_last = changed;
+            sw->reseeds += s_reseed;
+            sw->active = s_active;
+            sw->pair_evals += pev;
+            sw->iter = j;
+            if (fin) sw->done = 1;
+            if (fz.st_host) {
+                KmDevState *hs = fz.st_host;
+                hs->moved_last = changed; hs->reseeds = sw->reseeds; hs->active = s_active; hs->pair_evals = sw->pair_evals; hs->iter = j;
+                __threadfence_system();
+                if (fin) hs->done = 1;
+            }
+            if (fz.st_ring) poll_record(fz.st_ring, j, sw);
+        }
+        if (fin) return;
+    } else {
+        if (fz.on && blockIdx.x == 0) {
+            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
+            if (fz.st_ring && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
+        }
+        if (!fz.on && !FIRST && !(ss.no_skip & 1u)) {  // an update kernel ran in between: its list of the centroids it changed
+            const uint32_t nmv = moved_g[0];
+            if (nmv >= K) { if (threadIdx.x < 8) s_mm[threadIdx.x] = 0xffffffffu; }
+            else for (uint32_t i = threadIdx.x; i < nmv; i += THREADS) { const uint32_t k = moved_g[1 + i]; atomicOr(&s_mm[k >> 5], 1u << (k & 31)); }
+            __syncthreads();
+        }
+    }
+    RG_PHASE(0);
+    const uint32_t dbg_stop = (ss.no_skip >> 8) & 255u;  // timing experiments (CNIIC_SUP_STOP): leave after a stage; the run is kept going by a fake `moved` count
+    if (dbg_stop && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&partials[5 * (size_t)K], 1ull);
+    if (dbg_stop == 1) return;
+    const uint32_t p_lo = ss.cell_start[sup << kSuperShift], p_hi = ss.cell_start[(sup + 1) << kSuperShift];  // (uniform: scalar loads)
     uint32_t moved = 0;
     unsigned long long evals = 0;
-    // Item i belongs to the last super-cell whose prefix is <= i (lane l looks at prefixes 8 l .. 8 l + 7); the item is
-    // fetched as one word per lane (lanes 0 .. kItemWords - 1) and read out with lane reads where it is needed, so that
-    // the next item can be in flight at the price of one register.
-    auto fetch_item = [&](uint32_t idx) -> uint32_t {
-        const uint4 a = *reinterpret_cast<const uint4 *>(&s_pre[8 * lane]), b = *reinterpret_cast<const uint4 *>(&s_pre[8 * lane + 4]);
-        const uint32_t c = (a.x <= idx) + (a.y <= idx) + (a.z <= idx) + (a.w <= idx) + (b.x <= idx) + (b.y <= idx) + (b.z <= idx) + (b.w <= idx);
-        const uint32_t sp = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_reduce_sum(c)) - 1;  // prefixes <= idx, the first being 0
-        const uint32_t *ip = ss.wl + ((size_t)sp * 64 + (idx - s_pre[sp])) * kItemWords;
-        return (uint32_t)lane < kItemWords ? ip[lane] : 0u;
-    };
-    auto item_word = [&](uint32_t it, int t) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)it, t); };
-    auto load_sweep = [&](uint32_t base, uint32_t end, uint32_t sw, uint32_t (&pp)[kSweep], uint32_t (&cc)[kSweep], uint32_t (&ww)[kSweep]) {
+    if (p_lo != p_hi) {
+        // ================================================================= S: the centroids that can win somewhere in the super-cell
+        uint2 mycc = make_uint2(0u, 0u);
+        uint32_t nS = 0;
+        {
+            constexpr int32_t exts = (1 << (kCellShift + 2)) - 1;
+            const CellBox sbx = super_box(sup);
+            const bool isc = wid < kSupCW && threadIdx.x < K;
+            if (wid < kSupCW) {  // (one LDS atomic per wave: 256 lanes on one word would be served one by one)
+                uint32_t key = 0xffffffffu;
+                if (isc) { mycc = tab[threadIdx.x]; key = (centre_dist(mycc.x, sbx, exts) << 8) | threadIdx.x; }
+                key = wave_reduce_min(key);
+                if (lane == 0) atomicMin(&s_pmin, key);
+            }
+            __syncthreads();
+            bool keep = false;
+            if (isc) {
+                Dominance dms;
+                dms.set(sbx, exts, tab[s_pmin & 255].x);
+                keep = dms.worst(mycc.x) >= 0;
+            }
+            const unsigned long long bm = __ballot(keep);
+            if (wid < kSupCW && lane == 0) s_wcnt[wid] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t pos = (uint32_t)__popcll(bm & lt_mask);
 #pragma unroll
-        for (int u = 0; u < kSweep; u++) {
-            const uint32_t q = base + u * 64 + lane;
-            pp[u] = q < end ? ckeys[q] : 0u;
-            ww[u] = q < end ? cweight[q] : 0u;
-            cc[u] = sw ? sw - 1 : (q < end ? (uint32_t)labels[q] : 0u);
+            for (int w = 0; w < kSupCW; w++) { const uint32_t c = s_wcnt[w]; nS += c; if (w < wid) pos += c; }
+            if (keep) S[pos] = mycc;  // ascending id
+            __syncthreads();
         }
-    };
-    RG_PHASE(0);
-    uint32_t i = blockIdx.x * WAVES + wid;
-    uint32_t itw = 0;
-    uint32_t p[kSweep], cur[kSweep], wt[kSweep];
-    if (i < total) {
-        itw = fetch_item(i);
-        load_sweep(item_word(itw, 1), item_word(itw, 2), item_word(itw, 0) >> 16, p, cur, wt);
-    }
-    while (i < total) {
-        const uint32_t in = i + nwaves;
-        uint32_t itn = 0;  // an item of zeros: no points
-        if (in < total) itn = fetch_item(in);
-        RG_PHASE(1);
-        const uint32_t s = item_word(itw, 1), e = item_word(itw, 2), stw = item_word(itw, 0) >> 16;
-        uint32_t ncand = 0;
-        unsigned long long arw = 0, agw = 0, abw = 0, aww = 0;  // iteration 0: the cell's aggregate
-        for (uint32_t base = s; base < e; base += 64 * kSweep) {
-            const bool more = base + 64 * kSweep < e;
-            uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-            if (more) load_sweep(base + 64 * kSweep, e, stw, pn, curn, wtn);
-            else load_sweep(item_word(itn, 1), item_word(itn, 2), item_word(itn, 0) >> 16, pn, curn, wtn);
-            if (FIRST) {
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) {  // (slots past the cell's end hold weight 0)
-                    const unsigned long long w = wt[u];
-                    arw += ((p[u] >> 16) & 255) * w; agw += ((p[u] >> 8) & 255) * w; abw += (p[u] & 255) * w; aww += w;
+        RG_PHASE(2);
+        if (dbg_stop == 2) return;
+        // ================================================================= classification (waves 0 .. kSupCW - 1: lane = cell, wave = every kSupCW-th member of S)
+        constexpr int32_t ext = (1 << kCellShift) - 1;
+        const CellBox bx = cell_box(cell);
+        uint32_t rec_state = r2.x;
+        if (wid < kSupCW) {
+            uint32_t bd = 0xffffffffu;
+            for (uint32_t jx = wid; jx < nS; jx += kSupCW) bd = min(bd, (centre_dist(S[jx].x, bx, ext) << 8) | jx);  // (S[jx]: same address in every lane)
+            atomicMin(&s_cmin[lane], bd);
+        }
+        __syncthreads();
+        if (wid < kSupCW) {
+            Dominance dm;
+            dm.set(bx, ext, S[s_cmin[lane] & 255].x);
+            uint32_t nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t jx = wid; jx < nS; jx += kSupCW) {
+                const uint2 cc = S[jx];
+                const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(IDMASK - (cc.y & IDMASK)));
+                const uint32_t bit = dm.worst(cc.x) >= 0 ? (1u << (id & 31)) : 0u;
+                switch (id >> 5) {  // (uniform)
+                case 0: nm[0] |= bit; break; case 1: nm[1] |= bit; break; case 2: nm[2] |= bit; break; case 3: nm[3] |= bit; break;
+                case 4: nm[4] |= bit; break; case 5: nm[5] |= bit; break; case 6: nm[6] |= bit; break; default: nm[7] |= bit; break;
                 }
             }
-            sweep_masked<FIRST>(p, cur, wt, base, e, lane, itw, stw != 0, tab, K, labels, acc, moved, ncand);
 #pragma unroll
-            for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
+            for (int i = 0; i < 8; i++)
+                if (nm[i]) atomicOr(&s_mask[i * 64 + lane], nm[i]);
         }
-        if (FIRST) {
-            arw = wave_reduce_sum64(arw); agw = wave_reduce_sum64(agw); abw = wave_reduce_sum64(abw); aww = wave_reduce_sum64(aww);
-            if (lane == 0) {
-                unsigned long long *ag = ss.cagg + (size_t)((item_word(itw, 3) << kSuperShift) | (item_word(itw, 0) & 63)) * 4;
-                ag[0] = arw; ag[1] = agw; ag[2] = abw; ag[3] = aww;
+        __syncthreads();
+        if (wid == 0) {
+            const uint32_t n = c_e - c_s;
+            s_cs[lane] = c_s;
+            if (lane == 63) s_cs[64] = c_e;
+            uint32_t nm[8];
+            uint32_t ncand = 0, lastid = 0, hitw = 0;
+            const uint32_t om[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                nm[i] = s_mask[i * 64 + lane];
+                ncand += (uint32_t)__popc(nm[i]);
+                if (nm[i]) lastid = 32u * i + (uint32_t)__builtin_ctz(nm[i]);
+                hitw |= (om[i] | nm[i]) & s_mm[i];
             }
+            const bool hit = hitw != 0;
+            const uint32_t state = r2.x;  // 0: labels in memory, 1 + a: uniform a
+            uint32_t nstate = state;
+            bool sweep = false, bulk = false;
+            if (n) {
+                if (ncand == 1) {
+                    if (state) bulk = state != 1 + lastid;
+                    else sweep = hit;  // (not hit: the labels in memory are all `lastid` already)
+                    nstate = 1 + lastid;
+                } else if (hit) {
+                    sweep = true;
+                    nstate = 0;
+                }
+            }
+            rec_state = nstate;  // (the record itself is stored after the barrier below: a store in front of it would be waited for)
+            if (bulk) {  // the whole cell changes cluster: its aggregate moves, no point is read
+                const unsigned long long rw = ag0.x, gw = ag0.y, bw = ag1.x, ww = ag1.y;
+                const uint32_t a = state - 1, b = lastid;
+                atomicAdd(&acc[3 * b + 0], rw); atomicAdd(&acc[3 * b + 1], gw); atomicAdd(&acc[3 * b + 2], bw);
+                atomicAdd(&acc[3 * K + b], ww); atomicAdd(&acc[4 * K + b], (unsigned long long)n);
+                atomicAdd(&acc[3 * a + 0], 0ull - rw); atomicAdd(&acc[3 * a + 1], 0ull - gw); atomicAdd(&acc[3 * a + 2], 0ull - bw);
+                atomicAdd(&acc[3 * K + a], 0ull - ww); atomicAdd(&acc[4 * K + a], 0ull - (unsigned long long)n);
+                moved += n;
+            }
+            const unsigned long long sm = __ballot(sweep);
+            if (sweep) s_list[__popcll(sm & lt_mask)] = (uint32_t)lane | (state << 8);
+            if (lane == 0) {
+                s_nlist = (uint32_t)__popcll(sm);
+                evals += (unsigned long long)nS * (uint32_t)__popcll(__ballot(n != 0));
+            }
+#ifdef CNIIC_RGBW_PHASES
+            {
+                unsigned int *L = g_rgbw_launch[(fz.on ? fz.launch_no : 0) & 127];
+                const uint32_t nsw = (uint32_t)__popcll(sm), psw = wave_reduce_sum(sweep ? n : 0u), nb = (uint32_t)__popcll(__ballot(bulk)),
+                               n1 = (uint32_t)__popcll(__ballot(n && ncand == 1)), nne = (uint32_t)__popcll(__ballot(n != 0));
+                if (lane == 0) { atomicAdd(&L[0], nsw); atomicAdd(&L[1], psw); atomicAdd(&L[2], nb); atomicAdd(&L[3], n1); atomicMax(&L[4], nsw); atomicAdd(&L[5], nne); atomicAdd(&L[6], nS); }
+            }
+#endif
         }
-        evals += (unsigned long long)(e - s) * (ncand + 1);
-        RG_PHASE(4);
-        i = in;
-        itw = itn;
+        RG_PHASE(3);
+        __syncthreads();
+        if (wid == 0 && c_e != c_s) {  // this launch's record of the cell: mask and state
+            uint4 *rp = reinterpret_cast<uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
+            rp[0] = make_uint4(s_mask[lane], s_mask[64 + lane], s_mask[128 + lane], s_mask[192 + lane]);
+            rp[1] = make_uint4(s_mask[256 + lane], s_mask[320 + lane], s_mask[384 + lane], s_mask[448 + lane]);
+            if (rec_state != r2.x) rp[2] = make_uint4(rec_state, 0, 0, 0);
+        }
+        if (dbg_stop == 3) return;
+        if (dbg_stop == 4) { if (threadIdx.x == 0) s_nlist = 0; __syncthreads(); }
+        // ================================================================= sweeps (all waves draw from the list)
+        const uint32_t nlist = s_nlist;
+        auto draw = [&]() -> uint32_t {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&s_draw, 1u);
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        };
+        auto load_sweep = [&](uint32_t base, uint32_t end, uint32_t sw, uint32_t (&pp)[kSweep], uint32_t (&cc)[kSweep], uint32_t (&ww)[kSweep]) {
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) {
+                const uint32_t q = base + u * 64 + lane;
+                pp[u] = q < end ? ckeys[q] : 0u;
+                ww[u] = q < end ? cweight[q] : 0u;
+                cc[u] = sw ? sw - 1 : (q < end ? (uint32_t)labels[q] : 0u);
+            }
+        };
+        uint32_t it = draw();
+        uint32_t s = 0, e = 0, cl = 0, stw = 0;
+        uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+        if (it < nlist) {
+            const uint32_t w = s_list[it];
+            cl = w & 63; stw = w >> 8; s = s_cs[cl]; e = s_cs[cl + 1];
+            load_sweep(s, e, stw, p, cur, wt);
+        }
+        RG_PHASE(1);
+        while (it < nlist) {
+            const uint32_t itn = draw();
+            uint32_t s_next = 0, e_next = 0, cl_next = 0, stw_next = 0;
+            if (itn < nlist) { const uint32_t w = s_list[itn]; cl_next = w & 63; stw_next = w >> 8; s_next = s_cs[cl_next]; e_next = s_cs[cl_next + 1]; }
+            uint32_t ncand = 0;
+            unsigned long long arw = 0, agw = 0, abw = 0, aww = 0;  // iteration 0: the cell's aggregate
+            for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                const bool more = base + 64 * kSweep < e;
+                uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
+                if (more) load_sweep(base + 64 * kSweep, e, stw, pn, curn, wtn);
+                else load_sweep(s_next, e_next, stw_next, pn, curn, wtn);
+                if (FIRST) {
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) {  // (slots past the cell's end hold weight 0)
+                        const unsigned long long w = wt[u];
+                        arw += ((p[u] >> 16) & 255) * w; agw += ((p[u] >> 8) & 255) * w; abw += (p[u] & 255) * w; aww += w;
+                    }
+                }
+                sweep_masked<FIRST>(p, cur, wt, base, e, lane, s_mask + cl, stw != 0, tab, K, labels, acc, moved, ncand);
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
+            }
+            if (FIRST) {
+                arw = wave_reduce_sum64(arw); agw = wave_reduce_sum64(agw); abw = wave_reduce_sum64(abw); aww = wave_reduce_sum64(aww);
+                if (lane == 0) {
+                    unsigned long long *ag = ss.cagg + (size_t)((sup << kSuperShift) | cl) * 4;
+                    ag[0] = arw; ag[1] = agw; ag[2] = abw; ag[3] = aww;
+                }
+            }
+            evals += (unsigned long long)(e - s) * (ncand + 1);
+            RG_PHASE(4);
+            it = itn; s = s_next; e = e_next; cl = cl_next; stw = stw_next;
+        }
     }
     RG_PHASE(11);
     moved = wave_reduce_sum(moved);
@@ -1433,19 +1448,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         if (evals) atomicAdd(&s_evals, evals);
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < 5 * K; t += THREADS)
-        if (acc[t]) atomicAdd(&partials[t], acc[t]);
+    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS)
+        if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
         if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
     }
     RG_PHASE(5);
 #ifdef CNIIC_RGBW_PHASES
-    if (lane == 0)
-        for (int t = 0; t < 12; t++)
-            if (ph_[t]) atomicAdd(&s_ph[t], ph_[t]);
-    __syncthreads();
-    if (threadIdx.x < 12 && s_ph[threadIdx.x]) atomicAdd(&g_rgbw_phase[threadIdx.x], s_ph[threadIdx.x]);
+    if (census && threadIdx.x == 0) { g_rgbw_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); g_rgbw_blk[blockIdx.x][3] = s_nlist; }
 #endif
 }
 
@@ -1649,12 +1660,12 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
-        s->sup = !s->wide && nshards == 1 && !(getenv("CNIIC_KM_WAVE_CELLS") && atoi(getenv("CNIIC_KM_WAVE_CELLS")));
+        // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
+        // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
+        s->sup = !s->wide && nshards == 1 && getenv("CNIIC_KM_SUP") && atoi(getenv("CNIIC_KM_SUP"));
         if (s->sup) {
             KM_ALLOC(s->sup_rec, (uint64_t)kNumCells * kSupRecWords * 4);
             KM_ALLOC(s->sup_agg, (uint64_t)kNumCells * 4 * 8);
-            KM_ALLOC(s->sup_wl, (uint64_t)kNumCells * kItemWords * 4);
-            KM_ALLOC(s->sup_wln, (uint64_t)kNumSupers * 4);
             (void)hipMemsetAsync(s->sup_rec.p, 0, (uint64_t)kNumCells * kSupRecWords * 4, c->stream);  // state 0: the labels are in memory
         }
         DevBuf count, cursor, cell_tot;
@@ -1786,24 +1797,21 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
                                s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
         } else if (s->sup) {
-            // an iteration = classify (one wave per super-cell; finishes the previous iteration first) + sweep (the work items of all
-            // lists dealt to every wave); profiling events: start of the first, end of the second
-            SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), s->sup_wl.as<uint32_t>(),
-                        s->sup_wln.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
+            SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
+            if (const char *ds = getenv("CNIIC_SUP_STOP")) ss.no_skip |= ((uint32_t)atoi(ds) & 255u) << 8;
+            if (const char *ds = getenv("CNIIC_DBG_LAUNCH")) ss.no_skip |= (uint32_t)atoi(ds) << 16;
             s->labels_stale = true;
             s->sup_force = false;
-            const size_t lds_c = (size_t)s->K * 8 * (1 + kClassifyWaves), lds_w = (size_t)s->K * (5 * 8 + 8);
+            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
             const bool first_launch = s->sup_launches++ == 0;  // (iteration 0: full sums, the cells' aggregates are written)
-            hipExtLaunchKernelGGL((k_rgbw_classify<kClassifyWaves>), dim3(kNumSupers / kClassifyWaves), dim3(64 * kClassifyWaves), (uint32_t)lds_c, c->stream,
-                                  ev_start, nullptr, 0, s->K, (const uint2 *)s->cconst.as<uint2>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
             if (first_launch)
-                hipExtLaunchKernelGGL((k_rgbw_sweep<kSweepWaves, true>), dim3(kSweepBlocks), dim3(64 * kSweepWaves), (uint32_t)lds_w, c->stream, nullptr, ev_stop, 0,
-                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K,
-                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, ss);
+                hipExtLaunchKernelGGL((k_rgbw_assign_sup<kSupWaves, true, 3>), dim3(kNumSupers), dim3(64 * kSupWaves), (uint32_t)lds, c->stream, ev_start, ev_stop, 0,
+                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K, (const uint2 *)s->cconst.as<uint2>(),
+                                      s->labels.as<uint8_t>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
             else
-                hipExtLaunchKernelGGL((k_rgbw_sweep<kSweepWaves, false>), dim3(kSweepBlocks), dim3(64 * kSweepWaves), (uint32_t)lds_w, c->stream, nullptr, ev_stop, 0,
-                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K,
-                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, ss);
+                hipExtLaunchKernelGGL((k_rgbw_assign_sup<kSupWaves, false, kSupMinW>), dim3(kNumSupers), dim3(64 * kSupWaves), (uint32_t)lds, c->stream, ev_start, ev_stop, 0,
+                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K, (const uint2 *)s->cconst.as<uint2>(),
+                                      s->labels.as<uint8_t>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
                                (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
@@ -2022,6 +2030,15 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
         CNIIC_HIP_TRY(c, hipDeviceSynchronize());
         CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_rgbw_phase), sizeof ph));
         CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_phase), zero, sizeof zero));
+        if (s->sup && getenv("CNIIC_DBG_LAUNCH")) {
+            static unsigned long long B[512][4];
+            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(B, HIP_SYMBOL(g_rgbw_blk), sizeof B));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int i = 0; i < 512; i++) if (B[i][0]) { t0 = std::min(t0, B[i][0]); t1 = std::max(t1, B[i][1]); }
+            fprintf(stderr, "census: launch spans %.2f us\n", (t1 - t0) / 100.0);
+            for (int i = 0; i < 512; i++)
+                fprintf(stderr, "blk %d start %.2f dur %.2f hwid %llx items %llu\n", i, (B[i][0] - t0) / 100.0, (B[i][1] - B[i][0]) / 100.0, B[i][2], B[i][3]);
+        }
         if (s->sup) {
             unsigned int L[128][8];
             CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(L, HIP_SYMBOL(g_rgbw_launch), sizeof L));
@@ -2030,8 +2047,8 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
             memset(L, 0, sizeof L);
             CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_launch), L, sizeof L));
         }
-        if (s->sup) fprintf(stderr, "classify (wave clocks): prologue %llu S build %llu classify %llu | sweep: set-up + scan %llu item fetch %llu sweeps %llu tail wait %llu flush %llu\n",
-                            ph[6], ph[7], ph[8], ph[0], ph[1], ph[4], ph[11], ph[5]);
+        if (s->sup) fprintf(stderr, "assign_sup (wave clocks): prologue %llu S build %llu classify %llu first loads %llu sweeps %llu tail wait %llu flush %llu\n",
+                            ph[0], ph[2], ph[3], ph[1], ph[4], ph[11], ph[5]);
         fprintf(stderr, "rgbw phases (wave clocks): prologue %llu draw %llu super %llu cell-build %llu sweep %llu epilogue %llu skip-test %llu "
                         "skip-build+sweep %llu | super builds %llu cells %llu iters %llu | first barrier+draw %llu tail %llu\n",
                 ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], (unsigned long long)h.iter, ph[10], ph[11]);

@@ -126,6 +126,36 @@ def test_kmeans_rgbw_brute_and_wide(ctx, K, flags):
     assert np.array_equal(got["members"], exp["members"])
 
 
+@pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (200, (300, 260))])
+@pytest.mark.parametrize("unfused", ["0", "1"])
+def test_kmeans_rgbw_run_super_cell_kernel(ctx, monkeypatch, K, shape, unfused):
+    """CNIIC_KM_SUP=1: the super-cell-major assign (one lane per cell, whole cells moved as aggregates, cells without a
+    moved candidate skipped) gives the oracle's run bit for bit, with the update folded in and as a separate kernel"""
+    monkeypatch.setenv("CNIIC_KM_SUP", "1")
+    monkeypatch.setenv("CNIIC_KM_UNFUSED", unfused)
+    img = synth_img(*shape, seed=11 + K)
+    keys, counts = O.count_freqs(keys_of(img))
+    w = counts.astype(np.uint32)
+    rc, got = ctx.kmeans_rgbw(keys, w, K)
+    rco, exp = O.kmeans(O.PT_RGBW, O.MODE_L, pts_of_keys(keys), w, K)
+    assert rc == rco == 0
+    assert got["stats"]["iterations"] == exp["stats"]["iterations"]
+    assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
+    assert np.array_equal(got["labels"], exp["labels"])
+    assert np.array_equal(got["members"], exp["members"])
+
+
+def test_cluster_colors_codec_super_cell_kernel(ctx, monkeypatch):
+    """the codec through the super-cell kernel, dense-table and pixel-partition routes: the oracle's bytes"""
+    monkeypatch.setenv("CNIIC_KM_SUP", "1")
+    img = synth_img(301, 299, seed=23, levels=200, noise=3)
+    rco, edata, est = O.encode("cluster-colors(64)", img, mode=O.MODE_L)
+    for sp_min in ("0", str(1 << 40)):
+        monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", sp_min)
+        rc, data, st = ctx.encode("cluster-colors(64)", img)
+        assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+
+
 def test_kmeans_rgbw_unsorted_input_order(ctx):
     """the point ORDER is the caller's (the reference clusters a HashMap-ordered Vec, clusterc.rs:21-24):
     a shuffled list must give the oracle's result for that same order"""
