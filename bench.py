@@ -2,18 +2,23 @@
 """bench.py -- headline benchmark of the cniic hot path on MI355X.
 
 Metric (BASELINE.json): Mpixels/sec encode, `cluster-colors` K=256.
-Workload at N=1: configs[1] = one 4096x4096 synthetic photo-like RGB image, resident in HBM;
-a "step" is one full Codec::encode (count_freqs dedup -> K-means to convergence -> remap ->
-Huffman), the encoded stream landing in an HBM buffer.  At N>1 every rank holds its own 4096x4096
-image (weak scaling) and the ranks cluster the UNION of their pixels into one shared palette:
-dense histograms and the K partial centroid sums are all-reduced over RCCL each iteration.
+
+  --config c2 (default at N=1)  configs[1]: one 4096x4096 synthetic photo-like RGB image per GPU, resident in HBM; a
+                                "step" is one full Codec::encode (count_freqs dedup -> K-means to convergence -> remap ->
+                                Huffman), the stream landing in an HBM buffer.
+  --config c4 (default at N>1)  configs[3]: a batch of 1920x1080 frames, --frames-per-gpu F of them per GPU (128: 1024 frames
+                                on 8 GPUs), ONE palette for the whole batch: every rank partitions its own frames' pixels,
+                                the colour occupancy is all-reduced once and the K partial centroid sums every iteration
+                                (RCCL, in-stream); each frame is then its own Hufman stream.  Weak scaling: per-GPU work is
+                                fixed, the palette is the union's.  A step = the whole batch encode.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` is the K-means assign kernel (dominant kernel), timed
-live with HIP events on the stream it runs on; `cpu_baseline` is the CPU restatement of the
-reference algorithm (oracle mode R) on a bounded sample, rank 0, N=1 only.
+Prints ONE JSON line (rank 0).  `roofline` is the K-means assign kernel (dominant kernel), timed live with HIP events
+attached to every dispatch on the stream it runs on; `cpu_baseline` is the CPU restatement of the reference algorithm
+(oracle mode R) on a bounded sample, rank 0, N=1 only.  At N=1 the c2 line also carries `c4_one_gpu`: the c4 workload on
+this one GPU, which is what the N>1 lines scale from.
 """
 import argparse
 import json
@@ -25,6 +30,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAME_W, FRAME_H = 1920, 1080
+
+
+def roofline_from_timers(ctx, U, K, note, traffic=None):
+    """roofline of the assign kernel from the per-dispatch event timers of the LAST profiled run on ctx.
+    Algorithmic bytes per launch = 10 B per distinct colour (dedup form: 4 B key + 4 B weight + 1 B label read
+    + 1 B written).  `frac` is over the WORKING launches (one per iteration, and the one that finishes the last iteration);
+    launches past convergence, which exit on the device-side flag, are listed apart."""
+    ms_all, n_all = ctx.kernel_time("kmeans_rgbw_assign")
+    ms_w, n_w = ctx.kernel_time("kmeans_rgbw_assign_working")
+    if not n_w:
+        return None
+    algo = 10.0 * U
+    launch_ms = ms_w / n_w
+    achieved = algo / (launch_ms * 1e-3) / 1e9
+    by = {}
+    for cls in ("first", "full", "skip", "final-update", "no-op"):
+        ms, n = ctx.kernel_time("kmeans_rgbw_assign_" + cls)
+        if n:
+            by[cls] = {"launches": int(n), "us": round(ms * 1e3 / n, 2), "GBps_algorithmic": round(algo / (ms / n * 1e-3) / 1e9, 1)}
+    return {"kernel": "k_rgbw_assign_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "launch_ms": round(launch_ms, 5), "launches": int(n_w),
+            "algorithmic_bytes_per_launch": algo, "no_op_launches": int(n_all - n_w),
+            "all_launches": {"launches": int(n_all), "launch_ms": round(ms_all / max(1, n_all), 5)},
+            "by_class": by, "note": note}
 
 
 def main():
@@ -32,10 +62,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=4096, help="image side (default: configs[1], 4096)")
+    ap.add_argument("--config", choices=["auto", "c2", "c4"], default="auto", help="auto: c2 on one GPU, c4 on several")
+    ap.add_argument("--frames-per-gpu", type=int, default=128, help="c4: 1920x1080 frames per GPU (128 x 8 GPUs = the 1024 of configs[3])")
+    ap.add_argument("--size", type=int, default=4096, help="c2: image side (default: configs[1], 4096)")
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--max-iters", type=int, default=0, help="0 = to convergence, like the reference")
-    ap.add_argument("--cpu-sample", type=int, default=2560, help="side of the crop timed on the CPU (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2560, help="side of the crop timed on the CPU (0 = skip every CPU leg)")
+    ap.add_argument("--no-extras", action="store_true", help="c2 at N=1: skip the c4_one_gpu and host-buffer legs")
     args = ap.parse_args()
 
     import numpy as np
@@ -43,12 +76,14 @@ def main():
 
     import cniic_amd
     from cniic_amd import _lib, synth
+    from cniic_amd.dist import ShardedClusterColors
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knob: CNIIC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (process group, collectives) with one rank
     sharded = world > 1 or os.environ.get("CNIIC_BENCH_FORCE_SHARDED") == "1"
+    config = args.config if args.config != "auto" else ("c4" if world > 1 else "c2")
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -65,125 +100,207 @@ def main():
         dist = None
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    W = H = args.size
     K = args.k
     expr = "cluster-colors(%d)" % K
-    seed = synth.SEED0 + 2 + rank  # config 2 of SURVEY 8(d); one image per rank
     # one non-default stream shared by torch (collectives) and the library (kernels): stream order
     # is the only synchronisation between them
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = cniic_amd.Context(local_rank, stream=stream.cuda_stream)
-
-    img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    ctx.synth_image(_lib.SYNTH_PHOTO, seed, W, H, out=img)
-    out = torch.empty(W * H * 4 + (1 << 20), dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()
-
-    if sharded:
-        from cniic_amd.dist import ShardedClusterColors
-        enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters,
-                                   collectives="native" if world == 1 and os.environ.get("CNIIC_COLLECTIVES", "native") == "native" else None)
-
-        def step():
-            return enc.encode(img, W, H, out)
-    else:
-        def step():
-            rc, ln, st = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters)
-            return ln, st
+    native = "native" if world == 1 and os.environ.get("CNIIC_COLLECTIVES", "native") == "native" else None
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nbytes, st = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    npx_total = W * H * world
-    value = npx_total * args.steps / dt / 1e6
-    ms_per_step = dt / args.steps * 1e3
-
-    # ---- roofline of the dominant kernel: K-means assign over the distinct colours (dedup form,
-    # 10 algorithmic bytes per colour per launch: 4 B key + 4 B weight + 1 B label read + 1 B written)
-    roofline = None
-    U = 0
-    if rank == 0:
-        keys, counts = ctx.hist_rgb24(img, npx=W * H)
-        U = int(keys.size)
-        del keys, counts
-        # one more encode of the same image with a HIP start/stop event pair attached to every assign dispatch
-        # (hipExtLaunchKernelGGL, on the stream the kernel runs on: the kernel's own begin and end, without the
-        # ~4 us of dispatch an event pair AROUND a launch adds): average over ALL launches of a real encode
-        rc, ln, stp = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE)
-        ms_sum, launches = ctx.kernel_time("kmeans_rgbw_assign")
-        launch_ms = ms_sum / max(1, launches)
-        algo_bytes = 10.0 * U
-        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see DESIGN.md 6
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("size") == W and tj.get("K") == K and tj.get("unique_colours") == U:
-                traffic = tj.get("hbm_bytes_per_launch")
-        roofline = {"kernel": "k_rgbw_assign_cells", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "launch_ms": round(launch_ms, 5), "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes,
-                    "note": "HIP start/stop events on each of the %d assign dispatches of one encode (%d iterations + launches that exit "
-                            "on the device-side done flag, as rocprofv3 --stats counts them); exact cell-pruned assign over %d distinct "
-                            "colours, K=%d; algorithmic bytes = 10 B/colour (SURVEY 8(d) dedup form); traffic = PMC "
-                            "2*FETCH_SIZE+WRITE_SIZE of a steady-state launch (profiles/traffic.json)" % (launches, stp["iterations"], U, K)}
-
-    # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        s = min(args.cpu_sample, W)
-        crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+    def timed(step, warmup, steps):
+        for _ in range(warmup):
+            step()
+        barrier()
         t0 = time.perf_counter()
-        rc, data, ost = O.encode(expr, crop, mode=O.MODE_R)
-        cdt = time.perf_counter() - t0
-        cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-               "sample": "%dx%d crop of the same image, oracle mode R (reference algorithm incl. neighbour pruning), "
-                         "%d iterations, %.1f s" % (s, s, ost["iterations"], cdt),
-               "bytes_per_px": round(len(data) / (s * s), 4)}
+        for _ in range(steps):
+            r = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, r
 
+    def make_frames(F, first_frame):
+        fr = torch.empty((F, FRAME_H, FRAME_W, 3), dtype=torch.uint8, device=dev)
+        for f in range(F):   # frame f of the batch uses seed + f (config 4)
+            ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 4 + first_frame + f, FRAME_W, FRAME_H, out=fr[f])
+        return fr
+
+    def run_c4(enc, F, warmup, steps, profile):
+        """-> (seconds for `steps` batch encodes, bytes of this rank's streams, stats, distinct colours of this rank, roofline)"""
+        frames = make_frames(F, rank * F)
+        stride = FRAME_W * FRAME_H  # 1 byte per pixel between streams: K = 256 labels need at most 8 bits each + the tree
+        out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        dt, (lens, st) = timed(lambda: enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride), warmup, steps)
+        roof, U = None, 0
+        if profile:
+            keys, counts = ctx.hist_rgb24(frames, npx=F * FRAME_W * FRAME_H)
+            U = int(keys.size)
+            del keys, counts
+            enc.flags = _lib.KM_PROFILE
+            enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride)
+            enc.flags = 0
+            roof = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one batch encode; exact cell-pruned assign over this "
+                                        "GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K))
+        return dt, int(sum(lens)), st, U, roof
+
+    line = None
+    if config == "c4":
+        F = args.frames_per_gpu
+        enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives=native)
+        dt, nbytes, st, U, roof = run_c4(enc, F, args.warmup, args.steps, profile=(rank == 0))
+        npx_total = F * FRAME_W * FRAME_H * world
+        if rank == 0:
+            cpu = None
+            if world == 1 and args.cpu_sample > 0:
+                cpu = cpu_all_cores(np, make_frames, expr)
+            line = {
+                "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
+                "config": {"workload": "configs[3]: cluster-colors(%d) over a batch of %d 1920x1080 photo-like synthetic frames (%d per GPU, frame f: seed "
+                                       "0x636E696963+4+f), one palette for the whole batch, one Hufman stream per frame, to convergence" % (K, F * world, F),
+                           "frames_per_gpu": F, "pixels_per_gpu": F * FRAME_W * FRAME_H, "unique_colours_rank0": U, "kmeans_iterations": int(st["iterations"]),
+                           "bytes_per_px": round(nbytes / (F * FRAME_W * FRAME_H), 4),
+                           "parallelism": "1 GPU" if world == 1 else "frames sharded over %d GPUs (each keeps its own frames' colours), shared palette: RCCL all-reduce of the "
+                                          "colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
+                                          % (world, "library communicator, in-stream" if enc.collectives == "native" else "torch.distributed")},
+                "roofline": roof, "cpu_baseline": cpu,
+            }
+        enc.close()
+    else:
+        W = H = args.size
+        seed = synth.SEED0 + 2 + rank  # config 2 of SURVEY 8(d); one image per rank
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, seed, W, H, out=img)
+        out = torch.empty(W * H * 4 + (1 << 20), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        enc = None
+        if sharded:
+            enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives=native)
+
+            def step():
+                return enc.encode(img, W, H, out)
+        else:
+            def step():
+                rc, ln, st = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters)
+                return ln, st
+        dt, (nbytes, st) = timed(step, args.warmup, args.steps)
+        npx_total = W * H * world
+        roofline, cpu, extras, U = None, None, {}, 0
+        if rank == 0:
+            keys, counts = ctx.hist_rgb24(img, npx=W * H)
+            U = int(keys.size)
+            del keys, counts
+            # one more encode of the same image with a HIP start/stop event pair attached to every assign dispatch
+            # (hipExtLaunchKernelGGL, on the stream the kernel runs on: the kernel's own begin and end, without the
+            # ~4 us of dispatch an event pair AROUND a launch adds)
+            rc, ln, stp = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see DESIGN.md 6
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("size") == W and tj.get("K") == K and tj.get("unique_colours") == U:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            roofline = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one encode (%d iterations); exact cell-pruned assign over %d "
+                                            "distinct colours, K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form); traffic = PMC 2*FETCH_SIZE+WRITE_SIZE "
+                                            "of a full-schedule launch (profiles/traffic.json)" % (stp["iterations"], U, K), traffic)
+        if rank == 0 and world == 1 and not sharded:
+            if not args.no_extras:
+                # the trait the reference calls is host image -> host bytes (bench.rs:33-35): the same encode with both buffers in host memory
+                himg = img.cpu().numpy()
+                ctx.encode(expr, himg)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    ctx.encode(expr, himg)
+                extras["host_io_ms_per_step"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                del himg
+                # configs[3] on this one GPU: what the N > 1 lines (128 frames per GPU, weak scaling) scale from
+                F = args.frames_per_gpu
+                e4 = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
+                d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=True)
+                e4.close()
+                extras["c4_one_gpu"] = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams" % (F, F),
+                                        "value": round(F * FRAME_W * FRAME_H * 2 / d4 / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3),
+                                        "kmeans_iterations": int(st4["iterations"]), "unique_colours": U4, "bytes_per_px": round(nb4 / (F * FRAME_W * FRAME_H), 4),
+                                        "roofline": roof4}
+                if args.cpu_sample > 0:
+                    extras["c4_one_gpu"]["cpu_baseline"] = cpu_all_cores(np, make_frames, expr)
+            # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
+            if args.cpu_sample > 0:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                s = min(args.cpu_sample, W)
+                crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+                t0 = time.perf_counter()
+                rc, data, ost = O.encode(expr, crop, mode=O.MODE_R)
+                cdt = time.perf_counter() - t0
+                cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                       "sample": "%dx%d crop of the same image, oracle mode R (reference algorithm incl. neighbour pruning), "
+                                 "%d iterations, %.1f s" % (s, s, ost["iterations"], cdt),
+                       "bytes_per_px": round(len(data) / (s * s), 4)}
+        if rank == 0:
+            line = {
+                "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
+                "config": {"workload": "configs[1]: cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
+                                       "(seed 0x636E696963+2+rank), to convergence" % (K, W, H),
+                           "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
+                           "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2) if "pair_evals" in st else None,
+                           "bytes_per_px": round(nbytes / (W * H), 4),
+                           "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
+                                                                       "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
+                                                                       % (world, "library communicator, in-stream" if enc.collectives == "native"
+                                                                          else "torch.distributed")},
+                "roofline": roofline, "cpu_baseline": cpu,
+            }
+            line.update(extras)
+        if enc is not None:
+            enc.close()
     if rank == 0:
-        line = {
-            "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(value, 3), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
-            "config": {"workload": "cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
-                                   "(seed 0x636E696963+2+rank), to convergence" % (K, W, H),
-                       "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
-                       "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2),
-                       "bytes_per_px": round(nbytes / (W * H), 4),
-                       "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
-                                                                   "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
-                                                                   % (world, "library communicator, in-stream" if enc.collectives == "native"
-                                                                      else "torch.distributed")},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()  # rank 0 did the roofline encode on its own: tear down together
-    if sharded:
-        enc.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_all_cores(np, make_frames, expr):
+    """the reference's own batch semantics -- one image per rayon worker, one palette per image
+    (bench.rs:24-35) -- as oracle mode R on every host core, one 1920x1080 frame per thread (ctypes releases the GIL)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.lib()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    frames = make_frames(cores, 0).cpu().numpy()
+    res = [None] * cores
+
+    def work(i):
+        res[i] = O.encode(expr, frames[i], mode=O.MODE_R)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    cdt = time.perf_counter() - t0
+    npx = cores * FRAME_W * FRAME_H
+    return {"value": round(npx / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d frames 1920x1080, one per thread, each with its own palette as the reference's harness does (oracle mode R), %.1f s" % (cores, cdt),
+            "bytes_per_px": round(sum(len(r[1]) for r in res) / npx, 4)}
 
 
 if __name__ == "__main__":

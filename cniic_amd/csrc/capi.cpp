@@ -498,6 +498,7 @@ int32_t cniic_cc_image_begin(cniic_ctx *c, const uint8_t *rgb_dev, uint64_t npx,
     if (!rgb_dev || !out || npx == 0 || !is_device_ptr(rgb_dev) || (reinterpret_cast<uintptr_t>(rgb_dev) & 15))
         return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_begin: a non-empty, 16-byte aligned device image and an out pointer are needed");
     if (npx >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "cc_image_begin: too many pixels");
+    c->ktimes.clear();
     CcSession *s = nullptr;
     CNIIC_TRY(cc_image_begin(c, rgb_dev, npx, &s));
     *out = new cniic_cc{c, s};
@@ -626,6 +627,18 @@ int32_t cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h
     In<uint8_t> in;
     CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3));
     return cc_finish(cc->s, in.d, w, h, local_table_dev, out, cap, len, stats);
+}
+
+int32_t cniic_cc_finish_frames(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t frames, uint8_t *out, uint64_t stride,
+                               uint64_t *lens, cniic_kmeans_stats *stats) {
+    if (!cc) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);
+    LOCK(c);
+    if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
+    if (!rgb || !out || !lens || !frames) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: null argument");
+    In<uint8_t> in;
+    CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3 * frames));
+    return cc_finish_frames(cc->s, in.d, w, h, frames, out, stride, lens, stats);
 }
 
 void cniic_cc_destroy(cniic_cc *cc) {

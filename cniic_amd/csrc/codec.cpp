@@ -7,6 +7,10 @@
 //   VoronoiCluster  src/codec/clusterc.rs:147 5-D K-means, centroids only; Voronoi repaint on decode
 //   Delta           src/codec/hilbertc.rs:404 Hilbert gather -> neighbour delta -> huf::encode_all
 //   Hilbert{RLE(0)} src/codec/hilbertc.rs:12  Hilbert gather -> exact run-length records
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
 #include "codec.hpp"
 
 #include <algorithm>
@@ -311,9 +315,12 @@ int cc_image_create(CcSession *s, const uint32_t *occ_d, uint32_t K, const cniic
     km_rgbw_cell_arrays(s->km, &cell_start, &ckeys, &cweight);
     CNIIC_TRY(sp_emit(c, &s->sp, cell_start, ckeys, cweight, km_rgbw_labels_internal(s->km, nullptr), km_rgbw_is_wide(s->km), K, s->gbits.p,
                       s->gprefix.as<uint32_t>(), 0, Ug_dev));
+    // this image's own colour count, fetched again here: the context's pinned slot sp_build copied it to may have been
+    // rewritten since by another session of the same context (a second cniic_cc_image_begin, a plain encode)
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(c->pinned_u + 2, s->sp.total.p, 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // (the all-reduced occupancy had to arrive anyway)
     const uint64_t Ug = *Ug_h;
-    s->sp.U = *c->pinned_u;  // sp_build's copy, ordered before the one above
+    s->sp.U = c->pinned_u[2];
     s->U = s->sp.U;
     if (Ug / K == 0 || s->U == 0)
         return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu distinct colours for %u clusters (src/kmeans.rs:68)", (unsigned long long)Ug, K);
@@ -451,6 +458,143 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     const int rc_fin = so.finish();
     host_trace().mark("so.finish");
     return rc_fin;
+}
+
+// A batch of F equally sized frames (contiguous in rgb_d) coded with ONE palette -- north_star config 4: the K-means ran over the
+// union of all the pixels (of all ranks); every frame is then its own Hufman stream (clusterc.rs:31-52 per frame: the reduced
+// frame's own histogram, tree and payload), written at out + f * stride.  One pass gives every pixel's label, one kernel the
+// pixels per (frame, cluster), the host builds the F small trees on a few threads and the F packs are enqueued back to back.
+int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t F, uint8_t *out, uint64_t stride, uint64_t *lens,
+                     cniic_kmeans_stats *stats) {
+    Ctx *c = s->c;
+    const uint32_t K = s->K;
+    const uint64_t U = s->U, npf = (uint64_t)w * h, n = npf * F;
+    KmRgbwState *km = s->km;
+    if (!F || !npf) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: empty batch");
+    if (stride & 3) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: the stride between streams must be a multiple of 4");
+    if (s->sp_mode && s->sp.npx != n) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: the session was opened on %llu pixels, the batch has %llu",
+                                                     (unsigned long long)s->sp.npx, (unsigned long long)n);
+    std::vector<uint8_t> cent(3 * (size_t)K);
+    std::vector<uint64_t> members(K), wsum(K);
+    cniic_kmeans_stats st{};
+    CNIIC_TRY(km_rgbw_result_begin(km));
+    const bool wide = km_rgbw_is_wide(km);
+    const uint64_t lb = wide ? 2 : 1;
+    DevBuf lab_d, key2label, pixlab, pixlab_al, cnt_d;
+    CNIIC_HIP_TRY(c, pixlab.alloc(n * lb + 16));
+    if (s->sp_mode) {
+        uint32_t *cell_start, *ckeys, *cweight;
+        km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
+        CNIIC_TRY(sp_pixel_labels(c, &s->sp, rgb_d, cell_start, ckeys, km_rgbw_labels_internal(km, nullptr), wide, pixlab.p));
+    } else {
+        CNIIC_HIP_TRY(c, lab_d.alloc(U * lb));
+        CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
+        CNIIC_HIP_TRY(c, key2label.alloc((1ull << 24) * lb));
+        CNIIC_TRY(scatter_labels_by_key(c, s->keys_d.as<uint32_t>(), lab_d.p, wide, U, key2label.p));
+        CNIIC_TRY(pixel_labels(c, rgb_d, n, key2label.p, wide, pixlab.p));
+    }
+    // frames whose label run does not start on a 16-byte boundary are moved apart (the pack reads 16 labels per load)
+    const void *labs = pixlab.p;
+    uint64_t lab_stride = npf;
+    if ((npf * lb) & 15) {
+        lab_stride = (npf + 15) & ~15ull;
+        CNIIC_HIP_TRY(c, pixlab_al.alloc(lab_stride * lb * F + 16));
+        CNIIC_HIP_TRY(c, hipMemcpy2DAsync(pixlab_al.p, lab_stride * lb, pixlab.p, npf * lb, npf * lb, F, hipMemcpyDeviceToDevice, c->stream));
+        labs = pixlab_al.p;
+    }
+    CNIIC_HIP_TRY(c, cnt_d.alloc((uint64_t)F * K * 4));
+    CNIIC_TRY(frame_label_hist(c, labs, npf, lab_stride, F, wide, K, cnt_d.as<uint32_t>()));
+    std::vector<uint32_t> cnt((size_t)F * K);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(cnt.data(), cnt_d.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_TRY(km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st));
+    if (stats) *stats = st;
+    uint64_t min_cc = (uint64_t)(0.99 * (double)K);  // check_enough_active_clusters (kmeans.rs:41-57)
+    if (U < min_cc) min_cc = U;
+    if (st.active < min_cc)
+        return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
+                       (unsigned long long)st.active, (unsigned long long)min_cc);
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // ---- per frame on the host: histogram of the reduced frame = its pixels per centroid COLOUR (two clusters with one mean
+    // are one symbol), tree, serialised decoder, per-cluster code
+    std::vector<std::vector<uint8_t>> headers(F);
+    std::vector<uint8_t> clen((size_t)F * K, 0);
+    std::vector<uint64_t> ccode((size_t)F * K, 0), nbits(F, 0);
+    std::atomic<int> bad{0};
+    auto one_frame = [&](uint32_t f) {
+        const uint32_t *fc = cnt.data() + (size_t)f * K;
+        std::vector<std::pair<uint32_t, uint64_t>> kc;
+        kc.reserve(K);
+        for (uint32_t k = 0; k < K; k++)
+            if (fc[k]) kc.emplace_back(((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2], fc[k]);
+        std::sort(kc.begin(), kc.end());
+        std::vector<uint32_t> skeys;
+        std::vector<uint64_t> scounts;
+        for (auto &e : kc) {
+            if (!skeys.empty() && skeys.back() == e.first) scounts.back() += e.second;
+            else { skeys.push_back(e.first); scounts.push_back(e.second); }
+        }
+        HuffTree tree;
+        std::vector<uint8_t> slen;
+        std::vector<uint64_t> scode;
+        if (!huff_build_tree(scounts.data(), scounts.size(), tree) || !huff_codes(tree, slen, scode)) { bad = 1; return; }
+        std::vector<uint8_t> &hd = headers[f];
+        put_u32(hd, w);
+        put_u32(hd, h);
+        huff_serialize_tree(tree, CNIIC_SYM_RGB, skeys.data(), hd);
+        uint64_t nb = 0;
+        for (size_t i = 0; i < scounts.size(); i++) nb += scounts[i] * slen[i];
+        nbits[f] = nb;
+        for (uint32_t k = 0; k < K; k++) {
+            if (!fc[k]) continue;
+            const uint32_t key = ((uint32_t)cent[3 * k] << 16) | ((uint32_t)cent[3 * k + 1] << 8) | cent[3 * k + 2];
+            const size_t si = std::lower_bound(skeys.begin(), skeys.end(), key) - skeys.begin();
+            clen[(size_t)f * K + k] = slen[si];
+            ccode[(size_t)f * K + k] = scode[si];
+        }
+    };
+    {
+        const uint32_t nthr = std::max(1u, std::min({F, 16u, std::thread::hardware_concurrency()}));
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() { for (uint32_t f; (f = next.fetch_add(1)) < F;) one_frame(f); };
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nthr; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
+    if (bad) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code");
+    uint64_t hmax = 0;
+    for (uint32_t f = 0; f < F; f++) {
+        lens[f] = headers[f].size() + (nbits[f] + 7) / 8;
+        if (((lens[f] + 3) & ~3ull) > stride)
+            return c->fail(CNIIC_ERR_CAPACITY, "encode: stream of frame %u is %llu bytes, %llu between streams", f, (unsigned long long)lens[f], (unsigned long long)stride);
+        hmax = std::max<uint64_t>(hmax, headers[f].size());
+    }
+    hmax = (hmax + 3) & ~3ull;
+    // ---- output: device memory is written in place, a host buffer through a staging copy
+    const bool direct = is_device_ptr(out) && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+    DevBuf staging, hdr_d, clen_d, ccode_d;
+    uint8_t *dev = out;
+    if (!direct) { CNIIC_HIP_TRY(c, staging.alloc(stride * F + 16)); dev = staging.as<uint8_t>(); }
+    CNIIC_HIP_TRY(c, hipMemsetAsync(dev, 0, stride * F, c->stream));
+    std::vector<uint8_t> hdr_all(hmax * F, 0);
+    std::vector<uint64_t> bit_base(F), totals(F, 0);
+    for (uint32_t f = 0; f < F; f++) { memcpy(hdr_all.data() + hmax * f, headers[f].data(), headers[f].size()); bit_base[f] = headers[f].size() * 8; }
+    CNIIC_HIP_TRY(c, hdr_d.alloc(hdr_all.size()));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(hdr_d.p, hdr_all.data(), hdr_all.size(), hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpy2DAsync(dev, stride, hdr_d.p, hmax, hmax, F, hipMemcpyDeviceToDevice, c->stream));  // (zero padding behind a header = the pre-zeroed payload)
+    CNIIC_HIP_TRY(c, clen_d.alloc(clen.size()));
+    CNIIC_HIP_TRY(c, ccode_d.alloc(ccode.size() * 8));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), clen.size(), hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), ccode.size() * 8, hipMemcpyHostToDevice, c->stream));
+    CNIIC_TRY(huff_pack_labels_frames(c, labs, npf, lab_stride, F, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), dev, stride, bit_base.data(), totals.data()));
+    for (uint32_t f = 0; f < F; f++)
+        if (totals[f] != nbits[f])
+            return c->fail(CNIIC_ERR_HIP, "cluster-colors: frame %u packed %llu bits, its histogram predicts %llu", f, (unsigned long long)totals[f], (unsigned long long)nbits[f]);
+    if (!direct) {
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(out, dev, stride * F, is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return CNIIC_OK;
 }
 
 // images of at least this many pixels take the super-cell partition (k_points.hip); CNIIC_SP_MIN_PIXELS overrides (tests: 0)

@@ -50,6 +50,9 @@ int cc_image_begin(Ctx *c, const uint8_t *rgb_d, uint64_t npx, CcSession **out);
 int cc_image_create(CcSession *s, const uint32_t *occ_d, uint32_t K, const cniic_kmeans_opts *opts, void *partials_dev);
 int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const uint32_t *local_counts_d, uint8_t *out,
               uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+// a batch of F frames coded with the session's one palette: F Hufman streams, stream f at out + f * stride, its length in lens[f]
+int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t F, uint8_t *out, uint64_t stride, uint64_t *lens,
+                     cniic_kmeans_stats *stats);
 
 // header carries any prefix already serialised (image dimensions); the decoder trie is appended
 // to it and the whole stream lands in out[0..*len)  (out: host or device memory).

@@ -130,6 +130,7 @@ struct Ctx {
                                    // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
+    const void *poll_owner = nullptr;  // the K-means state whose lagged polls own `pinned` / poll_ev (one loop at a time per context)
 
     int fail(int code, const char *fmt, ...) {
         char buf[512];
@@ -222,6 +223,7 @@ struct KmDevState {
     uint64_t active;
     uint64_t pair_evals;
     uint64_t changed_ring[kHistRing];
+    uint32_t nmoved_ring[kHistRing];  // centroids whose value changed in the update that closed iteration i (colour K-means: picks the schedule of the next launch)
 };
 
 // One launch's view of the scalar state, written by that launch into slot (launch number % kPollRing) of a pinned ring:
@@ -520,5 +522,9 @@ int pixel_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label
 int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32_t K, const uint8_t *clen_d,
                      const uint64_t *ccode_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
 int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, bool wide, uint64_t U, void *key2label_d);
+// a batch of equally sized frames sharing one palette: labels per (frame, cluster), and the label pack of every frame in one go
+int frame_label_hist(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, uint32_t *out_d /* u32[frames][K] */);
+int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, const uint8_t *clen_d,
+                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h);
 
 }  // namespace cniic

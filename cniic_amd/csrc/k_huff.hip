@@ -362,6 +362,74 @@ int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32
     return CNIIC_OK;
 }
 
+// ---- a batch of frames coded with one palette (north_star config 4): per-frame label histograms, and the label pack
+// of every frame enqueued back to back (no host round trip per frame)
+template <typename LabelT>
+__global__ __launch_bounds__(256) void k_frame_label_hist(const LabelT *__restrict__ pixlab, uint64_t npf, uint64_t lab_stride, uint32_t K,
+                                                          uint32_t *__restrict__ out /* [frames][K] */) {
+    extern __shared__ uint32_t s_hist[];  // [K]
+    for (uint32_t i = threadIdx.x; i < K; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const LabelT *base = pixlab + (size_t)blockIdx.y * lab_stride;
+    const uint64_t per = (npf + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < npf ? lo + per : npf;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&s_hist[base[i]], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < K; i += 256)
+        if (s_hist[i]) atomicAdd(&out[(size_t)blockIdx.y * K + i], s_hist[i]);
+}
+
+int frame_label_hist(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, uint32_t *out_d) {
+    if (!frames || !npf) return CNIIC_OK;
+    CNIIC_HIP_TRY(c, hipMemsetAsync(out_d, 0, (uint64_t)frames * K * 4, c->stream));
+    const uint32_t bx = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(npf, 1u << 16), 1), 64);
+    if (wide)
+        hipLaunchKernelGGL(k_frame_label_hist<uint16_t>, dim3(bx, frames), dim3(256), (size_t)K * 4, c->stream,
+                           reinterpret_cast<const uint16_t *>(pixlab_d), npf, lab_stride, K, out_d);
+    else
+        hipLaunchKernelGGL(k_frame_label_hist<uint8_t>, dim3(bx, frames), dim3(256), (size_t)K * 4, c->stream,
+                           reinterpret_cast<const uint8_t *>(pixlab_d), npf, lab_stride, K, out_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// huff_pack_labels for `frames` frames of npf labels each (frame f starts at element f lab_stride, 16-byte aligned): frame f
+// uses the code table at clen_d + f K / ccode_d + f K and writes behind bit_base[f] of out_d + f stride.  Everything is
+// enqueued back to back; one synchronisation at the end brings totals_h[f] (bits packed per frame).
+int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, const uint8_t *clen_d,
+                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h) {
+    if (!frames || !npf) return CNIIC_OK;
+    if ((reinterpret_cast<uintptr_t>(out_d) & 3) || (stride & 3)) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output and stride must be 4-byte aligned");
+    const uint32_t nchunks = (uint32_t)ceil_div(npf, kPackChunk);
+    DevBuf cb, co, tot;
+    CNIIC_HIP_TRY(c, cb.alloc((uint64_t)frames * nchunks * 4));
+    CNIIC_HIP_TRY(c, co.alloc((uint64_t)frames * nchunks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc((uint64_t)frames * 8));
+    const size_t lb = wide ? 2 : 1;
+    for (uint32_t f = 0; f < frames; f++) {
+        const uint8_t *lab = static_cast<const uint8_t *>(pixlab_d) + (size_t)f * lab_stride * lb;
+        uint32_t *cbf = cb.as<uint32_t>() + (size_t)f * nchunks;
+        uint64_t *cof = co.as<uint64_t>() + (size_t)f * nchunks;
+        const uint8_t *cl = clen_d + (size_t)f * K;
+        const uint64_t *cc = ccode_d + (size_t)f * K;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out_d + (size_t)f * stride);
+        if (wide)
+            hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, reinterpret_cast<const uint16_t *>(lab), npf, K, cl, cbf);
+        else
+            hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, lab, npf, K, cl, cbf);
+        CNIIC_TRY(pack_scan(c, cbf, nchunks, cof, tot.as<uint64_t>() + f));
+        if (wide)
+            hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
+                               reinterpret_cast<const uint16_t *>(lab), npf, K, cl, cc, cof, dst, bit_base_h[f]);
+        else
+            hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, lab, npf, K, cl, cc, cof, dst, bit_base_h[f]);
+    }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(totals_h, tot.p, (size_t)frames * 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
+}
+
 // interior words of a chunk that are all-zero must still be written: the output is pre-zeroed.
 
 template <int SRC>

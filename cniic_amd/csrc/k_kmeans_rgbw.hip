@@ -788,6 +788,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             KmDevState *sw = fz.st_rw;
             sw->changed_ring[(j - 1) % kHistRing] = changed;
+            sw->nmoved_ring[(j - 1) % kHistRing] = s_nmoved;
             sw->moved_last = changed;
             sw->reseeds += s_reseed;
             sw->active = s_active;
@@ -1225,6 +1226,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(MINW
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             KmDevState *sw = fz.st_rw;
             sw->changed_ring[(j - 1) % kHistRing] = changed;
+            sw->nmoved_ring[(j - 1) % kHistRing] = s_nmoved;
             sw->moved_last = changed;
             sw->reseeds += s_reseed;
             sw->active = s_active;
@@ -1524,6 +1526,7 @@ __global__ __launch_bounds__(256) void k_rgbw_update(uint64_t *__restrict__ part
         partials[5 * (size_t)K] = 0;
         partials[5 * (size_t)K + 1] = 0;
         st->changed_ring[iter % kHistRing] = changed;
+        st->nmoved_ring[iter % kHistRing] = s_nmoved;
         st->moved_last = changed;
         st->reseeds += s_reseed;
         st->active = s_active;
@@ -2010,18 +2013,30 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
         KernelTime &kw = c->ktimes["kmeans_rgbw_assign_working"];
         kw.ms += wms;
         kw.launches += working;
-        if (const char *path = getenv("CNIIC_KM_LAUNCH_TRACE")) {  // one line per launch: number, duration, points moved by its iteration
-            if (FILE *f = fopen(path, "w")) {
-                fprintf(f, "launch,us,moved,class\n");
-                for (size_t i = 0; i < lt.used / 2; i++) {
-                    float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, lt.ev[2 * i], lt.ev[2 * i + 1]);
-                    const bool in_ring = i < h.iter && h.iter - i <= kHistRing;
-                    fprintf(f, "%zu,%.2f,%lld,%s\n", i, ms * 1e3, in_ring ? (long long)h.changed_ring[i % kHistRing] : -1ll,
-                            i >= working ? "no-op" : i == 0 ? "first" : (s->fused && i == (size_t)h.iter) ? "final-update" : "iteration");
-                }
-                fclose(f);
-            }
+        // per class of launch: iteration 0 (every point adds to the sums), full schedule (more than kMaxMovedSkip centroids moved in
+        // the update before it), skip schedule, the launch that only finishes the last iteration, launches past convergence
+        KmDevState hf;
+        CNIIC_TRY(read_state(s, &hf));  // (the polled copy carries the scalars only)
+        const char *names[5] = {"first", "full", "skip", "final-update", "no-op"};
+        double cms[5] = {0, 0, 0, 0, 0};
+        uint64_t cn[5] = {0, 0, 0, 0, 0};
+        FILE *f = nullptr;
+        if (const char *path = getenv("CNIIC_KM_LAUNCH_TRACE")) f = fopen(path, "w");  // one line per launch: number, duration, class, what the iteration before it moved
+        if (f) fprintf(f, "launch,us,class,centroids_moved_before,points_moved\n");
+        for (size_t i = 0; i < lt.used / 2; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, lt.ev[2 * i], lt.ev[2 * i + 1]);
+            const bool prev_in_ring = i >= 1 && i - 1 < hf.iter && hf.iter - (i - 1) <= kHistRing;
+            const long long nmv = prev_in_ring ? (long long)hf.nmoved_ring[(i - 1) % kHistRing] : -1;
+            const bool in_ring = i < hf.iter && hf.iter - i <= kHistRing;
+            int cls = i >= working ? 4 : i == 0 ? 0 : (s->fused && i == (size_t)hf.iter) ? 3 : (nmv >= 0 && nmv <= (long long)kMaxMovedSkip && !s->no_skip) ? 2 : 1;
+            cms[cls] += ms; cn[cls]++;
+            if (f) fprintf(f, "%zu,%.2f,%s,%lld,%lld\n", i, ms * 1e3, names[cls], nmv, in_ring ? (long long)hf.changed_ring[i % kHistRing] : -1ll);
+        }
+        if (f) fclose(f);
+        for (int k = 0; k < 5; k++) {
+            KernelTime &kc = c->ktimes[std::string("kmeans_rgbw_assign_") + names[k]];
+            kc.ms += cms[k]; kc.launches += cn[k];
         }
     }
 #ifdef CNIIC_RGBW_PHASES

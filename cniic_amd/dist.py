@@ -56,10 +56,10 @@ class HipBackend:
         self.ctx._check(self.L.cniic_occupancy_pack(self.ctx.h, C.c_void_p(table.data_ptr()), C.c_void_p(occ.data_ptr())))
         return occ
 
-    def cc_create_local(self, table, occ, K, partials, max_iters=0, seed=0):
+    def cc_create_local(self, table, occ, K, partials, max_iters=0, seed=0, flags=0):
         """K-means state over this rank's colours (table: its counts, overwritten), placed in the list of all occupied colours"""
         h = C.c_void_p()
-        o = _lib.KmOpts(seed, max_iters, 0, 0)
+        o = _lib.KmOpts(seed, max_iters, flags, 0)
         self.ctx._check(self.L.cniic_cc_create_local(self.ctx.h, C.c_void_p(table.data_ptr()), C.c_void_p(occ.data_ptr()), C.c_uint32(K),
                                                      C.byref(o), C.c_void_p(partials.data_ptr()), C.byref(h)))
         return h
@@ -78,8 +78,8 @@ class HipBackend:
         self.ctx._check(self.L.cniic_cc_image_occupancy(h, C.c_void_p(occ.data_ptr())))
         return occ
 
-    def image_create(self, h, occ, K, partials, max_iters=0, seed=0):
-        o = _lib.KmOpts(seed, max_iters, 0, 0)
+    def image_create(self, h, occ, K, partials, max_iters=0, seed=0, flags=0):
+        o = _lib.KmOpts(seed, max_iters, flags, 0)
         self.ctx._check(self.L.cniic_cc_image_create(h, C.c_void_p(occ.data_ptr()), C.c_uint32(K), C.byref(o), C.c_void_p(partials.data_ptr())))
 
     def assign(self, h):
@@ -119,6 +119,14 @@ class HipBackend:
         self.ctx._check(self.L.cniic_cc_finish(h, C.c_void_p(img.data_ptr()), C.c_uint32(w), C.c_uint32(hh), lt,
                                                C.c_void_p(out.data_ptr()), C.c_uint64(cap), C.byref(ln), C.byref(st)))
         return ln.value, st.as_dict()
+
+    def finish_frames(self, h, frames, w, hh, F, out, stride):
+        """F streams, frame f's at out[f * stride:], lengths as a list"""
+        lens = (C.c_uint64 * F)()
+        st = _lib.KmStats()
+        self.ctx._check(self.L.cniic_cc_finish_frames(h, C.c_void_p(frames.data_ptr()), C.c_uint32(w), C.c_uint32(hh), C.c_uint32(F),
+                                                      C.c_void_p(out.data_ptr()), C.c_uint64(stride), lens, C.byref(st)))
+        return list(lens), st.as_dict()
 
     def destroy(self, h):
         self.L.cniic_cc_destroy(h)
@@ -219,6 +227,7 @@ class ShardedClusterColors:
         self.poll_every = poll_every
         self.dist = dist
         self.max_iters = max_iters
+        self.flags = 0   # cniic_kmeans_opts.flags of the sessions (bench.py: KM_PROFILE for the per-launch timers)
         self.be = backend if backend is not None else HipBackend(ctx, device)
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
@@ -243,27 +252,45 @@ class ShardedClusterColors:
         elif self.dist is not None and self.world > 1:
             self.dist.all_reduce(t)  # SUM
 
+    def encode_frames(self, frames, w, h, F, out, stride):
+        """north_star config 4: this rank's F frames (one contiguous [F][h][w][3] buffer) and every other rank's are clustered
+        into ONE palette; frame f's stream lands at out[f * stride:].  -> (list of F lengths, K-means stats)"""
+        handle, partials = self._cluster(frames, w * h * F)
+        try:
+            return self.be.finish_frames(handle, frames, w, h, F, out, stride)
+        finally:
+            self.be.destroy(handle)
+
     def encode(self, img, w, h, out):
+        handle, partials = self._cluster(img, w * h)
+        try:
+            return self.be.finish(handle, img, w, h, None, out)   # its own colours, labels and cluster weights: nothing to exchange
+        finally:
+            self.be.destroy(handle)
+
+    def _cluster(self, img, npx):
+        """the shared K-means over this rank's npx pixels and everybody else's: -> (session handle, partials buffer)"""
         be = self.be
         partials = be.new_partials(self.K)
-        handle = be.image_begin(img, w * h) if hasattr(be, "image_begin") else None
+        handle = be.image_begin(img, npx) if hasattr(be, "image_begin") else None
         if handle is not None:                      # large image: utils::count_freqs through the pixel partition (k_points.hip)
             try:
                 occ = be.image_occupancy(handle)
                 self._all_reduce(occ)               # which colours occur on any rank (nibble sums, <= 15 ranks)
-                be.image_create(handle, occ, self.K, partials, self.max_iters)
+                be.image_create(handle, occ, self.K, partials, self.max_iters, 0, self.flags) if self.flags else be.image_create(handle, occ, self.K, partials, self.max_iters)
             except Exception:
                 be.destroy(handle)
                 raise
         else:
-            local = be.hist_dense(img, w * h)       # utils::count_freqs of this rank's pixels, dense table
+            local = be.hist_dense(img, npx)         # utils::count_freqs of this rank's pixels, dense table
             occ = be.occupancy(local)
             self._all_reduce(occ)
-            handle = be.cc_create_local(local, occ, self.K, partials, self.max_iters)
+            handle = be.cc_create_local(local, occ, self.K, partials, self.max_iters, 0, self.flags) if self.flags else be.cc_create_local(local, occ, self.K, partials, self.max_iters)
         try:
-            if self.comm is not None:               # one C call: assign -> ncclAllReduce -> update per iteration, in-stream
-                be.run(handle, self.comm)
-            while self.comm is None:                # kmeans.rs:26-32 `while changed_assignment`
+            in_library = self.comm is not None or (self.world == 1 and hasattr(be, "run"))
+            if in_library:                          # one C call: assign -> ncclAllReduce -> update per iteration, in-stream
+                be.run(handle, self.comm)           # (one rank and no communicator: the plain loop, nothing to reduce)
+            while not in_library:                   # kmeans.rs:26-32 `while changed_assignment`
                 for _ in range(self.poll_every):    # no host round trip inside a batch; iterations issued after
                     be.assign(handle)               # convergence are no-ops on every rank (device-side flag)
                     self._all_reduce(partials)      # K partial centroid sums (+ moved count), identical on all ranks
@@ -277,6 +304,7 @@ class ShardedClusterColors:
                     it, done = be.poll(handle)
                 if done:
                     break
-            return be.finish(handle, img, w, h, None, out)   # its own colours, labels and cluster weights: nothing to exchange
-        finally:
+            return handle, partials
+        except Exception:
             be.destroy(handle)
+            raise

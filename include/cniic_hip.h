@@ -193,6 +193,14 @@ int32_t  cniic_cc_import_labels(cniic_cc *cc, const void *src_dev);
 int32_t  cniic_cc_finish(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h,
                          const uint32_t *local_table_dev /* this image's own counts, or NULL = single image */,
                          uint8_t *out, uint64_t cap, uint64_t *len, cniic_kmeans_stats *stats);
+/* A BATCH of equally sized frames, contiguous in memory, coded with the session's one palette (north_star: "pixels of an image
+ * batch shard across the GPUs ... all-reduce of the K partial centroid sums"; the harness's many-images loop, bench.rs:24-35,
+ * with a shared palette -- an extension, the reference has one palette per image).  Open the session on ALL the pixels
+ * (cniic_cc_image_begin(frames, F * w * h), or the dense-table calls), run the loop, then this instead of cniic_cc_finish:
+ * frame f's Hufman stream (clusterc.rs:31-52 applied to frame f: dims, its own tree, its payload) is written at
+ * out + f * stride (stride: a multiple of 4, at least the longest stream rounded up to 4) and its length to lens[f]. */
+int32_t  cniic_cc_finish_frames(cniic_cc *cc, const uint8_t *rgb, uint32_t w, uint32_t h, uint32_t frames,
+                                uint8_t *out, uint64_t stride, uint64_t *lens, cniic_kmeans_stats *stats);
 void     cniic_cc_destroy(cniic_cc *cc);
 
 /* The same shared palette with every rank holding ONLY ITS OWN image's colours (per-rank work and memory do not

@@ -106,6 +106,14 @@ class OracleBackend:
         out[:len(data)] = self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8)
         return len(data), dict(iterations=st["it"])
 
+    def finish_frames(self, st, frames, w, h, F, out, stride):
+        frames = np.asarray(frames).reshape(F, h, w, 3)
+        lens = []
+        for f in range(F):
+            n, _ = self.finish(st, frames[f], w, h, None, out[f * stride:])
+            lens.append(n)
+        return lens, dict(iterations=st["it"])
+
     def destroy(self, st):
         pass
 
@@ -126,6 +134,82 @@ def expected_streams(imgs, K):
         rc, data, _ = O.encode("hufman", reduced)
         outs.append(data)
     return outs, r["stats"]["iterations"]
+
+
+def make_frames(rank, F, h, w):
+    """this rank's F frames, one contiguous [F][h][w][3] array (frame f of the batch uses seed + f)"""
+    from cniic_amd import synth
+    return np.stack([synth.photo(w, h, synth.SEED0 + 4 + rank * F + f) for f in range(F)])
+
+
+def _frames_worker(rank, world, port, K, use_hip, q, F, h, w, env=None):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cniic_amd.dist import ShardedClusterColors
+        frames = make_frames(rank, F, h, w)
+        stride = (w * h * 16 + 4096 + 3) & ~3
+        if use_hip:
+            import cniic_amd
+            dev = torch.device("cuda", 0)
+            torch.cuda.set_device(0)
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+            ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+            enc = ShardedClusterColors(ctx, K, dist, dev, collectives=(env or {}).get("TEST_COLLECTIVES"))
+            tf = torch.from_numpy(frames).to(dev)
+            out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
+        else:
+            enc = ShardedClusterColors(None, K, dist, None, backend=OracleBackend())
+            tf = frames
+            out = torch.zeros(stride * F, dtype=torch.uint8)
+        lens, st = enc.encode_frames(tf, w, h, F, out, stride)
+        host = out.cpu().numpy()
+        q.put((rank, [bytes(host[f * stride:f * stride + lens[f]].tobytes()) for f in range(F)], int(st["iterations"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_frames(world, K, use_hip, F, h, w, env=None):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, K, use_hip, q, F, h, w, env), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(world):
+            r, data, it = q.get(timeout=180)
+            res[r] = (data, it)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:       # a rank that died leaves its peers in a collective: end them instead of waiting for gloo's timeout
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res
+
+
+def _check_frames(res, world, K, F, h, w):
+    allframes = [fr for r in range(world) for fr in make_frames(r, F, h, w)]
+    exp, iters = expected_streams(allframes, K)
+    for r in range(world):
+        assert res[r][1] == iters
+        for f in range(F):
+            assert res[r][0][f] == exp[r * F + f], "rank %d frame %d: stream differs from the union clustering" % (r, f)
+
+
+def test_frame_batch_gloo_world2_three_frames_per_rank():
+    """north_star config 4 in small: two ranks x three frames, ONE palette over all six (the oracle clusters the union of
+    their pixels in one process), six Hufman streams; frame size 45 x 31: no power of two, a label run that is not 16-byte aligned"""
+    K, F, h, w = 8, 3, 31, 45
+    _check_frames(_run_frames(2, K, False, F, h, w), 2, K, F, h, w)
 
 
 def _free_port():
@@ -172,16 +256,22 @@ def _run(world, K, use_hip, env=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, K, use_hip, q, env)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, use_hip, q, env), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(world):
-        r, data, it = q.get(timeout=120)
-        res[r] = (data, it)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        for _ in range(world):
+            r, data, it = q.get(timeout=120)
+            res[r] = (data, it)
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:       # a rank that died leaves its peers in a collective: end them instead of waiting for gloo's timeout
+            if p.is_alive():
+                p.terminate()
+                p.join(10)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return res
 
 
@@ -308,3 +398,74 @@ def test_native_loop_world4_over_a_host_transport():
     for r in range(4):
         assert res[r][0] == exp[r], "rank %d stream differs" % r
         assert res[r][1] == iters
+
+
+# ------------------------------------------------------------------ config 4: a batch of frames, one palette
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["dense", "partition"])
+@pytest.mark.parametrize("F,h,w", [(4, 48, 64), (3, 29, 37)])
+def test_frame_batch_hip_one_rank_equals_union_clustering(monkeypatch, route, F, h, w):
+    """one rank, F frames: cniic_cc_finish_frames gives, per frame, the stream of the oracle's union clustering
+    (label runs aligned to 16 bytes and not; dense-table and pixel-partition routes)"""
+    import torch
+    import cniic_amd
+    from cniic_amd.dist import ShardedClusterColors
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "0" if route == "partition" else str(1 << 40))
+    K = 16
+    frames = make_frames(0, F, h, w)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    stride = (w * h * 4 + 4096 + 3) & ~3
+    out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
+    lens, st = ShardedClusterColors(ctx, K, None, dev).encode_frames(torch.from_numpy(frames).to(dev), w, h, F, out, stride)
+    exp, iters = expected_streams(list(frames), K)
+    host = out.cpu().numpy()
+    assert st["iterations"] == iters
+    for f in range(F):
+        assert bytes(host[f * stride:f * stride + lens[f]].tobytes()) == exp[f], "frame %d" % f
+        rc, back = ctx.decode("cluster-colors(%d)" % K, exp[f])
+        assert rc == 0 and back.shape == (h, w, 3)
+    # a host output buffer takes the staging route
+    import ctypes as C
+    from cniic_amd import _lib
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_frame_batch_hip_world2_over_a_host_transport():
+    """two ranks x three frames through the library's own loop (host-transport communicator, both ranks on the test box's GPU)"""
+    K, F, h, w = 8, 3, 31, 45
+    _check_frames(_run_frames(2, K, True, F, h, w, env={"TEST_COLLECTIVES": "host", "CNIIC_SP_MIN_PIXELS": "0"}), 2, K, F, h, w)
+
+
+@pytest.mark.gpu
+def test_two_image_sessions_open_on_one_context(monkeypatch):
+    """two cniic_cc_image_begin sessions opened on ONE context before either K-means state is created (and a plain encode in
+    between): each keeps its own colour count (it used to be read from a slot of the context that the later calls overwrite)"""
+    import torch
+    import cniic_amd
+    from cniic_amd.dist import HipBackend
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    be = HipBackend(ctx, dev)
+    K = 16
+    imgs = [make_img(7, 40, 56), make_img(8, 96, 160)]          # different numbers of distinct colours
+    exp = [ctx.encode("cluster-colors(%d)" % K, im)[1] for im in imgs]
+    t = [torch.from_numpy(im).to(dev) for im in imgs]
+    hs = [be.image_begin(t[i], imgs[i].shape[0] * imgs[i].shape[1]) for i in range(2)]
+    ctx.encode("cluster-colors(4)", make_img(9, 64, 64))        # one more count through the context in between
+    got = []
+    for i in (0, 1):
+        occ = be.image_occupancy(hs[i])
+        part = be.new_partials(K)
+        be.image_create(hs[i], occ, K, part)
+        be.run(hs[i], None)
+        out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        n, _ = be.finish(hs[i], t[i], imgs[i].shape[1], imgs[i].shape[0], None, out)
+        got.append(out[:n].cpu().numpy().tobytes())
+        be.destroy(hs[i])
+    assert got == exp
+    ctx.close()
