@@ -1,120 +1,87 @@
 // huff_host.cpp -- see huff_host.hpp.  Reference: src/huf.rs, src/ser.rs, src/bit.rs:256-259.
 #include "huff_host.hpp"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 
 #include "../../include/cniic_hip.h"
 
 namespace cniic {
 
+// huf.rs:58-117 `build`: the two rarest subtrees become the left (first popped) and right (second popped) child of a new
+// branch, until one tree is left.  The reference takes them off a BinaryHeap fed in the iteration order of a std HashMap
+// (huf.rs:30-31, 96), so which of several EQUALLY rare subtrees comes first is random per process there, and nothing
+// depends on it (all such trees cost the same).  One rule is fixed here and in the parity checker (deviation D1):
+//     the rarest first; among equally rare ones a leaf before a branch, leaves by ascending symbol key, branches in the
+//     order they were made.
+// Leaves sorted by (count, key) + branches appended as they are made (their counts never decrease) = the two-queue
+// merge: O(n) after the sort, sequential memory, no heap (the heap was 2.3 of the 3.3 ms of a 4096^2 `delta` encode).
 namespace {
 
-// One heap entry: huf.rs:63-66 `Suffix { freq, tree }` with Ord reversed on freq (huf.rs:80-85),
-// so "greater" means "smaller frequency" and the max-heap pops the rarest subtree first.
-// FreqT = u32 whenever the total fits (every image this library takes: < 2^32 pixels): 8-byte entries, half the
-// memory the sift loops walk; u64 otherwise.
-template <typename FreqT> struct SuffixT {
-    FreqT freq;
-    uint32_t node;
-};
-template <typename S> inline bool le(const S &a, const S &b) { return a.freq >= b.freq; }  // a <= b in reversed order
-template <typename S> inline bool lt(const S &a, const S &b) { return a.freq > b.freq; }
-
-// std::collections::BinaryHeap restated: the exact sift routines decide how equal frequencies are
-// ordered, hence the tree shape.
-template <typename Suffix> class RustMaxHeap {
-  public:
-    explicit RustMaxHeap(std::vector<Suffix> v) : d_(std::move(v)) {  // From<Vec<T>> -> rebuild()
-        for (size_t n = d_.size() / 2; n > 0;) sift_down_range(--n, d_.size());
+// stable LSD radix sort of (count << 32 | leaf) by count, 11 bits a pass, only over the bits some count has
+void sort_leaves(std::vector<uint64_t> &a, uint32_t maxc) {
+    const size_t n = a.size();
+    if (n < 2) return;
+    std::vector<uint64_t> tmp(n);
+    uint64_t *src = a.data(), *dst = tmp.data();
+    for (int sh = 32; sh < 64 && (maxc >> (sh - 32)); sh += 11) {
+        size_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; i++) cnt[((src[i] >> sh) & 2047) + 1]++;
+        for (int i = 0; i < 2048; i++) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 2047]++] = src[i];
+        std::swap(src, dst);
     }
-    size_t size() const { return d_.size(); }
-    void push(Suffix s) {
-        d_.push_back(s);
-        sift_up(0, d_.size() - 1);
-    }
-    Suffix pop() {
-        Suffix item = d_.back();
-        d_.pop_back();
-        if (!d_.empty()) {
-            std::swap(item, d_[0]);
-            sift_down_to_bottom();
-        }
-        return item;
-    }
-
-  private:
-    std::vector<Suffix> d_;
-    void sift_up(size_t start, size_t pos) {
-        Suffix hole = d_[pos];
-        while (pos > start) {
-            size_t parent = (pos - 1) / 2;
-            if (le(hole, d_[parent])) break;
-            d_[pos] = d_[parent];
-            pos = parent;
-        }
-        d_[pos] = hole;
-    }
-    void sift_down_range(size_t pos, size_t end) {
-        Suffix hole = d_[pos];
-        size_t child = 2 * pos + 1;
-        while (end >= 2 && child <= end - 2) {
-            if (le(d_[child], d_[child + 1])) child++;  // the greater of the two children
-            if (!lt(hole, d_[child])) { d_[pos] = hole; return; }  // hole >= child: in order
-            d_[pos] = d_[child];
-            pos = child;
-            child = 2 * pos + 1;
-        }
-        if (end >= 1 && child == end - 1 && lt(hole, d_[child])) {
-            d_[pos] = d_[child];
-            pos = child;
-        }
-        d_[pos] = hole;
-    }
-    void sift_down_to_bottom() {
-        const size_t end = d_.size();
-        size_t pos = 0;
-        Suffix hole = d_[0];
-        size_t child = 1;
-        Suffix *d = d_.data();
-        // every level's address depends on the compare of the level above: the walk is a chain of cache misses once
-        // the array outgrows L1.  The four grandchildren of (child, child + 1) are one contiguous run, and so are
-        // their eight children: both are requested before the compare that picks one of them.
-        while (end >= 2 && child <= end - 2) {
-            __builtin_prefetch(d + 4 * child + 3);
-            __builtin_prefetch(d + 4 * child + 3 + 64 / sizeof(Suffix) - 1);
-            child += le(d[child], d[child + 1]) ? 1 : 0;
-            d[pos] = d[child];
-            pos = child;
-            child = 2 * pos + 1;
-        }
-        if (end >= 1 && child == end - 1) {
-            d[pos] = d[child];
-            pos = child;
-        }
-        d[pos] = hole;
-        sift_up(0, pos);
-    }
-};
+    if (src != a.data()) memcpy(a.data(), src, n * sizeof(uint64_t));
+}
 
 }  // namespace
 
-template <typename FreqT> static void build_tree_with(const uint64_t *counts, uint64_t n, HuffTree &t) {
-    using Suffix = SuffixT<FreqT>;
-    std::vector<Suffix> items(n);
-    for (uint64_t i = 0; i < n; i++) items[i] = Suffix{(FreqT)counts[i], (uint32_t)i};
-    RustMaxHeap<Suffix> heap(std::move(items));
-    uint32_t next = (uint32_t)n;
-    while (heap.size() > 1) {  // huf.rs:100-110
-        Suffix l = heap.pop();
-        Suffix r = heap.pop();
-        t.left[next - n] = l.node;
-        t.right[next - n] = r.node;
-        heap.push(Suffix{(FreqT)(l.freq + r.freq), next});
-        next++;
+// counts below 2^32 (every image this library takes has fewer pixels): leaves packed as count << 32 | leaf
+static void build_tree_u32(const uint64_t *counts, uint64_t n, HuffTree &t) {
+    std::vector<uint64_t> leaf(n);
+    uint32_t maxc = 0;
+    for (uint64_t i = 0; i < n; i++) { leaf[i] = (counts[i] << 32) | i; maxc |= (uint32_t)counts[i]; }
+    sort_leaves(leaf, maxc);  // (count, key): the leaf ids are ascending keys and the sort is stable
+    std::vector<uint64_t> bfreq(n > 1 ? n - 1 : 0);
+    uint64_t li = 0, bi = 0, made = 0;
+    while (made + 1 < n) {
+        uint32_t node[2];
+        uint64_t f[2];
+        for (int k = 0; k < 2; k++) {
+            if (li < n && (bi >= made || (leaf[li] >> 32) <= bfreq[bi])) { f[k] = leaf[li] >> 32; node[k] = (uint32_t)leaf[li]; li++; }
+            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); bi++; }
+        }
+        t.left[made] = node[0];
+        t.right[made] = node[1];
+        bfreq[made] = f[0] + f[1];
+        made++;
     }
-    t.root = heap.pop().node;
+    t.root = n > 1 ? (uint32_t)(n + made - 1) : 0;
+}
+
+// any counts: the same rule through a comparison sort
+static void build_tree_u64(const uint64_t *counts, uint64_t n, HuffTree &t) {
+    std::vector<uint32_t> order(n);
+    for (uint64_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return counts[a] < counts[b]; });
+    std::vector<uint64_t> bfreq(n > 1 ? n - 1 : 0);
+    uint64_t li = 0, bi = 0, made = 0;
+    while (made + 1 < n) {
+        uint32_t node[2];
+        uint64_t f[2];
+        for (int k = 0; k < 2; k++) {
+            if (li < n && (bi >= made || counts[order[li]] <= bfreq[bi])) { f[k] = counts[order[li]]; node[k] = order[li]; li++; }
+            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); bi++; }
+        }
+        t.left[made] = node[0];
+        t.right[made] = node[1];
+        bfreq[made] = f[0] + f[1];
+        made++;
+    }
+    t.root = n > 1 ? (uint32_t)(n + made - 1) : 0;
 }
 
 bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
@@ -125,8 +92,8 @@ bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
     uint64_t total = 0;
     bool small = true;
     for (uint64_t i = 0; i < n && small; i++) { total += counts[i]; small = total < (1ull << 32) && counts[i] < (1ull << 32); }
-    if (small) build_tree_with<uint32_t>(counts, n, t);
-    else build_tree_with<uint64_t>(counts, n, t);
+    if (small) build_tree_u32(counts, n, t);
+    else build_tree_u64(counts, n, t);
     return true;
 }
 

@@ -1,10 +1,8 @@
 /*
  * huf.c -- oracle (test infrastructure only): histogram + Huffman coder of the reference.
  * Restates src/utils.rs:4-16 (count_freqs) and src/huf.rs (build / Enc / Dec / BinTrie /
- * serialisation).  The min-heap is Rust's std::collections::BinaryHeap restated (from_iter =
- * heapify by sift_down from n/2-1; pop = swap-remove + sift_down_to_bottom + sift_up; push =
- * sift_up), with the reversed-frequency ordering of huf.rs:68-85, so that for a given item
- * order the tree shape equals the reference's.  Item order = ascending symbol key (deviation D1).
+ * serialisation).  Item order = ascending symbol key, ties between equally rare subtrees by one fixed
+ * rule (both deviation D1: the reference's own order is a HashMap's, random per process).
  */
 #include "cniic_oracle.h"
 #include <stdlib.h>
@@ -53,81 +51,27 @@ int orc_count_freqs(const uint32_t *syms, uint64_t n, uint32_t *keys, uint64_t *
 }
 
 /* ---------------- huf.rs:58-117 build ---------------- */
-
+/*
+ * The reference pops the two rarest subtrees off a BinaryHeap and pushes their parent (left = first popped,
+ * right = second popped, huf.rs:100-110).  WHICH of several equally rare subtrees comes first is decided by the
+ * heap's array mechanics applied to the iteration order of a std HashMap (huf.rs:30-31, 96) -- random per process:
+ * the reference itself does not produce the same tree twice, and nothing depends on it (every such tree has the
+ * same cost, huf.rs:22-43 serialises whichever it built).  The oracle and the product therefore fix ONE rule
+ * (deviation D1, like the ascending-key item order):
+ *     the rarest subtree first; among equally rare ones a leaf before a branch, leaves by ascending symbol key,
+ *     branches in the order they were made.
+ * With leaves sorted by (count, key) and branches appended as they are made (their counts never decrease), that is the
+ * classic two-queue merge: no heap at all.
+ */
 typedef struct {
     uint64_t freq;
     uint32_t node;
 } suffix_t; /* huf.rs:63-66 */
 
-/* Ord for Suffix is the REVERSE of the frequency order (huf.rs:80-85). */
-static inline int suf_le(const suffix_t *a, const suffix_t *b) { return a->freq >= b->freq; } /* a <= b */
-static inline int suf_ge(const suffix_t *a, const suffix_t *b) { return a->freq <= b->freq; } /* a >= b */
-static inline int suf_lt(const suffix_t *a, const suffix_t *b) { return a->freq > b->freq; }  /* a <  b */
-
-static void heap_sift_down_range(suffix_t *d, size_t pos, size_t end) {
-    suffix_t elt = d[pos];
-    size_t child = 2 * pos + 1;
-    size_t lim = end >= 2 ? end - 2 : 0;
-    while (child <= lim && end >= 2) {
-        child += suf_le(&d[child], &d[child + 1]) ? 1 : 0;
-        if (suf_ge(&elt, &d[child])) { d[pos] = elt; return; }
-        d[pos] = d[child];
-        pos = child;
-        child = 2 * pos + 1;
-    }
-    if (end >= 1 && child == end - 1 && suf_lt(&elt, &d[child])) {
-        d[pos] = d[child];
-        pos = child;
-    }
-    d[pos] = elt;
-}
-
-static size_t heap_sift_up(suffix_t *d, size_t start, size_t pos) {
-    suffix_t elt = d[pos];
-    while (pos > start) {
-        size_t parent = (pos - 1) / 2;
-        if (suf_le(&elt, &d[parent])) break;
-        d[pos] = d[parent];
-        pos = parent;
-    }
-    d[pos] = elt;
-    return pos;
-}
-
-static void heap_sift_down_to_bottom(suffix_t *d, size_t len) {
-    size_t pos = 0, start = 0, end = len;
-    suffix_t elt = d[pos];
-    size_t child = 1;
-    size_t lim = end >= 2 ? end - 2 : 0;
-    while (child <= lim && end >= 2) {
-        child += suf_le(&d[child], &d[child + 1]) ? 1 : 0;
-        d[pos] = d[child];
-        pos = child;
-        child = 2 * pos + 1;
-    }
-    if (end >= 1 && child == end - 1) {
-        d[pos] = d[child];
-        pos = child;
-    }
-    d[pos] = elt;
-    heap_sift_up(d, start, pos);
-}
-
-static suffix_t heap_pop(suffix_t *d, size_t *len) {
-    suffix_t item = d[--(*len)];
-    if (*len > 0) {
-        suffix_t t = d[0];
-        d[0] = item;
-        item = t;
-        heap_sift_down_to_bottom(d, *len);
-    }
-    return item;
-}
-
-static void heap_push(suffix_t *d, size_t *len, suffix_t s) {
-    size_t old = *len;
-    d[(*len)++] = s;
-    heap_sift_up(d, 0, old);
+static int suffix_cmp(const void *pa, const void *pb) {
+    const suffix_t *a = (const suffix_t *)pa, *b = (const suffix_t *)pb;
+    if (a->freq != b->freq) return a->freq < b->freq ? -1 : 1;
+    return a->node < b->node ? -1 : a->node > b->node ? 1 : 0;
 }
 
 /* BinTrie (huf.rs:167-171) as arrays: nodes 0..n-1 are leaves (symbol index = node id),
@@ -143,24 +87,26 @@ static int trie_build(const uint64_t *counts, uint64_t n, trie_t *t) {
     t->nleaf = n;
     t->left = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
     t->right = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-    suffix_t *heap = (suffix_t *)malloc(n * sizeof(suffix_t));
-    if (!t->left || !t->right || !heap) { free(t->left); free(t->right); free(heap); return ORC_ERR_NOMEM; }
-    for (uint64_t i = 0; i < n; i++) { heap[i].freq = counts[i]; heap[i].node = (uint32_t)i; }
-    size_t len = n;
-    /* BinaryHeap::from_iter -> rebuild() */
-    for (size_t k = len / 2; k > 0;) { k--; heap_sift_down_range(heap, k, len); }
-    uint32_t next = (uint32_t)n;
-    while (len > 1) { /* huf.rs:100-110 */
-        suffix_t l = heap_pop(heap, &len);
-        suffix_t r = heap_pop(heap, &len);
-        t->left[next - n] = l.node;
-        t->right[next - n] = r.node;
-        suffix_t s = { l.freq + r.freq, next };
-        next++;
-        heap_push(heap, &len, s);
+    suffix_t *leaf = (suffix_t *)malloc(n * sizeof(suffix_t));
+    uint64_t *bfreq = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!t->left || !t->right || !leaf || !bfreq) { free(t->left); free(t->right); free(leaf); free(bfreq); return ORC_ERR_NOMEM; }
+    for (uint64_t i = 0; i < n; i++) { leaf[i].freq = counts[i]; leaf[i].node = (uint32_t)i; }
+    qsort(leaf, n, sizeof(suffix_t), suffix_cmp); /* (count, key): node ids are ascending keys */
+    uint64_t li = 0, bi = 0, made = 0;
+    while (made + 1 < n) { /* huf.rs:100-110 */
+        suffix_t two[2];
+        for (int k = 0; k < 2; k++) {
+            if (li < n && (bi >= made || leaf[li].freq <= bfreq[bi])) two[k] = leaf[li++];
+            else { two[k].freq = bfreq[bi]; two[k].node = (uint32_t)(n + bi); bi++; }
+        }
+        t->left[made] = two[0].node;
+        t->right[made] = two[1].node;
+        bfreq[made] = two[0].freq + two[1].freq;
+        made++;
     }
-    t->root = heap_pop(heap, &len).node;
-    free(heap);
+    t->root = n > 1 ? (uint32_t)(n + made - 1) : 0;
+    free(leaf);
+    free(bfreq);
     return ORC_OK;
 }
 
