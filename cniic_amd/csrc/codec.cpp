@@ -157,14 +157,19 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
     if (!c->huf_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->huf_ev, hipEventDisableTiming));
     CNIIC_HIP_TRY(c, hipEventRecord(c->huf_ev, c->stream));
-    // While the host builds the tree the GPU turns every symbol into its rank in the compacted list -- the one random
-    // read per symbol into the dense table (it now holds rank + 1), which needs no code -- in place over the symbol
-    // stream when it is ours.  The pack then reads that stream and the small per-rank length / code tables.
+    // `delta` symbols on a buffer of ours: nothing to do while the host builds the tree -- the pack looks (length, code) up
+    // in an LDS table of the cube of small differences (huff_pack_code32_hot).  Otherwise the GPU meanwhile turns every
+    // symbol into its rank in the compacted list -- the one random read per symbol into the dense table (it now holds
+    // rank + 1), which needs no code -- in place over the symbol stream when it is ours; the pack then reads that stream
+    // and the small per-rank length / code tables.
+    const bool hot_route = sym_kind == CNIIC_SYM_SIGNED && syms_d && syms_scratch && U < (1ull << 26) && (reinterpret_cast<uintptr_t>(syms_d) & 15) == 0;
     DevBuf ranks_own;
     uint32_t *ranks = syms_d;
-    if (!syms_d || !syms_scratch) { CNIIC_HIP_TRY(c, ranks_own.alloc(n * 4 + 16)); ranks = ranks_own.as<uint32_t>(); }
     const bool inline_codes = U < (1ull << 26);  // (len, code) of a symbol in one u32 looked up by rank; else per-rank tables
-    CNIIC_TRY(huff_rank_stream(c, syms_d, rgb_d, n, table_d, ranks, !inline_codes));
+    if (!hot_route) {
+        if (!syms_d || !syms_scratch) { CNIIC_HIP_TRY(c, ranks_own.alloc(n * 4 + 16)); ranks = ranks_own.as<uint32_t>(); }
+        CNIIC_TRY(huff_rank_stream(c, syms_d, rgb_d, n, table_d, ranks, !inline_codes));
+    }
     CNIIC_HIP_TRY(c, hipEventSynchronize(c->huf_ev));
     host_trace().mark("huf: hist + compaction + D2H");
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
@@ -188,7 +193,10 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
     uint64_t packed_bits = 0;
     ScopedKernelTimer timer(c, "huff_pack");
-    if (inline_codes) {
+    if (hot_route) {
+        CNIIC_TRY(huff_pack_code32_hot(c, syms_d, n, table_d, keys_d.as<uint32_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, syms_d, so.dev,
+                                       (uint64_t)header.size() * 8, &packed_bits));
+    } else if (inline_codes) {
         DevBuf code32;
         CNIIC_HIP_TRY(c, code32.alloc(U * 4));
         CNIIC_TRY(huff_pack_code32(c, ranks, nullptr, n, code32.as<uint32_t>(), nullptr, len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, ranks,

@@ -517,6 +517,9 @@ int huff_pack_ranks(Ctx *c, const uint32_t *ranks_d, uint64_t n, const uint8_t *
 int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_or_null_d, uint64_t n, uint32_t *table_d,
                      const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint32_t *packed_d,
                      uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
+// the same for SignedColor (`delta`) symbols: the (length, code) words of the cube of small differences sit in LDS
+int huff_pack_code32_hot(Ctx *c, const uint32_t *syms_d, uint64_t n, uint32_t *dense_d, const uint32_t *keys_d, const uint8_t *len_d,
+                         const uint64_t *code_d, uint64_t U, uint32_t *packed_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h);
 // cluster-colors path: pixel -> cluster label through a dense colour->label table, codes per cluster
 int pixel_labels(Ctx *c, const uint8_t *rgb_d, uint64_t n, const void *key2label_d, bool wide, void *pixlab_d);
 int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32_t K, const uint8_t *clen_d,

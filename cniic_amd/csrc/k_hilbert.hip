@@ -292,6 +292,96 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
     }
 }
 
+// The same on 2^n squares of side >= 8, one scan position per LANE: the 64 positions of an aligned group share every
+// level of the curve but the last three, so the wave walks the shared levels once (the same table entries in every lane)
+// and a lane finishes with ONE look-up of its own -- its 6 low bits in the state the group ends in -- instead of five
+// dependent ones per pixel; a wave owns a contiguous run of groups, the predecessor of a group's first pixel is the
+// previous group's last one (carried in a register), and the symbol store of a group is one coalesced 256-byte row.
+template <bool HIST>
+__global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta_p2(const uint8_t *__restrict__ rgb, uint32_t order, const HilbertLut *__restrict__ lut,
+                                                                    uint32_t *__restrict__ syms, uint32_t *__restrict__ table) {
+    extern __shared__ uint32_t s_bins[];  // HIST: u32[kHotBins]
+    __shared__ uint16_t s_l4[1024];
+    __shared__ uint8_t s_l1[16];
+    __shared__ uint8_t s_l3[4 * 64];  // three levels from state s for the 6 low bits q: x:3 | y:3 << 3
+    if (HIST)
+        for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) s_bins[i] = 0;
+    const uint32_t w = 1u << order;
+    const Scan sc = load_scan(w, w, order, lut, s_l4, s_l1);
+    if (threadIdx.x < 256) {
+        uint32_t st = threadIdx.x >> 6, x = 0, y = 0;
+        for (int lv = 2; lv >= 0; lv--) {
+            const uint32_t e = s_l1[st * 4 + ((threadIdx.x >> (2 * lv)) & 3)];
+            x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2;
+        }
+        s_l3[threadIdx.x] = (uint8_t)(x | (y << 3));
+    }
+    __syncthreads();
+    const uint64_t n = (uint64_t)w * w;
+    const uint32_t ngroups = (uint32_t)(n >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t nwaves = gridDim.x * (kDeltaThreads / 64), gw = blockIdx.x * (kDeltaThreads / 64) + (threadIdx.x >> 6);
+    const uint32_t per = (ngroups + nwaves - 1) / nwaves;
+    const uint32_t g0 = gw * per, g1 = g0 + per < ngroups ? g0 + per : ngroups;
+    uint32_t carried = 0;  // START = (0, 0, 0) hilbertc.rs:445
+    if (g0 < g1 && g0 > 0) {
+        uint32_t x, y;
+        sc.xy((uint64_t)g0 * 64 - 1, x, y);
+        carried = px_le24(rgb, (uint64_t)y * w + x, n);
+    }
+    const uint32_t top = order - 3;  // levels the 64 positions of a group share
+    constexpr int kBatch = 4;        // groups whose pixel loads are in flight together (one block per CU: the waves must hide the latency themselves)
+    for (uint32_t gb = g0; gb < g1; gb += kBatch) {
+        uint32_t px[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            const uint32_t g = gb + j;
+            px[j] = 0;
+            if (g < g1) {
+                uint32_t st = 0, x = 0, y = 0, rem = top;
+                while (rem >= 4) {
+                    const uint32_t e = s_l4[st * 256 + ((g >> (2 * (rem - 4))) & 255)];
+                    x = (x << 4) | (e & 15); y = (y << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4;
+                }
+                while (rem >= 1) {
+                    const uint32_t e = s_l1[st * 4 + ((g >> (2 * (rem - 1))) & 3)];
+                    x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
+                }
+                const uint32_t e3 = s_l3[st * 64 + lane];
+                const uint32_t X = (x << 3) | (e3 & 7), Y = (y << 3) | (e3 >> 3);
+                px[j] = px_le24(rgb, (uint64_t)Y * w + X, n);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            const uint32_t g = gb + j;
+            if (g >= g1) break;
+            uint32_t prev = __shfl_up(px[j], 1, 64);
+            if (lane == 0) prev = carried;
+            carried = __shfl(px[j], 63, 64);
+            const int32_t dr = (int32_t)(px[j] & 255) - (int32_t)(prev & 255), dg = (int32_t)((px[j] >> 8) & 255) - (int32_t)((prev >> 8) & 255),
+                          db = (int32_t)((px[j] >> 16) & 255) - (int32_t)((prev >> 16) & 255);
+            const uint32_t key = ((uint32_t)(dr + 255) << 18) | ((uint32_t)(dg + 255) << 9) | (uint32_t)(db + 255);
+            if (HIST) {
+                const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
+                if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
+                else atomicAdd(&table[key], 1u);
+            }
+            if (syms) syms[(uint64_t)g * 64 + lane] = key;
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) {
+            const uint32_t cnt = s_bins[i];
+            if (cnt) {
+                const uint32_t dr = (i >> 10) + 255 - 16, dg = ((i >> 5) & 31) + 255 - 16, db = (i & 31) + 255 - 16;
+                atomicAdd(&table[(dr << 18) | (dg << 9) | db], cnt);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host
 static inline uint32_t hgrid(uint64_t items) {
     return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(items, 256), 1), 256 * 16);
@@ -378,7 +468,24 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
                                   (int)(kHotBins * 4));
     });
     ScopedKernelTimer timer(c, "hilbert_delta");
-    if (table_d)
+    const uint32_t order = pow2_order(w, h);
+    // Measured at 16384^2: without the histogram the lane-per-position kernel takes 0.75 ms against 0.89 ms; with it 1.30 against
+    // 1.14 ms (one block per CU for the 128 KiB of bins either way), so the fused encode keeps the 4-positions-per-thread kernel.
+    // CNIIC_HILBERT_LANE_SCAN=1 / 0 forces one or the other (tests run both).
+    const char *ls = getenv("CNIIC_HILBERT_LANE_SCAN");
+    const bool lane_scan = ls ? atoi(ls) != 0 : table_d == nullptr;
+    if (order >= 3 && lane_scan) {  // 2^n squares from 8 x 8: one position per lane, the shared levels walked once per group of 64
+        static std::once_flag attr2;
+        std::call_once(attr2, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_delta_p2<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHotBins * 4));
+        });
+        const uint32_t ngroups = (uint32_t)(n >> 6);
+        const uint32_t g2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(ngroups, kDeltaThreads / 64), 1), table_d ? 256 : 1024);
+        if (table_d)
+            hipLaunchKernelGGL(k_hilbert_delta_p2<true>, dim3(g2), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, order, lut, syms_d, table_d);
+        else
+            hipLaunchKernelGGL(k_hilbert_delta_p2<false>, dim3(g2), dim3(kDeltaThreads), 0, c->stream, rgb_d, order, lut, syms_d, table_d);
+    } else if (table_d)
         hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, pow2_order(w, h), lut,
                            syms_d, table_d);
     else

@@ -10,6 +10,8 @@
 //      the (at most two) words shared with neighbouring chunks go out with global atomicOr.
 // Symbols reach their code through the rank table left behind by the histogram compaction
 // (key -> rank+1), then len[rank] / code[rank].
+#include <mutex>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -599,6 +601,109 @@ int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_
         hipLaunchKernelGGL(k_pack_count32<SRC_RGB>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, rgb_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_pack_count32<SRC_KEYS>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, syms_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
+    CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
+    hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
+                       reinterpret_cast<uint32_t *>(out_d), bit_base);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *nbits_h = total;
+    return CNIIC_OK;
+}
+
+// ---- `delta` symbols (SignedColor keys, 27 bits): almost every symbol lies in the cube [-16, 15]^3 of small differences
+// (the cube k_hilbert_delta counts in LDS).  Its 32768 (length, code) words fit the LDS of one persistent block per CU,
+// so the per-symbol look-up -- one L2 request per lane and 1.2 ms at 16384^2 when it goes to memory, after 1.7 ms for
+// turning symbols into ranks first -- is an LDS read; only the rare outlier reads the dense table.
+constexpr uint32_t kHotCodes = 32 * 32 * 32;
+constexpr int kHotThreads = 1024;
+__device__ __forceinline__ uint32_t hot_index(uint32_t key) {  // < kHotCodes inside the cube, >= kHotCodes outside
+    const uint32_t hr = (key >> 18) - (255 - 16), hg = ((key >> 9) & 511) - (255 - 16), hb = (key & 511) - (255 - 16);
+    return (hr | hg | hb) < 32u ? (hr << 10) | (hg << 5) | hb : 0xffffffffu;
+}
+
+// dense[key] and, inside the cube, hot[index]: len << 26 | code (codes longer than 26 bits: escape to the per-rank tables)
+__global__ void k_fill_code32_hot(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ len, const uint64_t *__restrict__ code, uint64_t U,
+                                  uint32_t *__restrict__ dense, uint32_t *__restrict__ hot) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride) {
+        const uint32_t v = len[i] <= 26 ? ((uint32_t)len[i] << 26) | (uint32_t)code[i] : (kEscape << 26) | (uint32_t)i;
+        const uint32_t k = keys[i];
+        dense[k] = v;
+        const uint32_t hx = hot_index(k);
+        if (hx < kHotCodes) hot[hx] = v;
+    }
+}
+
+__global__ __launch_bounds__(kHotThreads) void k_pack_count_hot(const uint32_t *__restrict__ syms, uint64_t n, const uint32_t *__restrict__ hot,
+                                                                const uint32_t *__restrict__ dense, const uint8_t *__restrict__ len,
+                                                                uint32_t *__restrict__ packed, uint32_t *__restrict__ chunk_bits, uint32_t nchunks) {
+    extern __shared__ uint32_t s_hot[];  // [kHotCodes]
+    __shared__ uint32_t s_part[kHotThreads / 64];
+    for (uint32_t i = threadIdx.x; i < kHotCodes / 4; i += kHotThreads)
+        reinterpret_cast<uint4 *>(s_hot)[i] = reinterpret_cast<const uint4 *>(hot)[i];
+    __syncthreads();
+    constexpr int PER = kPackChunk / kHotThreads;  // 4 symbols per thread
+    static_assert(PER == 4, "one 16-byte load per thread");
+    for (uint32_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const uint64_t first = (uint64_t)ch * kPackChunk + (uint64_t)threadIdx.x * PER;
+        uint32_t key[PER];
+        const bool full = first + PER <= n;
+        if (full) { const uint4 q = *reinterpret_cast<const uint4 *>(syms + first); key[0] = q.x; key[1] = q.y; key[2] = q.z; key[3] = q.w; }
+        else
+            for (int i = 0; i < PER; i++) key[i] = first + i < n ? syms[first + i] : 0xffffffffu;
+        uint32_t v[PER], bits = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            v[i] = 0u;
+            if (full || first + i < n) {
+                const uint32_t hx = hot_index(key[i]);
+                v[i] = hx < kHotCodes ? s_hot[hx] : dense[key[i]];
+            }
+            const uint32_t L = v[i] >> 26;
+            bits += L == kEscape ? (uint32_t)len[v[i] & 0x3ffffffu] : L;
+        }
+        if (full) *reinterpret_cast<uint4 *>(packed + first) = make_uint4(v[0], v[1], v[2], v[3]);
+        else
+            for (int i = 0; i < PER; i++)
+                if (first + i < n) packed[first + i] = v[i];
+        bits = wave_reduce_sum(bits);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = bits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int i = 0; i < kHotThreads / 64; i++) t += s_part[i];
+            chunk_bits[ch] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// huff_pack_code32 for SignedColor symbols: dense_d = the 2^27-entry table (overwritten at the U keys), packed_d may alias syms_d
+int huff_pack_code32_hot(Ctx *c, const uint32_t *syms_d, uint64_t n, uint32_t *dense_d, const uint32_t *keys_d, const uint8_t *len_d,
+                         const uint64_t *code_d, uint64_t U, uint32_t *packed_d, uint8_t *out_d, uint64_t bit_base, uint64_t *nbits_h) {
+    *nbits_h = 0;
+    if (n == 0) return CNIIC_OK;
+    if ((reinterpret_cast<uintptr_t>(out_d) & 3) || (reinterpret_cast<uintptr_t>(syms_d) & 15) || (reinterpret_cast<uintptr_t>(packed_d) & 15))
+        return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: misaligned buffers");
+    const uint64_t nchunks64 = ceil_div(n, kPackChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: too many symbols");
+    const uint32_t nchunks = (uint32_t)nchunks64;
+    DevBuf cb, co, tot, hot;
+    CNIIC_HIP_TRY(c, cb.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, co.alloc((uint64_t)nchunks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    CNIIC_HIP_TRY(c, hot.alloc((uint64_t)kHotCodes * 4));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(hot.p, 0, (uint64_t)kHotCodes * 4, c->stream));
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pack_count_hot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHotCodes * 4));
+    });
+    hipLaunchKernelGGL(k_fill_code32_hot, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
+                       dense_d, hot.as<uint32_t>());
+    hipLaunchKernelGGL(k_pack_count_hot, dim3(std::min<uint32_t>(nchunks, 256)), dim3(kHotThreads), kHotCodes * 4, c->stream, syms_d, n,
+                       (const uint32_t *)hot.as<uint32_t>(), (const uint32_t *)dense_d, len_d, packed_d, cb.as<uint32_t>(), nchunks);
     CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
                        reinterpret_cast<uint32_t *>(out_d), bit_base);

@@ -248,6 +248,20 @@ def test_hilbert_linearize_and_delta(ctx, shape):
     assert np.array_equal(keys, ek) and np.array_equal(counts, ec) and np.array_equal(syms2, esyms)
 
 
+@pytest.mark.parametrize("lane_scan", ["0", "1"])
+@pytest.mark.parametrize("size", [8, 32, 256])
+def test_hilbert_delta_both_kernels_on_pow2_squares(ctx, monkeypatch, lane_scan, size):
+    """2^n squares: the one-position-per-lane kernel and the four-positions-per-thread kernel, with and without the
+    fused histogram, give the oracle's symbols and counts"""
+    monkeypatch.setenv("CNIIC_HILBERT_LANE_SCAN", lane_scan)
+    img = synth_img(size, size, seed=size)
+    esyms = O.delta_diff(O.hilbert_linearize(img))
+    assert np.array_equal(ctx.hilbert_delta(img), esyms)
+    keys, counts, syms2 = ctx.hilbert_delta_hist(img, want_syms=True)
+    ek, ec = O.count_freqs(esyms)
+    assert np.array_equal(keys, ek) and np.array_equal(counts, ec) and np.array_equal(syms2, esyms)
+
+
 # ------------------------------------------------------------------ huf::encode_all
 @pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 50000])
 def test_huf_encode_all_rgb(ctx, n):
