@@ -2,7 +2,9 @@
 //   cniic_bench --codec=<expr> <image>...
 // per image: encode -> size -> ratio vs w*h*24 -> decode -> MSE -> CSV row
 //   name,compressed_size,compression_ratio,error            (bench.rs:68-75)
-// written to output/<codec.name()>.csv (bench.rs:85-91) and echoed to stdout.  A lossless codec whose
+// written to output/<codec.name()>.csv (bench.rs:85-91) and echoed to stdout with four more columns:
+//   mpix_per_s, iters (K-means iterations), hbm_gbps (algorithmic bytes of the encode, SURVEY 8(d), over its wall time),
+//   roofline_frac (that over the 8 TB/s of HBM3E).  A lossless codec whose
 // decode differs is an error (bench.rs:50-59).  Images are binary PPM (P6) files or synthetic specs
 // "synth:P:4096x4096:2" / "synth:U:512x512:1" (kind, size, seed offset).
 // The raw size is computed in 64 bits (the reference's u32 h*w*24 wraps above 13377^2 pixels).
@@ -92,6 +94,8 @@ int main(int argc, char **argv) {
                 if (cniic_dev_alloc(ctx, npx * 3, &dimg) != CNIIC_OK) { fail("device allocation"); continue; }
                 if (im.synth) cniic_synth_image(ctx, im.kind, im.seed, im.w, im.h, (uint8_t *)dimg);
                 else cniic_memcpy(ctx, dimg, im.rgb.data(), npx * 3);
+                uint64_t distinct = 0;  // (outside the timed encode: the algorithmic bytes of cluster-colors depend on it)
+                if (strncmp(name, "cluster-colors", 14) == 0) cniic_hist_rgb24(ctx, (const uint8_t *)dimg, npx, nullptr, nullptr, 0, &distinct);
                 std::vector<uint8_t> data(64 + npx * 16 + (1 << 16));
                 uint64_t len = 0;
                 cniic_kmeans_stats st{};
@@ -112,9 +116,20 @@ int main(int argc, char **argv) {
                 cniic_dev_free(ctx, dback);
                 std::lock_guard<std::mutex> lk(mu);
                 if (mse != 0.0 && lossless) { fprintf(stderr, "%s: Decoded image doesn't match\n", p.c_str()); failures++; continue; }
-                if (!wrote_header) { fprintf(csv, "name,compressed_size,compression_ratio,error\n"); printf("name,compressed_size,compression_ratio,error,mpix_per_s,iters\n"); wrote_header = true; }
+                // algorithmic bytes of the encode: hufman 3 B/px histogram + 3 B/px pack; delta 3 B/px gather + 4 B/px symbols
+                // written + 4 read; hilbert-rle 3 + 3 B/px; voronoi 7 B/px/iteration; cluster-colors 3 B/px histogram + 10 B/colour/iteration
+                // + 4 B/px remap; every codec + the stream it writes
+                double algo = (double)len;
+                if (!strcmp(name, "Hufman")) algo += 6.0 * npx;
+                else if (!strcmp(name, "delta")) algo += 11.0 * npx;
+                else if (!strcmp(name, "hilbert-rle")) algo += 6.0 * npx;
+                else if (!strncmp(name, "voronoi", 7)) algo += 7.0 * npx * (double)st.iterations;
+                else algo += 7.0 * npx + 10.0 * (double)distinct * (double)st.iterations;
+                const double gbps = algo / (enc_ms * 1e-3) / 1e9;
+                if (!wrote_header) { fprintf(csv, "name,compressed_size,compression_ratio,error\n"); printf("name,compressed_size,compression_ratio,error,mpix_per_s,iters,hbm_gbps,roofline_frac\n"); wrote_header = true; }
                 fprintf(csv, "%s,%llu,%.17g,%.17g\n", p.c_str(), (unsigned long long)len, ratio * 100.0, mse);
-                printf("%s,%llu,%.6f,%.4f,%.1f,%llu\n", p.c_str(), (unsigned long long)len, ratio * 100.0, mse, npx / enc_ms / 1e3, (unsigned long long)st.iterations);
+                printf("%s,%llu,%.6f,%.4f,%.1f,%llu,%.1f,%.4f\n", p.c_str(), (unsigned long long)len, ratio * 100.0, mse, npx / enc_ms / 1e3, (unsigned long long)st.iterations,
+                       gbps, gbps / 8000.0);
             }
             cniic_ctx_destroy(ctx);
         });
