@@ -22,6 +22,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;  // optional
 };
 
 const Rccl &rccl() {
@@ -39,6 +41,8 @@ const Rccl &rccl() {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
     });
     return r;
@@ -54,6 +58,7 @@ struct Comm {
     int32_t (*host_sum)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes) = nullptr;
     void *user = nullptr;
     std::vector<uint8_t> bounce;
+    bool dead = false;  // aborted after a failure on this rank or a peer: every later collective fails at once
 };
 
 int comm_unique_id(uint8_t *id128) {
@@ -94,6 +99,29 @@ void comm_destroy(Comm *cm) {
     delete cm;
 }
 
+// A rank that fails inside a loop of collectives must not simply return: its peers sit in (or are about to enter) an
+// all-reduce that will never complete.  RCCL: abort the communicator -- the peers' collectives then end with an error
+// (they poll comm_async_error while they wait, below) instead of hanging.  Host transport: the caller's callback is told
+// once with (buf = NULL, count = 0, elem_bytes = -1) so that it can tear its own transport down.
+void comm_abort(Comm *cm) {
+    if (!cm || cm->dead) return;
+    cm->dead = true;
+    if (cm->host_sum) { (void)cm->host_sum(cm->user, nullptr, 0, -1); return; }
+    if (cm->comm && rccl().CommAbort) { (void)rccl().CommAbort(cm->comm); cm->comm = nullptr; }
+}
+
+// has the communicator seen a failure (of this rank or, reported by the transport, of a peer)?  CNIIC_OK = healthy
+int comm_async_error(Comm *cm) {
+    if (!cm) return CNIIC_OK;
+    if (cm->dead) return CNIIC_ERR_RCCL;
+    if (cm->comm && rccl().CommGetAsyncError) {
+        ncclResult_t st = ncclSuccess;
+        if (rccl().CommGetAsyncError(cm->comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress)
+            return cm->c->fail(CNIIC_ERR_RCCL, "RCCL reports an asynchronous error: %s", rccl().GetErrorString(st));
+    }
+    return CNIIC_OK;
+}
+
 Ctx *comm_ctx(Comm *cm) { return cm->c; }
 uint32_t comm_size(const Comm *cm) { return cm->nranks; }
 
@@ -102,18 +130,19 @@ int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind) {
     Ctx *c = cm->c;
     const ncclDataType_t dt = kind == 0 ? ncclUint8 : kind == 1 ? ncclUint32 : ncclUint64;
     if (kind < 0 || kind > 2) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce: unknown element kind %d", kind);
+    if (cm->dead) return c->fail(CNIIC_ERR_RCCL, "all_reduce: the communicator was aborted after a failure");
     if (cm->host_sum) {  // through the host: drain the stream, bounce, let the caller's transport sum, put it back
         const int eb = kind == 0 ? 1 : kind == 1 ? 4 : 8;
         cm->bounce.resize((size_t)count * eb);
         CNIIC_HIP_TRY(c, hipMemcpyAsync(cm->bounce.data(), buf_d, cm->bounce.size(), hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (cm->host_sum(cm->user, cm->bounce.data(), count, eb) != 0) return c->fail(CNIIC_ERR_HIP, "all_reduce: the host transport failed");
+        if (cm->host_sum(cm->user, cm->bounce.data(), count, eb) != 0) { cm->dead = true; return c->fail(CNIIC_ERR_RCCL, "all_reduce: the host transport failed"); }
         CNIIC_HIP_TRY(c, hipMemcpyAsync(buf_d, cm->bounce.data(), cm->bounce.size(), hipMemcpyHostToDevice, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         return CNIIC_OK;
     }
     const ncclResult_t e = rccl().AllReduce(buf_d, buf_d, (size_t)count, dt, ncclSum, cm->comm, c->stream);
-    if (e != ncclSuccess) return c->fail(CNIIC_ERR_HIP, "ncclAllReduce: %s", rccl().GetErrorString(e));
+    if (e != ncclSuccess) return c->fail(CNIIC_ERR_RCCL, "ncclAllReduce: %s", rccl().GetErrorString(e));
     return CNIIC_OK;
 }
 

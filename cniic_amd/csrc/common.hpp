@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cniic_hip.h"
@@ -232,6 +233,10 @@ struct KmDevState {
 struct PollRec { uint64_t iter; uint32_t done; uint32_t seq; uint64_t moved_last, reseeds, active, pair_evals; };
 constexpr uint32_t kPollRing = 16;
 
+struct Comm;
+void comm_abort(Comm *cm);
+int comm_async_error(Comm *cm);
+
 // Lagged convergence polling.  The K-means loops enqueue batches of (assign, update) launches; every
 // kernel exits at once when the device-side `done` flag is set.  After each batch the state is copied to
 // a pinned slot and an event recorded, but the host only waits for the copy of the PREVIOUS batch, so the
@@ -243,6 +248,7 @@ struct LaggedPoll {
     bool mapped = false;  // the kernels write the state into the third pinned slot themselves: no copy to enqueue
     bool ring = false;    // ... or every launch into its own slot of the ring behind the three slots (deterministic per launch)
     uint32_t last_prev = 0;
+    Comm *watch = nullptr;  // set by loops with collectives
     LaggedPoll(Ctx *ctx, const void *dstate_d) : c(ctx), dstate(dstate_d) {}
     static constexpr size_t ring_offset() { return (3 * sizeof(KmDevState) + 63) & ~size_t(63); }
     int ring_slot(PollRec **dev_ptr) {
@@ -280,6 +286,15 @@ struct LaggedPoll {
         CNIIC_HIP_TRY(c, hipEventRecord(c->poll_ev[slot], c->stream));
         *have = pending > 0;
         if (pending) {
+            if (watch) {  // a loop with collectives: a peer that failed leaves this rank's stream stuck in an all-reduce -- look at the communicator while waiting
+                for (;;) {
+                    const hipError_t q = hipEventQuery(c->poll_ev[slot ^ 1]);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return c->fail(CNIIC_ERR_HIP, "kmeans: waiting for a batch: %s", hipGetErrorString(q));
+                    CNIIC_TRY(comm_async_error(watch));
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));
+                }
+            }
             CNIIC_HIP_TRY(c, hipEventSynchronize(c->poll_ev[slot ^ 1]));
             if (ring) {  // the record the previous batch's last launch wrote: complete before its event, untouched for kPollRing launches
                 const volatile PollRec *r = reinterpret_cast<const volatile PollRec *>(static_cast<uint8_t *>(c->pinned) + ring_offset()) + last_prev % kPollRing;
@@ -425,6 +440,8 @@ void comm_destroy(Comm *cm);
 Ctx *comm_ctx(Comm *cm);
 uint32_t comm_size(const Comm *cm);
 int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind);  // in place, sum; kind 0 = u8, 1 = u32, 2 = u64
+void comm_abort(Comm *cm);        // after a failure on this rank: the peers' collectives end with an error instead of hanging
+int comm_async_error(Comm *cm);   // CNIIC_OK while healthy; an error once this rank aborted or the transport reports a peer's failure
 
 int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs

@@ -1925,7 +1925,17 @@ struct LaunchTimer {
 // result is exactly that of the reference's `while changed_assignment` loop (kmeans.rs:26-32).
 // With CNIIC_KM_PROFILE every assign launch is bracketed by HIP events on the ctx stream and the
 // summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
+static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm);
+
+// With a communicator, a failure on this rank (a launch error, a collective that fails, a missing state record) must not
+// strand the peers in their next all-reduce: the communicator is aborted before the error is returned (comm.cpp).
 int km_rgbw_run(KmRgbwState *s, Comm *cm) {
+    const int rc = km_rgbw_run_loop(s, cm);
+    if (rc != CNIIC_OK && cm) comm_abort(cm);
+    return rc;
+}
+
+static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
     const int batch = cm ? 2 : 4;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
                                    // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
@@ -1933,6 +1943,9 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
     LaunchTimer lt;
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
+    poll.watch = cm;
+    const char *fail_at_env = getenv("CNIIC_TEST_FAIL_AT_LAUNCH");  // fault injection (tests): this rank fails before enqueuing launch n
+    const long fail_at = fail_at_env ? atol(fail_at_env) : -1;
     KmDevState *st_host = nullptr;
     // The mapped slot shows the host a state AT LEAST as new as the batch it asks about -- how much newer depends on timing.
     // Alone that only ends the loop a little earlier; with collectives every rank must leave after the SAME batch (a rank
@@ -1950,6 +1963,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
                 // assign j with update j - 1 in its prologue; the sums are triple-buffered, running sums and the
                 // centroids to compare with ping-pong (see FusedUpdate)
                 const uint32_t j = launch_no++;
+                if (fail_at >= 0 && (long)j == fail_at) return c->fail(CNIIC_ERR_HIP, "injected failure before launch %u (CNIIC_TEST_FAIL_AT_LAUNCH)", j);
                 auto *P = s->fused_partials.as<unsigned long long>();
                 auto *Rn = s->fused_running.as<unsigned long long>();
                 auto *Cn = s->fused_cent.as<uint32_t>();

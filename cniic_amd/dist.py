@@ -184,6 +184,9 @@ class HipBackend:
         import numpy as np
 
         def host_sum(user, buf, count, elem_bytes):
+            if elem_bytes < 0:       # this rank failed inside the library's loop: its peers must not wait for it
+                self.host_aborted = True
+                return 0
             try:
                 dt = {1: np.uint8, 4: np.int32, 8: np.int64}[elem_bytes]   # (two's complement: the sum is the unsigned one)
                 a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(count * elem_bytes,)).view(dt)

@@ -246,7 +246,13 @@ int32_t  cniic_comm_all_reduce(cniic_comm *comm, void *buf_dev, uint64_t count, 
 /* The same communicator over the caller's own transport (MPI, sockets, gloo ...) where RCCL is not wanted: every
  * all-reduce drains the stream, hands `count` elements of `elem_bytes` bytes to fn in HOST memory and expects the
  * in-place unsigned sum over all ranks there when fn returns 0.  Slower (a host round trip per iteration), same
- * results; cniic_cc_run / cniic_comm_all_reduce take it like the RCCL one. */
+ * results; cniic_cc_run / cniic_comm_all_reduce take it like the RCCL one.
+ * Failures: a rank that fails inside cniic_cc_run (a launch error, a failed collective) aborts its communicator before
+ * it returns, so that its peers leave their next all-reduce with CNIIC_ERR_RCCL instead of waiting for it for ever --
+ * RCCL: ncclCommAbort here, ncclCommGetAsyncError polled by the peers while they wait for a batch; host transport: fn is
+ * called once with (buf_host = NULL, count = 0, elem_bytes = -1) and should tear the caller's transport down (a peer
+ * whose fn then fails returns non-zero, which ends that peer's loop the same way).  The communicator is unusable
+ * afterwards (every call returns CNIIC_ERR_RCCL): destroy it. */
 typedef int32_t (*cniic_host_sum_fn)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes);
 int32_t  cniic_comm_create_host(cniic_ctx *ctx, uint32_t rank, uint32_t nranks, cniic_host_sum_fn fn, void *user, cniic_comm **out);
 int32_t  cniic_cc_run(cniic_cc *cc, cniic_comm *comm /* NULL: one rank */, cniic_kmeans_stats *stats);

@@ -469,3 +469,64 @@ def test_two_image_sessions_open_on_one_context(monkeypatch):
         be.destroy(hs[i])
     assert got == exp
     ctx.close()
+
+
+# ------------------------------------------------------------------ a rank that fails must not strand its peers
+def _failing_worker(rank, world, port, q):
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CNIIC_SP_MIN_PIXELS="0")
+    if rank == 1:
+        os.environ["CNIIC_TEST_FAIL_AT_LAUNCH"] = "3"       # fault injection: rank 1 fails before enqueuing its fourth assign launch
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    import cniic_amd
+    from cniic_amd import _lib
+    from cniic_amd.dist import ShardedClusterColors
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    enc = ShardedClusterColors(ctx, 8, dist, dev, collectives="host")
+    img = make_img(rank)
+    h, w = img.shape[:2]
+    out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8, device=dev)
+    code, msg = 0, ""
+    try:
+        enc.encode(torch.from_numpy(img).to(dev), w, h, out)
+    except _lib.CniicError as e:
+        code, msg = e.code, str(e)
+    finally:
+        aborted = bool(getattr(enc.be, "host_aborted", False))
+        try:
+            dist.destroy_process_group()                     # (rank 1 leaves: rank 0's pending all-reduce fails instead of waiting)
+        except Exception:
+            pass
+    q.put((rank, code, aborted, msg))
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_aborts_its_communicator_and_its_peer_errors_out():
+    """rank 1 fails inside cniic_cc_run (injected before launch 3): it aborts its communicator -- the host transport's callback
+    is told -- and returns the error; rank 0, already waiting in the all-reduce of that iteration, comes back with
+    CNIIC_ERR_RCCL when the transport gives up on the missing peer, instead of hanging"""
+    import torch.multiprocessing as mp
+    from cniic_amd import _lib
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, code, aborted, msg = q.get(timeout=150)
+            res[r] = (code, aborted, msg)
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.terminate()
+    assert res[1][0] == _lib.HIP and res[1][1], res          # the injected failure, and the abort notification reached the transport
+    assert res[0][0] == _lib.RCCL, res                       # the peer: an error, not a hang
