@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything under profiles/ for one round, on one MI355X:  tools/make_profiles.sh r02   (writes gpurun_out/prof_<tag>/, copy what is wanted)
+set -e
+TAG=${1:-r02}
+R=$(cd "$(dirname "$0")/.." && pwd)
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+python3 $R/bench.py > $O/${TAG}_bench_unprofiled.json 2> $O/bench.err
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python3 $R/bench.py --no-extras --cpu-sample 0 > $O/${TAG}_bench_profiled.json 2>> $O/bench.err
+cp $O/stats/*kernel_stats.csv $O/${TAG}_kernel_stats.csv 2>/dev/null || cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats.csv
+echo "stats done"
+python3 $R/tools/launch_trace.py $O/trace.csv > $O/launch_trace.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o p -- python3 $R/tools/launch_trace.py /tmp/x.csv > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o p -- python3 $R/tools/launch_trace.py /tmp/x.csv > /dev/null 2>&1
+U=$(python3 -c "import json;print(json.load(open('$O/${TAG}_bench_unprofiled.json'))['config']['unique_colours'])")
+mkdir -p $O/out
+python3 $R/tools/make_traffic.py $O/pmc_f $O/pmc_w $O/trace.csv 4096 256 $U $O/out/$TAG > $O/traffic.txt
+echo "traffic done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python3 $R/tools/launch_trace.py /tmp/x.csv > /dev/null 2>&1
+python3 $R/tools/pmc_rows.py $O/pmc_sq k_rgbw_assign > $O/${TAG}_pmc_sq_assign_per_launch.txt
+python3 $R/tools/bench_others.py > $O/${TAG}_others.jsonl 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_d16 -o d -- python3 $R/tools/bench_others.py delta16k > /dev/null 2>&1
+cp $(find $O/stats_d16 -name '*kernel_stats.csv' | head -1) $O/${TAG}_delta16k_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_v -o v -- python3 $R/tools/bench_others.py voronoi > /dev/null 2>&1
+cp $(find $O/stats_v -name '*kernel_stats.csv' | head -1) $O/${TAG}_voronoi_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -o c -- python3 $R/bench.py --config c4 --steps 2 --cpu-sample 0 > $O/${TAG}_c4_bench_profiled.json 2>> $O/bench.err
+cp $(find $O/stats_c4 -name '*kernel_stats.csv' | head -1) $O/${TAG}_c4_kernel_stats.csv
+rm -rf $O/stats $O/stats_d16 $O/stats_v $O/stats_c4 $O/pmc_f $O/pmc_w $O/pmc_sq
+ls -la $O $O/out
