@@ -71,6 +71,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="c2 at N=1: skip the c4_one_gpu and host-buffer legs")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: everything else a library prints there (RCCL's version banner when a communicator is made)
+    # goes to stderr -- file descriptor 1 points at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -270,7 +276,7 @@ def main():
         if enc is not None:
             enc.close()
     if rank == 0:
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()  # rank 0 did the roofline encode on its own: tear down together
     ctx.close()

@@ -234,8 +234,12 @@ __global__ __launch_bounds__(kPackThreads) void k_pixel_labels(const uint8_t *__
 template <typename LabelT>
 __global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const LabelT *__restrict__ pixlab, uint64_t n, uint32_t K,
                                                                  const uint8_t *__restrict__ clen,
-                                                                 uint32_t *__restrict__ chunk_bits) {
+                                                                 uint32_t *__restrict__ chunk_bits, uint64_t lab_stride = 0) {
     extern __shared__ uint8_t s_len[];  // [K]
+    // (a batch of frames: blockIdx.y = frame, its labels lab_stride elements further, its own code table and chunk row)
+    pixlab += (size_t)blockIdx.y * lab_stride;
+    clen += (size_t)blockIdx.y * K;
+    chunk_bits += (size_t)blockIdx.y * gridDim.x;
     for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) s_len[i] = clen[i];
     __syncthreads();
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
@@ -258,8 +262,15 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *_
                                                                  const uint8_t *__restrict__ clen,
                                                                  const uint64_t *__restrict__ ccode,
                                                                  const uint64_t *__restrict__ chunk_off,
-                                                                 uint32_t *__restrict__ out_words, uint64_t bit_base) {
+                                                                 uint32_t *__restrict__ out_words, uint64_t bit_base, uint64_t lab_stride = 0,
+                                                                 uint64_t out_stride_words = 0, const uint64_t *__restrict__ bit_base_frames = nullptr) {
     extern __shared__ __align__(8) unsigned long long s_tab[];  // [K] codes, then [K] lens (bytes)
+    pixlab += (size_t)blockIdx.y * lab_stride;   // (a batch of frames: blockIdx.y = frame)
+    clen += (size_t)blockIdx.y * K;
+    ccode += (size_t)blockIdx.y * K;
+    chunk_off += (size_t)blockIdx.y * gridDim.x;
+    out_words += (size_t)blockIdx.y * out_stride_words;
+    if (bit_base_frames) bit_base = bit_base_frames[blockIdx.y];
     __shared__ uint32_t img[kPackWords];
     __shared__ uint32_t wsum[kPackThreads / 64];
     __shared__ uint32_t s_total;
@@ -395,37 +406,69 @@ int frame_label_hist(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_st
     return CNIIC_OK;
 }
 
+// exclusive scan (u64) of each frame's row of chunk totals: one 1024-thread block per frame
+__global__ __launch_bounds__(1024) void k_pack_scan_frames(const uint32_t *__restrict__ chunk_bits, uint32_t nchunks, uint64_t *__restrict__ chunk_off,
+                                                           uint64_t *__restrict__ totals) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_carry;
+    const uint32_t *in = chunk_bits + (size_t)blockIdx.x * nchunks;
+    uint64_t *out = chunk_off + (size_t)blockIdx.x * nchunks;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nchunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < nchunks ? in[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_w[wid] = inc;
+        __syncthreads();
+        unsigned long long pre = s_carry;
+        for (int k = 0; k < wid; k++) pre += s_w[k];
+        if (i < nchunks) out[i] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = pre + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = s_carry;
+}
+
 // huff_pack_labels for `frames` frames of npf labels each (frame f starts at element f lab_stride, 16-byte aligned): frame f
-// uses the code table at clen_d + f K / ccode_d + f K and writes behind bit_base[f] of out_d + f stride.  Everything is
-// enqueued back to back; one synchronisation at the end brings totals_h[f] (bits packed per frame).
+// uses the code table at clen_d + f K / ccode_d + f K and writes behind bit_base[f] of out_d + f stride.  Three launches
+// for the whole batch (grid.y = frame; one launch triple per frame was 2 ms for 128 frames, two thirds of it launch
+// overhead); one synchronisation at the end brings totals_h[f] (bits packed per frame).
 int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, const uint8_t *clen_d,
                             const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h) {
     if (!frames || !npf) return CNIIC_OK;
     if ((reinterpret_cast<uintptr_t>(out_d) & 3) || (stride & 3)) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output and stride must be 4-byte aligned");
+    if (frames > 65535) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: at most 65535 frames per batch");
     const uint32_t nchunks = (uint32_t)ceil_div(npf, kPackChunk);
-    DevBuf cb, co, tot;
+    DevBuf cb, co, tot, bb;
     CNIIC_HIP_TRY(c, cb.alloc((uint64_t)frames * nchunks * 4));
     CNIIC_HIP_TRY(c, co.alloc((uint64_t)frames * nchunks * 8));
     CNIIC_HIP_TRY(c, tot.alloc((uint64_t)frames * 8));
-    const size_t lb = wide ? 2 : 1;
-    for (uint32_t f = 0; f < frames; f++) {
-        const uint8_t *lab = static_cast<const uint8_t *>(pixlab_d) + (size_t)f * lab_stride * lb;
-        uint32_t *cbf = cb.as<uint32_t>() + (size_t)f * nchunks;
-        uint64_t *cof = co.as<uint64_t>() + (size_t)f * nchunks;
-        const uint8_t *cl = clen_d + (size_t)f * K;
-        const uint64_t *cc = ccode_d + (size_t)f * K;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(out_d + (size_t)f * stride);
-        if (wide)
-            hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, reinterpret_cast<const uint16_t *>(lab), npf, K, cl, cbf);
-        else
-            hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), K, c->stream, lab, npf, K, cl, cbf);
-        CNIIC_TRY(pack_scan(c, cbf, nchunks, cof, tot.as<uint64_t>() + f));
-        if (wide)
-            hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
-                               reinterpret_cast<const uint16_t *>(lab), npf, K, cl, cc, cof, dst, bit_base_h[f]);
-        else
-            hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, lab, npf, K, cl, cc, cof, dst, bit_base_h[f]);
-    }
+    CNIIC_HIP_TRY(c, bb.alloc((uint64_t)frames * 8));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(bb.p, bit_base_h, (size_t)frames * 8, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid(nchunks, frames);
+    if (wide)
+        hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, grid, dim3(kPackThreads), K, c->stream, reinterpret_cast<const uint16_t *>(pixlab_d), npf, K, clen_d,
+                           cb.as<uint32_t>(), lab_stride);
+    else
+        hipLaunchKernelGGL(k_pack_count_lab<uint8_t>, grid, dim3(kPackThreads), K, c->stream, reinterpret_cast<const uint8_t *>(pixlab_d), npf, K, clen_d,
+                           cb.as<uint32_t>(), lab_stride);
+    hipLaunchKernelGGL(k_pack_scan_frames, dim3(frames), dim3(1024), 0, c->stream, (const uint32_t *)cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>());
+    if (wide)
+        hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint16_t *>(pixlab_d), npf, K,
+                           clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
+                           (const uint64_t *)bb.as<uint64_t>());
+    else
+        hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint8_t *>(pixlab_d), npf, K,
+                           clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
+                           (const uint64_t *)bb.as<uint64_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(totals_h, tot.p, (size_t)frames * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
