@@ -153,11 +153,14 @@ def main():
             keys, counts = ctx.hist_rgb24(frames, npx=F * FRAME_W * FRAME_H)
             U = int(keys.size)
             del keys, counts
-            enc.flags = _lib.KM_PROFILE
-            enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride)
-            enc.flags = 0
-            roof = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one batch encode; exact cell-pruned assign over this "
-                                        "GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K))
+            # one more batch encode with the per-dispatch timers on -- by THIS rank alone (the other ranks are not in it, so it must not
+            # be a collective: a one-rank session over this rank's own frames; same kernels, this GPU's colours, its own palette)
+            solo = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
+            solo.flags = _lib.KM_PROFILE
+            solo.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride)
+            solo.close()
+            roof = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one batch encode of rank 0's frames alone; exact cell-pruned assign "
+                                        "over this GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K))
         return dt, int(sum(lens)), st, U, roof
 
     line = None

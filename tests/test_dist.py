@@ -22,8 +22,19 @@ def keys_of(img):
     return (p[:, 0] << 16) | (p[:, 1] << 8) | p[:, 2]
 
 
+def reseed_img(rank):
+    """the colours of a forced-empty-cluster fixture (tests/golden/reseed_golden.npz) dealt to two ranks: the union is the fixture"""
+    G = np.load(os.path.join(HERE, "golden", "reseed_golden.npz"))
+    keys, wt = G["rgbw38_keys"][rank::2], G["rgbw38_weight"][rank::2]
+    k = np.repeat(keys, wt.astype(np.int64))
+    np.random.default_rng(rank).shuffle(k)
+    return np.stack([(k >> 16) & 255, (k >> 8) & 255, k & 255], 1).astype(np.uint8).reshape(1, -1, 3)
+
+
 def make_img(rank, h=40, w=56):
     from cniic_amd import synth
+    if os.environ.get("TEST_RESEED_IMAGES") == "1":
+        return reseed_img(rank)
     if "FUZZ_SEED0" in os.environ:  # tools/fuzz_dist.py: other sizes and seeds, the same in the spawned workers
         return synth.photo(int(os.environ["FUZZ_W"]), int(os.environ["FUZZ_H"]), 12345 + int(os.environ["FUZZ_SEED0"]) + rank)
     return synth.photo(w, h, synth.SEED0 + 40 + rank)
@@ -246,6 +257,8 @@ def _worker(rank, world, port, K, use_hip, q, env=None):
             timg = img
             out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8)
         n, st = enc.encode(timg, w, h, out)
+        if os.environ.get("TEST_RESEED_IMAGES") == "1":
+            assert int(st["empty_reseeds"]) == int(os.environ["TEST_EXPECT_RESEEDS"]), st
         q.put((rank, bytes(out[:n].cpu().numpy().tobytes()), int(st["iterations"])))
     finally:
         dist.destroy_process_group()
@@ -530,3 +543,24 @@ def test_a_failing_rank_aborts_its_communicator_and_its_peer_errors_out():
                 p.terminate()
     assert res[1][0] == _lib.HIP and res[1][1], res          # the injected failure, and the abort notification reached the transport
     assert res[0][0] == _lib.RCCL, res                       # the peer: an error, not a hang
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["dense", "partition"])
+def test_native_loop_world2_empty_cluster_reseed(route):
+    """the empty-cluster branch (kmeans.rs:117-134) with two ranks: the re-seed picks from the index of ALL ranks' colours
+    (gidx_select in the folded-in update); images = a forced-reseed fixture dealt to the ranks, result = the fixture's"""
+    G = np.load(os.path.join(HERE, "golden", "reseed_golden.npz"))
+    K, (iters, reseeds, _) = int(G["rgbw38_K"][0]), (int(v) for v in G["rgbw38_stats"])
+    assert reseeds >= 2
+    env = {"TEST_COLLECTIVES": "host", "TEST_RESEED_IMAGES": "1", "TEST_EXPECT_RESEEDS": str(reseeds),
+           "CNIIC_SP_MIN_PIXELS": "0" if route == "partition" else str(1 << 40)}
+    res = _run(2, K, use_hip=True, env=env)
+    os.environ["TEST_RESEED_IMAGES"] = "1"
+    try:
+        exp, it = expected_streams([make_img(0), make_img(1)], K)
+    finally:
+        del os.environ["TEST_RESEED_IMAGES"]
+    assert it == iters
+    for r in (0, 1):
+        assert res[r][0] == exp[r] and res[r][1] == iters
