@@ -259,3 +259,40 @@ def test_cluster_colors_16384_roundtrip_properties(env):
     assert int(torch.unique(keys).numel()) <= K
     err = (back[::64, ::64].to(torch.float32) - img[::64, ::64].to(torch.float32)).pow(2).mean().item()
     assert err < 400.0   # 256 colours for the whole cube: cells ~40 levels wide, i.e. ~12-16 levels rms per channel, not noise
+
+
+def test_config4_frame_batch_1080p(env):
+    """configs[3] at its frame size on one rank: 8 frames 1920 x 1080 (no power of two, 506.25 pack chunks per frame), ONE palette.
+    Every frame's stream decodes on its own; all frames share one palette of at most K colours; a frame decodes to exactly the
+    rows the plain encode of the stacked frames (one 1920 x 8640 image: the same union clustering) decodes to; each stream is as
+    long as its own label histogram predicts; the batch encode is deterministic."""
+    ctx, torch, dev = env
+    from cniic_amd import _lib
+    from cniic_amd.dist import ShardedClusterColors
+    F, w, h, K = 8, 1920, 1080, 256
+    frames = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
+    for f in range(F):
+        ctx.synth_image(1, SEED + 4 + f, w, h, out=frames[f])
+    stride = w * h
+    out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
+    enc = ShardedClusterColors(ctx, K, None, dev)
+    lens, st = enc.encode_frames(frames, w, h, F, out, stride)
+    host = out.cpu().numpy().copy()
+    lens2, st2 = enc.encode_frames(frames, w, h, F, out, stride)
+    assert lens2 == lens and st2["iterations"] == st["iterations"] and np.array_equal(out.cpu().numpy(), host)
+    big = torch.empty(F * w * h * 2, dtype=torch.uint8, device=dev)
+    rc, nb, stb = ctx.encode("cluster-colors(%d)" % K, frames, w=w, h=F * h, out=big)   # the stacked frames as one image
+    assert rc == 0 and stb["iterations"] == st["iterations"]
+    rc, whole = ctx.decode("cluster-colors(%d)" % K, big[:nb].cpu().numpy().tobytes())
+    assert rc == 0
+    palette = set()
+    for f in range(F):
+        data = host[f * stride:f * stride + lens[f]].tobytes()
+        rc, back = ctx.decode("cluster-colors(%d)" % K, data)
+        assert rc == 0 and back.shape == (h, w, 3)
+        assert np.array_equal(back, whole[f * h:(f + 1) * h]), "frame %d" % f
+        keys = (back[..., 0].astype(np.uint32) << 16) | (back[..., 1].astype(np.uint32) << 8) | back[..., 2]
+        pal, cnt = np.unique(keys, return_counts=True)
+        palette.update(pal.tolist())
+        assert ctx.huf_size(_lib.SYM_RGB, cnt.astype(np.uint64)) + 8 == lens[f]
+    assert len(palette) <= K
