@@ -39,37 +39,93 @@ __device__ __forceinline__ void load16px_keys(const uint4 *p, uint32_t key[16]) 
     }
 }
 
+// ---- wave-wide reductions on the DPP data path (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31): six VALU
+// instructions with a few cycles of latency each; the shuffle form (__shfl_down / __shfl_xor) compiles to six dependent
+// ds_bpermute_b32, each a trip through the LDS crossbar (~100 cycles).  The result is in EVERY lane (read from lane 63).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t identity, uint32_t v) {  // lanes without a source keep `identity`
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <class Op>
+__device__ __forceinline__ uint32_t wave_reduce_dpp(uint32_t v, uint32_t identity, Op op) {
+    v = op(v, dpp_move<0x111, 0xf, 0xf>(identity, v));  // row_shr:1
+    v = op(v, dpp_move<0x112, 0xf, 0xf>(identity, v));  // row_shr:2
+    v = op(v, dpp_move<0x114, 0xf, 0xe>(identity, v));  // row_shr:4  (lanes 4..15 of a row)
+    v = op(v, dpp_move<0x118, 0xf, 0xc>(identity, v));  // row_shr:8  (lanes 8..15): lane 15 of a row holds the row
+    v = op(v, dpp_move<0x142, 0xa, 0xf>(identity, v));  // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_move<0x143, 0xc, 0xf>(identity, v));  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;  // valid in lane 0
+    return wave_reduce_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 __device__ __forceinline__ uint64_t wave_reduce_sum64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto step = [&](uint32_t mlo, uint32_t mhi) { const uint64_t t = (((uint64_t)hi << 32) | lo) + (((uint64_t)mhi << 32) | mlo); lo = (uint32_t)t; hi = (uint32_t)(t >> 32); };
+    step(dpp_move<0x111, 0xf, 0xf>(0u, lo), dpp_move<0x111, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x112, 0xf, 0xf>(0u, lo), dpp_move<0x112, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x114, 0xf, 0xe>(0u, lo), dpp_move<0x114, 0xf, 0xe>(0u, hi));
+    step(dpp_move<0x118, 0xf, 0xc>(0u, lo), dpp_move<0x118, 0xf, 0xc>(0u, hi));
+    step(dpp_move<0x142, 0xa, 0xf>(0u, lo), dpp_move<0x142, 0xa, 0xf>(0u, hi));
+    step(dpp_move<0x143, 0xc, 0xf>(0u, lo), dpp_move<0x143, 0xc, 0xf>(0u, hi));
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
 }
 __device__ __forceinline__ uint32_t wave_reduce_min(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_down(v, off, 64));
-    return v;
+    return wave_reduce_dpp(v, 0xffffffffu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
 }
 __device__ __forceinline__ uint32_t wave_reduce_max(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_down(v, off, 64));
+    return wave_reduce_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+}
+
+// 64-bit minimum / maximum of the wave (argmin keys "distance << 32 | index"), in every lane
+template <bool MAX> __device__ __forceinline__ uint64_t wave_reduce_minmax64(uint64_t v) {
+    const uint32_t idl = MAX ? 0u : 0xffffffffu;
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto step = [&](uint32_t mlo, uint32_t mhi) {
+        const uint64_t a = ((uint64_t)hi << 32) | lo, b = ((uint64_t)mhi << 32) | mlo;
+        const uint64_t t = MAX ? (a > b ? a : b) : (a < b ? a : b);
+        lo = (uint32_t)t; hi = (uint32_t)(t >> 32);
+    };
+    step(dpp_move<0x111, 0xf, 0xf>(idl, lo), dpp_move<0x111, 0xf, 0xf>(idl, hi));
+    step(dpp_move<0x112, 0xf, 0xf>(idl, lo), dpp_move<0x112, 0xf, 0xf>(idl, hi));
+    step(dpp_move<0x114, 0xf, 0xe>(idl, lo), dpp_move<0x114, 0xf, 0xe>(idl, hi));
+    step(dpp_move<0x118, 0xf, 0xc>(idl, lo), dpp_move<0x118, 0xf, 0xc>(idl, hi));
+    step(dpp_move<0x142, 0xa, 0xf>(idl, lo), dpp_move<0x142, 0xa, 0xf>(idl, hi));
+    step(dpp_move<0x143, 0xc, 0xf>(idl, lo), dpp_move<0x143, 0xc, 0xf>(idl, hi));
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+}
+__device__ __forceinline__ uint64_t wave_reduce_min64(uint64_t v) { return wave_reduce_minmax64<false>(v); }
+__device__ __forceinline__ uint64_t wave_reduce_max64(uint64_t v) { return wave_reduce_minmax64<true>(v); }
+
+// inclusive scan across the 64 lanes of a wave: the same six DPP steps with every bank enabled (row_shr leaves the first
+// lanes of a row without a source, they add 0; the two row broadcasts carry the totals of the rows before)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += dpp_move<0x111, 0xf, 0xf>(0u, v);
+    v += dpp_move<0x112, 0xf, 0xf>(0u, v);
+    v += dpp_move<0x114, 0xf, 0xf>(0u, v);
+    v += dpp_move<0x118, 0xf, 0xf>(0u, v);
+    v += dpp_move<0x142, 0xa, 0xf>(0u, v);
+    v += dpp_move<0x143, 0xc, 0xf>(0u, v);
     return v;
 }
 
-// inclusive scan across the 64 lanes of a wave
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
+template <bool MAX> __device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v) {  // sum, or running maximum
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    auto step = [&](uint32_t mlo, uint32_t mhi) {
+        const uint64_t a = ((uint64_t)hi << 32) | lo, b = ((uint64_t)mhi << 32) | mlo;
+        const uint64_t t = MAX ? (a > b ? a : b) : a + b;
+        lo = (uint32_t)t; hi = (uint32_t)(t >> 32);
+    };
+    step(dpp_move<0x111, 0xf, 0xf>(0u, lo), dpp_move<0x111, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x112, 0xf, 0xf>(0u, lo), dpp_move<0x112, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x114, 0xf, 0xf>(0u, lo), dpp_move<0x114, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x118, 0xf, 0xf>(0u, lo), dpp_move<0x118, 0xf, 0xf>(0u, hi));
+    step(dpp_move<0x142, 0xa, 0xf>(0u, lo), dpp_move<0x142, 0xa, 0xf>(0u, hi));
+    step(dpp_move<0x143, 0xc, 0xf>(0u, lo), dpp_move<0x143, 0xc, 0xf>(0u, hi));
+    return ((uint64_t)hi << 32) | lo;
 }
+// value of the lane before (lane 0: `first`): wave_shr:1
+__device__ __forceinline__ uint32_t wave_prev_lane(uint32_t v, uint32_t first) { return dpp_move<0x138, 0xf, 0xf>(first, v); }
 
 // block-wide sum; result valid in thread 0 (and broadcast to all through LDS)
 template <int THREADS> __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v) {

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kUdThreads) void k_ud_sums(const uint32_t *__restri
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         int32_t v = s[ch];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        v = (int32_t)wave_reduce_sum((uint32_t)v);
         if ((threadIdx.x & 63) == 0) sh[ch][threadIdx.x >> 6] = v;
     }
     __syncthreads();
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kUdThreads) void k_ud_apply(const uint32_t *__restr
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {  // exclusive scan of the per-thread sums across the block
         int32_t inc = s[ch];
-        for (int off = 1; off < 64; off <<= 1) { const int32_t t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+        inc = (int32_t)wave_inclusive_scan((uint32_t)inc);
         if (lane == 63) wsum[ch][wid] = inc;
         run[ch] = inc - s[ch];
     }

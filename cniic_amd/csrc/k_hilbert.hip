@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
             }
         }
         // the pixel before the run is the neighbouring lane's last one (runs are consecutive across the lanes of a wave)
-        uint32_t prev = __shfl_up(px[kDeltaRun - 1], 1, 64);
+        uint32_t prev = wave_prev_lane(px[kDeltaRun - 1], 0u);
         if ((threadIdx.x & 63) == 0) {
             prev = 0;  // START = (0, 0, 0) hilbertc.rs:445
             if (d0 > 0) {
@@ -356,9 +356,8 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta_p2(const uint8_
         for (int j = 0; j < kBatch; j++) {
             const uint32_t g = gb + j;
             if (g >= g1) break;
-            uint32_t prev = __shfl_up(px[j], 1, 64);
-            if (lane == 0) prev = carried;
-            carried = __shfl(px[j], 63, 64);
+            const uint32_t prev = wave_prev_lane(px[j], carried);
+            carried = (uint32_t)__builtin_amdgcn_readlane((int)px[j], 63);
             const int32_t dr = (int32_t)(px[j] & 255) - (int32_t)(prev & 255), dg = (int32_t)((px[j] >> 8) & 255) - (int32_t)((prev >> 8) & 255),
                           db = (int32_t)((px[j] >> 16) & 255) - (int32_t)((prev >> 16) & 255);
             const uint32_t key = ((uint32_t)(dr + 255) << 18) | ((uint32_t)(dg + 255) << 9) | (uint32_t)(db + 255);

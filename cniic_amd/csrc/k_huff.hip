@@ -435,12 +435,7 @@ __global__ __launch_bounds__(1024) void k_pack_scan_frames(const uint32_t *__res
     for (uint32_t base = 0; base < nchunks; base += 1024) {
         const uint32_t i = base + threadIdx.x;
         const unsigned long long v = i < nchunks ? in[i] : 0ull;
-        unsigned long long inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
+        const unsigned long long inc = wave_inclusive_scan64<false>(v);
         if (lane == 63) s_w[wid] = inc;
         __syncthreads();
         unsigned long long pre = s_carry;

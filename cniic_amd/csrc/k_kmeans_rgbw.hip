@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__
             unsigned long long m = __ballot(active);
             if (!m) break;
             const int leader = __ffsll((long long)m) - 1;
-            const uint32_t lc = __shfl(cell, leader, 64);
+            const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell, leader);
             const bool same = active && cell == lc;
             const unsigned long long ms = __ballot(same);
             if (lane == leader) atomicAdd(&cell_count[lc], (uint32_t)__popcll(ms));
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void k_cell_scan(const uint32_t *__restrict__ c
     const uint32_t lane = threadIdx.x, grp = blockIdx.x;
     uint32_t ps = 0, pn = 0;
     for (uint32_t g = lane; g < grp; g += 64) { const uint2 t = tot[g]; ps += t.x; pn += t.y; }
-    const uint32_t base = __shfl(wave_reduce_sum(ps), 0, 64), nbase = __shfl(wave_reduce_sum(pn), 0, 64);
+    const uint32_t base = wave_reduce_sum(ps), nbase = wave_reduce_sum(pn);
     const uint32_t cell = grp * 64 + lane, v = cell_count[cell];
     const uint32_t start = base + wave_inclusive_scan(v) - v;
     cell_start[cell] = start;
@@ -356,12 +356,12 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const uint32_t *__restrict
             unsigned long long m = __ballot(active);
             if (!m) break;
             const int leader = __ffsll((long long)m) - 1;
-            const uint32_t lc = __shfl(cell, leader, 64);
+            const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)cell, leader);
             const bool same = active && cell == lc;
             const unsigned long long ms = __ballot(same);
             uint32_t b = 0;
             if (lane == leader) b = atomicAdd(&cursor[lc], (uint32_t)__popcll(ms));
-            b = __shfl(b, leader, 64);
+            b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
             if (same) pos = b + (uint32_t)__popcll(ms & ((1ull << lane) - 1));
             active = active && !same;
         }
@@ -437,11 +437,7 @@ struct Dominance {
     }
 };
 
-__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor(v, off, 64));
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) { return wave_reduce_min(v); }  // (DPP: the result is in every lane)
 
 // position in `list` (n entries, ascending cluster id) of the centroid nearest the cube centre; lowest position on ties
 __device__ __forceinline__ uint32_t nearest_to_centre(const uint2 *list, uint32_t n, const CellBox &bx, int32_t ext, int lane) {

@@ -327,8 +327,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 const uint32_t k = threadIdx.x * R + i;
                 if ((uint32_t)i < R && k < K) key = min(key, ((unsigned long long)centre_dist(sb, mine[i]) << 12) | k);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned long long)__shfl_xor(key, off, 64));
+            key = wave_reduce_min64(key);
             if (lane == 0) atomicMin(&s_key, key);
             __syncthreads();
             const uint32_t pk = (uint32_t)(s_key & 4095ull);
@@ -364,8 +363,8 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 const uint32_t d = centre_dist(tb, S_c[e]);
                 if (d < bd) { bd = d; be = e; }
             }
-            const uint32_t dmin = __shfl(wave_reduce_min(bd), 0, 64);
-            const uint32_t pe = __shfl(wave_reduce_min(bd == dmin ? be : 0xffffffffu), 0, 64);
+            const uint32_t dmin = wave_reduce_min(bd);
+            const uint32_t pe = wave_reduce_min(bd == dmin ? be : 0xffffffffu);
             int4 pv = S_c[pe];
             Dominance dm;
             dm.set(tb, pv);
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     // labels: one wave reduction per label instead of 64 colliding LDS atomics.
                     unsigned long long todo = __ballot(ok);
                     while (todo) {
-                        const uint32_t lk = __shfl(nl, __ffsll((long long)todo) - 1, 64);
+                        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)nl, __ffsll((long long)todo) - 1);
                         const bool in = ok && nl == lk;
                         const unsigned long long grp = __ballot(in);
                         const uint32_t cn = (uint32_t)__popcll(grp);

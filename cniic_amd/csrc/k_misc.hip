@@ -234,8 +234,7 @@ __global__ __launch_bounds__(256) void k_voronoi_paint_tiles(const cniic_colorpo
         const int32_t dx = 2 * (int32_t)cent[k].x - cx2, dy = 2 * (int32_t)cent[k].y - cy2;
         key = min(key, ((unsigned long long)(uint32_t)(dx * dx + dy * dy) << 12) | k);  // (< 2^31: coordinates < 2^14)
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_xor(key, o, 64));
+    key = wave_reduce_min64(key);
     if ((threadIdx.x & 63) == 0) atomicMin(&s_key, key);
     __syncthreads();
     const uint32_t pk = (uint32_t)(s_key & 4095ull);

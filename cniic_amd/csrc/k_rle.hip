@@ -41,12 +41,7 @@ __device__ __forceinline__ uint32_t segment_starts(const uint8_t *__restrict__ l
 // inclusive max-scan over the 256 threads of a block, then exclusive (own value left out)
 __device__ __forceinline__ uint64_t block_exclusive_max(uint64_t v, uint64_t *wmax) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint64_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc = max(inc, t);
-    }
+    const uint64_t inc = wave_inclusive_scan64<true>(v);
     if (lane == 63) wmax[wid] = inc;
     __syncthreads();
     uint64_t pre = 0;
@@ -63,8 +58,7 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_last(const uint8_t *__restr
     const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
     const uint32_t m = segment_starts(lin, n, base);
     uint64_t last = m ? base + (31 - __clz((int)m)) + 1 : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) last = max(last, (uint64_t)__shfl_xor(last, off, 64));
+    last = wave_reduce_max64(last);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = last;
     __syncthreads();
     if (threadIdx.x == 0) chunk_last[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
