@@ -424,14 +424,15 @@ struct Dominance {
 #pragma unroll
         for (int i = 0; i < 3; i++) { a[2 * i] = p[i] - 2 * lo[i]; a[2 * i + 1] = p[i] - 2 * (lo[i] + ext); }
     }
-    // max over the cube of d(p, pivot) - d(p, c): c can be nearest (or tie) somewhere in the cube only if >= 0
+    // max over the cube of d(p, pivot) - d(p, c): c can be nearest (or tie) somewhere in the cube only if >= 0.
+    // Per channel max(d (v + a0), d (v + a1)) with a0 > a1 (lo < hi) = d (v + (d >= 0 ? a0 : a1)): one product, not two.
     __device__ __forceinline__ int32_t worst(uint32_t ck) const {
         const int32_t v[3] = {(int32_t)((ck >> 16) & 255), (int32_t)((ck >> 8) & 255), (int32_t)(ck & 255)};
         int32_t f = 0;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const int32_t d = p[i] - v[i];
-            f += max(__mul24(d, v[i] + a[2 * i]), __mul24(d, v[i] + a[2 * i + 1]));
+            f += __mul24(d, v[i] + (d >= 0 ? a[2 * i] : a[2 * i + 1]));
         }
         return f;
     }
@@ -635,6 +636,7 @@ struct CellState {
     uint32_t *rec;          // [M][cell_rec_words(MW)]
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
+    uint32_t dbg;           // measuring builds (-DCNIIC_RGBW_PHASES): 1 + the launch whose waves write their timeline (CNIIC_DBG_TIMELINE)
 };
 
 // Centroid update folded into the next assign launch (km_rgbw_run, K <= 256): launch j first finishes iteration
@@ -676,11 +678,18 @@ __device__ __forceinline__ void poll_record(PollRec *ring, uint32_t launch_no, c
 __device__ unsigned long long g_rgbw_phase[12];
 __device__ unsigned long long g_rgbw_blk[512][4];  // census of one launch (CNIIC_DBG_LAUNCH): per block start, end (100 MHz clock), HW id, items
 __device__ unsigned int g_rgbw_launch[128][8];  // per launch of the super-cell kernel: swept cells, swept points, bulk cells, single-candidate cells, longest list, non-empty cells, sum |S|
+__device__ unsigned long long g_wave_tl[8192][8];  // one launch (CNIIC_DBG_TIMELINE): per wave, the 100 MHz clock at entry, after the prologue, after the first tests / first build, at the end of the cell loop, after the barrier, at the end; [6] dirty cells, [7] cells
 #define RG_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
+#define RG_TL(i) do { if (tl_on_) tl_[i] = wall_clock64(); } while (0)
+#define RG_TL1(i) do { if (tl_on_ && !tl_[i]) tl_[i] = wall_clock64(); } while (0)
+#define RG_TLC(i, v) do { if (tl_on_) tl_[i] += (v); } while (0)
 #define RG_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
 #else
 #define RG_PHASE(i) do {} while (0)
 #define RG_COUNT(i, v) do {} while (0)
+#define RG_TL(i) do {} while (0)
+#define RG_TL1(i) do {} while (0)
+#define RG_TLC(i, v) do {} while (0)
 #endif
 
 template <typename LabelT, int IDBITS, int WAVES>
@@ -716,6 +725,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __shared__ unsigned long long s_ph[12];
     if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
+    const bool tl_on_ = cs.dbg && fz.launch_no + 1 == cs.dbg;
+    unsigned long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    RG_TL(0);
 #endif
     uint32_t moved = 0;
     unsigned long long evals = 0;
@@ -808,6 +820,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     }
     const bool skip_mode = !first && nS <= cs.max_moved;
     RG_PHASE(0);
+    RG_TL(1);
 
     if (!skip_mode) {
         // ================================================================= FULL schedule
@@ -850,6 +863,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                                                 : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
             RG_PHASE(3);
             RG_COUNT(9, 1);
+            RG_TL1(2);
+            RG_TLC(7, 1);
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
                 const uint32_t nts = more ? base + 64 * kSweep : s_next;
@@ -931,7 +946,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
                 if (k2 != 0xffffffffu) dirty = dirty || in2 || dm.worst(ck2) >= 0;
                 RG_PHASE(6);
+                RG_TLC(7, 1);
                 if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
+                RG_TLC(6, 1);
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
 #pragma unroll
@@ -958,18 +975,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 }
                 evals += (unsigned long long)(e - s) * (ncand + 1);
                 RG_PHASE(7);
+                RG_TL1(2);
                 __builtin_amdgcn_wave_barrier();
               }
             }
         }
     }
     RG_PHASE(11);
+    RG_TL(3);
     moved = wave_reduce_sum(moved);
     if (lane == 0) {
         if (moved) atomicAdd(&s_moved, moved);
         if (evals) atomicAdd(&s_evals, evals);
     }
     __syncthreads();
+    RG_TL(4);
     for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS)
         if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
@@ -977,7 +997,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
     }
     RG_PHASE(5);
+    RG_TL(5);
 #ifdef CNIIC_RGBW_PHASES
+    if (tl_on_ && lane == 0) {
+        const uint32_t wv_ = blockIdx.x * WAVES + wid;
+        if (wv_ < 8192)
+            for (int i = 0; i < 8; i++) g_wave_tl[wv_][i] = tl_[i];
+    }
     if (lane == 0)
         for (int i = 0; i < 12; i++)
             if (ph_[i]) atomicAdd(&s_ph[i], ph_[i]);
@@ -1789,7 +1815,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
-                     s->no_skip ? 0u : kMaxMovedSkip};
+                     s->no_skip ? 0u : kMaxMovedSkip, getenv("CNIIC_DBG_TIMELINE") ? (uint32_t)atoi(getenv("CNIIC_DBG_TIMELINE")) + 1u : 0u};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
@@ -2074,6 +2100,18 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         }
         if (s->sup) fprintf(stderr, "assign_sup (wave clocks): prologue %llu S build %llu classify %llu first loads %llu sweeps %llu tail wait %llu flush %llu\n",
                             ph[0], ph[2], ph[3], ph[1], ph[4], ph[11], ph[5]);
+        if (const char *tf = getenv("CNIIC_DBG_TIMELINE_FILE")) {
+            static unsigned long long T[8192][8];
+            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(T, HIP_SYMBOL(g_wave_tl), sizeof T));
+            if (FILE *f = fopen(tf, "w")) {
+                fprintf(f, "wave,t0,t1,t2,t3,t4,t5,dirty,cells\n");
+                for (int i = 0; i < 8192; i++)
+                    if (T[i][0]) fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, T[i][0], T[i][1], T[i][2], T[i][3], T[i][4], T[i][5], T[i][6], T[i][7]);
+                fclose(f);
+            }
+            memset(T, 0, sizeof T);
+            CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wave_tl), T, sizeof T));
+        }
         fprintf(stderr, "rgbw phases (wave clocks): prologue %llu draw %llu super %llu cell-build %llu sweep %llu epilogue %llu skip-test %llu "
                         "skip-build+sweep %llu | super builds %llu cells %llu iters %llu | first barrier+draw %llu tail %llu\n",
                 ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], (unsigned long long)h.iter, ph[10], ph[11]);

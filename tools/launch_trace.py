@@ -29,7 +29,14 @@ out = torch.empty(size * size * 4 + (1 << 20), dtype=torch.uint8, device=dev)
 expr = "cluster-colors(%d)" % K
 for _ in range(2):
     ctx.encode(expr, img, w=size, h=size, out=out)
-rc, ln, st = ctx.encode(expr, img, w=size, h=size, out=out, flags=_lib.KM_PROFILE)
+if os.environ.get("TRACE_DBG"):
+    k, v = os.environ["TRACE_DBG"].split("=")
+    os.environ[k] = v
+try:
+    rc, ln, st = ctx.encode(expr, img, w=size, h=size, out=out, flags=_lib.KM_PROFILE)
+except Exception as ex:  # (an experiment that breaks the result on purpose: the trace is written before the codec notices)
+    print("encode failed:", ex)
+    st = {"iterations": 0}
 ms, n = ctx.kernel_time("kmeans_rgbw_assign")
 wms, wn = ctx.kernel_time("kmeans_rgbw_assign_working")
 print("iterations %d, %d launches %.1f us total (%.2f us each); %d working launches %.1f us (%.2f us each)" %

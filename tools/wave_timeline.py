@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of ONE launch of the K-means assign kernel (a -DCNIIC_RGBW_PHASES build; CNIIC_DBG_TIMELINE): every wave
+writes the 100 MHz clock at entry, after the prologue (folded-in update), after its first tests / first candidate build, at the
+end of its cell loop, after the block barrier and at its end.  Prints where the launch's span goes.
+
+    python tools/wave_timeline.py <launch> [<launch> ...]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import cniic_amd  # noqa: E402
+from cniic_amd import _lib, synth  # noqa: E402
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+size, K = 4096, 256
+ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev)
+ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
+out = torch.empty(size * size * 4 + (1 << 20), dtype=torch.uint8, device=dev)
+expr = "cluster-colors(%d)" % K
+ctx.encode(expr, img, w=size, h=size, out=out)
+for L in sys.argv[1:]:
+    path = "/tmp/tl_%s.csv" % L
+    os.environ["CNIIC_DBG_TIMELINE"] = L
+    os.environ["CNIIC_DBG_TIMELINE_FILE"] = path
+    ctx.encode(expr, img, w=size, h=size, out=out, flags=_lib.KM_PROFILE)
+    a = np.loadtxt(path, delimiter=",", skiprows=1, dtype=np.int64)
+    t = a[:, 1:7].astype(np.float64) / 100.0  # us
+    t0 = t[:, 0].min()
+    t -= t0
+    dirty, cells = a[:, 7], a[:, 8]
+    print("launch %s: %d waves, span %.2f us; dirty cells %d of %d tested" % (L, len(a), t[:, 5].max(), dirty.sum(), cells.sum()))
+    names = ["entry", "prologue done", "first test/build done", "loop done", "barrier passed", "end"]
+    for i, n in enumerate(names):
+        v = t[:, i]
+        v = v[a[:, 1 + i] > 0]
+        if len(v):
+            print("  %-22s min %6.2f  p50 %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f" % (n, v.min(), np.percentile(v, 50), np.percentile(v, 90), np.percentile(v, 99), v.max()))
+    order = np.argsort(-t[:, 3])[:4]
+    for i in order:
+        print("    late wave %5d (block %4d): prologue done %.2f, first test/build %.2f, loop done %.2f, end %.2f | %d dirty of %d cells" %
+              (a[i, 0], a[i, 0] // 8, t[i, 1], t[i, 2], t[i, 3], t[i, 5], dirty[i], cells[i]))
+    loop = t[:, 3] - t[:, 1]
+    for d in range(0, 9):
+        sel = dirty == d
+        if sel.sum():
+            print("  waves with %d dirty cells: %5d, loop time mean %6.2f max %6.2f us" % (d, sel.sum(), loop[sel].mean(), loop[sel].max()))
+ctx.close()
