@@ -557,7 +557,7 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
 
 // the same sweep at iteration 0, where every point adds to the sums of its cluster (kept apart from
 // sweep_points: sharing the code cost the later iterations 30 % through the register allocation)
-template <typename LabelT, int IDBITS>
+template <typename LabelT, int IDBITS, bool ROUNDS = false>
 __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K,
@@ -585,7 +585,49 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
             if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
         }
     }
-    {
+    bool rem[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) rem[u] = base + u * 64 + lane < e;
+    if constexpr (ROUNDS) {
+        // Iteration 0: every point adds to the sums of its cluster.  A sweep lies inside one 8^3 cell and its points join one,
+        // two, three clusters: round by round, the cluster of the first point still to be booked, every point that joins it
+        // summed in the wave (DPP), one lane adds the totals -- ten LDS atomics per point on the same few words run one lane at
+        // a time instead (~300 cycles an instruction), and the CU's LDS did little else during this launch.  Whatever is left
+        // after six rounds goes point by point.
+        static_assert(kSweep == 4, "four slots per lane");
+#pragma unroll 1
+        for (int round = 0; round < 6; round++) {
+            const unsigned long long b0 = __ballot(rem[0]), b1 = __ballot(rem[1]), b2 = __ballot(rem[2]), b3 = __ballot(rem[3]);
+            if (!(b0 | b1 | b2 | b3)) return;
+            uint32_t pn;
+            if (b0) pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[0], __builtin_ctzll(b0));
+            else if (b1) pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[1], __builtin_ctzll(b1));
+            else if (b2) pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[2], __builtin_ctzll(b2));
+            else pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[3], __builtin_ctzll(b3));
+            uint32_t cnt = 0, mbits = 0;
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) {
+                const bool match = rem[u] && nl[u] == pn;
+                mbits |= match ? 1u << u : 0u;
+                cnt += (uint32_t)__popcll(__ballot(match));
+                rem[u] = rem[u] && !match;
+            }
+            // (one sum at a time: four 64-bit sums held together spill registers)
+            auto book = [&](int shift, uint32_t mask, size_t at) {
+                unsigned long long v = 0;
+#pragma unroll
+                for (int u = 0; u < kSweep; u++)
+                    if ((mbits >> u) & 1u) v += (unsigned long long)(mask ? (p[u] >> shift) & mask : 1u) * wt[u];
+                v = wave_reduce_sum64(v);
+                if (lane == 0) atomicAdd(&acc[at], v);
+            };
+            book(16, 255u, 3 * (size_t)pn + 0);
+            book(8, 255u, 3 * (size_t)pn + 1);
+            book(0, 255u, 3 * (size_t)pn + 2);
+            book(0, 0u, 3 * (size_t)K + pn);  // (mask 0: the factor is 1, the sum of the weights)
+            if (lane == 0) atomicAdd(&acc[4 * K + pn], (unsigned long long)cnt);
+        }
+    } else {
         // Iteration 0: every point adds to the sums of its cluster.  A sweep lies inside one 8^3 cell, so as a
         // rule all its points join the same cluster: one wave reduction and five LDS atomics instead of five
         // 64-way colliding atomics per slot.
@@ -594,8 +636,7 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
         unsigned long long rw = 0, gw = 0, bw = 0, ww = 0, cn = 0;
 #pragma unroll
         for (int u = 0; u < kSweep; u++) {
-            const uint32_t q = base + u * 64 + lane;
-            if (q < e) {
+            if (rem[u]) {
                 same = same && nl[u] == l0;
                 const uint64_t w = wt[u];
                 rw += ((p[u] >> 16) & 255) * w; gw += ((p[u] >> 8) & 255) * w; bw += (p[u] & 255) * w; ww += w; cn += 1;
@@ -613,8 +654,7 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
     }
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
-        const uint32_t q = base + u * 64 + lane;
-        if (q < e) {
+        if (rem[u]) {
             const uint32_t pp = p[u], n_ = nl[u];
             const uint64_t w = wt[u];  // loaded with the key: a gather here would stall every sweep that moves a point
             const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
@@ -692,7 +732,10 @@ __device__ unsigned long long g_wave_tl[8192][8];  // one launch (CNIIC_DBG_TIME
 #define RG_TLC(i, v) do {} while (0)
 #endif
 
-template <typename LabelT, int IDBITS, int WAVES>
+// FIRSTK: 1 = the launch of iteration 0, 0 = a later one, -1 = found out on the device.  The loop with the folded-in update
+// knows which launch it enqueues, and the two bodies share little: compiled apart, the first launch has registers to spare
+// (66 of 80) for booking its points round by round (sweep_points_first).
+template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
@@ -716,7 +759,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
     // iterations add/subtract only the points that moved.
-    const bool first = fz.on ? fz.launch_no == 0 : st->iter == 0;
+    const bool first = FIRSTK >= 0 ? FIRSTK != 0 : (fz.on ? fz.launch_no == 0 : st->iter == 0);
     uint32_t nS = fz.on ? K : cs.moved[0];
     const uint32_t *mlist = cs.moved + 1;  // ids of the centroids the last update changed
     const unsigned long long lt_mask = (1ull << lane) - 1;
@@ -877,7 +920,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                     curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
                     wtn[u] = qn < nte ? cweight[qn] : 0u;
                 }
-                if (first) sweep_points_first<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved);
+                if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved);
                 else sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
@@ -1840,17 +1883,14 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
         } else {
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
                                (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
-            if (ev_start)
-                hipExtLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), (uint32_t)lds,
-                                      c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
-                                      (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
-                                      (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
-                                      (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
-                                      part, st, cs, fz);
-            else
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint8_t, 8, kCellWaves>), dim3(s->nblocks), dim3(64 * kCellWaves), lds, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint8_t>(), part, st, cs, fz);
+            auto kern = !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
+                        : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
+            hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(64 * kCellWaves), (uint32_t)lds,
+                                  c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
+                                  (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
+                                  (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
+                                  (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
+                                  part, st, cs, fz);
         }
         return;
     }
