@@ -80,6 +80,7 @@ struct KmRgbwState {
     bool fused = false;
     bool sup = false;            // super-cell-major assign (k_rgbw_assign_sup): K <= 256, one shard
     bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
+    uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
     DevBuf sup_rec, sup_agg;     // per cell: candidate mask + state word; aggregate of its points
@@ -405,7 +406,9 @@ __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict_
 }
 
 __host__ __device__ constexpr uint32_t cell_rec_words(uint32_t MW) { return (2 + 2 * MW + 15) & ~15u; }  // u32 words of a cell's skip record (CellState below)
-constexpr uint32_t kMaxMovedSkip = 128;  // skip schedule when at most this many centroids moved (2 per lane)
+constexpr uint32_t kMaxMovedSkip = 64;  // skip schedule when at most this many centroids moved (one per lane of the test; measured on the
+                                        // headline encode: 128 -> 1.92 ms of assign launches, 96 -> 1.90, 64 -> 1.88, 40 -> 1.88: above ~60 moved
+                                        // centroids a third of the cells are dirty and dealing them round-robin costs more than the full schedule's ranges)
 
 // squared distance from colour key ck to the centre of the cube with low corner bx and side ext + 1
 __device__ __forceinline__ uint32_t centre_dist(uint32_t ck, const CellBox &bx, int32_t ext) {
@@ -932,11 +935,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         }
     } else {
         // ================================================================= SKIP schedule
-        // this shard's cells: [m_lo, m_hi); the (up to 2 per lane) centroids that moved
+        // this shard's cells: [m_lo, m_hi); the centroids that moved, one per lane
+        static_assert(kMaxMovedSkip <= 64, "one moved centroid per lane");
         const uint32_t m_lo = wfirst[gw0], m_hi = wfirst[gw0 + gridDim.x * WAVES];
         const uint32_t k1 = (uint32_t)lane < nS ? mlist[lane] : 0xffffffffu;
-        const uint32_t k2 = 64 + (uint32_t)lane < nS ? mlist[64 + lane] : 0xffffffffu;
-        const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u, ck2 = k2 != 0xffffffffu ? tab[k2].x : 0u;
+        const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u;
         // cells are dealt round-robin: what survives the skip test is clustered around the centroids that
         // moved, and striding spreads those clusters over all waves (a shared atomic queue would
         // saturate: one word serves ~90 dequeues/us)
@@ -963,31 +966,27 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 const uint32_t m = mb + bi * nwaves;
                 if (m >= m_hi) break;
                 uint32_t pvt, c;
-                bool in1, in2;
+                bool in1;
                 if (IDBITS == 8) {
                     const uint32_t r = bi < 4 ? rA : rB;
                     const int l0 = (int)((bi & 3) * 16);
                     pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
                     c = (uint32_t)__builtin_amdgcn_readlane((int)r, l0 + 1);
                     in1 = (((uint32_t)__shfl((int)r, l0 + 2 + (int)((k1 >> 5) & 7), 64) >> (k1 & 31)) & 1u) != 0;
-                    in2 = (((uint32_t)__shfl((int)r, l0 + 2 + (int)((k2 >> 5) & 7), 64) >> (k2 & 31)) & 1u) != 0;
                 } else {
                     pvt = (uint32_t)__builtin_amdgcn_readlane((int)rA, 0);
                     c = (uint32_t)__builtin_amdgcn_readlane((int)rA, 1);
-                    const uint32_t i1 = 2 + ((k1 & 0x7ffu) >> 5), i2 = 2 + ((k2 & 0x7ffu) >> 5);
-                    // (all four shuffles by every lane: a lane that sits out a shuffle is read as nothing by the others)
+                    const uint32_t i1 = 2 + ((k1 & 0x7ffu) >> 5);
+                    // (both shuffles by every lane: a lane that sits out a shuffle is read as nothing by the others)
                     const uint32_t a1 = (uint32_t)__shfl((int)rA, (int)(i1 & 63), 64), b1 = (uint32_t)__shfl((int)rB, (int)(i1 & 63), 64);
-                    const uint32_t a2 = (uint32_t)__shfl((int)rA, (int)(i2 & 63), 64), b2 = (uint32_t)__shfl((int)rB, (int)(i2 & 63), 64);
-                    const uint32_t w1 = i1 < 64 ? a1 : b1, w2 = i2 < 64 ? a2 : b2;
+                    const uint32_t w1 = i1 < 64 ? a1 : b1;
                     in1 = ((w1 >> (k1 & 31)) & 1u) != 0;
-                    in2 = ((w2 >> (k2 & 31)) & 1u) != 0;
                 }
                 Dominance dm;
                 dm.set(cell_box(c), (1 << kCellShift) - 1, pvt);
                 // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
                 bool dirty = false;
                 if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
-                if (k2 != 0xffffffffu) dirty = dirty || in2 || dm.worst(ck2) >= 0;
                 RG_PHASE(6);
                 RG_TLC(7, 1);
                 if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
@@ -1667,6 +1666,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->cells = !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE));
     s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
     s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
+    if (const char *ms = getenv("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
     const uint64_t n = hi - lo;
@@ -1858,7 +1858,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
-                     s->no_skip ? 0u : kMaxMovedSkip, getenv("CNIIC_DBG_TIMELINE") ? (uint32_t)atoi(getenv("CNIIC_DBG_TIMELINE")) + 1u : 0u};
+                     s->no_skip ? 0u : s->max_skip, getenv("CNIIC_DBG_TIMELINE") ? (uint32_t)atoi(getenv("CNIIC_DBG_TIMELINE")) + 1u : 0u};
         if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
             hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
@@ -2105,7 +2105,7 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
             const bool prev_in_ring = i >= 1 && i - 1 < hf.iter && hf.iter - (i - 1) <= kHistRing;
             const long long nmv = prev_in_ring ? (long long)hf.nmoved_ring[(i - 1) % kHistRing] : -1;
             const bool in_ring = i < hf.iter && hf.iter - i <= kHistRing;
-            int cls = i >= working ? 4 : i == 0 ? 0 : (s->fused && i == (size_t)hf.iter) ? 3 : (nmv >= 0 && nmv <= (long long)kMaxMovedSkip && !s->no_skip) ? 2 : 1;
+            int cls = i >= working ? 4 : i == 0 ? 0 : (s->fused && i == (size_t)hf.iter) ? 3 : (nmv >= 0 && nmv <= (long long)s->max_skip && !s->no_skip) ? 2 : 1;
             cms[cls] += ms; cn[cls]++;
             if (f) fprintf(f, "%zu,%.2f,%s,%lld,%lld\n", i, ms * 1e3, names[cls], nmv, in_ring ? (long long)hf.changed_ring[i % kHistRing] : -1ll);
         }
