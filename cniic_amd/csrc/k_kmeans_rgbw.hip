@@ -56,7 +56,11 @@ constexpr uint32_t kMaxBlocks = 512;
 constexpr int kCellWaves = CNIIC_CELL_WAVES;                  // waves per block (narrow labels); they share the block's cell range
 constexpr uint32_t kCellBlocks = 256 * (kCellWaves == 4 ? 6 : kCellWaves == 8 ? 3 : 2);  // every block resident at once (LDS, K <= 256)
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
-constexpr uint32_t kCellFixedCost = 1024; // per-cell overhead in point-equivalents (work split between waves)
+// The full schedule's split of the cells into ranges of equal estimated cost: a cell costs its candidate build plus one sweep
+// per 256 points (a sweep of 3 points takes as long as one of 256) -- 2 : 1 measured on the headline encode (assign launches
+// 1.87 ms with "1024 + points", 1.825 with 512 + 256 per sweep; 384 / 640 / 768 + 256: 1.87 / 1.84 / 1.85).
+constexpr uint32_t kCellFixedCost = 512;  // per cell (CNIIC_CELL_COST)
+constexpr uint32_t kCellSweepCost = 256;  // per sweep of 64 x kSweep points (CNIIC_CELL_SWEEP_COST; 0: the cell's points count instead)
 
 struct KmRgbwState {
     Ctx *c = nullptr;
@@ -263,34 +267,37 @@ __global__ __launch_bounds__(256) void k_cell_count(const uint32_t *__restrict__
 // Two launches of kNumCells / 64 one-wave blocks (a single 1024-thread block took 57 us: ~10^5 scattered store
 // requests from one CU): per 64 cells (points, non-empty cells), then every wave adds up the groups before its own.
 constexpr uint32_t kCellGroups = kNumCells / 64;
+// (tot[kCellGroups + g]: the group's sweeps, ceil(points / 256) per cell -- the full schedule's cost model counts them)
 __global__ __launch_bounds__(64) void k_cell_totals(const uint32_t *__restrict__ cell_count, uint2 *__restrict__ tot) {
     const uint32_t v = cell_count[blockIdx.x * 64 + threadIdx.x];
-    const uint32_t sum = wave_reduce_sum(v);
+    const uint32_t sum = wave_reduce_sum(v), sweeps = wave_reduce_sum((v + 64 * kSweep - 1) / (64 * kSweep));
     const uint32_t ne = (uint32_t)__popcll(__ballot(v != 0));
-    if (threadIdx.x == 0) tot[blockIdx.x] = make_uint2(sum, ne);
+    if (threadIdx.x == 0) { tot[blockIdx.x] = make_uint2(sum, ne); tot[kCellGroups + blockIdx.x] = make_uint2(sweeps, 0u); }
 }
 __global__ __launch_bounds__(64) void k_cell_scan(const uint32_t *__restrict__ cell_count, const uint2 *__restrict__ tot,
                                                   uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cursor,
                                                   uint32_t *__restrict__ ne_cell, uint32_t *__restrict__ ne_start,
-                                                  uint32_t *__restrict__ ne_cost, uint32_t *__restrict__ ne_count, uint32_t fixed_cost) {
+                                                  uint32_t *__restrict__ ne_cost, uint32_t *__restrict__ ne_count, uint32_t fixed_cost,
+                                                  uint32_t sweep_cost) {
+    // cost of a cell in the full schedule's split: fixed_cost + points if sweep_cost == 0, else fixed_cost + sweep_cost * sweeps
     const uint32_t lane = threadIdx.x, grp = blockIdx.x;
-    uint32_t ps = 0, pn = 0;
-    for (uint32_t g = lane; g < grp; g += 64) { const uint2 t = tot[g]; ps += t.x; pn += t.y; }
-    const uint32_t base = wave_reduce_sum(ps), nbase = wave_reduce_sum(pn);
-    const uint32_t cell = grp * 64 + lane, v = cell_count[cell];
-    const uint32_t start = base + wave_inclusive_scan(v) - v;
+    uint32_t ps = 0, pn = 0, pw = 0;
+    for (uint32_t g = lane; g < grp; g += 64) { const uint2 t = tot[g]; ps += t.x; pn += t.y; pw += tot[kCellGroups + g].x; }
+    const uint32_t base = wave_reduce_sum(ps), nbase = wave_reduce_sum(pn), wbase = wave_reduce_sum(pw);
+    const uint32_t cell = grp * 64 + lane, v = cell_count[cell], sw = (v + 64 * kSweep - 1) / (64 * kSweep);
+    const uint32_t start = base + wave_inclusive_scan(v) - v, swb = wbase + wave_inclusive_scan(sw) - sw;
     cell_start[cell] = start;
     if (cursor) cursor[cell] = start;
     const unsigned long long nzm = __ballot(v != 0);
     if (v) {
         const uint32_t m = nbase + (uint32_t)__popcll(nzm & ((1ull << lane) - 1ull));
-        ne_cell[m] = cell; ne_start[m] = start; ne_cost[m] = start + m * fixed_cost;
+        ne_cell[m] = cell; ne_start[m] = start; ne_cost[m] = (sweep_cost ? swb * sweep_cost : start) + m * fixed_cost;
     }
     if (grp == kCellGroups - 1 && lane == 63) {
         const uint32_t U = start + v, M = nbase + (uint32_t)__popcll(nzm);
         cell_start[kNumCells] = U;
         ne_start[M] = U;
-        ne_cost[M] = U + M * fixed_cost;
+        ne_cost[M] = (sweep_cost ? (swb + sw) * sweep_cost : U) + M * fixed_cost;
         *ne_count = M;
     }
 }
@@ -1738,15 +1745,16 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         }
         DevBuf count, cursor, cell_tot;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
-        KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8);
-        uint32_t fixed_cost = kCellFixedCost;
-        if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knob
+        KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8 * 2);
+        uint32_t fixed_cost = kCellFixedCost, sweep_cost = kCellSweepCost;
+        if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knobs
+        if (const char *ev = getenv("CNIIC_CELL_SWEEP_COST")) sweep_cost = (uint32_t)atoi(ev);
         if (points_follow) {
             // the caller's partition (k_points.hip) writes ckeys / cweight / labels itself, from cell_start
             hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, cell_count_d, cell_tot.as<uint2>());
             hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, cell_count_d, (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
                                (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
-                               s->ne_count.as<uint32_t>(), fixed_cost);
+                               s->ne_count.as<uint32_t>(), fixed_cost, sweep_cost);
         } else if (rank_table_d) {
             // codec path: the dense colour table (key -> canonical rank + 1) is walked cell by cell
             const uint32_t *cnt = cell_count_d;  // counted by the compaction on its way, else one more walk of the table
@@ -1757,7 +1765,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
             hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, cnt, cell_tot.as<uint2>());
             hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, cnt, (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
                                (uint32_t *)nullptr, s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
-                               s->ne_count.as<uint32_t>(), fixed_cost);
+                               s->ne_count.as<uint32_t>(), fixed_cost, sweep_cost);
             if (s->wide)
                 hipLaunchKernelGGL(k_cells_write_tbl<uint16_t>, dim3(kNumCells), dim3(512), 0, c->stream, rank_table_d, weight_d,
                                    s->cell_start.as<uint32_t>(), Ulist, K, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(),
@@ -1775,7 +1783,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
             hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, count.as<uint32_t>(), cell_tot.as<uint2>());
             hipLaunchKernelGGL(k_cell_scan, dim3(kCellGroups), dim3(64), 0, c->stream, count.as<uint32_t>(), (const uint2 *)cell_tot.as<uint2>(), s->cell_start.as<uint32_t>(),
                                cursor.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(), s->ne_cost.as<uint32_t>(),
-                               s->ne_count.as<uint32_t>(), fixed_cost);
+                               s->ne_count.as<uint32_t>(), fixed_cost, sweep_cost);
             hipLaunchKernelGGL(k_cell_scatter, dim3(g), dim3(256), 0, c->stream, keys_d, weight_d, U, cursor.as<uint32_t>(),
                                s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->crank.as<uint32_t>());
             // init_assignment (kmeans.rs:61-78) by canonical rank

@@ -24,6 +24,7 @@ ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
 out = torch.empty(size * size * 4 + (1 << 20), dtype=torch.uint8, device=dev)
 expr = "cluster-colors(%d)" % K
 ctx.encode(expr, img, w=size, h=size, out=out)
+block_end = {}
 for L in sys.argv[1:]:
     path = "/tmp/tl_%s.csv" % L
     os.environ["CNIIC_DBG_TIMELINE"] = L
@@ -45,9 +46,19 @@ for L in sys.argv[1:]:
     for i in order:
         print("    late wave %5d (block %4d): prologue done %.2f, first test/build %.2f, loop done %.2f, end %.2f | %d dirty of %d cells" %
               (a[i, 0], a[i, 0] // 8, t[i, 1], t[i, 2], t[i, 3], t[i, 5], dirty[i], cells[i]))
+    blk = (a[:, 0] // 8).astype(np.int64)
+    bend = np.zeros(blk.max() + 1)
+    np.maximum.at(bend, blk, t[:, 3])
+    block_end[L] = bend
+    print("  blocks: loop done min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (bend.min(), np.percentile(bend, 10), np.percentile(bend, 50), np.percentile(bend, 90), bend.max()))
     loop = t[:, 3] - t[:, 1]
     for d in range(0, 9):
         sel = dirty == d
         if sel.sum():
             print("  waves with %d dirty cells: %5d, loop time mean %6.2f max %6.2f us" % (d, sel.sum(), loop[sel].mean(), loop[sel].max()))
+Ls = list(block_end)
+for i in range(len(Ls) - 1):
+    x, y = block_end[Ls[i]], block_end[Ls[i + 1]]
+    if len(x) == len(y):
+        print("per-block end of loop, launch %s vs launch %s: correlation %.3f" % (Ls[i], Ls[i + 1], np.corrcoef(x, y)[0, 1]))
 ctx.close()
