@@ -51,6 +51,29 @@ for L in sys.argv[1:]:
     np.maximum.at(bend, blk, t[:, 3])
     block_end[L] = bend
     print("  blocks: loop done min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (bend.min(), np.percentile(bend, 10), np.percentile(bend, 50), np.percentile(bend, 90), bend.max()))
+    if a.shape[1] >= 13 and dirty.sum() == a[:, 7].sum() * 0 + dirty.sum() and a[:, 9].sum() > 0:
+        # full schedule: what a block's loop time is made of (least squares over the blocks)
+        nb = blk.max() + 1
+        X = np.zeros((nb, 6))
+        for col, src in enumerate((8, 7, 9, 10, 11, 12)):  # cells, sweeps, candidates, points, S builds, S lengths
+            np.add.at(X[:, col], blk, a[:, src].astype(np.float64))
+        bstart = np.full(nb, 1e9)
+        np.minimum.at(bstart, blk, t[:, 1])
+        y = bend - bstart
+        A = np.column_stack([np.ones(nb), X])
+        coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+        pred = A @ coef
+        names6 = ["const", "per cell", "per sweep", "per candidate", "per point", "per S build", "per S entry"]
+        print("  block loop time ~ " + ", ".join("%s %.4f" % (n, c) for n, c in zip(names6, coef)) + " (us); R^2 %.3f; block means: cells %.1f sweeps %.1f candidates %.0f points %.0f S builds %.1f" %
+              (1 - ((y - pred) ** 2).sum() / ((y - y.mean()) ** 2).sum(), X[:, 0].mean(), X[:, 1].mean(), X[:, 2].mean(), X[:, 3].mean(), X[:, 4].mean()))
+    nb_ = len(bend)
+    ids = np.arange(nb_)
+    for name, key in (("block %% 8 (XCD if blocks are dealt round-robin)", ids % 8), ("block // 256 (dispatch round)", ids // 256), ("block %% 32 // 8", ids % 32 // 8)):
+        ks = np.unique(key)
+        print(("  end of loop by " + name + ": ") + " ".join("%.1f" % bend[key == k].mean() for k in ks))
+    # how much of the variance is a smooth function of the block index (neighbouring blocks hold neighbouring cells)?
+    sm = np.convolve(bend, np.ones(9) / 9, mode="same")
+    print("  variance explained by a 9-block running mean over the block index: %.2f" % (1 - ((bend - sm)[8:-8] ** 2).sum() / ((bend - bend.mean())[8:-8] ** 2).sum()))
     loop = t[:, 3] - t[:, 1]
     for d in range(0, 9):
         sel = dirty == d
