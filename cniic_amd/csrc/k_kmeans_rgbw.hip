@@ -728,7 +728,7 @@ __device__ __forceinline__ void poll_record(PollRec *ring, uint32_t launch_no, c
 __device__ unsigned long long g_rgbw_phase[12];
 __device__ unsigned long long g_rgbw_blk[512][4];  // census of one launch (CNIIC_DBG_LAUNCH): per block start, end (100 MHz clock), HW id, items
 __device__ unsigned int g_rgbw_launch[128][8];  // per launch of the super-cell kernel: swept cells, swept points, bulk cells, single-candidate cells, longest list, non-empty cells, sum |S|
-__device__ unsigned long long g_wave_tl[8192][8];  // one launch (CNIIC_DBG_TIMELINE): per wave, the 100 MHz clock at entry, after the prologue, after the first tests / first build, at the end of the cell loop, after the barrier, at the end; [6] dirty cells, [7] cells
+__device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIMELINE): per wave, the 100 MHz clock at entry, after the prologue, after the first tests / first build, at the end of the cell loop, after the barrier, at the end; [6] dirty cells (skip) / sweeps (full), [7] cells, [8] candidates summed over the cells, [9] points, [10] super-cell list builds, [11] their lengths summed
 #define RG_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
 #define RG_TL(i) do { if (tl_on_) tl_[i] = wall_clock64(); } while (0)
 #define RG_TL1(i) do { if (tl_on_ && !tl_[i]) tl_[i] = wall_clock64(); } while (0)
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     __shared__ unsigned long long s_ph[12];
     if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
     const bool tl_on_ = cs.dbg && fz.launch_no + 1 == cs.dbg;
-    unsigned long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RG_TL(0);
 #endif
     uint32_t moved = 0;
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             uint32_t s_next = 0, e_next = 0, c_next = 0;
             if (mn < mb1) { s_next = ne_start[mn]; e_next = ne_start[mn + 1]; c_next = ne_cell[mn]; }
             RG_PHASE(1);
-            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); }
+            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
             RG_PHASE(2);
             const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
                                                 : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
@@ -918,6 +918,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             RG_COUNT(9, 1);
             RG_TL1(2);
             RG_TLC(7, 1);
+            RG_TLC(6, (e - s + 64 * kSweep - 1) / (64 * kSweep));
+            RG_TLC(8, ncand);
+            RG_TLC(9, e - s);
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
                 const uint32_t nts = more ? base + 64 * kSweep : s_next;
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     if (tl_on_ && lane == 0) {
         const uint32_t wv_ = blockIdx.x * WAVES + wid;
         if (wv_ < 8192)
-            for (int i = 0; i < 8; i++) g_wave_tl[wv_][i] = tl_[i];
+            for (int i = 0; i < 12; i++) g_wave_tl[wv_][i] = tl_[i];
     }
     if (lane == 0)
         for (int i = 0; i < 12; i++)
@@ -2149,12 +2152,12 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         if (s->sup) fprintf(stderr, "assign_sup (wave clocks): prologue %llu S build %llu classify %llu first loads %llu sweeps %llu tail wait %llu flush %llu\n",
                             ph[0], ph[2], ph[3], ph[1], ph[4], ph[11], ph[5]);
         if (const char *tf = getenv("CNIIC_DBG_TIMELINE_FILE")) {
-            static unsigned long long T[8192][8];
+            static unsigned long long T[8192][12];
             CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(T, HIP_SYMBOL(g_wave_tl), sizeof T));
             if (FILE *f = fopen(tf, "w")) {
-                fprintf(f, "wave,t0,t1,t2,t3,t4,t5,dirty,cells\n");
+                fprintf(f, "wave,t0,t1,t2,t3,t4,t5,dirty,cells,cands,points,sbuilds,slen\n");
                 for (int i = 0; i < 8192; i++)
-                    if (T[i][0]) fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, T[i][0], T[i][1], T[i][2], T[i][3], T[i][4], T[i][5], T[i][6], T[i][7]);
+                    if (T[i][0]) fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, T[i][0], T[i][1], T[i][2], T[i][3], T[i][4], T[i][5], T[i][6], T[i][7], T[i][8], T[i][9], T[i][10], T[i][11]);
                 fclose(f);
             }
             memset(T, 0, sizeof T);

@@ -51,7 +51,7 @@ for L in sys.argv[1:]:
     np.maximum.at(bend, blk, t[:, 3])
     block_end[L] = bend
     print("  blocks: loop done min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (bend.min(), np.percentile(bend, 10), np.percentile(bend, 50), np.percentile(bend, 90), bend.max()))
-    if a.shape[1] >= 13 and dirty.sum() == a[:, 7].sum() * 0 + dirty.sum() and a[:, 9].sum() > 0:
+    if a.shape[1] >= 13 and a[:, 10].sum() > 0:
         # full schedule: what a block's loop time is made of (least squares over the blocks)
         nb = blk.max() + 1
         X = np.zeros((nb, 6))
