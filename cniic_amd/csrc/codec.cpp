@@ -478,6 +478,7 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     const uint32_t K = s->K;
     const uint64_t U = s->U, npf = (uint64_t)w * h, n = npf * F;
     KmRgbwState *km = s->km;
+    host_trace().mark("frames: enter");
     if (!F || !npf) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: empty batch");
     if (stride & 3) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: the stride between streams must be a multiple of 4");
     if (s->sp_mode && s->sp.npx != n) return c->fail(CNIIC_ERR_BAD_ARG, "cc_finish_frames: the session was opened on %llu pixels, the batch has %llu",
@@ -489,11 +490,14 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     const bool wide = km_rgbw_is_wide(km);
     const uint64_t lb = wide ? 2 : 1;
     DevBuf lab_d, key2label, pixlab, pixlab_al, cnt_d;
+    host_trace().mark("frames: result_begin");
     CNIIC_HIP_TRY(c, pixlab.alloc(n * lb + 16));
+    host_trace().mark("frames: alloc pixel labels");
     if (s->sp_mode) {
         uint32_t *cell_start, *ckeys, *cweight;
         km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
         CNIIC_TRY(sp_pixel_labels(c, &s->sp, rgb_d, cell_start, ckeys, km_rgbw_labels_internal(km, nullptr), wide, pixlab.p));
+        host_trace().mark("frames: pixel labels enqueued");
     } else {
         CNIIC_HIP_TRY(c, lab_d.alloc(U * lb));
         CNIIC_TRY(km_rgbw_labels_canonical(km, lab_d.p));
@@ -512,8 +516,10 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     }
     CNIIC_HIP_TRY(c, cnt_d.alloc((uint64_t)F * K * 4));
     CNIIC_TRY(frame_label_hist(c, labs, npf, lab_stride, F, wide, K, cnt_d.as<uint32_t>()));
-    std::vector<uint32_t> cnt((size_t)F * K);
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(cnt.data(), cnt_d.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    const bool gpu_trees = !wide && K <= 256 && getenv("CNIIC_FRAME_TREES_HOST") == nullptr;
+    std::vector<uint32_t> cnt(gpu_trees ? 0 : (size_t)F * K);
+    if (!gpu_trees) CNIIC_HIP_TRY(c, hipMemcpyAsync(cnt.data(), cnt_d.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    host_trace().mark("frames: hist enqueued");
     CNIIC_TRY(km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st));
     if (stats) *stats = st;
     uint64_t min_cc = (uint64_t)(0.99 * (double)K);  // check_enough_active_clusters (kmeans.rs:41-57)
@@ -521,7 +527,48 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     if (st.active < min_cc)
         return c->fail(CNIIC_ERR_FEW_ACTIVE, "Not enough active clusters: requested %u, got %llu (min allowed: %llu)", K,
                        (unsigned long long)st.active, (unsigned long long)min_cc);
+    host_trace().mark("frames: result_end (sync)");
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    host_trace().mark("frames: wait for the histograms");
+    if (gpu_trees) {
+        // ---- K <= 256: codes, code tables and stream headers of all frames by one kernel (k_frame_trees); the host sees the
+        // lengths (it owes them to the caller and must hold them against the stride before anything is packed) and nothing else
+        const bool direct = is_device_ptr(out) && (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+        DevBuf staging, clen_d, ccode_d, meta_d;
+        uint8_t *dev = out;
+        if (!direct) { CNIIC_HIP_TRY(c, staging.alloc(stride * F + 16)); dev = staging.as<uint8_t>(); }
+        CNIIC_HIP_TRY(c, hipMemsetAsync(dev, 0, stride * F, c->stream));
+        CNIIC_HIP_TRY(c, clen_d.alloc((size_t)F * K));
+        CNIIC_HIP_TRY(c, ccode_d.alloc((size_t)F * K * 8));
+        CNIIC_HIP_TRY(c, meta_d.alloc((size_t)F * 24 + 8));  // bit base, payload bits, stream length per frame; error word
+        uint64_t *bb_d = meta_d.as<uint64_t>(), *nb_d = bb_d + F, *ln_d = nb_d + F;
+        uint32_t *err_d = reinterpret_cast<uint32_t *>(ln_d + F);
+        CNIIC_HIP_TRY(c, hipMemsetAsync(err_d, 0, 8, c->stream));
+        CNIIC_TRY(frame_trees(c, cnt_d.as<uint32_t>(), km_rgbw_centroids_dev(km), F, K, w, h, dev, stride, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), bb_d, nb_d, ln_d, err_d));
+        std::vector<uint64_t> meta((size_t)F * 3 + 1);
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(meta.data(), meta_d.p, (size_t)F * 24 + 8, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        host_trace().mark("frames: trees, codes, headers (GPU) + lengths back");
+        const uint32_t err = (uint32_t)meta[(size_t)F * 3];
+        if (err & 3u) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code");
+        for (uint32_t f = 0; f < F; f++) {
+            lens[f] = meta[2 * (size_t)F + f];
+            if ((err & 4u) || ((lens[f] + 3) & ~3ull) > stride)
+                return c->fail(CNIIC_ERR_CAPACITY, "encode: stream of frame %u is %llu bytes, %llu between streams", f, (unsigned long long)lens[f], (unsigned long long)stride);
+        }
+        std::vector<uint64_t> totals(F, 0);
+        CNIIC_TRY(huff_pack_labels_frames(c, labs, npf, lab_stride, F, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), dev, stride, nullptr, totals.data(), bb_d));
+        host_trace().mark("frames: pack (+sync)");
+        for (uint32_t f = 0; f < F; f++)
+            if (totals[f] != meta[(size_t)F + f])
+                return c->fail(CNIIC_ERR_HIP, "cluster-colors: frame %u packed %llu bits, its histogram predicts %llu", f, (unsigned long long)totals[f], (unsigned long long)meta[(size_t)F + f]);
+        if (!direct) {
+            CNIIC_HIP_TRY(c, hipMemcpyAsync(out, dev, stride * F, is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+            CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        host_trace().dump();
+        return CNIIC_OK;
+    }
     // ---- per frame on the host: histogram of the reduced frame = its pixels per centroid COLOUR (two clusters with one mean
     // are one symbol), tree, serialised decoder, per-cluster code
     std::vector<std::vector<uint8_t>> headers(F);
@@ -569,6 +616,7 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
         work();
         for (auto &t : pool) t.join();
     }
+    host_trace().mark("frames: trees, codes, headers (host threads)");
     if (bad) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code");
     uint64_t hmax = 0;
     for (uint32_t f = 0; f < F; f++) {
@@ -595,6 +643,7 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     CNIIC_HIP_TRY(c, hipMemcpyAsync(clen_d.p, clen.data(), clen.size(), hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(ccode_d.p, ccode.data(), ccode.size() * 8, hipMemcpyHostToDevice, c->stream));
     CNIIC_TRY(huff_pack_labels_frames(c, labs, npf, lab_stride, F, wide, K, clen_d.as<uint8_t>(), ccode_d.as<uint64_t>(), dev, stride, bit_base.data(), totals.data()));
+    host_trace().mark("frames: copies + pack (+sync)");
     for (uint32_t f = 0; f < F; f++)
         if (totals[f] != nbits[f])
             return c->fail(CNIIC_ERR_HIP, "cluster-colors: frame %u packed %llu bits, its histogram predicts %llu", f, (unsigned long long)totals[f], (unsigned long long)nbits[f]);
@@ -602,6 +651,7 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
         CNIIC_HIP_TRY(c, hipMemcpyAsync(out, dev, stride * F, is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    host_trace().dump();
     return CNIIC_OK;
 }
 

@@ -456,6 +456,7 @@ int km_rgbw_result_end(KmRgbwState *s, uint8_t *centroids_h, uint64_t *members_h
 int km_rgbw_time_assign(KmRgbwState *s, int reps, double *ms_per_launch);
 int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h);
 void *km_rgbw_partials_dev(KmRgbwState *s);
+const uint32_t *km_rgbw_centroids_dev(KmRgbwState *s);
 bool km_rgbw_is_wide(KmRgbwState *s);                     // u16 labels (K > 256) instead of u8
 int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d); // u8/u16 labels of all points, canonical order
 void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes);
@@ -545,6 +546,9 @@ int scatter_labels_by_key(Ctx *c, const uint32_t *keys_d, const void *labels_d, 
 // a batch of equally sized frames sharing one palette: labels per (frame, cluster), and the label pack of every frame in one go
 int frame_label_hist(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, uint32_t *out_d /* u32[frames][K] */);
 int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, const uint8_t *clen_d,
-                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h);
+                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h, const uint64_t *bit_base_d = nullptr);
+// the Huffman codes and stream headers of a batch's frames on the GPU (K <= 256; k_huff.hip k_frame_trees)
+int frame_trees(Ctx *c, const uint32_t *cnt_d, const uint32_t *cent_d, uint32_t frames, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d, uint64_t stride,
+                uint8_t *clen_d, uint64_t *ccode_d, uint64_t *bit_base_d, uint64_t *nbits_d, uint64_t *lens_d, uint32_t *err_d);
 
 }  // namespace cniic

@@ -422,6 +422,147 @@ int frame_label_hist(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_st
     return CNIIC_OK;
 }
 
+// ---- the Huffman code of every frame of a batch, on the GPU (K <= 256): one 256-thread block per frame does what the host did
+// per frame with std::sort + huff_build_tree + huff_codes + huff_serialize_tree (codec.cpp cc_finish_frames; huff_host.cpp) --
+// 128 frames took 16 host threads 0.6 ms between two stretches of GPU work.  Same rules, so the same bytes:
+//   symbols   the frame's clusters by centroid COLOUR, ascending (two clusters with one mean are one symbol; huf.rs:30, clusterc.rs:43-53)
+//   tree      leaves sorted by (count, symbol), two-queue merge: the rarest first, a leaf before a branch among equals
+//   codes     Bit::Zero = left, Bit::One = right from the root (huf.rs:125-135); longer than 64 bits is an error
+//   header    u32 w, u32 h, then the trie in pre-order: 0 + u64 3 + r g b for a leaf, 1 + left + right for a branch (huf.rs:305-321)
+// Out: the header at out + f stride, the code table of the frame's clusters, the header's bit length, the payload's bit count.
+__device__ __forceinline__ void bitonic_sort_256(unsigned long long *a, uint32_t tid) {
+    for (uint32_t k = 2; k <= 256; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            const uint32_t x = tid ^ j;
+            if (x > tid) {
+                const unsigned long long u = a[tid], v = a[x];
+                const bool up = (tid & k) == 0;
+                if ((u > v) == up) { a[tid] = v; a[x] = u; }
+            }
+        }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_frame_trees(const uint32_t *__restrict__ cnt /* [F][K] */, const uint32_t *__restrict__ cent /* [K] 0xRRGGBB */,
+                                                     uint32_t K, uint32_t w, uint32_t h, uint8_t *__restrict__ out, uint64_t stride,
+                                                     uint8_t *__restrict__ clen /* [F][K] */, unsigned long long *__restrict__ ccode /* [F][K] */,
+                                                     unsigned long long *__restrict__ bit_base /* [F] */, unsigned long long *__restrict__ nbits /* [F] */,
+                                                     unsigned long long *__restrict__ lens /* [F] */, uint32_t *__restrict__ err) {
+    __shared__ unsigned long long s_sort[256];
+    __shared__ uint32_t s_key[256], s_cnt[256], s_bfreq[256];
+    __shared__ unsigned short s_symk[256], s_left[256], s_right[256], s_parent[512], s_size[512];
+    __shared__ unsigned char s_side[512], s_len[256];
+    __shared__ unsigned long long s_code[256], s_bits;
+    __shared__ uint32_t s_wsum[4], s_n;
+    const uint32_t tid = threadIdx.x, f = blockIdx.x;
+    const uint32_t *fc = cnt + (size_t)f * K;
+    const uint32_t myc = tid < K ? fc[tid] : 0u;
+    // ---- symbols: (colour, cluster) sorted; heads of runs of one colour are the symbols
+    s_sort[tid] = myc ? (((unsigned long long)(cent[tid] & 0xffffffu) << 32) | tid) : ~0ull;
+    s_cnt[tid] = 0;
+    if (tid == 0) s_bits = 0;
+    bitonic_sort_256(s_sort, tid);
+    const unsigned long long me = s_sort[tid];
+    const bool valid = me != ~0ull;
+    const uint32_t key = (uint32_t)(me >> 32), k = (uint32_t)me & 0xffffu;
+    const bool head = valid && (tid == 0 || (uint32_t)(s_sort[tid - 1] >> 32) != key);
+    uint32_t inc = wave_inclusive_scan(head ? 1u : 0u);
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = inc;
+    __syncthreads();
+    for (uint32_t i = 0; i < (tid >> 6); i++) inc += s_wsum[i];
+    const uint32_t si = inc - 1;  // symbol of this (colour, cluster) entry
+    if (tid == 255) s_n = inc;
+    if (valid) {
+        s_symk[k] = (unsigned short)si;
+        if (head) s_key[si] = key;
+        atomicAdd(&s_cnt[si], fc[k]);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (n == 0) {  // (a frame without pixels cannot happen: npf > 0)
+        if (tid == 0) atomicOr(err, 1u);
+        return;
+    }
+    // ---- leaves by (count, symbol)
+    s_sort[tid] = tid < n ? (((unsigned long long)s_cnt[tid] << 32) | tid) : ~0ull;
+    bitonic_sort_256(s_sort, tid);
+    // ---- two-queue merge (build_tree_u32), one thread; sizes in bytes of the serialised subtrees on the way
+    if (tid < n) s_size[tid] = 12;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t li = 0, bi = 0, made = 0;
+        while (made + 1 < n) {
+            uint32_t node[2], fr[2];
+            for (int q = 0; q < 2; q++) {
+                const uint32_t lc = li < n ? (uint32_t)(s_sort[li] >> 32) : 0u;
+                if (li < n && (bi >= made || lc <= s_bfreq[bi])) { fr[q] = lc; node[q] = (uint32_t)s_sort[li] & 0xffffu; li++; }
+                else { fr[q] = s_bfreq[bi]; node[q] = n + bi; bi++; }
+            }
+            s_left[made] = (unsigned short)node[0];
+            s_right[made] = (unsigned short)node[1];
+            s_bfreq[made] = fr[0] + fr[1];
+            s_parent[node[0]] = (unsigned short)(n + made); s_side[node[0]] = 0;
+            s_parent[node[1]] = (unsigned short)(n + made); s_side[node[1]] = 1;
+            s_size[n + made] = (unsigned short)(1 + s_size[node[0]] + s_size[node[1]]);
+            made++;
+        }
+    }
+    __syncthreads();
+    const uint32_t root = n > 1 ? 2 * n - 2 : 0, nnodes = 2 * n - 1;
+    uint8_t *o = out + (size_t)f * stride;
+    const unsigned long long hbytes = 8ull + 12ull * n + (n - 1);
+    const bool fits = hbytes <= stride;  // (the caller checks the whole stream against the stride once the lengths are back; the header alone must not overrun it)
+    if (!fits && tid == 0) atomicOr(err, 4u);
+    if (fits && tid < 8) o[tid] = (uint8_t)((tid < 4 ? w : h) >> (8 * (tid & 3)));
+    // ---- every node walks up to the root: its offset in the pre-order stream, and for a leaf its code
+    for (uint32_t v = tid; v < nnodes; v += 256) {
+        uint32_t off = 0, depth = 0, cur = v;
+        unsigned long long code = 0;
+        while (cur != root) {
+            const uint32_t p = s_parent[cur], sd = s_side[cur];
+            off += 1 + (sd ? s_size[s_left[p - n]] : 0u);
+            if (v < n) { if (depth < 64) code |= (unsigned long long)sd << depth; depth++; }
+            cur = p;
+        }
+        uint8_t *b = o + 8 + off;
+        if (v < n) {
+            if (depth > 64) atomicOr(err, 2u);
+            s_len[v] = (unsigned char)(depth > 64 ? 0 : depth);
+            s_code[v] = code;
+            atomicAdd(&s_bits, (unsigned long long)s_cnt[v] * depth);
+            const uint32_t ky = s_key[v];
+            if (fits) {
+                b[0] = 0; b[1] = 3; b[2] = b[3] = b[4] = b[5] = b[6] = b[7] = b[8] = 0;
+                b[9] = (uint8_t)(ky >> 16); b[10] = (uint8_t)(ky >> 8); b[11] = (uint8_t)ky;
+            }
+        } else if (fits) {
+            b[0] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid < K) {
+        const uint32_t sy = s_symk[tid];
+        clen[(size_t)f * K + tid] = myc ? s_len[sy] : (unsigned char)0;
+        ccode[(size_t)f * K + tid] = myc ? s_code[sy] : 0ull;
+    }
+    if (tid == 0) {
+        bit_base[f] = hbytes * 8;
+        nbits[f] = s_bits;
+        lens[f] = hbytes + (s_bits + 7) / 8;
+    }
+}
+
+int frame_trees(Ctx *c, const uint32_t *cnt_d, const uint32_t *cent_d, uint32_t frames, uint32_t K, uint32_t w, uint32_t h, uint8_t *out_d, uint64_t stride,
+                uint8_t *clen_d, uint64_t *ccode_d, uint64_t *bit_base_d, uint64_t *nbits_d, uint64_t *lens_d, uint32_t *err_d) {
+    if (K > 256) return c->fail(CNIIC_ERR_BAD_ARG, "frame_trees: K <= 256");
+    hipLaunchKernelGGL(k_frame_trees, dim3(frames), dim3(256), 0, c->stream, cnt_d, cent_d, K, w, h, out_d, stride, clen_d,
+                       reinterpret_cast<unsigned long long *>(ccode_d), reinterpret_cast<unsigned long long *>(bit_base_d),
+                       reinterpret_cast<unsigned long long *>(nbits_d), reinterpret_cast<unsigned long long *>(lens_d), err_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
 // exclusive scan (u64) of each frame's row of chunk totals: one 1024-thread block per frame
 __global__ __launch_bounds__(1024) void k_pack_scan_frames(const uint32_t *__restrict__ chunk_bits, uint32_t nchunks, uint64_t *__restrict__ chunk_off,
                                                            uint64_t *__restrict__ totals) {
@@ -453,7 +594,8 @@ __global__ __launch_bounds__(1024) void k_pack_scan_frames(const uint32_t *__res
 // for the whole batch (grid.y = frame; one launch triple per frame was 2 ms for 128 frames, two thirds of it launch
 // overhead); one synchronisation at the end brings totals_h[f] (bits packed per frame).
 int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t lab_stride, uint32_t frames, bool wide, uint32_t K, const uint8_t *clen_d,
-                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h) {
+                            const uint64_t *ccode_d, uint8_t *out_d, uint64_t stride, const uint64_t *bit_base_h, uint64_t *totals_h,
+                            const uint64_t *bit_base_d) {
     if (!frames || !npf) return CNIIC_OK;
     if ((reinterpret_cast<uintptr_t>(out_d) & 3) || (stride & 3)) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output and stride must be 4-byte aligned");
     if (frames > 65535) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: at most 65535 frames per batch");
@@ -462,8 +604,11 @@ int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t
     CNIIC_HIP_TRY(c, cb.alloc((uint64_t)frames * nchunks * 4));
     CNIIC_HIP_TRY(c, co.alloc((uint64_t)frames * nchunks * 8));
     CNIIC_HIP_TRY(c, tot.alloc((uint64_t)frames * 8));
-    CNIIC_HIP_TRY(c, bb.alloc((uint64_t)frames * 8));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(bb.p, bit_base_h, (size_t)frames * 8, hipMemcpyHostToDevice, c->stream));
+    if (!bit_base_d) {
+        CNIIC_HIP_TRY(c, bb.alloc((uint64_t)frames * 8));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(bb.p, bit_base_h, (size_t)frames * 8, hipMemcpyHostToDevice, c->stream));
+        bit_base_d = bb.as<uint64_t>();
+    }
     const dim3 grid(nchunks, frames);
     if (wide)
         hipLaunchKernelGGL(k_pack_count_lab<uint16_t>, grid, dim3(kPackThreads), K, c->stream, reinterpret_cast<const uint16_t *>(pixlab_d), npf, K, clen_d,
@@ -475,11 +620,11 @@ int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t
     if (wide)
         hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint16_t *>(pixlab_d), npf, K,
                            clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
-                           (const uint64_t *)bb.as<uint64_t>());
+                           bit_base_d);
     else
         hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint8_t *>(pixlab_d), npf, K,
                            clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
-                           (const uint64_t *)bb.as<uint64_t>());
+                           bit_base_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(totals_h, tot.p, (size_t)frames * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));

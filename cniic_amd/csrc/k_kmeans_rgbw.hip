@@ -2205,6 +2205,7 @@ int km_rgbw_partials(KmRgbwState *s, uint64_t *sums_h, uint64_t *wsum_h, uint64_
 }
 
 void *km_rgbw_partials_dev(KmRgbwState *s) { return s->partials; }
+const uint32_t *km_rgbw_centroids_dev(KmRgbwState *s) { return s->cent.as<uint32_t>(); }  // [K] 0xRRGGBB, as of the last update
 bool km_rgbw_is_wide(KmRgbwState *s) { return s->wide; }
 
 // u8/u16 labels in CANONICAL point order on the device (dst holds U entries)

@@ -445,6 +445,57 @@ def test_frame_batch_hip_one_rank_equals_union_clustering(monkeypatch, route, F,
     ctx.close()
 
 
+def _encode_frames_hip(frames, K, env_host_trees):
+    import torch
+    import cniic_amd
+    from cniic_amd.dist import ShardedClusterColors
+    F, h, w = frames.shape[:3]
+    old = os.environ.pop("CNIIC_FRAME_TREES_HOST", None)
+    if env_host_trees:
+        os.environ["CNIIC_FRAME_TREES_HOST"] = "1"
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+        ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        stride = (w * h * 4 + 8192 + 3) & ~3
+        out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
+        lens, st = ShardedClusterColors(ctx, K, None, dev).encode_frames(torch.from_numpy(frames).to(dev), w, h, F, out, stride)
+        host = out.cpu().numpy()
+        ctx.close()
+        return [bytes(host[f * stride:f * stride + lens[f]].tobytes()) for f in range(F)], st
+    finally:
+        os.environ.pop("CNIIC_FRAME_TREES_HOST", None)
+        if old is not None:
+            os.environ["CNIIC_FRAME_TREES_HOST"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [2, 5, 64, 256])
+def test_frame_codes_on_the_gpu_equal_the_host_and_the_oracle(monkeypatch, K):
+    """the per-frame Huffman codes, code tables and stream headers made by k_frame_trees (K <= 256) against the host path
+    (CNIIC_FRAME_TREES_HOST=1) and the oracle's union clustering, on a batch with awkward frames: one of a single colour (a
+    one-symbol code: zero-length, huf.rs:140-142), one of two colours, one that uses few of the clusters, noisy ones"""
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "0")
+    from cniic_amd import synth
+    h, w = 37, 53
+    rng = np.random.default_rng(1234 + K)
+    frames = [synth.photo(w, h, synth.SEED0 + 40 + f) for f in range(3)]
+    frames.append(np.full((h, w, 3), 200, dtype=np.uint8))                                            # one colour
+    two = np.zeros((h, w, 3), dtype=np.uint8); two[:, w // 3:] = (250, 10, 40); frames.append(two)    # two colours
+    frames.append(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))                               # noise: every cluster in use
+    few = synth.photo(w, h, synth.SEED0 + 77) // 64 * 64; frames.append(few.astype(np.uint8))         # a coarse palette
+    frames = np.stack(frames)
+    gpu, st_g = _encode_frames_hip(frames, K, False)
+    host, st_h = _encode_frames_hip(frames, K, True)
+    assert st_g["iterations"] == st_h["iterations"]
+    for f in range(len(frames)):
+        assert gpu[f] == host[f], "frame %d: GPU and host code construction differ" % f
+    exp, iters = expected_streams(list(frames), K)
+    assert st_g["iterations"] == iters
+    for f in range(len(frames)):
+        assert gpu[f] == exp[f], "frame %d differs from the oracle's stream" % f
+
+
 @pytest.mark.gpu
 def test_frame_batch_hip_world2_over_a_host_transport():
     """two ranks x three frames through the library's own loop (host-transport communicator, both ranks on the test box's GPU)"""

@@ -4,7 +4,7 @@
 (relative), duration and the gap before it, the K-means launches folded into one line.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -o k -- python3 tools/trace_host.py
-    python3 tools/step_timeline.py gpurun_out/kt
+    python3 tools/step_timeline.py gpurun_out/kt [first-kernel-of-an-encode [which-encode]]
 """
 import csv
 import glob
@@ -16,9 +16,11 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # the encodes start with the first partition kernel (k_sp_count); take the last one
-starts = [i for i, n in enumerate(names) if "k_sp_count" in n]
-a = starts[-1]
-seg = rows[a:]
+first = sys.argv[2] if len(sys.argv) > 2 else "k_sp_count"   # the kernel an encode starts with
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # which encode of the trace
+starts = [i for i, n in enumerate(names) if first in n]
+a = starts[which]
+seg = rows[a:(starts[which + 1] if which != -1 and which + 1 < len(starts) else len(rows))]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
 km = None
