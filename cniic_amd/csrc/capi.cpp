@@ -586,8 +586,10 @@ int32_t cniic_cc_run(cniic_cc *cc, cniic_comm *cm, cniic_kmeans_stats *stats) {
     LOCK(c);
     if (!cc->s->km) return c->fail(CNIIC_ERR_BAD_ARG, "the session has no K-means state yet (cniic_cc_image_create comes first)");
     if (cm && cm->m && comm_ctx(cm->m) != cc->c) return c->fail(CNIIC_ERR_BAD_ARG, "cc_run: communicator of another context");
+    host_trace().mark("cc_run: enter");
     CNIIC_TRY(km_rgbw_run(cc->s->km, cm ? cm->m : nullptr));
-    if (stats) {
+    host_trace().mark("cc_run: the loop");
+    if (stats && !km_rgbw_run_stats(cc->s->km, stats)) {  // (the loop's own last look at the state; no wait for the launches past convergence)
         uint32_t d = 0;
         CNIIC_TRY(km_rgbw_poll(cc->s->km, stats, &d));
     }

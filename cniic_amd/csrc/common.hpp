@@ -446,6 +446,7 @@ int comm_async_error(Comm *cm);   // CNIIC_OK while healthy; an error once this 
 int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
+bool km_rgbw_run_stats(KmRgbwState *s, cniic_kmeans_stats *st);  // of the last km_rgbw_run; no stream work
 int km_rgbw_poll_lagged(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done, uint32_t *have);  // waits for the previous call's copy only
 int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats);

@@ -84,6 +84,8 @@ struct KmRgbwState {
     bool fused = false;
     bool sup = false;            // super-cell-major assign (k_rgbw_assign_sup): K <= 256, one shard
     bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
+    cniic_kmeans_stats run_stats{};  // the statistics km_rgbw_run ended on
+    bool run_stats_valid = false;
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
@@ -1946,6 +1948,13 @@ static int read_state(KmRgbwState *s, KmDevState *h) {
     return CNIIC_OK;
 }
 
+// the statistics of the last km_rgbw_run without touching the stream (false: no run has finished on this state)
+bool km_rgbw_run_stats(KmRgbwState *s, cniic_kmeans_stats *st) {
+    if (!s->run_stats_valid) return false;
+    *st = s->run_stats;
+    return true;
+}
+
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done) {
     KmDevState h;
     CNIIC_TRY(read_state(s, &h));
@@ -2086,6 +2095,11 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         CNIIC_TRY(poll.after_batch(&h, &have, launch_no ? launch_no - 1 : 0));
         if (have && h.done) break;
     }
+    // (the state the loop ended on is final -- launches past convergence change nothing: callers that only want the statistics
+    // need not wait for those launches, km_rgbw_run_stats)
+    s->run_stats.iterations = h.iter; s->run_stats.moved_last = h.moved_last; s->run_stats.empty_reseeds = h.reseeds;
+    s->run_stats.active = h.active; s->run_stats.pair_evals = h.pair_evals;
+    s->run_stats_valid = true;
     timer.stop(h.iter);
     if (s->profile) {
         // every launch that was issued counts, including the (at most batch-1) launches after
