@@ -86,6 +86,7 @@ struct KmRgbwState {
     bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
     cniic_kmeans_stats run_stats{};  // the statistics km_rgbw_run ended on
     bool run_stats_valid = false;
+    uint32_t agg_launches = 3;  // launches 1 .. agg_launches book their movers round by round (CNIIC_KM_AGG_LAUNCHES)
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
@@ -464,6 +465,11 @@ __device__ __forceinline__ uint32_t nearest_to_centre(const uint2 *list, uint32_
 }
 
 // S = the centroids of `tab` (ascending id) that can be nearest somewhere in super-cell `sup`; returns |S| >= 1
+// set bits of a ballot below this lane: v_mbcnt (two instructions, and no 64-bit lane mask kept in registers)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long bm) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+}
+
 __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, uint32_t sup, int lane, unsigned long long lt_mask,
                                                 uint2 *S, uint32_t cap) {
     constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
@@ -477,7 +483,7 @@ __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, ui
         bool keep = false;
         if (k < K) { cc = tab[k]; keep = dm.worst(cc.x) >= 0; }
         const unsigned long long bm = __ballot(keep);
-        const uint32_t pos = n + (uint32_t)__popcll(bm & lt_mask);
+        const uint32_t pos = n + lanes_below(bm);
         if (keep && pos < cap) S[pos] = cc;  // a longer list is not kept: the caller falls back to the whole table
         n += (uint32_t)__popcll(bm);
     }
@@ -508,7 +514,7 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
         if (e < n) { cc = list[e]; keep = dm.worst(cc.x) >= 0; }
         const unsigned long long bm = __ballot(keep);
         if (keep) {
-            cand[ncand + (uint32_t)__popcll(bm & lt_mask)] = cc;
+            cand[ncand + lanes_below(bm)] = cc;
             const uint32_t k = IDMASK - (cc.y & IDMASK);
             atomicOr(&wmask[k >> 6], 1ull << (k & 63));
         }
@@ -516,13 +522,23 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
-    for (uint32_t i = lane; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
+    uint32_t i_first = (uint32_t)lane;
+    asm volatile("" : "+v"(i_first));  // (or "cell_rec + 8 lane + 8" is computed once per launch and two registers hold it across the cell loop)
+    for (uint32_t i = i_first; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
     if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c);
     return ncand;
 }
 
-// one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip
-template <typename LabelT, int IDBITS, bool ALLWRITE = false>  // ALLWRITE: the labels in memory are stale (a cell kept as "uniform"): write every one
+// one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip.
+// AGG (the full schedule, where centroids still travel): when a centroid shifts, whole cells change hands -- every lane of the
+// sweep moves from the same old cluster to the same new one, and ten LDS atomics per point on the same ten words run one lane
+// at a time (~300 cycles per instruction, 12000 per sweep).  So, round by round: the (old, new) pair of the first point still to
+// be booked, every point that shares it summed in the wave (DPP), one lane adds the totals.  A cell that changes hands is one
+// round, a cell split between two new owners two; a handful of movers, and whatever is left after six rounds, go point by point.
+// (Not in the skip schedule: few points move per sweep there.  The kernel must not spill a single register for this: a
+// scratch segment costs every full-schedule launch 20 us)
+constexpr uint32_t kAggMin = 16;  // points that must share the first mover's (old, new) pair for a round to be worth it
+template <typename LabelT, int IDBITS, bool ALLWRITE = false, bool AGG = false>  // ALLWRITE: the labels in memory are stale (a cell kept as "uniform"): write every one
 __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
@@ -535,6 +551,81 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
         const uint2 cc = cand[j];  // same address in every lane: LDS broadcast
 #pragma unroll
         for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
+    }
+    if constexpr (AGG) {
+        static_assert(kSweep == 4, "four slots per lane");
+        uint32_t nl[kSweep];
+        bool rem[kSweep], anym = false;
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) {
+            const uint32_t q = base + u * 64 + lane;
+            nl[u] = cur[u];
+            rem[u] = false;
+            if (q < e) {
+                const uint2 cc = tab[cur[u]];
+                const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
+                rem[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+                if (rem[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
+            }
+            anym = anym || rem[u];
+        }
+        if (!__ballot(anym)) return;
+        uint32_t nmv = 0;
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) nmv += (uint32_t)__popcll(__ballot(rem[u]));
+        if (nmv >= kAggMin) {
+#pragma unroll 1
+            for (int round = 0; round < 6; round++) {
+                const unsigned long long b0 = __ballot(rem[0]), b1 = __ballot(rem[1]), b2 = __ballot(rem[2]), b3 = __ballot(rem[3]);
+                if (!(b0 | b1 | b2 | b3)) return;
+                uint32_t pn, po;
+                if (b0) { const int l = __builtin_ctzll(b0); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[0], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[0], l); }
+                else if (b1) { const int l = __builtin_ctzll(b1); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[1], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[1], l); }
+                else if (b2) { const int l = __builtin_ctzll(b2); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[2], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[2], l); }
+                else { const int l = __builtin_ctzll(b3); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[3], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[3], l); }
+                uint32_t cnt = 0;
+                bool mt[kSweep];  // (lane masks in scalar registers)
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) {
+                    mt[u] = rem[u] && nl[u] == pn && cur[u] == po;
+                    cnt += (uint32_t)__popcll(__ballot(mt[u]));
+                    rem[u] = rem[u] && !mt[u];
+                }
+                if (cnt < kAggMin) {  // a round costs ~130 instructions: it pays for a pair that many points share, not for a handful --
+                                      // these few book themselves, and so does everybody who is left
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) rem[u] = rem[u] || mt[u];
+                    break;
+                }
+                // (one sum at a time: four 64-bit sums held together spill registers)
+                auto book = [&](int shift, uint32_t mask, size_t at_new, size_t at_old) {
+                    unsigned long long v = 0;
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++)
+                        if (mt[u]) v += (unsigned long long)(mask ? (p[u] >> shift) & mask : 1u) * wt[u];
+                    v = wave_reduce_sum64(v);
+                    if (lane == 0) { atomicAdd(&acc[at_new], v); atomicAdd(&acc[at_old], 0ull - v); }
+                };
+                book(16, 255u, 3 * (size_t)pn + 0, 3 * (size_t)po + 0);
+                book(8, 255u, 3 * (size_t)pn + 1, 3 * (size_t)po + 1);
+                book(0, 255u, 3 * (size_t)pn + 2, 3 * (size_t)po + 2);
+                book(0, 0u, 3 * (size_t)K + pn, 3 * (size_t)K + po);  // (mask 0: the factor is 1, the sum of the weights)
+                if (lane == 0) { atomicAdd(&acc[4 * K + pn], (unsigned long long)cnt); atomicAdd(&acc[4 * K + po], 0ull - (unsigned long long)cnt); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) {
+            if (rem[u]) {
+                const uint32_t ol = cur[u], pp = p[u], n_ = nl[u];
+                const uint64_t w = wt[u];
+                const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
+                atomicAdd(&acc[3 * n_ + 0], rw); atomicAdd(&acc[3 * n_ + 1], gw); atomicAdd(&acc[3 * n_ + 2], bw);
+                atomicAdd(&acc[3 * K + n_], (unsigned long long)w); atomicAdd(&acc[4 * K + n_], 1ull);
+                atomicAdd(&acc[3 * ol + 0], 0ull - rw); atomicAdd(&acc[3 * ol + 1], 0ull - gw); atomicAdd(&acc[3 * ol + 2], 0ull - bw);
+                atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w); atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
@@ -744,9 +835,11 @@ __device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIM
 #define RG_TLC(i, v) do {} while (0)
 #endif
 
-// FIRSTK: 1 = the launch of iteration 0, 0 = a later one, -1 = found out on the device.  The loop with the folded-in update
-// knows which launch it enqueues, and the two bodies share little: compiled apart, the first launch has registers to spare
-// (66 of 80) for booking its points round by round (sweep_points_first).
+// FIRSTK: -1 = everything found out on the device (the loops without the folded-in update).  The loop with the folded-in update
+// knows which launch it enqueues: 1 = the launch of iteration 0 (alone that body has registers to spare for booking its points
+// round by round, sweep_points_first), 2 = one of the next three (the same body as 0 plus the rounds for movers that share an
+// (old, new) pair, sweep_points<AGG>: whole cells change hands while the centroids still travel; the rounds' code costs the
+// launches that do not need it 4-5 us each, so only these get it), 0 = a later one.
 template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
@@ -771,7 +864,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
     // iterations add/subtract only the points that moved.
-    const bool first = FIRSTK >= 0 ? FIRSTK != 0 : (fz.on ? fz.launch_no == 0 : st->iter == 0);
+    const bool first = FIRSTK >= 0 ? FIRSTK == 1 : (fz.on ? fz.launch_no == 0 : st->iter == 0);
     uint32_t nS = fz.on ? K : cs.moved[0];
     const uint32_t *mlist = cs.moved + 1;  // ids of the centroids the last update changed
     const unsigned long long lt_mask = (1ull << lane) - 1;
@@ -936,7 +1029,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                     wtn[u] = qn < nte ? cweight[qn] : 0u;
                 }
                 if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved);
-                else sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
@@ -1044,7 +1137,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     }
     __syncthreads();
     RG_TL(4);
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS)
+    uint32_t i_first = threadIdx.x;
+    asm volatile("" : "+v"(i_first));  // (or the flush's addresses are computed before the cell loops and held in two registers across them)
+    for (uint32_t i = i_first; i < 5 * K; i += THREADS)
         if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
@@ -1678,6 +1773,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->cells = !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE));
     s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
     s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
+    if (const char *al = getenv("CNIIC_KM_AGG_LAUNCHES")) s->agg_launches = (uint32_t)atoi(al);
     if (const char *ms = getenv("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
@@ -1897,7 +1993,8 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
                                (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
             auto kern = !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
-                        : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
+                        : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>
+                        : fz.launch_no <= s->agg_launches ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
             hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(64 * kCellWaves), (uint32_t)lds,
                                   c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                   (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
