@@ -257,13 +257,20 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const LabelT *_
     if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
 }
 
+// tests: CNIIC_TEST_PACK_IMG_WORDS caps the label pack's LDS bit image so that chunks take the direct-to-memory route
+static uint32_t pack_img_cap() {
+    const char *e = getenv("CNIIC_TEST_PACK_IMG_WORDS");
+    return e ? (uint32_t)atoi(e) : 0xffffffffu;
+}
+
 template <typename LabelT>
 __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *__restrict__ pixlab, uint64_t n, uint32_t K,
                                                                  const uint8_t *__restrict__ clen,
                                                                  const uint64_t *__restrict__ ccode,
                                                                  const uint64_t *__restrict__ chunk_off,
                                                                  uint32_t *__restrict__ out_words, uint64_t bit_base, uint64_t lab_stride = 0,
-                                                                 uint64_t out_stride_words = 0, const uint64_t *__restrict__ bit_base_frames = nullptr) {
+                                                                 uint64_t out_stride_words = 0, const uint64_t *__restrict__ bit_base_frames = nullptr,
+                                                                 uint32_t img_cap = 0xffffffffu /* tests: a smaller image forces the direct route */) {
     extern __shared__ __align__(8) unsigned long long s_tab[];  // [K] codes, then [K] lens (bytes)
     pixlab += (size_t)blockIdx.y * lab_stride;   // (a batch of frames: blockIdx.y = frame)
     clen += (size_t)blockIdx.y * K;
@@ -271,12 +278,15 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *_
     chunk_off += (size_t)blockIdx.y * gridDim.x;
     out_words += (size_t)blockIdx.y * out_stride_words;
     if (bit_base_frames) bit_base = bit_base_frames[blockIdx.y];
-    __shared__ uint32_t img[kPackWords];
+    // the chunk's bit image: 16 bits per symbol on average fit (a palette's codes average 8); a chunk of rarer symbols goes to
+    // memory piece by piece instead (below).  Sized for the worst case (64 bits per symbol, 32 KiB) the array held the kernel at
+    // four blocks per CU.
+    constexpr uint32_t kImgWords = kPackChunk / 2 + 2;
+    __shared__ uint32_t img[kImgWords];
     __shared__ uint32_t wsum[kPackThreads / 64];
     __shared__ uint32_t s_total;
     uint8_t *s_len = reinterpret_cast<uint8_t *>(s_tab + K);
     for (uint32_t i = threadIdx.x; i < K; i += kPackThreads) { s_tab[i] = ccode[i]; s_len[i] = clen[i]; }
-    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
     __syncthreads();
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
     uint32_t lab[kPackPer], l[kPackPer];
@@ -296,6 +306,33 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *_
     const uint64_t g0 = bit_base + chunk_off[blockIdx.x];
     const uint32_t skew = (uint32_t)(g0 & 31);
     uint32_t pos = skew + excl;
+    // the image is cleared only as far as this chunk's bits reach (the array is sized for 64 bits per symbol; a palette's codes
+    // average 8: clearing all of it was 8 LDS bytes per symbol)
+    if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
+    __syncthreads();
+    const uint32_t nw_all = (skew + s_total + 31) >> 5;
+    if (nw_all + 2 > min(kImgWords, img_cap)) {  // too many bits for the image: straight to memory (the output is pre-zeroed; words are big-endian bit order)
+        const uint64_t w0 = g0 >> 5;
+#pragma unroll 1
+        for (int i = 0; i < kPackPer; i++) {
+            const uint32_t L = l[i];
+            if (L == 0) continue;
+            const uint64_t cd = s_tab[lab[i]];
+            const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;
+            if (L <= room) {
+                atomicOr(&out_words[w0 + w], __builtin_bswap32((uint32_t)(cd << (room - L))));
+            } else {
+                const uint32_t rem = L - room;
+                atomicOr(&out_words[w0 + w], __builtin_bswap32((uint32_t)(cd >> rem)));
+                if (rem <= 32) atomicOr(&out_words[w0 + w + 1], __builtin_bswap32((uint32_t)(cd << (32 - rem))));
+                else { atomicOr(&out_words[w0 + w + 1], __builtin_bswap32((uint32_t)(cd >> (rem - 32)))); atomicOr(&out_words[w0 + w + 2], __builtin_bswap32((uint32_t)(cd << (64 - rem)))); }
+            }
+            pos += L;
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < nw_all + 2; i += kPackThreads) img[i] = 0;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPackPer; i++) {
         const uint32_t L = l[i];
@@ -312,7 +349,6 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write_lab(const LabelT *_
         }
         pos += L;
     }
-    if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
     __syncthreads();
     const uint32_t total = s_total;
     if (total == 0) return;
@@ -362,11 +398,11 @@ int huff_pack_labels(Ctx *c, const void *pixlab_d, uint64_t n, bool wide, uint32
     if (wide)
         hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
                            reinterpret_cast<const uint16_t *>(pixlab_d), n, K, clen_d, ccode_d, co.as<uint64_t>(),
-                           reinterpret_cast<uint32_t *>(out_d), bit_base);
+                           reinterpret_cast<uint32_t *>(out_d), bit_base, (uint64_t)0, (uint64_t)0, (const uint64_t *)nullptr, pack_img_cap());
     else
         hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, dim3(nchunks), dim3(kPackThreads), (size_t)K * 9 + 8, c->stream,
                            reinterpret_cast<const uint8_t *>(pixlab_d), n, K, clen_d, ccode_d, co.as<uint64_t>(),
-                           reinterpret_cast<uint32_t *>(out_d), bit_base);
+                           reinterpret_cast<uint32_t *>(out_d), bit_base, (uint64_t)0, (uint64_t)0, (const uint64_t *)nullptr, pack_img_cap());
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -620,11 +656,11 @@ int huff_pack_labels_frames(Ctx *c, const void *pixlab_d, uint64_t npf, uint64_t
     if (wide)
         hipLaunchKernelGGL(k_pack_write_lab<uint16_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint16_t *>(pixlab_d), npf, K,
                            clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
-                           bit_base_d);
+                           bit_base_d, pack_img_cap());
     else
         hipLaunchKernelGGL(k_pack_write_lab<uint8_t>, grid, dim3(kPackThreads), (size_t)K * 9 + 8, c->stream, reinterpret_cast<const uint8_t *>(pixlab_d), npf, K,
                            clen_d, ccode_d, (const uint64_t *)co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), (uint64_t)0, lab_stride, stride / 4,
-                           bit_base_d);
+                           bit_base_d, pack_img_cap());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(totals_h, tot.p, (size_t)frames * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
