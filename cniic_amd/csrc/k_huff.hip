@@ -20,7 +20,6 @@ namespace cniic {
 constexpr int kPackThreads = 256;
 constexpr int kPackPer = 16;
 constexpr int kPackChunk = kPackThreads * kPackPer;  // symbols per block
-constexpr int kPackWords = kPackChunk * 2 + 2;       // LDS words: 64 bits per symbol worst case
 
 enum { SRC_RGB = 0, SRC_KEYS = 1, SRC_SYM16 = 2, SRC_RANKS = 3 };
 
@@ -138,15 +137,42 @@ static int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uin
     return CNIIC_OK;
 }
 
+// tests: CNIIC_TEST_PACK_IMG_WORDS caps the packs' LDS bit image so that chunks take the direct-to-memory route
+static uint32_t pack_img_cap() {
+    const char *e = getenv("CNIIC_TEST_PACK_IMG_WORDS");
+    return e ? (uint32_t)atoi(e) : 0xffffffffu;
+}
+
+// one symbol's code into a bit image (LDS) or straight into the output words (memory; big-endian bit order, pre-zeroed)
+template <bool DIRECT>
+__device__ __forceinline__ void pack_put(uint32_t *words, uint32_t pos, uint32_t L, uint64_t cd) {
+    // place bits [pos, pos+L) MSB-first: word w bit (31 - b)
+    const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;  // room: bits left in word w
+    auto put = [&](uint32_t i, uint32_t v) { atomicOr(&words[i], DIRECT ? __builtin_bswap32(v) : v); };
+    if (L <= room) {
+        put(w, (uint32_t)(cd << (room - L)));
+    } else {
+        const uint32_t rem = L - room;  // bits after the first word
+        put(w, (uint32_t)(cd >> rem));
+        if (rem <= 32) put(w + 1, (uint32_t)(cd << (32 - rem)));
+        else { put(w + 1, (uint32_t)(cd >> (rem - 32))); put(w + 2, (uint32_t)(cd << (64 - rem))); }
+    }
+}
+
 template <int SRC>
 __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restrict__ src, uint64_t n,
                                                              const uint32_t *__restrict__ rank_table,
                                                              const uint8_t *__restrict__ len,
                                                              const uint64_t *__restrict__ code,
                                                              const uint64_t *__restrict__ chunk_off,
-                                                             uint32_t *__restrict__ out_words, uint64_t bit_base) {
-    __shared__ uint32_t img[kPackWords];
+                                                             uint32_t *__restrict__ out_words, uint64_t bit_base, uint32_t img_cap) {
+    // the chunk's bit image: 32 bits per symbol on average fit (the codes of 10^5 delta symbols average 14, of 7 M colours 23);
+    // a chunk of rarer symbols goes to memory piece by piece instead.  Sized for the worst case (64 bits per symbol, 32 KiB,
+    // all of it cleared for every chunk) the array held the kernel at four blocks per CU.
+    constexpr uint32_t kImgWords = kPackChunk + 2;
+    __shared__ uint32_t img[kImgWords];
     __shared__ uint32_t wsum[kPackThreads / 64];
+    __shared__ uint32_t s_total;
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
     uint32_t rank[kPackPer];
     fetch_ranks<SRC>(src, n, first, rank_table, rank);
@@ -157,41 +183,32 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write(const void *__restr
         l[i] = rank[i] != 0xffffffffu ? len[rank[i]] : 0;
         bits += l[i];
     }
-    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
-    uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);  // contains a __syncthreads after img clear
+    uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);
     const uint64_t g0 = bit_base + chunk_off[blockIdx.x];  // global bit offset of the chunk
     const uint32_t skew = (uint32_t)(g0 & 31);          // chunk image is aligned to the output word grid
     uint32_t pos = skew + excl;
-#pragma unroll
-    for (int i = 0; i < kPackPer; i++) {
-        uint32_t L = l[i];
-        if (L == 0) continue;                           // zero-length code (single-symbol alphabet, huf.rs:140-142)
-        uint64_t cd = code[rank[i]];                    // L significant bits, first stream bit = bit L-1
-        // place bits [pos, pos+L) MSB-first: word w bit (31 - b)
-        uint32_t w = pos >> 5, b = pos & 31;
-        uint32_t room = 32 - b;                          // bits left in word w
-        if (L <= room) {
-            atomicOr(&img[w], (uint32_t)(cd << (room - L)));
-        } else {
-            uint32_t rem = L - room;                     // bits after the first word
-            atomicOr(&img[w], (uint32_t)(cd >> rem));
-            if (rem <= 32) {
-                atomicOr(&img[w + 1], (uint32_t)(cd << (32 - rem)));
-            } else {
-                atomicOr(&img[w + 1], (uint32_t)(cd >> (rem - 32)));
-                atomicOr(&img[w + 2], (uint32_t)(cd << (64 - rem)));
-            }
-        }
-        pos += L;
-    }
-    __syncthreads();
-    __shared__ uint32_t s_total;
     if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
     __syncthreads();
     const uint32_t total = s_total;
-    if (total == 0) return;
+    if (total == 0) return;                             // (zero-length codes: a single-symbol alphabet, huf.rs:140-142)
     const uint32_t nwords = (skew + total + 31) >> 5;
     const uint64_t w0 = g0 >> 5;
+    if (nwords + 2 > min(kImgWords, img_cap)) {
+#pragma unroll 1
+        for (int i = 0; i < kPackPer; i++) {
+            if (l[i]) pack_put<true>(out_words + w0, pos, l[i], code[rank[i]]);  // L significant bits, first stream bit = bit L-1
+            pos += l[i];
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < nwords + 2; i += kPackThreads) img[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        if (l[i]) pack_put<false>(img, pos, l[i], code[rank[i]]);
+        pos += l[i];
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < nwords; i += kPackThreads) {
         uint32_t v = __builtin_bswap32(img[i]);          // MSB-first bit order -> big-endian bytes
         if (v == 0) continue;
@@ -255,12 +272,6 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count_lab(const LabelT *_
     }
     bits = block_reduce_sum<kPackThreads>(bits);
     if (threadIdx.x == 0) chunk_bits[blockIdx.x] = bits;
-}
-
-// tests: CNIIC_TEST_PACK_IMG_WORDS caps the label pack's LDS bit image so that chunks take the direct-to-memory route
-static uint32_t pack_img_cap() {
-    const char *e = getenv("CNIIC_TEST_PACK_IMG_WORDS");
-    return e ? (uint32_t)atoi(e) : 0xffffffffu;
 }
 
 template <typename LabelT>
@@ -690,7 +701,7 @@ static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *nbits_h = total;
     hipLaunchKernelGGL(k_pack_write<SRC>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, src_d, n, rank_table_d, len_d, code_d,
-                       co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base);
+                       co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base, pack_img_cap());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // cb/co/tot are released on return
     return CNIIC_OK;
@@ -756,8 +767,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_count32(const void *__res
 __global__ __launch_bounds__(kPackThreads) void k_pack_write32(const uint32_t *__restrict__ packed, uint64_t n,
                                                                const uint8_t *__restrict__ len, const uint64_t *__restrict__ code,
                                                                const uint64_t *__restrict__ chunk_off,
-                                                               uint32_t *__restrict__ out_words, uint64_t bit_base) {
-    __shared__ uint32_t img[kPackWords];
+                                                               uint32_t *__restrict__ out_words, uint64_t bit_base, uint32_t img_cap) {
+    constexpr uint32_t kImgWords = kPackChunk + 2;  // (32 bits per symbol on average; see k_pack_write)
+    __shared__ uint32_t img[kImgWords];
     __shared__ uint32_t wsum[kPackThreads / 64];
     __shared__ uint32_t s_total;
     const uint64_t first = (uint64_t)blockIdx.x * kPackChunk + (uint64_t)threadIdx.x * kPackPer;
@@ -778,33 +790,33 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write32(const uint32_t *_
         l[i] = L == kEscape ? (uint32_t)len[v[i] & 0x3ffffffu] : L;
         bits += l[i];
     }
-    for (int i = threadIdx.x; i < kPackWords; i += kPackThreads) img[i] = 0;
     const uint32_t excl = block_exclusive_scan<kPackThreads>(bits, wsum);
     const uint64_t g0 = bit_base + chunk_off[blockIdx.x];
     const uint32_t skew = (uint32_t)(g0 & 31);
     uint32_t pos = skew + excl;
-#pragma unroll
-    for (int i = 0; i < kPackPer; i++) {
-        const uint32_t L = l[i];
-        if (L == 0) continue;
-        const uint64_t cd = (v[i] >> 26) == kEscape ? code[v[i] & 0x3ffffffu] : (uint64_t)(v[i] & 0x3ffffffu);
-        const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;
-        if (L <= room) {
-            atomicOr(&img[w], (uint32_t)(cd << (room - L)));
-        } else {
-            const uint32_t rem = L - room;
-            atomicOr(&img[w], (uint32_t)(cd >> rem));
-            if (rem <= 32) atomicOr(&img[w + 1], (uint32_t)(cd << (32 - rem)));
-            else { atomicOr(&img[w + 1], (uint32_t)(cd >> (rem - 32))); atomicOr(&img[w + 2], (uint32_t)(cd << (64 - rem))); }
-        }
-        pos += L;
-    }
     if (threadIdx.x == kPackThreads - 1) s_total = excl + bits;
     __syncthreads();
     const uint32_t total = s_total;
     if (total == 0) return;
     const uint32_t nwords = (skew + total + 31) >> 5;
     const uint64_t w0 = g0 >> 5;
+    auto code_of = [&](int i) -> uint64_t { return (v[i] >> 26) == kEscape ? code[v[i] & 0x3ffffffu] : (uint64_t)(v[i] & 0x3ffffffu); };
+    if (nwords + 2 > min(kImgWords, img_cap)) {
+#pragma unroll 1
+        for (int i = 0; i < kPackPer; i++) {
+            if (l[i]) pack_put<true>(out_words + w0, pos, l[i], code_of(i));
+            pos += l[i];
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < nwords + 2; i += kPackThreads) img[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPackPer; i++) {
+        if (l[i]) pack_put<false>(img, pos, l[i], code_of(i));
+        pos += l[i];
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < nwords; i += kPackThreads) {
         const uint32_t o = __builtin_bswap32(img[i]);
         if (o == 0) continue;
@@ -838,7 +850,7 @@ int huff_pack_code32(Ctx *c, const uint32_t *syms_or_null_d, const uint8_t *rgb_
         hipLaunchKernelGGL(k_pack_count32<SRC_KEYS>, dim3(nchunks), dim3(kPackThreads), 0, c->stream, syms_or_null_d, n, table_d, len_d, packed_d, cb.as<uint32_t>());
     CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
-                       reinterpret_cast<uint32_t *>(out_d), bit_base);
+                       reinterpret_cast<uint32_t *>(out_d), bit_base, pack_img_cap());
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -941,7 +953,7 @@ int huff_pack_code32_hot(Ctx *c, const uint32_t *syms_d, uint64_t n, uint32_t *d
                        (const uint32_t *)hot.as<uint32_t>(), (const uint32_t *)dense_d, len_d, packed_d, cb.as<uint32_t>(), nchunks);
     CNIIC_TRY(pack_scan(c, cb.as<uint32_t>(), nchunks, co.as<uint64_t>(), tot.as<uint64_t>()));
     hipLaunchKernelGGL(k_pack_write32, dim3(nchunks), dim3(kPackThreads), 0, c->stream, packed_d, n, len_d, code_d, co.as<uint64_t>(),
-                       reinterpret_cast<uint32_t *>(out_d), bit_base);
+                       reinterpret_cast<uint32_t *>(out_d), bit_base, pack_img_cap());
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));

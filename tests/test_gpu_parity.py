@@ -375,16 +375,18 @@ def test_partition_path_equals_oracle(ctx, sp_path, expr, shape):
 
 
 @pytest.mark.parametrize("cap", ["3", "40"])
-@pytest.mark.parametrize("expr", ["cluster-colors(8)", "ccol(256)", "cluster-colors(300)"])
+@pytest.mark.parametrize("expr", ["cluster-colors(8)", "ccol(256)", "cluster-colors(300)", "hufman", "delta"])
 def test_label_pack_direct_route(ctx, monkeypatch, expr, cap):
-    """the label pack writes a chunk whose bits outgrow its LDS image straight to memory (64-bit codes would: 16 bits per symbol
+    """every pack kernel writes a chunk whose bits outgrow its LDS image straight to memory (64-bit codes would: 16 bits per symbol
     fit); CNIIC_TEST_PACK_IMG_WORDS shrinks the image so that every chunk (3 words) or the denser ones (40) go that way -- the
     stream must not change (u8 and u16 labels, several chunks, a partial last one)"""
     monkeypatch.setenv("CNIIC_TEST_PACK_IMG_WORDS", cap)
     img = synth_img(301, 299, seed=29, levels=200, noise=3)
     rc, data, st = ctx.encode(expr, img)
     rco, edata, est = O.encode(expr, img, mode=O.MODE_L)
-    assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+    assert rc == rco == 0 and data == edata
+    if "col" in expr:
+        assert st["iterations"] == est["iterations"]
 
 
 @pytest.mark.parametrize("kind", ["flat2", "dark", "noise"])
