@@ -391,7 +391,7 @@ struct SpPlan {
     uint64_t npx = 0, U = 0;     // pixels, distinct colours
     uint32_t nchunks = 0;
     DevBuf cnt, pre, bstart;     // pixels per (chunk, bucket), those in earlier chunks, first entry of every bucket
-    DevBuf part, prank;          // u16 per pixel: colour inside its bucket (bucket order), position inside its run (pixel order)
+    DevBuf part, prank;          // u16 per pixel: colour inside its bucket (bucket order), place in its chunk's bucket-sorted order (pixel order)
     DevBuf cell_count;           // distinct colours per K-means cell
     DevBuf sstart, sbin, scnt;   // per bucket: its distinct colours (colour inside the bucket, pixel count) staged in cell-major order
     DevBuf bits, wprefix;        // occupancy bitmap of the 2^24 colours + popcount prefix (GIdx)

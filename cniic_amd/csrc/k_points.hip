@@ -12,7 +12,7 @@
 //   k_sp_count     per 64 Ki-pixel chunk: pixels per bucket (LDS histogram)                     read 3 B/px
 //   k_sp_colscan / k_sp_bstart   where each (chunk, bucket) run starts
 //   k_sp_scatter   per chunk: 15-bit colour-in-bucket of every pixel, sorted by bucket in LDS and written as
-//                  512 runs; the pixel's position inside its run goes to prank[pixel]          read 3, write 2 + 2 B/px
+//                  512 runs; the pixel's place in the chunk's sorted order goes to prank[pixel]  read 3, write 2 + 2 B/px
 //   k_sp_hist      per bucket: LDS histogram of its 2^15 colours -> occupied colours per cell, occupancy bitmap,
 //                  and the bucket's distinct colours with their counts, staged in cell-major order
 //   (bitmap -> popcount prefix = GIdx: rank of a colour in the ascending list of all colours = the
@@ -20,7 +20,7 @@
 //   k_sp_emit      the staged colours, counts and their initial labels to their places in the K-means arrays
 //   ... K-means ...
 //   k_sp_partlab   per bucket: label of every partitioned pixel from an LDS table of the bucket's colours
-//   k_sp_pixlab    per chunk: its 512 label runs into LDS, each pixel picks run[prank]  -> label stream
+//   k_sp_pixlab    per chunk: its 512 label runs into LDS, each pixel picks stage[prank]  -> label stream   read 1 + 2, write 1 B/px
 //
 // No atomics on global memory, no table of 2^24 entries, and every pixel's label is found without a random
 // read.  Results are identical to the dense-table path (k_hist.hip + k_cells_write_tbl + k_pixel_labels): the
@@ -166,8 +166,10 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_scatter(const uint8_t *__rest
             rk[i] = 0;
             if (i < m) {
                 const uint32_t b = sp_bucket(key[i]);
-                rk[i] = atomicAdd(&cur[b], 1u);  // position inside the (chunk, bucket) run: any order, remembered per pixel
-                stage[off[b] + rk[i]] = (uint16_t)sp_bin(key[i]);
+                // its place in the chunk's bucket-sorted order (any order inside a run), remembered per pixel: the way back
+                // (k_sp_pixlab) is then one LDS read per pixel -- no colour, no bucket, no offset table
+                rk[i] = off[b] + atomicAdd(&cur[b], 1u);
+                stage[rk[i]] = (uint16_t)sp_bin(key[i]);
             }
         }
         if (m == 16) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_partlab(const uint16_t *__res
     });
 }
 
-// One block per chunk: its 512 label runs into LDS, then every pixel picks run(bucket)[prank].
+// One block per chunk: its 512 label runs into LDS (the chunk's pixels in bucket-sorted order), then every pixel picks stage[prank].
 // LDS (dynamic): stage LabelT[kSpChunk] | off u32[kSpBuckets + 1] | gsrc u32[kSpBuckets]
 template <typename LabelT>
 __global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restrict__ rgb, uint64_t npx, const uint32_t *__restrict__ cnt,
@@ -397,14 +399,19 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restr
             if (jb[t] != 0xffffffffu) stage[j + 64 * t] = got[t];
     });
     __syncthreads();
-    sp_for_pixels(rgb, npx, [&](uint64_t first, const uint32_t (&key)[16], uint32_t m) {
+    // every pixel picks stage[its place in the sorted order] (prank, written by k_sp_scatter): 2 + 1 bytes per pixel, the
+    // image itself is not read again
+    const uint64_t p0 = (uint64_t)blockIdx.x * kSpChunk, p1 = min(npx, p0 + kSpChunk);
+    for (uint64_t g = p0 / 16 + threadIdx.x; g * 16 < p1; g += kSpThreads) {
+        const uint64_t first = g * 16;
+        const uint32_t m = (uint32_t)min<uint64_t>(16, p1 - first);
         uint32_t lab[16];
         if (m == 16) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(prank + first);
             const uint4 r0 = rp[0], r1 = rp[1];
             const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-            for (uint32_t i = 0; i < 16; i++) lab[i] = stage[off[sp_bucket(key[i])] + ((rw[i >> 1] >> (16 * (i & 1))) & 0xffffu)];
+            for (uint32_t i = 0; i < 16; i++) lab[i] = stage[(rw[i >> 1] >> (16 * (i & 1))) & 0xffffu];
             if (sizeof(LabelT) == 1) {
                 uint32_t w[4];
 #pragma unroll
@@ -416,9 +423,9 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_pixlab(const uint8_t *__restr
                 d[1] = make_uint4(lab[8] | (lab[9] << 16), lab[10] | (lab[11] << 16), lab[12] | (lab[13] << 16), lab[14] | (lab[15] << 16));
             }
         } else {
-            for (uint32_t i = 0; i < m; i++) pixlab[first + i] = stage[off[sp_bucket(key[i])] + prank[first + i]];
+            for (uint32_t i = 0; i < m; i++) pixlab[first + i] = stage[prank[first + i]];
         }
-    });
+    }
 }
 
 // =========================================================================== host
