@@ -34,6 +34,8 @@ constexpr uint32_t kSpBuckets = 512;           // super-cells: r[7:5] g[7:5] b[7
 constexpr uint32_t kSpBins = 1u << 15;         // colours of a super-cell
 constexpr uint32_t kSpChunk = 1u << 16;        // pixels per chunk: a position inside a run fits 16 bits
 constexpr int kSpThreads = 1024;
+constexpr uint32_t kSpSliceMin = 1u << 17;     // k_sp_partlab: entries per slice of a bucket, at least
+constexpr uint32_t kSpSlices = 8;              // ... and slices per bucket, at most
 constexpr uint32_t kSpWaves = kSpThreads / 64;
 
 __device__ __forceinline__ uint32_t sp_bucket(uint32_t key) {
@@ -354,8 +356,20 @@ __global__ __launch_bounds__(kSpThreads) void k_sp_partlab(const uint16_t *__res
     extern __shared__ __align__(16) uint8_t sp_lds[];
     LabelT *lut = reinterpret_cast<LabelT *>(sp_lds);
     const uint32_t bucket = blockIdx.x;
-    const uint64_t s = bstart[bucket], e = bstart[bucket + 1];
+    uint64_t s = bstart[bucket], e = bstart[bucket + 1];
     if (s == e) return;
+    // a crowded bucket is several blocks' work (grid.y slices of at least kSpSliceMin entries; every slice builds the table: up to
+    // 2^15 colours against >= 2^17 pixels)
+    {
+        const uint64_t len = e - s;
+        const uint32_t slices = (uint32_t)min<uint64_t>(gridDim.y, max<uint64_t>(1, len / kSpSliceMin));
+        if (blockIdx.y >= slices) return;
+        const uint64_t per = ((len + slices - 1) / slices + 3) & ~3ull;
+        const uint64_t a = s + per * blockIdx.y;
+        e = min(e, a + per);
+        s = a;
+        if (s >= e) return;
+    }
     const uint32_t q0 = cell_start[bucket * 64], q1 = cell_start[bucket * 64 + 64];
     for (uint32_t i = q0 + threadIdx.x; i < q1; i += kSpThreads) lut[sp_bin(ckeys[i])] = labels[i];
     __syncthreads();
@@ -528,13 +542,13 @@ int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint
     const uint64_t lb = wide ? 2 : 1;
     CNIIC_HIP_TRY(c, partlab.alloc(plan->npx * lb + 16));
     if (wide) {
-        hipLaunchKernelGGL(k_sp_partlab<uint16_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins * 2, c->stream, plan->part.as<uint16_t>(),
+        hipLaunchKernelGGL(k_sp_partlab<uint16_t>, dim3(kSpBuckets, plan->npx >= 2 * (uint64_t)kSpSliceMin ? kSpSlices : 1), dim3(kSpThreads), (size_t)kSpBins * 2, c->stream, plan->part.as<uint16_t>(),
                            plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint16_t *>(labels_d), partlab.as<uint16_t>());
         hipLaunchKernelGGL(k_sp_pixlab<uint16_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk * 2 + kSpBuckets * 8 + 16, c->stream, rgb_d,
                            plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint16_t>(),
                            plan->prank.as<uint16_t>(), static_cast<uint16_t *>(pixlab_d));
     } else {
-        hipLaunchKernelGGL(k_sp_partlab<uint8_t>, dim3(kSpBuckets), dim3(kSpThreads), (size_t)kSpBins, c->stream, plan->part.as<uint16_t>(),
+        hipLaunchKernelGGL(k_sp_partlab<uint8_t>, dim3(kSpBuckets, plan->npx >= 2 * (uint64_t)kSpSliceMin ? kSpSlices : 1), dim3(kSpThreads), (size_t)kSpBins, c->stream, plan->part.as<uint16_t>(),
                            plan->bstart.as<uint32_t>(), cell_start_d, ckeys_d, static_cast<const uint8_t *>(labels_d), partlab.as<uint8_t>());
         hipLaunchKernelGGL(k_sp_pixlab<uint8_t>, dim3(plan->nchunks), dim3(kSpThreads), (size_t)kSpChunk + kSpBuckets * 8 + 16, c->stream, rgb_d,
                            plan->npx, plan->cnt.as<uint32_t>(), plan->pre.as<uint32_t>(), plan->bstart.as<uint32_t>(), partlab.as<uint8_t>(),

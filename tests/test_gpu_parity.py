@@ -374,6 +374,22 @@ def test_partition_path_equals_oracle(ctx, sp_path, expr, shape):
         assert data == edata and st["iterations"] == est["iterations"]
 
 
+def test_partition_path_crowded_bucket_in_slices(ctx, sp_path):
+    """560 K pixels in ONE super-cell (every colour below 32) and a second image with two crowded buckets: k_sp_partlab works a
+    bucket of more than 2^17 entries in slices (grid.y), every slice with its own table; slice borders fall on entries that are
+    not 4-aligned"""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 32, (700, 801, 3)).astype(np.uint8)
+    rc, data, st = ctx.encode("cluster-colors(16)", img)
+    rco, edata, est = O.encode("cluster-colors(16)", img, mode=O.MODE_L)
+    assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+    img2 = rng.integers(0, 32, (611, 523, 3)).astype(np.uint8)
+    img2[:, 200:] += 160        # the right part in another super-cell
+    rc, data, st = ctx.encode("cluster-colors(8)", img2)
+    rco, edata, est = O.encode("cluster-colors(8)", img2, mode=O.MODE_L)
+    assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+
+
 @pytest.mark.parametrize("cap", ["3", "40"])
 @pytest.mark.parametrize("expr", ["cluster-colors(8)", "ccol(256)", "cluster-colors(300)", "hufman", "delta"])
 def test_label_pack_direct_route(ctx, monkeypatch, expr, cap):
