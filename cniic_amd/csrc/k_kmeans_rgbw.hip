@@ -1067,17 +1067,47 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                   if ((uint32_t)lane < RW) rA = rec[lane];
                   if (64 + (uint32_t)lane < RW) rB = rec[64 + lane];
               }
+              // K <= 256: the batch's eight cells are tested TOGETHER, lane = (cell, one of eight moved centroids), ceil(nS / 8) steps --
+              // one step while few centroids move (the long tail of the run); a wave-wide test per cell cost ~30 instructions for
+              // each of the eight cells however few had moved.  dirty8: bits 8 i .. 8 i + 7 belong to cell i of the batch.
+              unsigned long long dirty8 = 0;
+              if (IDBITS == 8) {
+                  const uint32_t ci = (uint32_t)lane >> 3;
+                  const int src0 = (int)((ci & 3) * 16);
+                  const uint32_t pvA = (uint32_t)__shfl((int)rA, src0, 64), pvB = (uint32_t)__shfl((int)rB, src0, 64);
+                  const uint32_t ccA = (uint32_t)__shfl((int)rA, src0 + 1, 64), ccB = (uint32_t)__shfl((int)rB, src0 + 1, 64);
+                  const uint32_t pv = ci < 4 ? pvA : pvB, cc = ci < 4 ? ccA : ccB;
+                  const bool cell_ok = mb + ci * nwaves < m_hi;
+                  Dominance dmv;
+                  dmv.set(cell_box(cc), (1 << kCellShift) - 1, pv);
+                  bool dv = false;
+                  for (uint32_t j0 = 0; j0 < nS; j0 += 8) {
+                      const uint32_t j = j0 + ((uint32_t)lane & 7u);
+                      const bool has = j < nS;
+                      const uint32_t k = has ? mlist[j] : 0u;
+                      const uint32_t ck = tab[k].x;
+                      const int wl = src0 + 2 + (int)((k >> 5) & 7);
+                      const uint32_t wA = (uint32_t)__shfl((int)rA, wl, 64), wB = (uint32_t)__shfl((int)rB, wl, 64);
+                      const bool in = (((ci < 4 ? wA : wB) >> (k & 31)) & 1u) != 0;
+                      // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                      dv = dv || (has && (in || dmv.worst(ck) >= 0));
+                  }
+                  dirty8 = __ballot(dv && cell_ok);
+                  RG_PHASE(6);
+                  RG_TLC(7, 8);
+                  if (!dirty8) continue;
+              }
               for (uint32_t bi = 0; bi < kRecBatch; bi++) {
                 const uint32_t m = mb + bi * nwaves;
                 if (m >= m_hi) break;
                 uint32_t pvt, c;
-                bool in1;
+                bool in1 = false;
                 if (IDBITS == 8) {
+                    if (!((dirty8 >> (8 * bi)) & 0xffull)) continue;  // nothing that matters to this cell changed: every label repeats
                     const uint32_t r = bi < 4 ? rA : rB;
                     const int l0 = (int)((bi & 3) * 16);
                     pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
                     c = (uint32_t)__builtin_amdgcn_readlane((int)r, l0 + 1);
-                    in1 = (((uint32_t)__shfl((int)r, l0 + 2 + (int)((k1 >> 5) & 7), 64) >> (k1 & 31)) & 1u) != 0;
                 } else {
                     pvt = (uint32_t)__builtin_amdgcn_readlane((int)rA, 0);
                     c = (uint32_t)__builtin_amdgcn_readlane((int)rA, 1);
@@ -1087,14 +1117,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                     const uint32_t w1 = i1 < 64 ? a1 : b1;
                     in1 = ((w1 >> (k1 & 31)) & 1u) != 0;
                 }
-                Dominance dm;
-                dm.set(cell_box(c), (1 << kCellShift) - 1, pvt);
-                // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
-                bool dirty = false;
-                if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
-                RG_PHASE(6);
-                RG_TLC(7, 1);
-                if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
+                if (IDBITS != 8) {
+                    Dominance dm;
+                    dm.set(cell_box(c), (1 << kCellShift) - 1, pvt);
+                    // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                    bool dirty = false;
+                    if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
+                    RG_PHASE(6);
+                    RG_TLC(7, 1);
+                    if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
+                }
                 RG_TLC(6, 1);
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
