@@ -54,7 +54,8 @@ constexpr uint32_t kMaxBlocks = 512;
 #define CNIIC_CELL_WAVES 8
 #endif
 constexpr int kCellWaves = CNIIC_CELL_WAVES;                  // waves per block (narrow labels); they share the block's cell range
-constexpr uint32_t kCellBlocks = 256 * (kCellWaves == 4 ? 6 : kCellWaves == 8 ? 3 : 2);  // every block resident at once (LDS, K <= 256)
+constexpr uint32_t kCellWavesBig = 12;                        // ... and in the settled part of a run (launch_assign)
+constexpr uint32_t kCellBlocks = 256 * (kCellWaves == 4 ? 6 : kCellWaves == 6 ? 4 : kCellWaves == 8 ? 3 : 2);  // every block resident at once (LDS, K <= 256)
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
 // The full schedule's split of the cells into ranges of equal estimated cost: a cell costs its candidate build plus one sweep
 // per 256 points (a sweep of 3 points takes as long as one of 256) -- 2 : 1 measured on the headline encode (assign launches
@@ -86,6 +87,7 @@ struct KmRgbwState {
     bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
     cniic_kmeans_stats run_stats{};  // the statistics km_rgbw_run ended on
     bool run_stats_valid = false;
+    uint32_t big_blocks_from = 10;  // launches from this one on run in blocks of kCellWavesBig waves (CNIIC_KM_BIG_BLOCKS_FROM; a huge value: never)
     uint32_t agg_launches = 3;  // launches 1 .. agg_launches book their movers round by round (CNIIC_KM_AGG_LAUNCHES)
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
@@ -1806,6 +1808,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
     s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     if (const char *al = getenv("CNIIC_KM_AGG_LAUNCHES")) s->agg_launches = (uint32_t)atoi(al);
+    if (const char *bb = getenv("CNIIC_KM_BIG_BLOCKS_FROM")) s->big_blocks_from = (uint32_t)atoi(bb);
     if (const char *ms = getenv("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
@@ -2022,12 +2025,17 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
                                       (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K, (const uint2 *)s->cconst.as<uint2>(),
                                       s->labels.as<uint8_t>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
         } else {
-            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)kCellWaves * ((s->K + 1) / 2 + s->K) * 8 +
-                               (size_t)kCellWaves * ((s->K + 63) / 64) * 8;
-            auto kern = !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
+            // The same wave ranges in blocks of 12 waves, two per CU, once the run has settled (from launch big_blocks_from):
+            // measured on the headline encode, the first ten launches are 5-13 us faster in blocks of 8 (three per CU), every later
+            // one 1-3 us faster in blocks of 12.  (The ranges are per wave, so regrouping them needs nothing but a multiple of 12.)
+            const bool big = kCellWaves == 8 && fz.on && fz.launch_no >= s->big_blocks_from && (s->nblocks * (uint32_t)kCellWaves) % kCellWavesBig == 0;
+            const uint32_t wpb = big ? kCellWavesBig : (uint32_t)kCellWaves, nblk = s->nblocks * (uint32_t)kCellWaves / wpb;
+            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
+            auto kern = big ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>
+                        : !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
                         : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>
                         : fz.launch_no <= s->agg_launches ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
-            hipExtLaunchKernelGGL(kern, dim3(s->nblocks), dim3(64 * kCellWaves), (uint32_t)lds,
+            hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(64 * wpb), (uint32_t)lds,
                                   c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                   (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                   (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
