@@ -35,6 +35,7 @@ for L in sys.argv[1:]:
     t0 = t[:, 0].min()
     t -= t0
     dirty, cells = a[:, 7], a[:, 8]
+    WPB = 12 if int(L) >= int(os.environ.get("CNIIC_KM_BIG_BLOCKS_FROM", "10")) else 8  # waves per block of that launch
     print("launch %s: %d waves, span %.2f us; dirty cells %d of %d tested" % (L, len(a), t[:, 5].max(), dirty.sum(), cells.sum()))
     names = ["entry", "prologue done", "first test/build done", "loop done", "barrier passed", "end"]
     for i, n in enumerate(names):
@@ -45,8 +46,8 @@ for L in sys.argv[1:]:
     order = np.argsort(-t[:, 3])[:4]
     for i in order:
         print("    late wave %5d (block %4d): prologue done %.2f, first test/build %.2f, loop done %.2f, end %.2f | %d dirty of %d cells" %
-              (a[i, 0], a[i, 0] // 8, t[i, 1], t[i, 2], t[i, 3], t[i, 5], dirty[i], cells[i]))
-    blk = (a[:, 0] // 8).astype(np.int64)
+              (a[i, 0], a[i, 0] // WPB, t[i, 1], t[i, 2], t[i, 3], t[i, 5], dirty[i], cells[i]))
+    blk = (a[:, 0] // WPB).astype(np.int64)
     bend = np.zeros(blk.max() + 1)
     np.maximum.at(bend, blk, t[:, 3])
     block_end[L] = bend
