@@ -1130,6 +1130,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                     if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
                 }
                 RG_TLC(6, 1);
+#ifdef CNIIC_RGBW_PHASES
+                unsigned long long tq_ = tl_on_ ? wall_clock64() : 0ull;  // skip schedule, per dirty cell: [8] range + build, [9] wait for the points, [10] sweeps
+#endif
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
 #pragma unroll
@@ -1141,6 +1144,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 }
                 // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
                 const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+#ifdef CNIIC_RGBW_PHASES
+                if (tl_on_) {
+                    unsigned long long n_ = wall_clock64(); tl_[8] += n_ - tq_; tq_ = n_;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    n_ = wall_clock64(); tl_[9] += n_ - tq_; tq_ = n_;
+                }
+#endif
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
 #pragma unroll
@@ -1157,6 +1167,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 evals += (unsigned long long)(e - s) * (ncand + 1);
                 RG_PHASE(7);
                 RG_TL1(2);
+#ifdef CNIIC_RGBW_PHASES
+                if (tl_on_) { tl_[10] += wall_clock64() - tq_; tl_[11] += ncand; }
+#endif
                 __builtin_amdgcn_wave_barrier();
               }
             }

@@ -52,7 +52,7 @@ for L in sys.argv[1:]:
     np.maximum.at(bend, blk, t[:, 3])
     block_end[L] = bend
     print("  blocks: loop done min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f us" % (bend.min(), np.percentile(bend, 10), np.percentile(bend, 50), np.percentile(bend, 90), bend.max()))
-    if a.shape[1] >= 13 and a[:, 10].sum() > 0:
+    if a.shape[1] >= 13 and not (dirty.sum() <= cells.sum()):
         # full schedule: what a block's loop time is made of (least squares over the blocks)
         nb = blk.max() + 1
         X = np.zeros((nb, 6))
@@ -67,6 +67,11 @@ for L in sys.argv[1:]:
         names6 = ["const", "per cell", "per sweep", "per candidate", "per point", "per S build", "per S entry"]
         print("  block loop time ~ " + ", ".join("%s %.4f" % (n, c) for n, c in zip(names6, coef)) + " (us); R^2 %.3f; block means: cells %.1f sweeps %.1f candidates %.0f points %.0f S builds %.1f" %
               (1 - ((y - pred) ** 2).sum() / ((y - y.mean()) ** 2).sum(), X[:, 0].mean(), X[:, 1].mean(), X[:, 2].mean(), X[:, 3].mean(), X[:, 4].mean()))
+    is_skip = dirty.sum() <= cells.sum()   # (the full schedule counts sweeps in that slot: more than cells)
+    if a.shape[1] >= 13 and is_skip and dirty.sum():  # skip schedule: the dirty cells' chain
+        nd = float(dirty.sum())
+        print("  per dirty cell: range + candidate build %.2f us, then waiting for its points %.2f us, sweeps %.2f us (%.1f candidates)" %
+              (a[:, 9].sum() / 100.0 / nd, a[:, 10].sum() / 100.0 / nd, a[:, 11].sum() / 100.0 / nd, a[:, 12].sum() / nd))
     nb_ = len(bend)
     ids = np.arange(nb_)
     for name, key in (("block %% 8 (XCD if blocks are dealt round-robin)", ids % 8), ("block // 256 (dispatch round)", ids // 256), ("block %% 32 // 8", ids % 32 // 8)):
