@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void k_wave_ranges(const uint32_t *__restrict_
     wfirst[g] = g == G ? M : a;
 }
 
+constexpr uint32_t kRecComplete = 0x80000000u;  // word 1 of a record: the mask holds EVERY centroid its pivot does not dominate (skip schedule, K <= 256)
 __host__ __device__ constexpr uint32_t cell_rec_words(uint32_t MW) { return (2 + 2 * MW + 15) & ~15u; }  // u32 words of a cell's skip record (CellState below)
 constexpr uint32_t kMaxMovedSkip = 64;  // skip schedule when at most this many centroids moved (one per lane of the test; measured on the
                                         // headline encode: 128 -> 1.92 ms of assign launches, 96 -> 1.90, 64 -> 1.88, 40 -> 1.88: above ~60 moved
@@ -503,7 +504,8 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     constexpr int32_t ext = (1 << kCellShift) - 1;
     const CellBox bx = cell_box(c);
-    const uint32_t pv = list[nearest_to_centre(list, n, bx, ext, lane)].x;
+    const uint2 pvc = list[nearest_to_centre(list, n, bx, ext, lane)];
+    const uint32_t pv = pvc.x, pid = IDMASK - (pvc.y & IDMASK);
     Dominance dm;
     dm.set(bx, ext, pv);
     for (uint32_t i = lane; i < MW; i += 64) wmask[i] = 0ull;
@@ -524,10 +526,12 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
-    uint32_t i_first = (uint32_t)lane;
-    asm volatile("" : "+v"(i_first));  // (or "cell_rec + 8 lane + 8" is computed once per launch and two registers hold it across the cell loop)
+    // (the lane's index made afresh and pinned: or "cell_rec + 8 lane + 8" is computed once per launch and two registers hold it
+    // across the cell loop -- or are spilled, and a scratch reload per cell sits in front of the loads in flight)
+    uint32_t i_first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(i_first));
     for (uint32_t i = i_first; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
-    if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c);
+    if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c | (pid << 16));  // (cell ids are 15 bits, cluster ids at most 11; bit 31: kRecComplete)
     return ncand;
 }
 
@@ -655,6 +659,49 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
                     atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
                     atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
                 }
+            }
+        }
+    }
+}
+
+// one sweep with the candidates given as a bitmask of cluster ids (K <= 256) instead of a list: the set bits are walked on the
+// scalar unit, each candidate read from the block's table (no candidate list, no compaction)
+template <typename LabelT, int IDBITS>
+__device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
+                                                  uint32_t base, uint32_t e, int lane, const unsigned long long (&nm)[4],
+                                                  const uint2 *tab, uint32_t K, LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    uint32_t best[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) best[u] = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned long long mm = nm[w];
+        while (mm) {
+            const uint32_t k = 64 * w + (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint2 cc = tab[k];
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        const uint32_t q = base + u * 64 + lane;
+        if (q < e) {
+            const uint2 cc = tab[cur[u]];
+            const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
+            const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+            if (mv) {
+                const uint32_t ol = cur[u], pp = p[u], nl = IDMASK - (best[u] & IDMASK);
+                labels[q] = (LabelT)nl;
+                moved++;
+                const uint64_t w = wt[u];
+                const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
+                atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * nl + 2], bw);
+                atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[4 * K + nl], 1ull);
+                atomicAdd(&acc[3 * ol + 0], 0ull - rw); atomicAdd(&acc[3 * ol + 1], 0ull - gw); atomicAdd(&acc[3 * ol + 2], 0ull - bw);
+                atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w); atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
             }
         }
     }
@@ -851,6 +898,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
     __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
+    __shared__ unsigned long long s_mm[4];  // K <= 256: bit k <=> centroid k moved in the last update
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
     constexpr int THREADS = WAVES * 64;
@@ -884,7 +932,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
     if (!fz.on || first)
         for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; }
+    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_mm[0] = s_mm[1] = s_mm[2] = s_mm[3] = 0ull; }
     // fused update: one cluster per thread (K <= 256 <= THREADS); its ten sums and its old centroid are requested
     // together with the set-up loads above, before anything is waited for
     const bool upd = fz.on && !first;
@@ -928,6 +976,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             if (ck != oldc) {
                 const uint32_t pos = atomicAdd(&s_nmoved, 1u);
                 if (pos < kMaxMovedSkip) s_mlist[pos] = k;
+                atomicOr(&s_mm[(k >> 6) & 3], 1ull << (k & 63));
             }
             if (blockIdx.x == 0) {
 #pragma unroll
@@ -1047,6 +1096,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         const uint32_t m_lo = wfirst[gw0], m_hi = wfirst[gw0 + gridDim.x * WAVES];
         const uint32_t k1 = (uint32_t)lane < nS ? mlist[lane] : 0xffffffffu;
         const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u;
+        if (IDBITS == 8 && !upd) {  // (an update kernel ran in between: only its list is at hand) the moved ids as a bitmask
+            if (wid == 0 && k1 != 0xffffffffu) atomicOr(&s_mm[(k1 >> 6) & 3], 1ull << (k1 & 63));
+            __syncthreads();
+        }
         // cells are dealt round-robin: what survives the skip test is clustered around the centroids that
         // moved, and striding spreads those clusters over all waves (a shared atomic queue would
         // saturate: one word serves ~90 dequeues/us)
@@ -1081,7 +1134,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                   const uint32_t pv = ci < 4 ? pvA : pvB, cc = ci < 4 ? ccA : ccB;
                   const bool cell_ok = mb + ci * nwaves < m_hi;
                   Dominance dmv;
-                  dmv.set(cell_box(cc), (1 << kCellShift) - 1, pv);
+                  dmv.set(cell_box(cc & 0xffffu), (1 << kCellShift) - 1, pv);
                   bool dv = false;
                   for (uint32_t j0 = 0; j0 < nS; j0 += 8) {
                       const uint32_t j = j0 + ((uint32_t)lane & 7u);
@@ -1099,20 +1152,115 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                   RG_TLC(7, 8);
                   if (!dirty8) continue;
               }
+              if constexpr (IDBITS == 8) {
+                // the moved ids as a bitmask laid out like a register of records (lanes 16 i + 2 .. 16 i + 9 = the eight mask words)
+                const uint32_t jw = ((uint32_t)lane & 15u) - 2u;
+                const uint32_t mmv = jw < 8u ? reinterpret_cast<const uint32_t *>(s_mm)[jw] : 0u;
+#pragma unroll 1
+                for (uint32_t bi = 0; bi < kRecBatch; bi++) {
+                    const uint32_t m = mb + bi * nwaves;
+                    if (m >= m_hi) break;
+                    if (!((dirty8 >> (8 * bi)) & 0xffull)) continue;  // nothing that matters to this cell changed: every label repeats
+                    RG_TLC(6, 1);
+#ifdef CNIIC_RGBW_PHASES
+                    unsigned long long tq_ = tl_on_ ? wall_clock64() : 0ull;  // per dirty cell: [8] range + mask, [9] wait for the points, [10] sweeps
+#endif
+                    const uint32_t r = bi < 4 ? rA : rB;
+                    const int l0 = (int)((bi & 3) * 16);
+                    const uint32_t pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
+                    const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)r, l0 + 1);
+                    const uint32_t c = cw & 0xffffu, pid = (cw >> 16) & 0x7fffu;
+                    const uint32_t s = ne_start[m], e = ne_start[m + 1];
+                    uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) {
+                        const uint32_t q = s + u * 64 + lane;
+                        p[u] = q < e ? ckeys[q] : 0u;
+                        cur[u] = q < e ? (uint32_t)labels[q] : 0u;
+                        wt[u] = q < e ? cweight[q] : 0u;
+                    }
+                    // A mask is COMPLETE if it holds every centroid of the table that the cell's pivot does not dominate (the full
+                    // schedule builds from the super-cell's list instead: what that list left out was beaten by ANOTHER centroid,
+                    // which may have moved since).  While the pivot of a complete mask stands where it stood, every centroid that
+                    // has not moved keeps its verdict against it; the moved ones are tested here: new mask = old mask without the
+                    // moved ids + the moved ids that pass.  Otherwise the mask is rebuilt from the whole table with a fresh pivot,
+                    // one ballot per 64 ids -- and is complete from then on.  Either way there is no candidate list: the sweep
+                    // walks the mask on the scalar unit.
+                    constexpr int32_t ext = (1 << kCellShift) - 1;
+                    const CellBox bx = cell_box(c);
+                    const bool keep_pivot = (cw & kRecComplete) && (((uint32_t)__builtin_amdgcn_readlane((int)mmv, 2 + (int)((pid >> 5) & 7)) >> (pid & 31)) & 1u) == 0u;
+                    unsigned long long nm[4];
+                    Dominance dm;
+                    if (keep_pivot) {
+                        dm.set(bx, ext, pvt);
+                        unsigned long long f1 = __ballot(k1 != 0xffffffffu && dm.worst(ck1) >= 0);
+                        const uint32_t nmv = r & ~mmv;
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)nmv, l0 + 3 + 2 * w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)nmv, l0 + 2 + 2 * w);
+                        while (f1) {
+                            const int l = __builtin_ctzll(f1);
+                            f1 &= f1 - 1;
+                            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)k1, l);
+                            const unsigned long long b = 1ull << (k & 63);
+                            const uint32_t w = (k >> 6) & 3;
+                            nm[0] |= w == 0 ? b : 0ull; nm[1] |= w == 1 ? b : 0ull; nm[2] |= w == 2 ? b : 0ull; nm[3] |= w == 3 ? b : 0ull;
+                        }
+                    } else {
+                        const uint32_t npid = nearest_to_centre(tab, K, bx, ext, lane);  // (the table is in id order)
+                        const uint32_t npv = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[npid].x);
+                        dm.set(bx, ext, npv);
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const uint32_t k = 64 * w + lane;
+                            nm[w] = __ballot(k < K && dm.worst(tab[k < K ? k : 0].x) >= 0);
+                        }
+                        if (lane == 0) *reinterpret_cast<uint2 *>(cs.rec + (size_t)m * 16) = make_uint2(npv, c | (npid << 16) | kRecComplete);
+                    }
+                    {   // the lanes that hold the cell's mask words write the ones that changed
+                        uint32_t wv = 0;
+#pragma unroll
+                        for (int t = 0; t < 8; t++)
+                            if (jw == (uint32_t)t) wv = (uint32_t)(nm[t >> 1] >> (32 * (t & 1)));
+                        if ((lane >> 4) == (int)(bi & 3) && jw < 8u && wv != r) cs.rec[(size_t)m * 16 + 2 + jw] = wv;
+                    }
+                    const uint32_t ncand = (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
+#ifdef CNIIC_RGBW_PHASES
+                    if (tl_on_) {
+                        unsigned long long n_ = wall_clock64(); tl_[8] += n_ - tq_; tq_ = n_;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        n_ = wall_clock64(); tl_[9] += n_ - tq_; tq_ = n_;
+                    }
+#endif
+                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                        uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
+#pragma unroll
+                        for (int u = 0; u < kSweep; u++) {
+                            const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
+                            pn[u] = qn < e ? ckeys[qn] : 0u;
+                            curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
+                            wtn[u] = qn < e ? cweight[qn] : 0u;
+                        }
+                        sweep_points_mask<LabelT, IDBITS>(p, cur, wt, base, e, lane, nm, tab, K, labels, acc, moved);
+#pragma unroll
+                        for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
+                    }
+                    evals += (unsigned long long)(e - s) * (ncand + 1);
+                    RG_PHASE(7);
+                    RG_TL1(2);
+#ifdef CNIIC_RGBW_PHASES
+                    if (tl_on_) { tl_[10] += wall_clock64() - tq_; tl_[11] += ncand; }
+#endif
+                }
+              } else {
               for (uint32_t bi = 0; bi < kRecBatch; bi++) {
                 const uint32_t m = mb + bi * nwaves;
                 if (m >= m_hi) break;
                 uint32_t pvt, c;
                 bool in1 = false;
-                if (IDBITS == 8) {
-                    if (!((dirty8 >> (8 * bi)) & 0xffull)) continue;  // nothing that matters to this cell changed: every label repeats
-                    const uint32_t r = bi < 4 ? rA : rB;
-                    const int l0 = (int)((bi & 3) * 16);
-                    pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
-                    c = (uint32_t)__builtin_amdgcn_readlane((int)r, l0 + 1);
-                } else {
+                {
                     pvt = (uint32_t)__builtin_amdgcn_readlane((int)rA, 0);
-                    c = (uint32_t)__builtin_amdgcn_readlane((int)rA, 1);
+                    c = (uint32_t)__builtin_amdgcn_readlane((int)rA, 1) & 0xffffu;
                     const uint32_t i1 = 2 + ((k1 & 0x7ffu) >> 5);
                     // (both shuffles by every lane: a lane that sits out a shuffle is read as nothing by the others)
                     const uint32_t a1 = (uint32_t)__shfl((int)rA, (int)(i1 & 63), 64), b1 = (uint32_t)__shfl((int)rB, (int)(i1 & 63), 64);
@@ -1171,6 +1319,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 if (tl_on_) { tl_[10] += wall_clock64() - tq_; tl_[11] += ncand; }
 #endif
                 __builtin_amdgcn_wave_barrier();
+              }
               }
             }
         }
