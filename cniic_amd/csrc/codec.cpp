@@ -110,7 +110,16 @@ struct StreamOut {
     uint64_t total = 0;
     StreamOut(Ctx *ctx, uint8_t *out, uint64_t capacity, uint64_t *len_out) : c(ctx), caller(out), cap(capacity), len(len_out) {}
     int begin(const std::vector<uint8_t> &header, uint64_t payload_bytes) {
-        total = header.size() + payload_bytes;
+        CNIIC_TRY(begin_sized(header.size(), payload_bytes));
+        return put_header(header);
+    }
+    // the header's bytes may follow the payload (put_header): its size is enough to place the payload
+    int put_header(const std::vector<uint8_t> &header) {
+        if (!header.empty()) CNIIC_HIP_TRY(c, hipMemcpyAsync(dev, header.data(), header.size(), hipMemcpyHostToDevice, c->stream));
+        return CNIIC_OK;
+    }
+    int begin_sized(uint64_t header_bytes, uint64_t payload_bytes, bool zero = true) {
+        total = header_bytes + payload_bytes;
         *len = total;
         if (total > cap) return c->fail(CNIIC_ERR_CAPACITY, "encode: stream is %llu bytes, capacity %llu",
                                         (unsigned long long)total, (unsigned long long)cap);
@@ -118,8 +127,7 @@ struct StreamOut {
         direct = is_device_ptr(caller) && (reinterpret_cast<uintptr_t>(caller) & 3) == 0 && padded <= cap;
         if (direct) dev = caller;
         else { CNIIC_HIP_TRY(c, staging.alloc(padded + 16)); dev = staging.as<uint8_t>(); }
-        CNIIC_HIP_TRY(c, hipMemsetAsync(dev, 0, padded, c->stream));
-        if (!header.empty()) CNIIC_HIP_TRY(c, hipMemcpyAsync(dev, header.data(), header.size(), hipMemcpyHostToDevice, c->stream));
+        if (zero) CNIIC_HIP_TRY(c, hipMemsetAsync(dev, 0, padded, c->stream));
         return CNIIC_OK;
     }
     int finish() {
@@ -725,12 +733,11 @@ static int encode_voronoi(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, 
 }
 
 // ------------------------------------------------------------------ Delta::encode (hilbertc.rs:405-415)
-static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len) {
+// The 32-bit route: symbols as packed keys (hilbert_delta + huf_encode_all_dev).  Taken when many differences fall
+// outside the cube [-16, 15]^3 (a noisy image), or with CNIIC_DELTA_ROUTE=32.
+static int encode_delta_syms32(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, std::vector<uint8_t> &header, uint8_t *out, uint64_t cap,
+                               uint64_t *len) {
     const uint64_t n = (uint64_t)w * h;
-    std::vector<uint8_t> header;
-    put_u32(header, w);
-    put_u32(header, h);
-    if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "delta: empty image (src/huf.rs:99 asserts)");
     uint32_t *table = nullptr;
     CNIIC_TRY(dense_table(c, 27, &table));
     DevBuf syms;
@@ -739,6 +746,92 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     // second (bit-pack) pass instead of recomputing the scan as the reference does (huf.rs:30,38)
     CNIIC_TRY(hilbert_delta(c, rgb_d, w, h, syms.as<uint32_t>(), table));
     return huf_encode_all_dev(c, CNIIC_SYM_SIGNED, nullptr, syms.as<uint32_t>(), true, n, table, true, header, out, cap, len);
+}
+
+static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len) {
+    const uint64_t n = (uint64_t)w * h;
+    std::vector<uint8_t> header;
+    put_u32(header, w);
+    put_u32(header, h);
+    if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "delta: empty image (src/huf.rs:99 asserts)");
+    const char *route = getenv("CNIIC_DELTA_ROUTE");  // "32": the 32-bit route whatever the image (tests)
+    if (route && atoi(route) == 32) return encode_delta_syms32(c, rgb_d, w, h, header, out, cap, len);
+    host_trace().mark("delta: enter");
+    // 1. linearize + DiffStream + count_freqs (hilbertc.rs:408-410, huf.rs:30): the symbols as a 16-bit stream (k_delta.hip)
+    uint32_t *table = nullptr;
+    uint8_t *pages = nullptr;
+    CNIIC_TRY(delta_table(c, &table, &pages));
+    DevBuf hot16, coldkeys, chunk_cold, small;
+    const uint64_t nchunks = delta_stream_len(n) / 512;
+    CNIIC_HIP_TRY(c, hot16.alloc(delta_stream_len(n) * 2));
+    CNIIC_HIP_TRY(c, coldkeys.alloc(nchunks * 64 * 4));  // (written where cold symbols are)
+    CNIIC_HIP_TRY(c, chunk_cold.alloc(nchunks));
+    CNIIC_HIP_TRY(c, small.alloc(32));  // [0] cold symbols, [1] a chunk with more than 64 of them, [2] bits packed
+    CNIIC_HIP_TRY(c, hipMemsetAsync(small.p, 0, 32, c->stream));
+    CNIIC_TRY(delta_gather_hist(c, rgb_d, w, h, hot16.as<uint16_t>(), table, pages, coldkeys.as<uint32_t>(), chunk_cold.as<uint8_t>(),
+                                small.as<unsigned long long>()));
+    CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], small.p, 16, hipMemcpyDeviceToHost, c->stream));
+    CompactPlan plan;
+    CNIIC_TRY(hist_compact_count(c, table, 27, &plan, nullptr, pages));  // (waits for the stream)
+    const uint64_t U = plan.n_unique, cold = c->pinned_u[2];
+    if (host_trace().on) fprintf(stderr, "[host] delta: %llu symbols, %llu distinct, %llu outside the cube%s\n", (unsigned long long)n, (unsigned long long)U,
+                                 (unsigned long long)cold, c->pinned_u[3] ? " (a chunk has more than 64: the 32-bit route)" : "");
+    if (U >= (1ull << 26) || c->pinned_u[3]) {
+        CNIIC_TRY(delta_table_clean(c));
+        return encode_delta_syms32(c, rgb_d, w, h, header, out, cap, len);
+    }
+    DevBuf keys_d, counts_d;
+    CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
+    CNIIC_HIP_TRY(c, counts_d.alloc(U * 8));
+    CNIIC_TRY(hist_compact_write(c, table, &plan, keys_d.as<uint32_t>(), counts_d.as<uint64_t>(), nullptr));
+    std::vector<uint32_t> keys(U);
+    std::vector<uint64_t> counts(U);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    host_trace().mark("delta: gather + hist + compaction + D2H");
+    // 2. build() (huf.rs:31)
+    HuffTree tree;
+    std::vector<uint8_t> clen;
+    std::vector<uint64_t> code;
+    if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, clen, code))
+        return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+    host_trace().mark("delta: tree + codes (host)");
+    // 3. payload (huf.rs:37-41) behind the serialised decoder (huf.rs:34), whose size follows from U alone: U leaves of
+    //    1 + 6 bytes and U - 1 branch tags -- the GPU packs while the host writes the decoder out
+    uint64_t nbits = 0;
+    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
+    const uint64_t header_bytes = header.size() + U * (1 + (uint64_t)huff_symbol_size(CNIIC_SYM_SIGNED)) + (U - 1);
+    StreamOut so(c, out, cap, len);
+    CNIIC_TRY(so.begin_sized(header_bytes, (nbits + 7) / 8, /*zero=*/false));  // (the pack stores every word of the payload)
+    DevBuf len_d, code_d;
+    CNIIC_HIP_TRY(c, len_d.alloc(U));
+    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen.data(), U, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
+    DeltaPackScratch scratch;
+    if (nbits) {  // (a single symbol: the zero-length code and no payload, huf.rs:140-142)
+        ScopedKernelTimer timer(c, "huff_pack");
+        CNIIC_TRY(delta_pack16(c, hot16.as<uint16_t>(), n, coldkeys.as<uint32_t>(), chunk_cold.as<uint8_t>(), table, keys_d.as<uint32_t>(),
+                               len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, so.dev, header_bytes * 8, small.as<uint64_t>() + 2, &scratch));
+        timer.stop(1);
+    }
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[3], small.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_TRY(delta_table_clean(c));
+    host_trace().mark("delta: pack enqueued");
+    huff_serialize_tree(tree, CNIIC_SYM_SIGNED, keys.data(), header);
+    host_trace().mark("delta: serialise trie (host)");
+    if (header.size() != header_bytes) return c->fail(CNIIC_ERR_HIP, "delta: decoder of %llu bytes, expected %llu", (unsigned long long)header.size(),
+                                                      (unsigned long long)header_bytes);
+    CNIIC_TRY(so.put_header(header));
+    const int rc_fin = so.finish();  // (waits for the stream)
+    host_trace().mark("delta: pack + finish");
+    host_trace().dump();
+    if (rc_fin != CNIIC_OK) return rc_fin;
+    if (c->pinned_u[3] != nbits)
+        return c->fail(CNIIC_ERR_HIP, "huffman: packed %llu bits, histogram predicts %llu", (unsigned long long)c->pinned_u[3], (unsigned long long)nbits);
+    return CNIIC_OK;
 }
 
 // ------------------------------------------------------------------ Hilbert{RLE(0.0)}::encode (hilbertc.rs:26-39)

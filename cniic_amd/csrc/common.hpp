@@ -121,6 +121,8 @@ struct Ctx {
     DevPool pool;           // recycled scratch HBM (all DevBufs created inside an ABI call)
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
+    DevBuf dense27, dense27_pages;  // `delta`: u32[2^27] SignedColor counts + a flag per 4096-entry page, all zero between calls (k_delta.hip)
+    bool   dense27_clean = false;
     DevBuf hilbert_lut;     // state-machine tables of the 2^n Hilbert scan (k_hilbert.hip)
     void  *pinned = nullptr; // 4 KiB of pinned host memory: two KmDevState slots for lagged convergence polling
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -380,6 +382,7 @@ struct CompactPlan {
     DevBuf   blockoff;
     uint64_t n_unique = 0;
     uint32_t bits = 0;
+    const uint8_t *pages = nullptr;  // (optional) a flag per 4096-entry page: pages without one are skipped
 };
 // occupancy across ranks: nibble per key (k_hist.hip), and the index of all occupied keys built from the summed nibbles
 int occupancy_pack(Ctx *c, const uint32_t *table_d, uint32_t *occ_d);  // u32[2^24] counts -> u32[2^21] nibble words
@@ -407,7 +410,8 @@ int sp_occupancy(Ctx *c, const SpPlan *plan, uint32_t *occ_d);  // this image's 
 int sp_pixel_labels(Ctx *c, const SpPlan *plan, const uint8_t *rgb_d, const uint32_t *cell_start_d, const uint32_t *ckeys_d,
                     const void *labels_d, bool wide, void *pixlab_d);
 // cell_count_d (optional, 24-bit tables): zeroed u32[32768] receiving the occupied bins per K-means colour cell
-int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d = nullptr);
+int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d = nullptr,
+                       const uint8_t *pages_d = nullptr);
 // After this call the table holds, for every occupied bin, its RANK (index into the compacted
 // list) + 1; empty bins stay 0.  Outputs are optional device arrays of plan->n_unique entries.
 int hist_compact_write(Ctx *c, uint32_t *table_d, const CompactPlan *plan, uint32_t *keys_d, uint64_t *counts_d,
@@ -519,7 +523,22 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
 int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t *syms_d, uint32_t *table_d);
 int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d);
 
+// ---- k_delta.hip: the `delta` encoder's passes over a 16-bit symbol stream ----
+constexpr uint32_t kPageShift = 12;  // a page of a dense table = the 4096 entries one block of the compaction reads
+int delta_table(Ctx *c, uint32_t **table_d, uint8_t **pages_d);  // the context's clean 2^27-bin table + page flags
+int delta_table_clean(Ctx *c);                                   // touched pages back to zero (enqueued)
+uint64_t delta_stream_len(uint64_t n);                           // u16 entries of the symbol stream of n pixels
+int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint16_t *hot16_d, uint32_t *table_d, uint8_t *pages_d,
+                      uint32_t *coldkeys_d, uint8_t *chunk_cold_d, unsigned long long *cold_d);
+struct DeltaPackScratch { DevBuf cb, co, edge, hot, hotlen; };
+int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
+                 const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint8_t *out_d, uint64_t bit_base, uint64_t *total_d,
+                 DeltaPackScratch *keep);
+
 // ---- k_huff.hip ----
+// chunk_off[i] = exclusive prefix (u64) of chunk_bits[0 .. nchunks); *total_d = the sum
+int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *chunk_off_d, uint64_t *total_d);
+uint32_t pack_img_cap();  // tests: CNIIC_TEST_PACK_IMG_WORDS caps the packs' LDS bit image
 // MSB-first bit-pack of n symbols at bit offset bit_base of out_d (4-byte aligned, pre-zeroed,
 // large enough; bytes before bit_base may already hold the stream header).
 // Generic path: symbol -> rank (dense table left by the compaction) -> len_d / code_d per rank.

@@ -228,4 +228,27 @@ __device__ __forceinline__ uint32_t init_label24(uint32_t i, uint32_t n, uint32_
     return min(q, K - 1);
 }
 
+// ---- bit packing (k_huff.hip, k_delta.hip)
+constexpr uint32_t kEscape = 63;  // length field of a len << 26 | code word that redirects to the per-rank tables (U < 2^26)
+
+// one symbol's code as up to three pieces of 32-bit words: emit(word index, bits to OR in; MSB-first inside the word)
+template <typename Emit>
+__device__ __forceinline__ void pack_pieces(uint32_t pos, uint32_t L, uint64_t cd, Emit emit) {
+    // place bits [pos, pos+L) MSB-first: word w bit (31 - b)
+    const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;  // room: bits left in word w
+    if (L <= room) {
+        emit(w, (uint32_t)(cd << (room - L)));
+    } else {
+        const uint32_t rem = L - room;  // bits after the first word
+        emit(w, (uint32_t)(cd >> rem));
+        if (rem <= 32) emit(w + 1, (uint32_t)(cd << (32 - rem)));
+        else { emit(w + 1, (uint32_t)(cd >> (rem - 32))); emit(w + 2, (uint32_t)(cd << (64 - rem))); }
+    }
+}
+// ... into a bit image (LDS) or straight into the output words (memory; big-endian bit order, pre-zeroed)
+template <bool DIRECT>
+__device__ __forceinline__ void pack_put(uint32_t *words, uint32_t pos, uint32_t L, uint64_t cd) {
+    pack_pieces(pos, L, cd, [&](uint32_t i, uint32_t v) { atomicOr(&words[i], DIRECT ? __builtin_bswap32(v) : v); });
+}
+
 }  // namespace cniic

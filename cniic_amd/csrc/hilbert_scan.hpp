@@ -1,0 +1,107 @@
+// hilbert_scan.hpp -- the scan d -> (x, y) as device code shared by k_hilbert.hip and k_delta.hip
+// (reference: src/hilbert.rs:34-43; the curve's definition is frozen in DESIGN.md, "Hilbert scan: parity unpinned").
+#pragma once
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace cniic {
+
+// ---------------------------------------------------------------- generic rectangles
+__device__ __forceinline__ int32_t sgn32(int32_t v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int32_t floordiv2(int32_t v) { return v >> 1; }  // arithmetic shift = floor
+
+// position d of the scan of a w x h rectangle (d < w*h < 2^32, sides < 2^31)
+__device__ __forceinline__ void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t d0, uint32_t &xo, uint32_t &yo) {
+    int32_t x = 0, y = 0, ax, ay, bx, by;
+    int64_t d = (int64_t)d0;
+    if (w0 >= h0) { ax = (int32_t)w0; ay = 0; bx = 0; by = (int32_t)h0; }
+    else { ax = 0; ay = (int32_t)h0; bx = (int32_t)w0; by = 0; }
+    for (;;) {
+        const int32_t w = abs(ax + ay), h = abs(bx + by);
+        const int32_t dax = sgn32(ax), day = sgn32(ay), dbx = sgn32(bx), dby = sgn32(by);
+        if (h == 1) { x += dax * (int32_t)d; y += day * (int32_t)d; break; }
+        if (w == 1) { x += dbx * (int32_t)d; y += dby * (int32_t)d; break; }
+        int32_t ax2 = floordiv2(ax), ay2 = floordiv2(ay), bx2 = floordiv2(bx), by2 = floordiv2(by);
+        const int32_t w2 = abs(ax2 + ay2), h2 = abs(bx2 + by2);
+        if (2 * (int64_t)w > 3 * (int64_t)h) {  // long rectangle: two halves
+            if ((w2 & 1) && w > 2) { ax2 += dax; ay2 += day; }
+            const int64_t n1 = (int64_t)abs(ax2 + ay2) * h;
+            if (d < n1) { ax = ax2; ay = ay2; }
+            else { d -= n1; x += ax2; y += ay2; ax -= ax2; ay -= ay2; }
+        } else {  // up, across, down
+            if ((h2 & 1) && h > 2) { bx2 += dbx; by2 += dby; }
+            const int32_t hh = abs(bx2 + by2);
+            const int64_t n1 = (int64_t)hh * w2;
+            const int64_t n2 = (int64_t)w * (h - hh);
+            if (d < n1) {
+                ax = bx2; ay = by2; bx = ax2; by = ay2;
+            } else if (d < n1 + n2) {
+                d -= n1; x += bx2; y += by2; bx -= bx2; by -= by2;
+            } else {
+                d -= n1 + n2;
+                x += (ax - dax) + (bx2 - dbx);
+                y += (ay - day) + (by2 - dby);
+                const int32_t nbx = -(ax - ax2), nby = -(ay - ay2);
+                ax = -bx2; ay = -by2; bx = nbx; by = nby;
+            }
+        }
+    }
+    xo = (uint32_t)x;
+    yo = (uint32_t)y;
+}
+
+// ---------------------------------------------------------------- 2^n squares: state machine (tables built in k_hilbert.hip)
+struct HilbertLut {
+    uint16_t l4[4 * 256];  // x:4 | y:4 << 4 | state << 8, four levels per look-up
+    uint8_t  l1[4 * 4];    // x:1 | y:1 << 1 | state << 2, one level
+};
+
+__device__ __forceinline__ void pow2_d2xy(const uint16_t *l4, const uint8_t *l1, uint32_t order, uint32_t d, uint32_t &xo, uint32_t &yo) {
+    uint32_t st = 0, x = 0, y = 0, rem = order;
+    while (rem >= 4) {
+        const uint32_t e = l4[st * 256 + ((d >> (2 * (rem - 4))) & 255)];
+        x = (x << 4) | (e & 15); y = (y << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4;
+    }
+    while (rem >= 1) {
+        const uint32_t e = l1[st * 4 + ((d >> (2 * (rem - 1))) & 3)];
+        x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
+    }
+    xo = x; yo = y;
+}
+
+// scan position -> pixel; order > 0 selects the table-driven path (w == h == 1 << order)
+struct Scan {
+    uint32_t w, h, order;
+    const uint16_t *l4;
+    const uint8_t *l1;
+    __device__ __forceinline__ void xy(uint64_t d, uint32_t &x, uint32_t &y) const {
+        if (order) pow2_d2xy(l4, l1, order, (uint32_t)d, x, y);
+        else gilbert_d2xy(w, h, d, x, y);
+    }
+};
+
+__device__ __forceinline__ Scan load_scan(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *lut, uint16_t *s_l4, uint8_t *s_l1) {
+    if (order) {
+        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) s_l4[i] = lut->l4[i];
+        if (threadIdx.x < 16) s_l1[threadIdx.x] = lut->l1[threadIdx.x];
+        __syncthreads();
+    }
+    return Scan{w, h, order, s_l4, s_l1};
+}
+
+// pixel idx as r | g << 8 | b << 16 (bits 24..31 unspecified) with one load; the buffer's last pixel by bytes
+__device__ __forceinline__ uint32_t px_le24(const uint8_t *__restrict__ rgb, uint64_t idx, uint64_t n) {
+    if (idx + 1 < n) {
+        uint32_t v;
+        __builtin_memcpy(&v, rgb + 3 * idx, 4);
+        return v;
+    }
+    const uint8_t *p = rgb + 3 * idx;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+// the context's copy of the tables (built and self-checked once per process); order of a 2^n square (n >= 1), else 0
+int hilbert_lut(Ctx *c, const HilbertLut **lut_d);
+uint32_t pow2_order(uint32_t w, uint32_t h);
+
+}  // namespace cniic

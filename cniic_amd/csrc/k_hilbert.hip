@@ -20,62 +20,14 @@
 
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "hilbert_scan.hpp"
 
 namespace cniic {
-
-// ---------------------------------------------------------------- generic rectangles
-__device__ __forceinline__ int32_t sgn32(int32_t v) { return (v > 0) - (v < 0); }
-__device__ __forceinline__ int32_t floordiv2(int32_t v) { return v >> 1; }  // arithmetic shift = floor
-
-// position d of the scan of a w x h rectangle (d < w*h < 2^32, sides < 2^31)
-__device__ __forceinline__ void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t d0, uint32_t &xo, uint32_t &yo) {
-    int32_t x = 0, y = 0, ax, ay, bx, by;
-    int64_t d = (int64_t)d0;
-    if (w0 >= h0) { ax = (int32_t)w0; ay = 0; bx = 0; by = (int32_t)h0; }
-    else { ax = 0; ay = (int32_t)h0; bx = (int32_t)w0; by = 0; }
-    for (;;) {
-        const int32_t w = abs(ax + ay), h = abs(bx + by);
-        const int32_t dax = sgn32(ax), day = sgn32(ay), dbx = sgn32(bx), dby = sgn32(by);
-        if (h == 1) { x += dax * (int32_t)d; y += day * (int32_t)d; break; }
-        if (w == 1) { x += dbx * (int32_t)d; y += dby * (int32_t)d; break; }
-        int32_t ax2 = floordiv2(ax), ay2 = floordiv2(ay), bx2 = floordiv2(bx), by2 = floordiv2(by);
-        const int32_t w2 = abs(ax2 + ay2), h2 = abs(bx2 + by2);
-        if (2 * (int64_t)w > 3 * (int64_t)h) {  // long rectangle: two halves
-            if ((w2 & 1) && w > 2) { ax2 += dax; ay2 += day; }
-            const int64_t n1 = (int64_t)abs(ax2 + ay2) * h;
-            if (d < n1) { ax = ax2; ay = ay2; }
-            else { d -= n1; x += ax2; y += ay2; ax -= ax2; ay -= ay2; }
-        } else {  // up, across, down
-            if ((h2 & 1) && h > 2) { bx2 += dbx; by2 += dby; }
-            const int32_t hh = abs(bx2 + by2);
-            const int64_t n1 = (int64_t)hh * w2;
-            const int64_t n2 = (int64_t)w * (h - hh);
-            if (d < n1) {
-                ax = bx2; ay = by2; bx = ax2; by = ay2;
-            } else if (d < n1 + n2) {
-                d -= n1; x += bx2; y += by2; bx -= bx2; by -= by2;
-            } else {
-                d -= n1 + n2;
-                x += (ax - dax) + (bx2 - dbx);
-                y += (ay - day) + (by2 - dby);
-                const int32_t nbx = -(ax - ax2), nby = -(ay - ay2);
-                ax = -bx2; ay = -by2; bx = nbx; by = nby;
-            }
-        }
-    }
-    xo = (uint32_t)x;
-    yo = (uint32_t)y;
-}
 
 // ---------------------------------------------------------------- 2^n squares: state machine
 // One level: quadrant q of a sub-curve in state s sits at block (x,y) and continues in state s'.
 // Base state 0 (enter at (0,0), leave at (n-1,0)): q0 -> (0,0) transposed, q1 -> (0,1), q2 -> (1,1),
 // q3 -> (1,0) anti-transposed.  States: 0 id, 1 transpose, 2 anti-transpose, 3 rot180.
-struct HilbertLut {
-    uint16_t l4[4 * 256];  // x:4 | y:4 << 4 | state << 8, four levels per look-up
-    uint8_t  l1[4 * 4];    // x:1 | y:1 << 1 | state << 2, one level
-};
-
 static void lut1_entry(int s, int q, int &x, int &y, int &ns) {
     static const int bx[4] = {0, 0, 1, 1}, by[4] = {0, 1, 1, 0}, bs[4] = {1, 0, 0, 2};
     int X = bx[q], Y = by[q];
@@ -133,39 +85,6 @@ static bool build_hilbert_lut(HilbertLut &L) {
     return true;
 }
 
-__device__ __forceinline__ void pow2_d2xy(const uint16_t *l4, const uint8_t *l1, uint32_t order, uint32_t d, uint32_t &xo, uint32_t &yo) {
-    uint32_t st = 0, x = 0, y = 0, rem = order;
-    while (rem >= 4) {
-        const uint32_t e = l4[st * 256 + ((d >> (2 * (rem - 4))) & 255)];
-        x = (x << 4) | (e & 15); y = (y << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4;
-    }
-    while (rem >= 1) {
-        const uint32_t e = l1[st * 4 + ((d >> (2 * (rem - 1))) & 3)];
-        x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
-    }
-    xo = x; yo = y;
-}
-
-// scan position -> pixel; order > 0 selects the table-driven path (w == h == 1 << order)
-struct Scan {
-    uint32_t w, h, order;
-    const uint16_t *l4;
-    const uint8_t *l1;
-    __device__ __forceinline__ void xy(uint64_t d, uint32_t &x, uint32_t &y) const {
-        if (order) pow2_d2xy(l4, l1, order, (uint32_t)d, x, y);
-        else gilbert_d2xy(w, h, d, x, y);
-    }
-};
-
-__device__ __forceinline__ Scan load_scan(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *lut, uint16_t *s_l4, uint8_t *s_l1) {
-    if (order) {
-        for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) s_l4[i] = lut->l4[i];
-        if (threadIdx.x < 16) s_l1[threadIdx.x] = lut->l1[threadIdx.x];
-        __syncthreads();
-    }
-    return Scan{w, h, order, s_l4, s_l1};
-}
-
 // hilbert::iter (hilbert.rs:40-43)
 __global__ __launch_bounds__(256) void k_hilbert_xy(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *__restrict__ lut,
                                                     uint32_t *__restrict__ xy) {
@@ -179,17 +98,6 @@ __global__ __launch_bounds__(256) void k_hilbert_xy(uint32_t w, uint32_t h, uint
         sc.xy(d, x, y);
         reinterpret_cast<uint2 *>(xy)[d] = make_uint2(x, y);
     }
-}
-
-// pixel idx as r | g << 8 | b << 16 (bits 24..31 unspecified) with one load; the buffer's last pixel by bytes
-__device__ __forceinline__ uint32_t px_le24(const uint8_t *__restrict__ rgb, uint64_t idx, uint64_t n) {
-    if (idx + 1 < n) {
-        uint32_t v;
-        __builtin_memcpy(&v, rgb + 3 * idx, 4);
-        return v;
-    }
-    const uint8_t *p = rgb + 3 * idx;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 
 // hilbert::linearize (hilbert.rs:10-12, 34-38): out[d] = pixel(scan(d)); SCATTER = inverse
@@ -393,14 +301,14 @@ static int check_dims(Ctx *c, uint32_t w, uint32_t h) {
 }
 
 // order of a 2^n square (n >= 1), else 0
-static uint32_t pow2_order(uint32_t w, uint32_t h) {
+uint32_t pow2_order(uint32_t w, uint32_t h) {
     if (w != h || w < 2 || (w & (w - 1))) return 0;
     uint32_t o = 0;
     while ((1u << o) < w) o++;
     return o;
 }
 
-static int get_lut(Ctx *c, const HilbertLut **lut_d) {
+int hilbert_lut(Ctx *c, const HilbertLut **lut_d) {
     if (!c->hilbert_lut.p) {
         static HilbertLut host_lut;
         static bool ok = false;
@@ -424,7 +332,7 @@ int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d) {
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
-    CNIIC_TRY(get_lut(c, &lut));
+    CNIIC_TRY(hilbert_lut(c, &lut));
     hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, pow2_order(w, h), lut, xy_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
@@ -435,7 +343,7 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
-    CNIIC_TRY(get_lut(c, &lut));
+    CNIIC_TRY(hilbert_lut(c, &lut));
     hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, pow2_order(w, h), lut, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
@@ -446,7 +354,7 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
-    CNIIC_TRY(get_lut(c, &lut));
+    CNIIC_TRY(hilbert_lut(c, &lut));
     hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
@@ -457,7 +365,7 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
-    CNIIC_TRY(get_lut(c, &lut));
+    CNIIC_TRY(hilbert_lut(c, &lut));
     const uint64_t nruns = ceil_div(n, kDeltaRun);
     // persistent blocks: one 1024-thread block per CU keeps the LDS bins private for as long as possible
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nruns, kDeltaThreads), 1), 256);

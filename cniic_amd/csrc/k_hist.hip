@@ -216,8 +216,12 @@ constexpr int kScanChunk = kScanThreads * kScanPerThread;  // 4096 table entries
 // follows.  A 4096-key chunk is one r, 16 g and all 256 b values: 2 x 32 cells, counted in LDS first.
 __global__ __launch_bounds__(kScanThreads) void k_compact_count(const uint32_t *__restrict__ table,
                                                                 uint32_t *__restrict__ blocksum,
-                                                                uint32_t *__restrict__ cell_count) {
+                                                                uint32_t *__restrict__ cell_count, const uint8_t *__restrict__ pages) {
     __shared__ uint32_t s_cell[64];
+    if (pages && !pages[blockIdx.x]) {  // a page nothing was counted into
+        if (threadIdx.x == 0) blocksum[blockIdx.x] = 0;
+        return;
+    }
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
     const uint4 *v = reinterpret_cast<const uint4 *>(table + base);
     if (cell_count) {
@@ -275,8 +279,9 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_write(uint32_t *__rest
                                                                 const uint32_t *__restrict__ blockoff,
                                                                 uint32_t *__restrict__ keys,
                                                                 uint64_t *__restrict__ counts,
-                                                                uint32_t *__restrict__ weights) {
+                                                                uint32_t *__restrict__ weights, const uint8_t *__restrict__ pages) {
     __shared__ uint32_t wsum[kScanThreads / 64];
+    if (pages && !pages[blockIdx.x]) return;
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanPerThread;
     uint4 *v = reinterpret_cast<uint4 *>(table + base);
     uint32_t val[kScanPerThread];
@@ -309,14 +314,16 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_write(uint32_t *__rest
 }
 
 // phase A+B: number of occupied bins (host out-param; stream synced) + per-block rank offsets
-int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d) {
+int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPlan *plan, uint32_t *cell_count_d, const uint8_t *pages_d) {
+    static_assert(kScanChunk == (1 << kPageShift), "a page flag per block of the compaction");
+    plan->pages = pages_d;
     const uint64_t entries = 1ull << bits;
     const uint32_t nblocks = (uint32_t)(entries / kScanChunk);
     DevBuf tot;
     CNIIC_HIP_TRY(c, plan->blockoff.alloc((uint64_t)nblocks * 4));
     CNIIC_HIP_TRY(c, tot.alloc(8));
     hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>(),
-                       bits == 24 ? cell_count_d : nullptr);
+                       bits == 24 ? cell_count_d : nullptr, pages_d);
     {
         const uint32_t nparts = (nblocks + 1023) / 1024;
         DevBuf parttot;
@@ -342,7 +349,7 @@ int hist_compact_write(Ctx *c, uint32_t *table_d, const CompactPlan *plan, uint3
                        uint32_t *weights_d) {
     const uint32_t nblocks = (uint32_t)((1ull << plan->bits) / kScanChunk);
     hipLaunchKernelGGL(k_compact_write, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d,
-                       plan->blockoff.as<uint32_t>(), keys_d, counts_d, weights_d);
+                       plan->blockoff.as<uint32_t>(), keys_d, counts_d, weights_d, plan->pages);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

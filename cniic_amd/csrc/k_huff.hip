@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_pack_scan_add(uint32_t nchunks, uint64
     if (i < nchunks) chunk_off[i] += before;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_bits = before + blocktot[blockIdx.x];
 }
-static int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *chunk_off_d, uint64_t *total_d) {
+int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *chunk_off_d, uint64_t *total_d) {
     const uint32_t nb = (nchunks + 1023) / 1024;
     DevBuf blocktot;
     CNIIC_HIP_TRY(c, blocktot.alloc((uint64_t)nb * 8));
@@ -138,25 +138,9 @@ static int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uin
 }
 
 // tests: CNIIC_TEST_PACK_IMG_WORDS caps the packs' LDS bit image so that chunks take the direct-to-memory route
-static uint32_t pack_img_cap() {
+uint32_t pack_img_cap() {
     const char *e = getenv("CNIIC_TEST_PACK_IMG_WORDS");
     return e ? (uint32_t)atoi(e) : 0xffffffffu;
-}
-
-// one symbol's code into a bit image (LDS) or straight into the output words (memory; big-endian bit order, pre-zeroed)
-template <bool DIRECT>
-__device__ __forceinline__ void pack_put(uint32_t *words, uint32_t pos, uint32_t L, uint64_t cd) {
-    // place bits [pos, pos+L) MSB-first: word w bit (31 - b)
-    const uint32_t w = pos >> 5, b = pos & 31, room = 32 - b;  // room: bits left in word w
-    auto put = [&](uint32_t i, uint32_t v) { atomicOr(&words[i], DIRECT ? __builtin_bswap32(v) : v); };
-    if (L <= room) {
-        put(w, (uint32_t)(cd << (room - L)));
-    } else {
-        const uint32_t rem = L - room;  // bits after the first word
-        put(w, (uint32_t)(cd >> rem));
-        if (rem <= 32) put(w + 1, (uint32_t)(cd << (32 - rem)));
-        else { put(w + 1, (uint32_t)(cd >> (rem - 32))); put(w + 2, (uint32_t)(cd << (64 - rem))); }
-    }
 }
 
 template <int SRC>
@@ -707,7 +691,6 @@ static int pack_impl(Ctx *c, const void *src_d, uint64_t n, const uint32_t *rank
     return CNIIC_OK;
 }
 
-constexpr uint32_t kEscape = 63;  // length field value that redirects to the per-rank tables (U < 2^26)
 
 // ---------------------------------------------------------------- generic fast path (codes <= 26 bits inline)
 // The dense symbol table is overwritten with (len << 26 | code) per symbol key, so a symbol costs

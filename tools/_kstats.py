@@ -1,0 +1,4 @@
+import csv,sys,glob
+f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    print(r['Name'][:70].ljust(70), r['Calls'].rjust(5), ('%.1f'%(float(r['AverageNs'])/1000)).rjust(10), r['Percentage'])
