@@ -766,18 +766,21 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     CNIIC_HIP_TRY(c, hot16.alloc(delta_stream_len(n) * 2));
     CNIIC_HIP_TRY(c, coldkeys.alloc(nchunks * 64 * 4));  // (written where cold symbols are)
     CNIIC_HIP_TRY(c, chunk_cold.alloc(nchunks));
-    CNIIC_HIP_TRY(c, small.alloc(32));  // [0] cold symbols, [1] a chunk with more than 64 of them, [2] bits packed
+    CNIIC_HIP_TRY(c, small.alloc(32));  // u64 [0]: a chunk with more than 64 cold symbols, [2]: bits packed
     CNIIC_HIP_TRY(c, hipMemsetAsync(small.p, 0, 32, c->stream));
     CNIIC_TRY(delta_gather_hist(c, rgb_d, w, h, hot16.as<uint16_t>(), table, pages, coldkeys.as<uint32_t>(), chunk_cold.as<uint8_t>(),
-                                small.as<unsigned long long>()));
+                                small.as<uint32_t>()));
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], small.p, 16, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], small.p, 8, hipMemcpyDeviceToHost, c->stream));
+    host_trace().mark("delta: gather + hist enqueued");
     CompactPlan plan;
     CNIIC_TRY(hist_compact_count(c, table, 27, &plan, nullptr, pages));  // (waits for the stream)
-    const uint64_t U = plan.n_unique, cold = c->pinned_u[2];
-    if (host_trace().on) fprintf(stderr, "[host] delta: %llu symbols, %llu distinct, %llu outside the cube%s\n", (unsigned long long)n, (unsigned long long)U,
-                                 (unsigned long long)cold, c->pinned_u[3] ? " (a chunk has more than 64: the 32-bit route)" : "");
-    if (U >= (1ull << 26) || c->pinned_u[3]) {
+    host_trace().mark("delta: ... + count of the distinct (wait)");
+    const uint64_t U = plan.n_unique;
+    const bool overflow = c->pinned_u[2] != 0;
+    if (host_trace().on) fprintf(stderr, "[host] delta: %llu symbols, %llu distinct%s\n", (unsigned long long)n, (unsigned long long)U,
+                                 overflow ? " (a chunk with more than 64 symbols outside the cube: the 32-bit route)" : "");
+    if (U >= (1ull << 26) || overflow) {
         CNIIC_TRY(delta_table_clean(c));
         return encode_delta_syms32(c, rgb_d, w, h, header, out, cap, len);
     }
@@ -789,8 +792,8 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     std::vector<uint64_t> counts(U);
     CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    host_trace().mark("delta: gather + hist + compaction + D2H");
+    CNIIC_HIP_TRY(c, ctx_spin_sync(c));
+    host_trace().mark("delta: compaction + D2H (wait)");
     // 2. build() (huf.rs:31)
     HuffTree tree;
     std::vector<uint8_t> clen;
@@ -810,6 +813,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen.data(), U, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
+    host_trace().mark("delta: H2D codes enqueued");
     DeltaPackScratch scratch;
     if (nbits) {  // (a single symbol: the zero-length code and no payload, huf.rs:140-142)
         ScopedKernelTimer timer(c, "huff_pack");
@@ -825,6 +829,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     if (header.size() != header_bytes) return c->fail(CNIIC_ERR_HIP, "delta: decoder of %llu bytes, expected %llu", (unsigned long long)header.size(),
                                                       (unsigned long long)header_bytes);
     CNIIC_TRY(so.put_header(header));
+    host_trace().mark("delta: header H2D");
     const int rc_fin = so.finish();  // (waits for the stream)
     host_trace().mark("delta: pack + finish");
     host_trace().dump();

@@ -154,6 +154,14 @@ struct Ctx {
                                hipGetErrorString(_e));                                    \
     } while (0)
 
+// Waits for the context's stream without giving the core up: a blocking wait of a few hundred microseconds sends the core to
+// sleep, and the host work that follows (the Huffman tree of a `delta` encode) then runs at half speed.
+inline hipError_t ctx_spin_sync(Ctx *c) {
+    hipError_t e;
+    while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
+    return e;
+}
+
 inline hipError_t ctx_pinned_u(Ctx *c) {
     if (c->pinned_u) return hipSuccess;
     return hipHostMalloc(reinterpret_cast<void **>(&c->pinned_u), 64 * 1024, hipHostMallocDefault);
@@ -529,7 +537,7 @@ int delta_table(Ctx *c, uint32_t **table_d, uint8_t **pages_d);  // the context'
 int delta_table_clean(Ctx *c);                                   // touched pages back to zero (enqueued)
 uint64_t delta_stream_len(uint64_t n);                           // u16 entries of the symbol stream of n pixels
 int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint16_t *hot16_d, uint32_t *table_d, uint8_t *pages_d,
-                      uint32_t *coldkeys_d, uint8_t *chunk_cold_d, unsigned long long *cold_d);
+                      uint32_t *coldkeys_d, uint8_t *chunk_cold_d, uint32_t *overflow_d);
 struct DeltaPackScratch { DevBuf cb, co, edge, hot, hotlen; };
 int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
                  const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint8_t *out_d, uint64_t bit_base, uint64_t *total_d,

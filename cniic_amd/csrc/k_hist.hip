@@ -337,7 +337,7 @@ int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPl
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CNIIC_HIP_TRY(c, pages_d ? ctx_spin_sync(c) : hipStreamSynchronize(c->stream));
     plan->n_unique = total;
     plan->bits = bits;
     return CNIIC_OK;
