@@ -259,10 +259,10 @@ __global__ __launch_bounds__(256) void k_delta_clean_pages(uint32_t *__restrict_
 
 // ---------------------------------------------------------------- codes: dense[key] and, inside the cube, hot[] / hotlen[]
 __global__ void k_delta_fill_codes(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ len, const uint64_t *__restrict__ code, uint64_t U,
-                                   uint32_t *__restrict__ dense, uint32_t *__restrict__ hot, uint8_t *__restrict__ hotlen) {
+                                   uint32_t *__restrict__ dense, uint32_t *__restrict__ hot, uint8_t *__restrict__ hotlen, uint32_t inline_max) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < U; i += stride) {
-        const uint32_t v = len[i] <= 26 ? ((uint32_t)len[i] << 26) | (uint32_t)code[i] : (kEscape << 26) | (uint32_t)i;
+        const uint32_t v = len[i] <= inline_max ? ((uint32_t)len[i] << 26) | (uint32_t)code[i] : (kEscape << 26) | (uint32_t)i;
         const uint32_t k = keys[i];
         dense[k] = v;
         const uint32_t hr = (k >> 18) - (255 - 16), hg = ((k >> 9) & 511) - (255 - 16), hb = (k & 511) - (255 - 16);
@@ -581,8 +581,12 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_write16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWriteLds);
     });
+    // codes of up to 26 bits sit in the word itself; longer ones (nearly never) send the pack to the per-rank tables -- tests
+    // lower the limit (CNIIC_TEST_INLINE_CODE_BITS) so that ordinary images take that way
+    const char *im = getenv("CNIIC_TEST_INLINE_CODE_BITS");
+    const uint32_t inline_max = im ? std::min<uint32_t>((uint32_t)atoi(im), 26u) : 26u;
     hipLaunchKernelGGL(k_delta_fill_codes, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
-                       dense_d, keep->hot.as<uint32_t>(), keep->hotlen.as<uint8_t>());
+                       dense_d, keep->hot.as<uint32_t>(), keep->hotlen.as<uint8_t>(), inline_max);
     hipLaunchKernelGGL(k_delta_cold_codes, dim3(ceil_div(nchunks, 32u)), dim3(256), 0, c->stream, coldkeys_d, chunk_cold_d, nchunks, (const uint32_t *)dense_d);
     hipLaunchKernelGGL(k_delta_count16, dim3(std::min<uint32_t>(ceil_div(nchunks, 4u), 256 * 4)), dim3(256), 0, c->stream, hot16_d, nchunks,
                        (const uint8_t *)keep->hotlen.as<uint8_t>(), (const uint32_t *)coldkeys_d, chunk_cold_d, len_d, keep->cb.as<uint32_t>());

@@ -318,6 +318,49 @@ def test_codec_edge_cases(ctx):
     assert rc == _lib.DECODE
 
 
+
+def _delta_img(kind, h, w):
+    rng = np.random.default_rng(17)
+    y, x = np.mgrid[0:h, 0:w]
+    ramp = np.stack([x // 2 + y // 3, x // 3 + (2 * y) // 5, (x + y) // 4], axis=2) + rng.integers(-2, 3, (h, w, 3))
+    if kind == "smooth":                      # differences inside the cube [-16, 15]^3 but where a ramp wraps from 255 to 0
+        return (ramp & 255).astype(np.uint8)
+    if kind == "mixed":                       # about one per cent of the differences outside it, spread thin
+        hit = rng.random((h, w)) < 0.004
+        ramp[hit] += rng.integers(-120, 120, (int(hit.sum()), 3))
+        return (ramp & 255).astype(np.uint8)
+    if kind == "noise":                       # nearly all of them outside: a chunk's 64 side entries overflow -> the 32-bit route
+        return rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    return np.full((h, w, 3), 77, np.uint8)   # "flat": two symbols, the first pixel's and (0, 0, 0)
+
+
+@pytest.mark.parametrize("knob", ["", "CNIIC_DELTA_ROUTE=32", "CNIIC_DELTA_GATHER=any", "CNIIC_TEST_PACK_IMG_WORDS=24", "CNIIC_TEST_INLINE_CODE_BITS=5"])
+@pytest.mark.parametrize("kind", ["smooth", "mixed", "noise", "flat"])
+@pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 75), (240, 321), (8, 8), (1, 700)])
+def test_delta_routes_equal_oracle(ctx, monkeypatch, shape, kind, knob):
+    """the `delta` encoder's 16-bit symbol stream (tile gather on 2^n squares from 64 x 64, per-position gather elsewhere; cold
+    symbols through the side array; chunks that outgrow the bit image; codes that leave the inline word) and the 32-bit route it
+    falls back to on noisy images: the same bytes as the oracle's, and they decode to the image"""
+    if knob:
+        k, v = knob.split("=")
+        monkeypatch.setenv(k, v)
+    img = _delta_img(kind, *shape)
+    rc, data, _ = ctx.encode("delta", img)
+    rco, edata, _ = O.encode("delta", img)
+    assert rc == rco == 0 and data == edata
+    rc, back = ctx.decode("delta", data)
+    assert rc == 0 and np.array_equal(back, img)
+
+
+def test_delta_single_symbol_and_back_to_back_calls(ctx):
+    """an all-zero image is ONE symbol (zero-length code, no payload, huf.rs:140-142); the 2^27-bin table must be clean again for
+    the call after a call, whichever route that took"""
+    zero = np.zeros((64, 64, 3), np.uint8)
+    imgs = [zero, _delta_img("noise", 64, 64), _delta_img("mixed", 128, 128), zero, _delta_img("smooth", 100, 75)]
+    for img in imgs + imgs[::-1]:
+        rc, data, _ = ctx.encode("delta", img)
+        assert rc == 0 and data == O.encode("delta", img)[1]
+
 @pytest.mark.parametrize("case", ["flat", "stripes", "levels2", "long_runs", "wide", "tall"])
 def test_hilbert_rle_runs_equal_oracle(ctx, case):
     """run boundaries, the 255 cap across chunk borders (4096 positions per block) and ragged sizes"""
