@@ -49,17 +49,27 @@ __device__ __forceinline__ uint32_t lanes_before(uint64_t mask) {  // set bits o
 
 // ---------------------------------------------------------------- pass 1: gather + differences
 // 2^n squares of side >= 64 (rows of 16-byte aligned 48-byte pieces).  A tile is 4096 consecutive positions; wave v of
-// the block walks positions 1024 v .. 1024 v + 1023 of it, 64 at a time (an 8 x 8 block of pixels: with the row index
-// folded into the column's 8-pixel group the 64 reads hit 64 banks), the predecessor of a lane's pixel is the lane
-// before and the wave's last pixel is carried to its next step.
+// the block walks positions 1024 v .. 1024 v + 1023 of it, 64 at a time: an 8 x 8 block of pixels.  In LDS a pixel is
+// three 10-bit fields  b + 528 | (g + 528) << 10 | (r + 528) << 20, so that ONE subtraction gives the three differences
+// (fields c - p + 528, no borrow between them), one mask test says whether they all lie in [-16, 15] and three shifts make
+// the cube index.  The tile is kept block by block (64 words per 8 x 8 block, the row inside a block XOR-ed with a number
+// that differs between the blocks a wave writes together): a step's 64 reads are the 64 words of one block, its address
+// the block's base (wave-uniform, scalar) plus the lane's place in the block for the orientation the curve has there --
+// four possibilities, six bits each, packed in one register per lane for the whole kernel.  The predecessor of a lane's
+// pixel is the lane before; the wave's last pixel is carried to its next step.
+constexpr uint32_t kField = 528;                                      // c - p + 528 in [273, 783]: ten bits, never negative
+constexpr uint32_t kFields = 1u | (1u << 10) | (1u << 20);
+__device__ __forceinline__ uint32_t px_fields(uint32_t px) {         // r | g << 8 | b << 16 (bits 24..31: anything)
+    return ((px >> 16) & 255u) + (((px >> 8) & 255u) << 10) + ((px & 255u) << 20) + kField * kFields;
+}
 __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restrict__ rgb, uint32_t order, const HilbertLut *__restrict__ lut,
                                                          uint16_t *__restrict__ hot16, uint32_t *__restrict__ table, uint8_t *__restrict__ pages,
                                                          uint32_t *__restrict__ coldkeys, uint8_t *__restrict__ chunk_cold,
                                                          uint32_t *__restrict__ overflow /* = 1 when a chunk has more cold symbols than fit */) {
-    __shared__ uint32_t s_tile[64 * 64];
+    __shared__ __align__(16) uint32_t s_tile[64 * 64];
     __shared__ uint16_t s_l4[1024];
     __shared__ uint8_t s_l1[16];
-    __shared__ uint8_t s_l3[4 * 64];  // three levels from state s for six bits q: x:3 | y:3 << 3 | end state << 6
+    __shared__ __align__(16) uint8_t s_l3[4 * 64];  // three levels from state s for six bits q: x:3 | y:3 << 3 | end state << 6
     const uint32_t w = 1u << order;
     const Scan sc = load_scan(w, w, order, lut, s_l4, s_l1);
     {
@@ -75,6 +85,12 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
     const uint32_t ntiles = (uint32_t)(n >> 12);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t row = threadIdx.x >> 2, seg = threadIdx.x & 3;
+    // the lane's place (y3 * 8 + x3) inside a block the curve crosses in orientation 0 .. 3
+    const uint32_t places = (s_l3[lane] & 63u) | ((s_l3[64 + lane] & 63u) << 6) | ((s_l3[128 + lane] & 63u) << 12) | ((s_l3[192 + lane] & 63u) << 18);
+    // a block's word base and the XOR of its rows, from x:3 | y:3 << 3
+    auto blk_base = [](uint32_t e) { return (e & 63u) << 6; };
+    auto blk_xor = [](uint32_t e) { return (((e >> 1) & 3u) | (((e >> 3) & 1u) << 2)) << 3; };
+    constexpr uint32_t kC = kField * kFields, kMask = 0x3e0u * kFields, kHotBits = 0x200u * kFields;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // where the tile lies and in which orientation the curve enters it: the levels above the tile
         uint32_t st = 0, tx = 0, ty = 0, rem = order - 6;
@@ -86,44 +102,57 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
             const uint32_t e = s_l1[st * 4 + ((tile >> (2 * (rem - 1))) & 3)];
             tx = (tx << 1) | (e & 1); ty = (ty << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
         }
+        st = (uint32_t)__builtin_amdgcn_readfirstlane((int)st);
+        // (reading the next tile while this one is walked made the kernel slower, 441 against 394 us at 16384^2: the walk's
+        // stores sit between a read and its use, and the wait for the read waits for them all.  The kernel is bound by
+        // instruction issue anyway: ~1000 per wave and tile.)
         const uint4 *src = reinterpret_cast<const uint4 *>(rgb + ((uint64_t)((ty << 6) + row) * w + (tx << 6) + seg * 16) * 3);
         const uint4 q0 = src[0], q1 = src[1], q2 = src[2];
-        uint32_t carried = 0;  // the pixel before the wave's first one; START = (0, 0, 0) hilbertc.rs:445
+        uint32_t carried = kC;  // the pixel before the wave's first one; START = (0, 0, 0) hilbertc.rs:445
         if (wave == 0 && tile > 0) {
             uint32_t x, y;
             sc.xy((uint64_t)tile * 4096 - 1, x, y);
-            carried = px_le24(rgb, (uint64_t)y * w + x, n);
+            carried = px_fields(px_le24(rgb, (uint64_t)y * w + x, n));
         }
         const uint32_t q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
         __syncthreads();  // the walk of the tile before is over
+        {
+            const uint32_t yhi = row >> 3, y3 = row & 7;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {  // pixels 4 g .. 4 g + 3 of the piece: bytes 12 g .. 12 g + 11 (bits 24..31 of a pixel word: anything)
-            const uint32_t a = q[3 * g], b = q[3 * g + 1], c = q[3 * g + 2];
-            const uint4 px4 = make_uint4(a, (a >> 24) | (b << 8), (b >> 16) | (c << 16), c >> 8);
-            *reinterpret_cast<uint4 *>(&s_tile[row * 64 + ((seg * 16 + 4 * g) ^ ((row & 7) << 3))]) = px4;
+            for (int g = 0; g < 4; g++) {  // pixels 4 g .. 4 g + 3 of the piece: bytes 12 g .. 12 g + 11
+                const uint32_t a = q[3 * g], b = q[3 * g + 1], c = q[3 * g + 2];
+                const uint4 px4 = make_uint4(px_fields(a), px_fields((a >> 24) | (b << 8)), px_fields((b >> 16) | (c << 16)), px_fields(c >> 8));
+                const uint32_t e = (seg * 2 + (g >> 1)) | (yhi << 3);  // the block of pixels 8 (g / 2) .. of the piece
+                *reinterpret_cast<uint4 *>(&s_tile[blk_base(e) + (((y3 << 3) ^ blk_xor(e)) | ((g & 1) << 2))]) = px4;
+            }
         }
         __syncthreads();
-        if (wave > 0) {  // (uniform per wave)
-            const uint32_t p = wave * 1024 - 1;
-            const uint32_t e1 = s_l3[st * 64 + (p >> 6)], e2 = s_l3[(e1 >> 6) * 64 + 63];
-            const uint32_t X = ((e1 & 7) << 3) | (e2 & 7), Y = (((e1 >> 3) & 7) << 3) | ((e2 >> 3) & 7);
-            carried = s_tile[Y * 64 + (X ^ ((Y & 7) << 3))];
+        // the wave's sixteen blocks: x:3 | y:3 << 3 | orientation << 6, a byte each (wave-uniform: scalar registers)
+        const uint4 ev = *reinterpret_cast<const uint4 *>(&s_l3[st * 64 + wave * 16]);
+        const uint32_t es[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)ev.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)ev.y),
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)ev.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)ev.w)};
+        if (wave > 0) {  // (uniform per wave) the last pixel of the block before
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_l3[st * 64 + wave * 16 - 1]);
+            const uint32_t place = s_l3[(e >> 6) * 64 + 63] & 63u;
+            carried = s_tile[blk_base(e) + (place ^ blk_xor(e))];
         }
         uint16_t *o = hot16 + (uint64_t)tile * 4096 + wave * 1024 + lane;
         uint32_t crank = 0;  // cold symbols of the chunk so far (a wave's 1024 positions are two chunks)
-#pragma unroll 4
+#pragma unroll
         for (uint32_t j = 0; j < 16; j++) {
-            const uint32_t e1 = s_l3[st * 64 + wave * 16 + j], e2 = s_l3[(e1 >> 6) * 64 + lane];
-            const uint32_t X = ((e1 & 7) << 3) | (e2 & 7), Y = (((e1 >> 3) & 7) << 3) | ((e2 >> 3) & 7);
-            const uint32_t px = s_tile[Y * 64 + (X ^ ((Y & 7) << 3))];
-            const uint32_t prev = wave_prev_lane(px, carried);
-            carried = (uint32_t)__builtin_amdgcn_readlane((int)px, 63);
-            uint32_t hot;
-            const uint32_t key = delta_key(px, prev, hot);
-            const uint64_t cm = __builtin_amdgcn_ballot_w64(hot == kCold16);
-            const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
+            const uint32_t e = (es[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t place = (places >> (6 * (e >> 6))) & 63u;
+            const uint32_t t = s_tile[blk_base(e) + (place ^ blk_xor(e))];
+            const uint32_t d = t - wave_prev_lane(t, carried) + kC;  // fields c - p + 528
+            carried = (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
+            const bool cold = (d & kMask) != kHotBits;              // some field outside [512, 543]
+            uint32_t hot = ((d >> 10) & 0x7c00u) | ((d >> 5) & 0x3e0u) | (d & 31u);
+            const uint64_t cm = __builtin_amdgcn_ballot_w64(cold);
             if (cm) {
-                if (hot == kCold16) {
+                const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
+                if (cold) {
+                    const uint32_t key = ((((d >> 20) & 1023u) - (kField - 255)) << 18) | ((((d >> 10) & 1023u) - (kField - 255)) << 9) |
+                                         ((d & 1023u) - (kField - 255));
                     atomicAdd(&table[key], 1u);
                     pages[key >> kPageShift] = 1;
                     const uint32_t r = crank + lanes_before(cm);
@@ -135,6 +164,7 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
             o[j * 64] = (uint16_t)hot;
             if ((j & 7) == 7) {
                 if (lane == 0) {
+                    const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
                     chunk_cold[ch] = (uint8_t)min(crank, 255u);
                     if (crank > kColdPerChunk) *overflow = 1;
                 }
