@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     uint16_t *W_k = S_k + kSCap;
     // 16-byte aligned: the u16 arrays before it hold 16 * (64 + wcap) * 2 bytes
     int4 *tab = reinterpret_cast<int4 *>(W_k + (size_t)kXWaves * wcap);
-    __shared__ unsigned long long s_key;
+    __shared__ unsigned long long s_key, s_evals;
     __shared__ uint32_t s_n;
     __shared__ uint32_t wsum[kXWaves], s_dirty[2][kXWaves], s_ncand[kXWaves];
     const uint32_t done = st->done;  // acted on once the set-up loads are out
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             c.w = (int32_t)k;
             M_c[j] = c;
         }
-    if (threadIdx.x == 0) s_key = ~0ull;
+    if (threadIdx.x == 0) { s_key = ~0ull; s_evals = 0; }
     if (use_tab)
         for (uint32_t k = threadIdx.x; k < K; k += kXThreads) tab[k] = cent[k];
     // this thread's slice of the centroid table, for the whole launch: [t R, (t+1) R) so lists come out ascending
@@ -514,8 +514,14 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
     }
     moved = block_reduce_sum<kXThreads>(moved);
-    if (threadIdx.x == 0 && moved) atomicAdd(&partials[6 * (size_t)K], (unsigned long long)moved);
-    if (lane == 0 && evals) atomicAdd(&partials[6 * (size_t)K + 1], evals);
+    // ONE atomic per block and counter: atomics on one address are served ~26 ns apart, and an addition per wave (4096 a
+    // launch) kept every launch busy for ~0.1 ms whatever else it did
+    if (lane == 0 && evals) atomicAdd(&s_evals, evals);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (moved) atomicAdd(&partials[6 * (size_t)K], (unsigned long long)moved);
+        if (s_evals) atomicAdd(&partials[6 * (size_t)K + 1], s_evals);
+    }
     XY_PHASE(6);
 #ifdef CNIIC_XY_PHASES
     if (lane == 0)
