@@ -83,6 +83,7 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     for (auto e : c->poll_ev) if (e) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
+    if (c->pinned_huf) (void)hipHostFree(c->pinned_huf);
     if (c->res_ev) (void)hipEventDestroy(c->res_ev);
     if (c->pinned_u) (void)hipHostFree(c->pinned_u);
     if (c->u_ev) (void)hipEventDestroy(c->u_ev);

@@ -132,6 +132,8 @@ struct Ctx {
     uint64_t *pinned_u = nullptr;  // 64 KiB of pinned host memory: [0] sp_build's distinct-colour count, [1] the point list's length,
                                    // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
+    void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
+    uint64_t pinned_huf_bytes = 0;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
     const void *poll_owner = nullptr;  // the K-means state whose lagged polls own `pinned` / poll_ev (one loop at a time per context)
 
@@ -159,6 +161,16 @@ struct Ctx {
 inline hipError_t ctx_spin_sync(Ctx *c) {
     hipError_t e;
     while ((e = hipStreamQuery(c->stream)) == hipErrorNotReady) {}
+    return e;
+}
+
+inline hipError_t ctx_pinned_huf(Ctx *c, uint64_t bytes) {  // at least `bytes` of pinned memory at c->pinned_huf (contents lost when it grows)
+    if (c->pinned_huf_bytes >= bytes) return hipSuccess;
+    if (c->pinned_huf) (void)hipHostFree(c->pinned_huf);
+    c->pinned_huf = nullptr; c->pinned_huf_bytes = 0;
+    const uint64_t want = bytes + bytes / 4 + 65536;
+    const hipError_t e = hipHostMalloc(&c->pinned_huf, want, hipHostMallocDefault);
+    if (e == hipSuccess) c->pinned_huf_bytes = want;
     return e;
 }
 

@@ -98,10 +98,14 @@ bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
 }
 
 bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code) {
+    len.resize(t.nleaf);
+    code.resize(t.nleaf);
+    return huff_codes_into(t, len.data(), code.data());
+}
+
+bool huff_codes_into(const HuffTree &t, uint8_t *len, uint64_t *code) {
     const uint64_t n = t.nleaf;
-    len.assign(n, 0);
-    code.assign(n, 0);
-    if (n == 1) return true;  // a single symbol: the zero-length code (huf.rs:140-142)
+    if (n == 1) { len[0] = 0; code[0] = 0; return true; }  // a single symbol: the zero-length code (huf.rs:140-142)
     // An inner node is made after its two children, so it has the larger id and the root the largest: walking the
     // ids downwards meets every parent before its children (Bit::Zero = left, Bit::One = right).  No stack.
     const uint64_t ninner = n - 1;
@@ -115,7 +119,7 @@ bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64
         for (int s = 0; s < 2; s++) {
             const uint64_t cb = (d <= 64 ? (b << 1) : 0) | (uint64_t)s;
             if (kid[s] < n) {
-                if (d > 64) { ok = false; continue; }
+                if (d > 64) { ok = false; len[kid[s]] = 0; code[kid[s]] = 0; continue; }
                 len[kid[s]] = (uint8_t)d;
                 code[kid[s]] = cb;
             } else {
@@ -166,11 +170,16 @@ static void put_symbol(std::vector<uint8_t> &o, int kind, uint32_t key) {
 }
 
 void huff_serialize_tree(const HuffTree &t, int sym_kind, const uint32_t *keys, std::vector<uint8_t> &out) {
+    const uint64_t base = out.size();
+    out.resize(base + huff_tree_bytes(sym_kind, t.nleaf));
+    huff_serialize_tree_into(t, sym_kind, keys, out.data() + base);
+}
+
+uint64_t huff_tree_bytes(int sym_kind, uint64_t n) { return n * (1 + (uint64_t)huff_symbol_size(sym_kind)) + (n - 1); }
+
+void huff_serialize_tree_into(const HuffTree &t, int sym_kind, const uint32_t *keys, uint8_t *o) {
     const uint64_t n = t.nleaf;
     // the size is known (n leaves of 1 + S bytes, n - 1 branch tags): written through a pointer, not byte by byte
-    const uint64_t S = (uint64_t)huff_symbol_size(sym_kind), base = out.size();
-    out.resize(base + n * (1 + S) + (n - 1));
-    uint8_t *o = out.data() + base;
     std::vector<uint32_t> st;
     st.reserve(128);
     st.push_back(t.root);

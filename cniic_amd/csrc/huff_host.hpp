@@ -21,8 +21,11 @@ struct HuffTree {
 bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t);
 // Enc::from(&Dec) (huf.rs:125-135): code length and code bits (MSB-first in the low bits) per leaf.
 bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code);
+bool huff_codes_into(const HuffTree &t, uint8_t *len, uint64_t *code);  // len / code: t.nleaf entries (pinned memory, say)
 // BinTrie::serialize (huf.rs:305-321), pre-order: 0+symbol for a leaf, 1+left+right for a branch.
 void huff_serialize_tree(const HuffTree &t, int sym_kind, const uint32_t *keys, std::vector<uint8_t> &out);
+uint64_t huff_tree_bytes(int sym_kind, uint64_t n);  // bytes of the serialised decoder of n leaves
+void huff_serialize_tree_into(const HuffTree &t, int sym_kind, const uint32_t *keys, uint8_t *out);  // huff_tree_bytes() bytes
 int  huff_symbol_size(int sym_kind);
 // total stream size of encode_all for this histogram
 uint64_t huff_stream_size(int sym_kind, const uint64_t *counts, const uint8_t *len, uint64_t n);
