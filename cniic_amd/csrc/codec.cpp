@@ -860,7 +860,8 @@ static int encode_hilbert_rle(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t
     CNIIC_TRY(hilbert_linearize(c, rgb_d, w, h, lin.as<uint8_t>()));  // hilbert::linearize (:29)
     RlePlan plan;
     CNIIC_TRY(rle_plan(c, lin.as<uint8_t>(), n, &plan));             // rle_exact (:34)
-    CNIIC_TRY(so.begin(header, plan.nruns * 12));                    // count.serialize + color.serialize per run (:35-36)
+    CNIIC_TRY(so.begin_sized(header.size(), plan.nruns * 12, /*zero=*/false));  // count.serialize + color.serialize per run (:35-36):
+    CNIIC_TRY(so.put_header(header));                                            // three whole words each, nothing left to clear
     CNIIC_TRY(rle_emit(c, lin.as<uint8_t>(), &plan, reinterpret_cast<uint32_t *>(so.dev + 8)));
     return so.finish();
 }

@@ -119,6 +119,105 @@ __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict_
     }
 }
 
+// The same on 2^n squares of side >= 64 with 16-byte aligned buffers, by 64 x 64 tiles = 4096 consecutive scan positions
+// (k_delta_gather_p2's scheme): the image side of a tile is read or written as rows of 48-byte pieces, the scan side as
+// 48-byte pieces of 16 positions, and the permutation happens in LDS -- one word per pixel, stored 8 x 8 block by block
+// (a block is 64 consecutive positions) with the rows of a block XOR-ed so that neither side's accesses pile up on a bank.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_hilbert_move_p2(const uint8_t *__restrict__ src, uint32_t order, const HilbertLut *__restrict__ lut,
+                                                         uint8_t *__restrict__ dst) {
+    __shared__ __align__(16) uint32_t s_tile[64 * 64];
+    __shared__ uint16_t s_l4[1024];
+    __shared__ uint8_t s_l1[16];
+    __shared__ uint8_t s_l3[4 * 64];  // three levels from state s for six bits q: x:3 | y:3 << 3 | end state << 6
+    const uint32_t w = 1u << order;
+    load_scan(w, w, order, lut, s_l4, s_l1);
+    {
+        uint32_t st = threadIdx.x >> 6, x = 0, y = 0;
+        for (int lv = 2; lv >= 0; lv--) {
+            const uint32_t e = s_l1[st * 4 + ((threadIdx.x >> (2 * lv)) & 3)];
+            x = (x << 1) | (e & 1); y = (y << 1) | ((e >> 1) & 1); st = e >> 2;
+        }
+        s_l3[threadIdx.x] = (uint8_t)(x | (y << 3) | (st << 6));
+    }
+    __syncthreads();
+    const uint32_t ntiles = (uint32_t)(((uint64_t)w * w) >> 12);
+    const uint32_t row = threadIdx.x >> 2, seg = threadIdx.x & 3;
+    auto blk_base = [](uint32_t e) { return (e & 63u) << 6; };                                        // from x:3 | y:3 << 3
+    auto blk_xor = [](uint32_t e) { return (((e >> 1) & 3u) | (((e >> 3) & 1u) << 2)) << 3; };
+    // 16 pixels <-> 12 words (r, g, b bytes in a row; a pixel word is r | g << 8 | b << 16, bits 24..31 anything on the way in)
+    auto unpack4 = [](uint32_t a, uint32_t b, uint32_t c) { return make_uint4(a, (a >> 24) | (b << 8), (b >> 16) | (c << 16), c >> 8); };
+    auto pack4 = [](uint4 p, uint32_t &a, uint32_t &b, uint32_t &c) {
+        a = (p.x & 0xffffffu) | (p.y << 24);
+        b = ((p.y >> 8) & 0xffffu) | (p.z << 16);
+        c = ((p.z >> 16) & 0xffu) | (p.w << 8);
+    };
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint32_t st = 0, tx = 0, ty = 0, rem = order - 6;  // where the tile lies, in which orientation the curve enters it
+        while (rem >= 4) {
+            const uint32_t e = s_l4[st * 256 + ((tile >> (2 * (rem - 4))) & 255)];
+            tx = (tx << 4) | (e & 15); ty = (ty << 4) | ((e >> 4) & 15); st = e >> 8; rem -= 4;
+        }
+        while (rem >= 1) {
+            const uint32_t e = s_l1[st * 4 + ((tile >> (2 * (rem - 1))) & 3)];
+            tx = (tx << 1) | (e & 1); ty = (ty << 1) | ((e >> 1) & 1); st = e >> 2; rem -= 1;
+        }
+        // the image side: row `row` of the tile, pixels 16 seg ..; the scan side: positions 16 t .. of the tile
+        uint8_t *const img_piece = const_cast<uint8_t *>(SCATTER ? dst : src) + ((uint64_t)((ty << 6) + row) * w + (tx << 6) + seg * 16) * 3;
+        uint8_t *const lin_piece = const_cast<uint8_t *>(SCATTER ? src : dst) + ((uint64_t)tile * 4096 + threadIdx.x * 16) * 3;
+        const uint4 *in = reinterpret_cast<const uint4 *>(SCATTER ? lin_piece : img_piece);
+        const uint4 q0 = in[0], q1 = in[1], q2 = in[2];
+        const uint32_t q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        // this thread's 16 positions lie in one block: block number threadIdx.x / 4 of the tile's 64, places 16 (t & 3) ..
+        const uint32_t eb = s_l3[st * 64 + (threadIdx.x >> 2)];
+        const uint32_t yhi = row >> 3, y3 = row & 7;
+        __syncthreads();  // the tile before has left LDS
+        if (!SCATTER) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t e = (seg * 2 + (g >> 1)) | (yhi << 3);
+                *reinterpret_cast<uint4 *>(&s_tile[blk_base(e) + (((y3 << 3) ^ blk_xor(e)) | ((g & 1) << 2))]) = unpack4(q[3 * g], q[3 * g + 1], q[3 * g + 2]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint4 p4 = unpack4(q[3 * g], q[3 * g + 1], q[3 * g + 2]);
+                const uint32_t p[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t place = s_l3[(eb >> 6) * 64 + (threadIdx.x & 3) * 16 + 4 * g + i] & 63u;
+                    s_tile[blk_base(eb) + (place ^ blk_xor(eb))] = p[i];
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t o[12];
+        if (!SCATTER) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t p[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t place = s_l3[(eb >> 6) * 64 + (threadIdx.x & 3) * 16 + 4 * g + i] & 63u;
+                    p[i] = s_tile[blk_base(eb) + (place ^ blk_xor(eb))];
+                }
+                pack4(make_uint4(p[0], p[1], p[2], p[3]), o[3 * g], o[3 * g + 1], o[3 * g + 2]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t e = (seg * 2 + (g >> 1)) | (yhi << 3);
+                const uint4 p4 = *reinterpret_cast<const uint4 *>(&s_tile[blk_base(e) + (((y3 << 3) ^ blk_xor(e)) | ((g & 1) << 2))]);
+                pack4(p4, o[3 * g], o[3 * g + 1], o[3 * g + 2]);
+            }
+        }
+        uint4 *out = reinterpret_cast<uint4 *>(SCATTER ? img_piece : lin_piece);
+        out[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        out[1] = make_uint4(o[4], o[5], o[6], o[7]);
+        out[2] = make_uint4(o[8], o[9], o[10], o[11]);
+    }
+}
+
 // DiffStream (hilbertc.rs:449-477) over the Hilbert-ordered pixels, START = [0;3] (hilbertc.rs:445).
 // Each thread owns 4 consecutive scan positions (one extra look-up for the predecessor of the
 // first).  The packed SignedColor key goes to syms (16-B store per thread) and, when HIST, into the
@@ -327,6 +426,12 @@ int hilbert_lut(Ctx *c, const HilbertLut **lut_d) {
     return CNIIC_OK;
 }
 
+// 2^n squares from 64 x 64 with 16-byte aligned buffers go by tiles (CNIIC_HILBERT_MOVE=any: the per-position kernel; tests)
+static bool move_by_tiles(uint32_t w, uint32_t h, const void *a, const void *b) {
+    const char *e = getenv("CNIIC_HILBERT_MOVE");
+    return pow2_order(w, h) >= 6 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !(e && e[0] == 'a');
+}
+
 int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d) {
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
@@ -344,7 +449,11 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
     CNIIC_TRY(hilbert_lut(c, &lut));
-    hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, pow2_order(w, h), lut, out_d);
+    if (move_by_tiles(w, h, rgb_d, out_d))
+        hipLaunchKernelGGL(k_hilbert_move_p2<false>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, rgb_d, pow2_order(w, h), lut,
+                           out_d);
+    else
+        hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, pow2_order(w, h), lut, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -355,7 +464,11 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     if (!n) return CNIIC_OK;
     const HilbertLut *lut = nullptr;
     CNIIC_TRY(hilbert_lut(c, &lut));
-    hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
+    if (move_by_tiles(w, h, lin_d, rgb_out_d))
+        hipLaunchKernelGGL(k_hilbert_move_p2<true>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, lin_d, pow2_order(w, h), lut,
+                           rgb_out_d);
+    else
+        hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

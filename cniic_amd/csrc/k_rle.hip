@@ -7,11 +7,11 @@
 // with s(i) = the last position <= i whose colour differs from its predecessor (position 0 counts).
 //
 //   k_rle_last      per 4096-position chunk: its last segment start                      reads 3 B/px
-//   k_rle_carry     exclusive max-scan over the chunks (single block)
+//   k_rle_carry_*   exclusive max-scan over the chunks (1024 per block, then the blocks before)
 //   k_rle_flags     run-start flags (16 per thread, one u16) + runs per chunk            reads 3 B/px
 //   k_rle_offsets   exclusive sum-scan of the runs per chunk (single block) + total
-//   k_rle_starts    start position of every run, in order                                reads the flags
-//   k_rle_emit      (count:u8, colour: u64 len = 3 + 3 bytes) = three aligned words per run, behind the header
+//   k_rle_records   (count:u8, colour: u64 len = 3 + 3 bytes) = three aligned words per run, behind the header: a run ends
+//                   where the next flag is                                               reads the flags + 3 B per run
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -64,23 +64,36 @@ __global__ __launch_bounds__(kRleThreads) void k_rle_last(const uint8_t *__restr
     if (threadIdx.x == 0) chunk_last[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
 }
 
-// single block: carry[c] = max over chunks before c (0 = none)
-__global__ __launch_bounds__(1024) void k_rle_carry(const uint64_t *__restrict__ chunk_last, uint32_t nchunks, uint64_t *__restrict__ carry) {
-    __shared__ uint64_t sh[1024];
-    const uint32_t per = (nchunks + 1023) / 1024;
-    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nchunks);
-    uint64_t m = 0;
-    for (uint32_t i = lo; i < hi; i++) m = max(m, chunk_last[i]);
-    sh[threadIdx.x] = m;
+// carry[c] = max over chunks before c (0 = none).  Up to 1024 chunks: one block; more (a 16384^2 image has 65536): every
+// 1024-chunk block scans its own part and leaves its maximum, then every block takes in the maxima before it (a single block
+// walking 64 values per thread took 0.12 ms there).
+__global__ __launch_bounds__(1024) void k_rle_carry_local(const uint64_t *__restrict__ chunk_last, uint32_t nchunks, uint64_t *__restrict__ carry,
+                                                          uint64_t *__restrict__ blockmax) {
+    __shared__ uint64_t wmax[1024 / 64];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint64_t v = i < nchunks ? chunk_last[i] : 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t inc = wave_inclusive_scan64<true>(v);
+    if (lane == 63) wmax[wid] = inc;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint64_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] = max(sh[threadIdx.x], t);
-        __syncthreads();
-    }
-    uint64_t run = threadIdx.x ? sh[threadIdx.x - 1] : 0;
-    for (uint32_t i = lo; i < hi; i++) { carry[i] = run; run = max(run, chunk_last[i]); }
+    uint64_t pre = 0;
+    for (int k = 0; k < wid; k++) pre = max(pre, wmax[k]);
+    uint64_t ex = __shfl_up(inc, 1, 64);
+    if (lane == 0) ex = 0;
+    if (i < nchunks) carry[i] = max(pre, ex);
+    if (threadIdx.x == 1023) blockmax[blockIdx.x] = max(pre, inc);
+}
+__global__ __launch_bounds__(1024) void k_rle_carry_add(uint32_t nchunks, uint64_t *__restrict__ carry, const uint64_t *__restrict__ blockmax) {
+    __shared__ unsigned long long s_before;
+    unsigned long long mine = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 1024) mine = max(mine, (unsigned long long)blockmax[b]);
+    if (threadIdx.x == 0) s_before = 0;
+    __syncthreads();
+    mine = wave_reduce_max64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicMax(&s_before, mine);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < nchunks) carry[i] = max(carry[i], (uint64_t)s_before);
 }
 
 __global__ __launch_bounds__(kRleThreads) void k_rle_flags(const uint8_t *__restrict__ lin, uint64_t n, const uint64_t *__restrict__ carry,
@@ -124,26 +137,46 @@ __global__ __launch_bounds__(1024) void k_rle_offsets(const uint32_t *__restrict
     if (threadIdx.x == 1023) *total = sh[1023];
 }
 
-__global__ __launch_bounds__(kRleThreads) void k_rle_starts(const uint16_t *__restrict__ flags, const uint64_t *__restrict__ run_off,
-                                                            uint64_t *__restrict__ start_pos) {
-    __shared__ uint32_t wsum[kRleThreads / 64];
-    const uint32_t f = flags[(size_t)blockIdx.x * kRleThreads + threadIdx.x];
-    uint64_t r = run_off[blockIdx.x] + block_exclusive_scan<kRleThreads>((uint32_t)__popc(f), wsum);
-    const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
-    for (uint32_t m = f; m; m &= m - 1) start_pos[r++] = base + (uint32_t)(__ffs((int)m) - 1);
-}
-
+// The records of a chunk's runs, straight from the flags (a list of run starts in between -- 8 B written and read per run,
+// 4.3 GB at 16384^2 on a noisy image -- took 1.2 + 1.35 ms there).  A run ends where the next one starts: a later bit of the
+// thread's own flags, else the first bit of a following thread's -- at most 16 threads on, a run has at most 255 elements --
+// else the end of the image.
 // record = count:u8 | len:u64 = 3 | r g b  = 12 bytes = words { count | 3 << 8, 0, r << 8 | g << 16 | b << 24 }
-__global__ __launch_bounds__(256) void k_rle_emit(const uint8_t *__restrict__ lin, uint64_t n, const uint64_t *__restrict__ start_pos,
-                                                  uint64_t nruns, uint32_t *__restrict__ out_words) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride) {
-        const uint64_t s = start_pos[r], e = r + 1 < nruns ? start_pos[r + 1] : n;
-        const uint8_t *p = lin + 3 * s;
-        out_words[3 * r + 0] = (uint32_t)(e - s) | (3u << 8);
-        out_words[3 * r + 1] = 0u;
-        out_words[3 * r + 2] = ((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24);
+__global__ __launch_bounds__(kRleThreads) void k_rle_records(const uint8_t *__restrict__ lin, uint64_t n, const uint16_t *__restrict__ flags,
+                                                             const uint64_t *__restrict__ run_off, uint32_t nchunks, uint32_t *__restrict__ out_words) {
+    __shared__ uint32_t wsum[kRleThreads / 64];
+    __shared__ uint16_t s_f[kRleThreads + 16];
+    __shared__ uint32_t s_rec[3 * kRleChunk];  // the chunk's records, written out as whole rows of words (a thread's records are
+                                               // 192 bytes from the next thread's: stored one by one the kernel took 2.3 ms)
+    __shared__ uint32_t s_total;
+    const uint32_t f = flags[(size_t)blockIdx.x * kRleThreads + threadIdx.x];
+    s_f[threadIdx.x] = (uint16_t)f;
+    if (threadIdx.x < 16) s_f[kRleThreads + threadIdx.x] = blockIdx.x + 1 < nchunks ? flags[(size_t)(blockIdx.x + 1) * kRleThreads + threadIdx.x] : (uint16_t)0;
+    const uint32_t mine = (uint32_t)__popc(f);
+    uint32_t r = block_exclusive_scan<kRleThreads>(mine, wsum);  // (its barriers also complete s_f)
+    if (threadIdx.x == kRleThreads - 1) s_total = r + mine;
+    if (f) {
+        const uint64_t base = (uint64_t)blockIdx.x * kRleChunk + (uint64_t)threadIdx.x * kRlePer;
+        // where the run that is open at the end of this thread's positions ends
+        uint64_t after = n;
+        for (uint32_t k = 1; k <= 16; k++) {
+            const uint32_t g = s_f[threadIdx.x + k];
+            if (g) { after = base + (uint64_t)k * kRlePer + (uint32_t)(__ffs((int)g) - 1); break; }
+        }
+        if (after > n) after = n;
+        for (uint32_t m = f; m; r++) {
+            const uint32_t j = (uint32_t)(__ffs((int)m) - 1);
+            m &= m - 1;
+            const uint64_t s = base + j, e = m ? base + (uint32_t)(__ffs((int)m) - 1) : after;
+            const uint8_t *p = lin + 3 * s;
+            s_rec[3 * r] = (uint32_t)(e - s) | (3u << 8);
+            s_rec[3 * r + 1] = 0u;
+            s_rec[3 * r + 2] = ((uint32_t)p[0] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 24);
+        }
     }
+    __syncthreads();
+    uint32_t *o = out_words + 3 * run_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < 3 * s_total; i += kRleThreads) o[i] = s_rec[i];
 }
 
 // lin_d: the image in Hilbert order (3 B/px).  Phase 1 counts the runs (host out-param, stream synced) and keeps
@@ -164,11 +197,22 @@ int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan) {
     CNIIC_HIP_TRY(c, plan->flags.alloc((uint64_t)nchunks * kRleThreads * 2));
     CNIIC_HIP_TRY(c, plan->run_off.alloc((uint64_t)nchunks * 8));
     hipLaunchKernelGGL(k_rle_last, dim3(nchunks), dim3(kRleThreads), 0, c->stream, lin_d, n, chunk_last.as<uint64_t>());
-    hipLaunchKernelGGL(k_rle_carry, dim3(1), dim3(1024), 0, c->stream, chunk_last.as<uint64_t>(), nchunks, carry.as<uint64_t>());
+    {
+        const uint32_t nb = (nchunks + 1023) / 1024;
+        DevBuf blockmax;
+        CNIIC_HIP_TRY(c, blockmax.alloc((uint64_t)nb * 8));
+        hipLaunchKernelGGL(k_rle_carry_local, dim3(nb), dim3(1024), 0, c->stream, chunk_last.as<uint64_t>(), nchunks, carry.as<uint64_t>(),
+                           blockmax.as<uint64_t>());
+        if (nb > 1)
+            hipLaunchKernelGGL(k_rle_carry_add, dim3(nb), dim3(1024), 0, c->stream, nchunks, carry.as<uint64_t>(), (const uint64_t *)blockmax.as<uint64_t>());
+    }
     hipLaunchKernelGGL(k_rle_flags, dim3(nchunks), dim3(kRleThreads), 0, c->stream, lin_d, n, carry.as<uint64_t>(),
                        plan->flags.as<uint16_t>(), chunk_runs.as<uint32_t>());
-    hipLaunchKernelGGL(k_rle_offsets, dim3(1), dim3(1024), 0, c->stream, chunk_runs.as<uint32_t>(), nchunks, plan->run_off.as<uint64_t>(),
-                       tot.as<uint64_t>());
+    if (nchunks > 1024)  // (one block walking 64 chunks per thread took 0.11 ms at 16384^2)
+        CNIIC_TRY(pack_scan(c, chunk_runs.as<uint32_t>(), nchunks, plan->run_off.as<uint64_t>(), tot.as<uint64_t>()));
+    else
+        hipLaunchKernelGGL(k_rle_offsets, dim3(1), dim3(1024), 0, c->stream, chunk_runs.as<uint32_t>(), nchunks, plan->run_off.as<uint64_t>(),
+                           tot.as<uint64_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -179,12 +223,8 @@ int rle_plan(Ctx *c, const uint8_t *lin_d, uint64_t n, RlePlan *plan) {
 
 int rle_emit(Ctx *c, const uint8_t *lin_d, const RlePlan *plan, uint32_t *out_words_d) {
     if (plan->nruns == 0) return CNIIC_OK;
-    DevBuf start_pos;
-    CNIIC_HIP_TRY(c, start_pos.alloc(plan->nruns * 8));
-    hipLaunchKernelGGL(k_rle_starts, dim3(plan->nchunks), dim3(kRleThreads), 0, c->stream, plan->flags.as<uint16_t>(),
-                       plan->run_off.as<uint64_t>(), start_pos.as<uint64_t>());
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(plan->nruns, 256), 1), 4096);
-    hipLaunchKernelGGL(k_rle_emit, dim3(grid), dim3(256), 0, c->stream, lin_d, plan->n, start_pos.as<uint64_t>(), plan->nruns, out_words_d);
+    hipLaunchKernelGGL(k_rle_records, dim3(plan->nchunks), dim3(kRleThreads), 0, c->stream, lin_d, plan->n, (const uint16_t *)plan->flags.as<uint16_t>(),
+                       (const uint64_t *)plan->run_off.as<uint64_t>(), plan->nchunks, out_words_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

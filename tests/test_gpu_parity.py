@@ -248,6 +248,24 @@ def test_hilbert_linearize_and_delta(ctx, shape):
     assert np.array_equal(keys, ek) and np.array_equal(counts, ec) and np.array_equal(syms2, esyms)
 
 
+@pytest.mark.parametrize("move", ["", "any"])
+@pytest.mark.parametrize("size", [64, 128, 512])
+def test_hilbert_move_by_tiles_and_by_positions(ctx, monkeypatch, size, move):
+    """2^n squares from 64 x 64: the tile kernel (rows <-> LDS <-> scan positions) and the per-position kernel give the oracle's
+    linearised image, and `hilbert(rle)` / `delta` decode (the scatter) gives the image back"""
+    if move:
+        monkeypatch.setenv("CNIIC_HILBERT_MOVE", move)
+    img = np.random.default_rng(size).integers(0, 256, (size, size, 3)).astype(np.uint8)
+    assert np.array_equal(ctx.hilbert_linearize(img), O.hilbert_linearize(img))
+    flat = img.copy()
+    flat[:, : size // 2] = 9  # runs for the RLE
+    for expr, im in (("hilbert(rle)", flat), ("delta", img)):
+        rc, data, _ = ctx.encode(expr, im)
+        assert rc == 0 and data == O.encode(expr, im)[1]
+        rc, back = ctx.decode(expr, data)
+        assert rc == 0 and np.array_equal(back, im)
+
+
 @pytest.mark.parametrize("lane_scan", ["0", "1"])
 @pytest.mark.parametrize("size", [8, 32, 256])
 def test_hilbert_delta_both_kernels_on_pow2_squares(ctx, monkeypatch, lane_scan, size):
