@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
     __shared__ uint16_t s_l4[1024];
     __shared__ uint8_t s_l1[16];
     __shared__ __align__(16) uint8_t s_l3[4 * 64];  // three levels from state s for six bits q: x:3 | y:3 << 3 | end state << 6
+    __shared__ uint32_t s_cold[4 * kColdPerChunk];  // per wave: the differences (three fields) of the chunk's cold symbols so far
     const uint32_t w = 1u << order;
     const Scan sc = load_scan(w, w, order, lut, s_l4, s_l1);
     {
@@ -148,23 +149,30 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
             const bool cold = (d & kMask) != kHotBits;              // some field outside [512, 543]
             uint32_t hot = ((d >> 10) & 0x7c00u) | ((d >> 5) & 0x3e0u) | (d & 31u);
             const uint64_t cm = __builtin_amdgcn_ballot_w64(cold);
-            if (cm) {
-                const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
+            if (cm) {  // (one step in two: one lane in 90 is cold) the lane's differences go to the wave's list in LDS
                 if (cold) {
-                    const uint32_t key = ((((d >> 20) & 1023u) - (kField - 255)) << 18) | ((((d >> 10) & 1023u) - (kField - 255)) << 9) |
-                                         ((d & 1023u) - (kField - 255));
-                    atomicAdd(&table[key], 1u);
-                    pages[key >> kPageShift] = 1;
                     const uint32_t r = crank + lanes_before(cm);
-                    if (r < kColdPerChunk) coldkeys[(uint64_t)ch * kColdPerChunk + r] = key;
+                    if (r < kColdPerChunk) s_cold[wave * kColdPerChunk + r] = d;
                     hot = kCold16 + min(r, kColdPerChunk - 1);
                 }
                 crank += (uint32_t)__popcll(cm);
             }
             o[j * 64] = (uint16_t)hot;
-            if ((j & 7) == 7) {
+            if ((j & 7) == 7) {  // the chunk's cold symbols, once: keys to the side array (a row), counts to the table
+                const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < min(crank, kColdPerChunk)) {
+                    const uint32_t dd = s_cold[wave * kColdPerChunk + lane];
+                    const uint32_t key = ((((dd >> 20) & 1023u) - (kField - 255)) << 18) | ((((dd >> 10) & 1023u) - (kField - 255)) << 9) |
+                                         ((dd & 1023u) - (kField - 255));
+                    atomicAdd(&table[key], 1u);
+                    pages[key >> kPageShift] = 1;
+                    coldkeys[(uint64_t)ch * kColdPerChunk + lane] = key;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 if (lane == 0) {
-                    const uint32_t ch = tile * 8 + wave * 2 + (j >> 3);
                     chunk_cold[ch] = (uint8_t)min(crank, 255u);
                     if (crank > kColdPerChunk) *overflow = 1;
                 }
