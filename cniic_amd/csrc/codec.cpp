@@ -159,10 +159,24 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
     CNIIC_HIP_TRY(c, counts_d.alloc(U * 8));
     CNIIC_TRY(hist_compact_write(c, table_d, &plan, keys_d.as<uint32_t>(), counts_d.as<uint64_t>(), nullptr));
-    std::vector<uint32_t> keys(U);
-    std::vector<uint64_t> counts(U);
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts.data(), counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    // A large alphabet (a photograph's colours): the host only merges the tree; codes and the serialised decoder are the
+    // GPU's (huff_tree_codes).  The counts land in pinned memory, the tree's arrays are written there, the keys stay put.
+    const char *gmin = getenv("CNIIC_HUF_GPU_CODES_MIN");  // (tests: 0)
+    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2 && U < (1ull << 30);
+    std::vector<uint32_t> keys(gpu_codes ? 0 : U);
+    std::vector<uint64_t> counts_v(gpu_codes ? 0 : U);
+    uint64_t *counts = counts_v.data();
+    uint32_t *left_h = nullptr, *right_h = nullptr, *nl_h = nullptr;
+    if (gpu_codes) {
+        CNIIC_HIP_TRY(c, ctx_pinned_huf(c, U * 8 + 3 * (U - 1) * 4 + 64));
+        counts = static_cast<uint64_t *>(c->pinned_huf);
+        left_h = reinterpret_cast<uint32_t *>(counts + U);
+        right_h = left_h + (U - 1);
+        nl_h = right_h + (U - 1);
+    } else {
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
     if (!c->huf_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->huf_ev, hipEventDisableTiming));
     CNIIC_HIP_TRY(c, hipEventRecord(c->huf_ev, c->stream));
     // `delta` symbols on a buffer of ours: nothing to do while the host builds the tree -- the pack looks (length, code) up
@@ -181,36 +195,68 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_HIP_TRY(c, hipEventSynchronize(c->huf_ev));
     host_trace().mark("huf: hist + compaction + D2H");
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
-    HuffTree tree;
-    std::vector<uint8_t> clen;
-    std::vector<uint64_t> code;
-    if (!huff_build_tree(counts.data(), U, tree) || !huff_codes(tree, clen, code))
-        return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
-    host_trace().mark("huf: tree + codes (host)");
-    huff_serialize_tree(tree, sym_kind, keys.data(), header);
-    host_trace().mark("huf: serialise trie (host)");
-    // 3. payload (huf.rs:37-41), packed in place behind the header
-    uint64_t nbits = 0;
-    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
-    StreamOut so(c, out, cap, len);
-    CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
+    if (!c->huf_scratch) c->huf_scratch = std::make_shared<HuffScratch>();
+    HuffScratch *scratch = static_cast<HuffScratch *>(c->huf_scratch.get());
     DevBuf len_d, code_d;
     CNIIC_HIP_TRY(c, len_d.alloc(U));
     CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen.data(), U, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
+    uint64_t nbits = 0, header_bytes = 0;
+    StreamOut so(c, out, cap, len);
+    if (gpu_codes) {
+        uint32_t root = 0;
+        if (!huff_build_tree_into(counts, U, left_h, right_h, nl_h, &root, scratch))
+            return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        host_trace().mark("huf: tree (host)");
+        DevBuf tree_d, off_d, totals_d;
+        CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));
+        CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
+        CNIIC_HIP_TRY(c, totals_d.alloc(16));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(tree_d.p, left_h, 3 * (U - 1) * 4, hipMemcpyHostToDevice, c->stream));
+        const uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (U - 1), *nl_d = right_d + (U - 1);
+        CNIIC_TRY(huff_tree_codes(c, left_d, right_d, nl_d, counts_d.as<uint64_t>(), (uint32_t)U, root, sym_kind, len_d.as<uint8_t>(),
+                                  code_d.as<uint64_t>(), off_d.as<uint64_t>(), totals_d.as<uint64_t>()));
+        CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], totals_d.p, 16, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->pinned_u[3]) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        nbits = c->pinned_u[2];
+        host_trace().mark("huf: codes (GPU)");
+        const uint64_t trie_bytes = huff_tree_bytes(sym_kind, U), head = header.size();
+        CNIIC_TRY(so.begin_sized(head + trie_bytes, (nbits + 7) / 8));
+        CNIIC_TRY(so.put_header(header));
+        CNIIC_TRY(huff_tree_serialize_dev(c, keys_d.as<uint32_t>(), off_d.as<uint64_t>(), (uint32_t)U, sym_kind, so.dev + head, trie_bytes));
+        header_bytes = head + trie_bytes;  // (what the pack below starts behind; the decoder's bytes are on the device)
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // tree_d / off_d go back to the pool
+        host_trace().mark("huf: serialise trie (GPU)");
+    } else {
+        HuffTree tree;
+        std::vector<uint8_t> clen;
+        std::vector<uint64_t> code;
+        if (!huff_build_tree(counts, U, tree, scratch) || !huff_codes(tree, clen, code))
+            return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        host_trace().mark("huf: tree + codes (host)");
+        huff_serialize_tree(tree, sym_kind, keys.data(), header);
+        host_trace().mark("huf: serialise trie (host)");
+        // 3. payload (huf.rs:37-41), packed in place behind the header
+        for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
+        CNIIC_TRY(so.begin(header, (nbits + 7) / 8));
+        header_bytes = header.size();
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen.data(), U, hipMemcpyHostToDevice, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code.data(), U * 8, hipMemcpyHostToDevice, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // (clen / code are locals of this branch)
+    }
     uint64_t packed_bits = 0;
     ScopedKernelTimer timer(c, "huff_pack");
     if (hot_route) {
         CNIIC_TRY(huff_pack_code32_hot(c, syms_d, n, table_d, keys_d.as<uint32_t>(), len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, syms_d, so.dev,
-                                       (uint64_t)header.size() * 8, &packed_bits));
+                                       header_bytes * 8, &packed_bits));
     } else if (inline_codes) {
         DevBuf code32;
         CNIIC_HIP_TRY(c, code32.alloc(U * 4));
         CNIIC_TRY(huff_pack_code32(c, ranks, nullptr, n, code32.as<uint32_t>(), nullptr, len_d.as<uint8_t>(), code_d.as<uint64_t>(), U, ranks,
-                                   so.dev, (uint64_t)header.size() * 8, &packed_bits));
+                                   so.dev, header_bytes * 8, &packed_bits));
     } else {
-        CNIIC_TRY(huff_pack_ranks(c, ranks, n, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev, (uint64_t)header.size() * 8, &packed_bits));
+        CNIIC_TRY(huff_pack_ranks(c, ranks, n, len_d.as<uint8_t>(), code_d.as<uint64_t>(), so.dev, header_bytes * 8, &packed_bits));
     }
     timer.stop(1);
     host_trace().mark("huf: pack");

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -132,6 +133,7 @@ struct Ctx {
     uint64_t *pinned_u = nullptr;  // 64 KiB of pinned host memory: [0] sp_build's distinct-colour count, [1] the point list's length,
                                    // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
+    std::shared_ptr<void> huf_scratch;  // host arrays of the Huffman tree build, kept between calls (HuffScratch, codec.cpp)
     void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
     uint64_t pinned_huf_bytes = 0;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
@@ -556,6 +558,10 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
                  DeltaPackScratch *keep);
 
 // ---- k_huff.hip ----
+// codes and the serialised decoder of a tree the host built, for large alphabets (see k_huff.hip)
+int huff_tree_codes(Ctx *c, const uint32_t *left_d, const uint32_t *right_d, const uint32_t *nleaves_d, const uint64_t *counts_d, uint32_t n,
+                    uint32_t root, int sym_kind, uint8_t *len_d, uint64_t *code_d, uint64_t *off_d, uint64_t *totals_d);
+int huff_tree_serialize_dev(Ctx *c, const uint32_t *keys_d, const uint64_t *off_d, uint32_t n, int sym_kind, uint8_t *trie_d, uint64_t trie_bytes);
 // chunk_off[i] = exclusive prefix (u64) of chunk_bits[0 .. nchunks); *total_d = the sum
 int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *chunk_off_d, uint64_t *total_d);
 uint32_t pack_img_cap();  // tests: CNIIC_TEST_PACK_IMG_WORDS caps the packs' LDS bit image

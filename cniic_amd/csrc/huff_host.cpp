@@ -22,10 +22,10 @@ namespace cniic {
 namespace {
 
 // stable LSD radix sort of (count << 32 | leaf) by count, 11 bits a pass, only over the bits some count has
-void sort_leaves(std::vector<uint64_t> &a, uint32_t maxc) {
+void sort_leaves(std::vector<uint64_t> &a, std::vector<uint64_t> &tmp, uint32_t maxc) {
     const size_t n = a.size();
     if (n < 2) return;
-    std::vector<uint64_t> tmp(n);
+    tmp.resize(n);
     uint64_t *src = a.data(), *dst = tmp.data();
     for (int sh = 32; sh < 64 && (maxc >> (sh - 32)); sh += 11) {
         size_t cnt[2049] = {0};
@@ -40,61 +40,71 @@ void sort_leaves(std::vector<uint64_t> &a, uint32_t maxc) {
 }  // namespace
 
 // counts below 2^32 (every image this library takes has fewer pixels): leaves packed as count << 32 | leaf
-static void build_tree_u32(const uint64_t *counts, uint64_t n, HuffTree &t) {
-    std::vector<uint64_t> leaf(n);
+static void build_tree_u32(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc) {
+    std::vector<uint64_t> &leaf = sc.leaf, &bfreq = sc.bfreq;
+    leaf.resize(n);
     uint32_t maxc = 0;
     for (uint64_t i = 0; i < n; i++) { leaf[i] = (counts[i] << 32) | i; maxc |= (uint32_t)counts[i]; }
-    sort_leaves(leaf, maxc);  // (count, key): the leaf ids are ascending keys and the sort is stable
-    std::vector<uint64_t> bfreq(n > 1 ? n - 1 : 0);
+    sort_leaves(leaf, sc.tmp, maxc);  // (count, key): the leaf ids are ascending keys and the sort is stable
+    bfreq.resize(n > 1 ? n - 1 : 0);
     uint64_t li = 0, bi = 0, made = 0;
     while (made + 1 < n) {
-        uint32_t node[2];
+        uint32_t node[2], leaves = 0;
         uint64_t f[2];
         for (int k = 0; k < 2; k++) {
-            if (li < n && (bi >= made || (leaf[li] >> 32) <= bfreq[bi])) { f[k] = leaf[li] >> 32; node[k] = (uint32_t)leaf[li]; li++; }
-            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); bi++; }
+            if (li < n && (bi >= made || (leaf[li] >> 32) <= bfreq[bi])) { f[k] = leaf[li] >> 32; node[k] = (uint32_t)leaf[li]; li++; leaves += 1; }
+            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); if (nl) leaves += nl[bi]; bi++; }
         }
-        t.left[made] = node[0];
-        t.right[made] = node[1];
+        left[made] = node[0];
+        right[made] = node[1];
+        if (nl) nl[made] = leaves;
         bfreq[made] = f[0] + f[1];
         made++;
     }
-    t.root = n > 1 ? (uint32_t)(n + made - 1) : 0;
 }
 
 // any counts: the same rule through a comparison sort
-static void build_tree_u64(const uint64_t *counts, uint64_t n, HuffTree &t) {
+static void build_tree_u64(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc) {
     std::vector<uint32_t> order(n);
     for (uint64_t i = 0; i < n; i++) order[i] = (uint32_t)i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return counts[a] < counts[b]; });
-    std::vector<uint64_t> bfreq(n > 1 ? n - 1 : 0);
+    std::vector<uint64_t> &bfreq = sc.bfreq;
+    bfreq.resize(n > 1 ? n - 1 : 0);
     uint64_t li = 0, bi = 0, made = 0;
     while (made + 1 < n) {
-        uint32_t node[2];
+        uint32_t node[2], leaves = 0;
         uint64_t f[2];
         for (int k = 0; k < 2; k++) {
-            if (li < n && (bi >= made || counts[order[li]] <= bfreq[bi])) { f[k] = counts[order[li]]; node[k] = order[li]; li++; }
-            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); bi++; }
+            if (li < n && (bi >= made || counts[order[li]] <= bfreq[bi])) { f[k] = counts[order[li]]; node[k] = order[li]; li++; leaves += 1; }
+            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); if (nl) leaves += nl[bi]; bi++; }
         }
-        t.left[made] = node[0];
-        t.right[made] = node[1];
+        left[made] = node[0];
+        right[made] = node[1];
+        if (nl) nl[made] = leaves;
         bfreq[made] = f[0] + f[1];
         made++;
     }
-    t.root = n > 1 ? (uint32_t)(n + made - 1) : 0;
 }
 
-bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t) {
+bool huff_build_tree_into(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root, HuffScratch *scratch) {
     if (n == 0 || n > 0x7fffffffull) return false;  // huf.rs:99 assert!(min_heap.len() > 0)
-    t.nleaf = n;
-    t.left.assign(n > 1 ? n - 1 : 0, 0);
-    t.right.assign(n > 1 ? n - 1 : 0, 0);
+    HuffScratch local;
+    HuffScratch &sc = scratch ? *scratch : local;
     uint64_t total = 0;
     bool small = true;
     for (uint64_t i = 0; i < n && small; i++) { total += counts[i]; small = total < (1ull << 32) && counts[i] < (1ull << 32); }
-    if (small) build_tree_u32(counts, n, t);
-    else build_tree_u64(counts, n, t);
+    if (small) build_tree_u32(counts, n, left, right, nleaves, sc);
+    else build_tree_u64(counts, n, left, right, nleaves, sc);
+    *root = n > 1 ? (uint32_t)(2 * n - 2) : 0;
     return true;
+}
+
+bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t, HuffScratch *scratch) {
+    if (n == 0 || n > 0x7fffffffull) return false;
+    t.nleaf = n;
+    t.left.resize(n - 1);  // (every entry is written)
+    t.right.resize(n - 1);
+    return huff_build_tree_into(counts, n, t.left.data(), t.right.data(), nullptr, &t.root, scratch);
 }
 
 bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code) {

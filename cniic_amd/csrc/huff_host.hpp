@@ -18,7 +18,11 @@ struct HuffTree {
 
 // huf.rs:58-117 build(): min-heap merge.  Heap = Rust std BinaryHeap semantics, item order = the
 // given (ascending key) order.
-bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t);
+struct HuffScratch { std::vector<uint64_t> leaf, tmp, bfreq; };  // kept between calls: no 54 MB of fresh pages per array and call
+bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t, HuffScratch *scratch = nullptr);
+// the same into arrays of the caller's (n - 1 entries each; pinned memory, say); nleaves (optional): leaves below every branch
+bool huff_build_tree_into(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root,
+                          HuffScratch *scratch = nullptr);
 // Enc::from(&Dec) (huf.rs:125-135): code length and code bits (MSB-first in the low bits) per leaf.
 bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code);
 bool huff_codes_into(const HuffTree &t, uint8_t *len, uint64_t *code);  // len / code: t.nleaf entries (pinned memory, say)

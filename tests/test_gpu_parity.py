@@ -300,6 +300,43 @@ def test_huf_encode_all_long_codes(ctx):
     assert ctx.huf_encode_all(2, syms) == O.huf_encode_all(O.SYM_SIGNED, syms)
 
 
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("n", [2, 3, 17, 4097, 60000])
+def test_huf_codes_and_decoder_on_the_gpu(ctx, monkeypatch, kind, n):
+    """large alphabets: the host merges the tree, every leaf's code and its place in the serialised decoder come from a walk to
+    the root on the GPU (CNIIC_HUF_GPU_CODES_MIN=0: for these small ones too) -- the oracle's bytes for both symbol kinds, skewed
+    and flat histograms, and through the `hufman` codec and the 32-bit route of `delta` on a noisy image"""
+    monkeypatch.setenv("CNIIC_HUF_GPU_CODES_MIN", "0")
+    rng = np.random.default_rng(n * 3 + kind)
+    top = (1 << 24) if kind == 1 else (1 << 27)
+    distinct = rng.choice(top, size=min(n, 5000), replace=False).astype(np.uint32)
+    if kind == 2:  # SignedColor keys: three 9-bit fields holding d + 255, d in -255 .. 255
+        distinct = (distinct & ~np.uint32(0)) % np.uint32(511) + ((distinct >> 9) % np.uint32(511) << 9) + ((distinct >> 18) % np.uint32(511) << 18)
+        distinct = np.unique(distinct.astype(np.uint32))
+    p = rng.random(len(distinct)) ** 6
+    syms = distinct[rng.choice(len(distinct), size=n, p=p / p.sum())].astype(np.uint32)
+    assert ctx.huf_encode_all(kind, syms) == O.huf_encode_all(O.SYM_RGB if kind == 1 else O.SYM_SIGNED, syms)
+    if n == 60000 and kind == 1:
+        img = rng.integers(0, 256, (120, 130, 3)).astype(np.uint8)
+        for expr in ("hufman", "delta"):
+            rc, data, _ = ctx.encode(expr, img)
+            assert rc == 0 and data == O.encode(expr, img)[1]
+            rc, back = ctx.decode(expr, data)
+            assert rc == 0 and np.array_equal(back, img)
+
+
+def test_huf_long_codes_on_the_gpu(ctx, monkeypatch):
+    """Fibonacci-like counts: codes of up to 39 bits through the GPU's walk"""
+    monkeypatch.setenv("CNIIC_HUF_GPU_CODES_MIN", "0")
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    fib = [min(f, 3000) if i > 20 else f for i, f in enumerate(fib)]
+    syms = np.concatenate([np.full(f, i * 7 + 1, np.uint32) for i, f in enumerate(fib)])
+    np.random.default_rng(0).shuffle(syms)
+    assert ctx.huf_encode_all(2, syms) == O.huf_encode_all(O.SYM_SIGNED, syms)
+
+
 # ------------------------------------------------------------------ codecs end to end
 @pytest.mark.parametrize("expr", ["hufman", "delta", "hilbert(rle)", "cluster-colors(8)", "ccol(256)", "voronoi(6)", "voronoi(40)"])
 @pytest.mark.parametrize("shape", [(48, 40), (64, 64), (100, 75)])
