@@ -834,37 +834,61 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     CNIIC_HIP_TRY(c, keys_d.alloc(U * 4));
     CNIIC_HIP_TRY(c, counts_d.alloc(U * 8));
     CNIIC_TRY(hist_compact_write(c, table, &plan, keys_d.as<uint32_t>(), counts_d.as<uint64_t>(), nullptr));
-    // counts and codes cross the bus through pinned memory [counts u64 | code u64 | len u8]; the keys and the decoder stay in
-    // ordinary memory (the host reads the keys at random and writes the decoder byte by byte: 0.20 ms in pinned memory, 0.12 here)
+    // Counts (and codes) cross the bus through pinned memory.  From 32768 distinct symbols on -- any photograph -- the host only
+    // merges the tree; codes, lengths and the serialised decoder come from the GPU (huff_tree_codes: 0.1 ms of host work less,
+    // and no 0.13-0.28 ms of writing the decoder out beside the pack).  Below: [counts u64 | code u64 | len u8], the keys and
+    // the decoder in ordinary memory (the host reads the keys at random and writes the decoder byte by byte: 0.20 ms in pinned
+    // memory, 0.12 there).
     const uint64_t decoder_bytes = huff_tree_bytes(CNIIC_SYM_SIGNED, U), header_bytes = header.size() + decoder_bytes;
+    const char *gmin = getenv("CNIIC_HUF_GPU_CODES_MIN");  // (tests: 0, or a large number for the host's way)
+    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2;
     const uint64_t off_code = U * 8, off_len = off_code + U * 8;
-    CNIIC_HIP_TRY(c, ctx_pinned_huf(c, off_len + U));
+    CNIIC_HIP_TRY(c, ctx_pinned_huf(c, gpu_codes ? U * 8 + 3 * (U - 1) * 4 + 64 : off_len + U));
     uint8_t *const pin = static_cast<uint8_t *>(c->pinned_huf);
-    uint64_t *const counts = reinterpret_cast<uint64_t *>(pin), *const code = reinterpret_cast<uint64_t *>(pin + off_code);
-    uint8_t *const clen = pin + off_len;
-    std::vector<uint32_t> keys_v(U);
-    uint32_t *const keys = keys_v.data();
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(keys, keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+    uint64_t *const counts = reinterpret_cast<uint64_t *>(pin);
+    std::vector<uint32_t> keys_v(gpu_codes ? 0 : U);
+    if (!gpu_codes) CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_v.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, ctx_spin_sync(c));
     host_trace().mark("delta: compaction + D2H (wait)");
-    // 2. build() (huf.rs:31)
-    HuffTree tree;
-    if (!huff_build_tree(counts, U, tree) || !huff_codes_into(tree, clen, code))
-        return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
-    host_trace().mark("delta: tree + codes (host)");
-    // 3. payload (huf.rs:37-41) behind the serialised decoder (huf.rs:34), whose size follows from U alone: U leaves of
-    //    1 + 6 bytes and U - 1 branch tags -- the GPU packs while the host writes the decoder out
-    uint64_t nbits = 0;
-    for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
-    StreamOut so(c, out, cap, len);
-    CNIIC_TRY(so.begin_sized(header_bytes, (nbits + 7) / 8, /*zero=*/false));  // (the pack stores every word of the payload)
-    DevBuf len_d, code_d;
+    // 2. build() (huf.rs:31); 3. the payload (huf.rs:37-41) behind the serialised decoder (huf.rs:34), whose size follows
+    //    from U alone: U leaves of 1 + 6 bytes and U - 1 branch tags
+    if (!c->huf_scratch) c->huf_scratch = std::make_shared<HuffScratch>();
+    HuffScratch *hscratch = static_cast<HuffScratch *>(c->huf_scratch.get());
+    DevBuf len_d, code_d, tree_d, off_d;
     CNIIC_HIP_TRY(c, len_d.alloc(U));
     CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen, U, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code, U * 8, hipMemcpyHostToDevice, c->stream));
-    host_trace().mark("delta: H2D codes enqueued");
+    HuffTree tree;
+    uint64_t nbits = 0;
+    if (gpu_codes) {
+        uint32_t *left_h = reinterpret_cast<uint32_t *>(counts + U), *right_h = left_h + (U - 1), *nl_h = right_h + (U - 1), root = 0;
+        if (!huff_build_tree_into(counts, U, left_h, right_h, nl_h, &root, hscratch))
+            return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        host_trace().mark("delta: tree (host)");
+        CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));
+        CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(tree_d.p, left_h, 3 * (U - 1) * 4, hipMemcpyHostToDevice, c->stream));
+        const uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (U - 1), *nl_d = right_d + (U - 1);
+        CNIIC_TRY(huff_tree_codes(c, left_d, right_d, nl_d, counts_d.as<uint64_t>(), (uint32_t)U, root, CNIIC_SYM_SIGNED, len_d.as<uint8_t>(),
+                                  code_d.as<uint64_t>(), off_d.as<uint64_t>(), small.as<uint64_t>() + 2));  // small[2] bits, [3] too long
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[4], small.as<uint64_t>() + 2, 16, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, ctx_spin_sync(c));
+        if (c->pinned_u[5]) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        nbits = c->pinned_u[4];
+        host_trace().mark("delta: codes (GPU)");
+    } else {
+        uint64_t *const code = reinterpret_cast<uint64_t *>(pin + off_code);
+        uint8_t *const clen = pin + off_len;
+        if (!huff_build_tree(counts, U, tree, hscratch) || !huff_codes_into(tree, clen, code))
+            return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+        host_trace().mark("delta: tree + codes (host)");
+        for (uint64_t i = 0; i < U; i++) nbits += counts[i] * clen[i];
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, clen, U, hipMemcpyHostToDevice, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, code, U * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    StreamOut so(c, out, cap, len);
+    CNIIC_TRY(so.begin_sized(header_bytes, (nbits + 7) / 8, /*zero=*/false));  // (the pack stores every word of the payload)
+    CNIIC_HIP_TRY(c, hipMemsetAsync(small.as<uint64_t>() + 2, 0, 8, c->stream));
     DeltaPackScratch scratch;
     if (nbits) {  // (a single symbol: the zero-length code and no payload, huf.rs:140-142)
         ScopedKernelTimer timer(c, "huff_pack");
@@ -875,12 +899,19 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[3], small.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_TRY(delta_table_clean(c));
     host_trace().mark("delta: pack enqueued");
-    huff_serialize_tree(tree, CNIIC_SYM_SIGNED, keys, header);
-    host_trace().mark("delta: serialise trie (host)");
-    if (header.size() != header_bytes) return c->fail(CNIIC_ERR_HIP, "delta: decoder of %llu bytes, expected %llu", (unsigned long long)header.size(),
-                                                      (unsigned long long)header_bytes);
-    CNIIC_TRY(so.put_header(header));
-    host_trace().mark("delta: header H2D");
+    // the decoder goes in AFTER the pack, whose first word comes out with zeros where the decoder's last bytes are
+    if (gpu_codes) {
+        const uint64_t head = header.size();
+        CNIIC_TRY(so.put_header(header));
+        CNIIC_TRY(huff_tree_serialize_dev(c, keys_d.as<uint32_t>(), off_d.as<uint64_t>(), (uint32_t)U, CNIIC_SYM_SIGNED, so.dev + head, decoder_bytes));
+    } else {
+        huff_serialize_tree(tree, CNIIC_SYM_SIGNED, keys_v.data(), header);  // (the GPU packs meanwhile)
+        host_trace().mark("delta: serialise trie (host)");
+        if (header.size() != header_bytes) return c->fail(CNIIC_ERR_HIP, "delta: decoder of %llu bytes, expected %llu", (unsigned long long)header.size(),
+                                                          (unsigned long long)header_bytes);
+        CNIIC_TRY(so.put_header(header));
+    }
+    host_trace().mark("delta: header");
     const int rc_fin = so.finish();  // (waits for the stream)
     host_trace().mark("delta: pack + finish");
     host_trace().dump();

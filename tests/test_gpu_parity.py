@@ -389,7 +389,8 @@ def _delta_img(kind, h, w):
     return np.full((h, w, 3), 77, np.uint8)   # "flat": two symbols, the first pixel's and (0, 0, 0)
 
 
-@pytest.mark.parametrize("knob", ["", "CNIIC_DELTA_ROUTE=32", "CNIIC_DELTA_GATHER=any", "CNIIC_TEST_PACK_IMG_WORDS=24", "CNIIC_TEST_INLINE_CODE_BITS=5"])
+@pytest.mark.parametrize("knob", ["", "CNIIC_DELTA_ROUTE=32", "CNIIC_DELTA_GATHER=any", "CNIIC_TEST_PACK_IMG_WORDS=24", "CNIIC_TEST_INLINE_CODE_BITS=5",
+                                  "CNIIC_HUF_GPU_CODES_MIN=0"])
 @pytest.mark.parametrize("kind", ["smooth", "mixed", "noise", "flat"])
 @pytest.mark.parametrize("shape", [(64, 64), (256, 256), (100, 75), (240, 321), (8, 8), (1, 700)])
 def test_delta_routes_equal_oracle(ctx, monkeypatch, shape, kind, knob):
