@@ -162,7 +162,7 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     // A large alphabet (a photograph's colours): the host only merges the tree; codes and the serialised decoder are the
     // GPU's (huff_tree_codes).  The counts land in pinned memory, the tree's arrays are written there, the keys stay put.
     const char *gmin = getenv("CNIIC_HUF_GPU_CODES_MIN");  // (tests: 0)
-    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2 && U < (1ull << 30);
+    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2 && U < (1ull << 30) && n < (1ull << 32);
     std::vector<uint32_t> keys(gpu_codes ? 0 : U);
     std::vector<uint64_t> counts_v(gpu_codes ? 0 : U);
     uint64_t *counts = counts_v.data();
@@ -176,7 +176,17 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     } else {
         CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     }
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    // (large alphabet: the leaves come back sorted by (count, key) -- huff_sort_leaves_dev -- and the host only merges)
+    DevBuf sort_a, sort_b;
+    if (gpu_codes) {
+        uint64_t *sorted_d = nullptr;
+        CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
+        CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
+        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     if (!c->huf_ev) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->huf_ev, hipEventDisableTiming));
     CNIIC_HIP_TRY(c, hipEventRecord(c->huf_ev, c->stream));
     // `delta` symbols on a buffer of ours: nothing to do while the host builds the tree -- the pack looks (length, code) up
@@ -204,7 +214,7 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     StreamOut so(c, out, cap, len);
     if (gpu_codes) {
         uint32_t root = 0;
-        if (!huff_build_tree_into(counts, U, left_h, right_h, nl_h, &root, scratch))
+        if (!huff_merge_sorted_into(counts /* sorted leaves */, U, left_h, right_h, nl_h, &root, scratch))
             return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
         host_trace().mark("huf: tree (host)");
         DevBuf tree_d, off_d, totals_d;
@@ -847,8 +857,17 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     uint8_t *const pin = static_cast<uint8_t *>(c->pinned_huf);
     uint64_t *const counts = reinterpret_cast<uint64_t *>(pin);
     std::vector<uint32_t> keys_v(gpu_codes ? 0 : U);
-    if (!gpu_codes) CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_v.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    DevBuf sort_a, sort_b;
+    if (gpu_codes) {  // the leaves come back sorted by (count, key): the host only merges
+        uint64_t *sorted_d = nullptr;
+        CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
+        CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
+        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_v.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     CNIIC_HIP_TRY(c, ctx_spin_sync(c));
     host_trace().mark("delta: compaction + D2H (wait)");
     // 2. build() (huf.rs:31); 3. the payload (huf.rs:37-41) behind the serialised decoder (huf.rs:34), whose size follows
@@ -862,7 +881,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     uint64_t nbits = 0;
     if (gpu_codes) {
         uint32_t *left_h = reinterpret_cast<uint32_t *>(counts + U), *right_h = left_h + (U - 1), *nl_h = right_h + (U - 1), root = 0;
-        if (!huff_build_tree_into(counts, U, left_h, right_h, nl_h, &root, hscratch))
+        if (!huff_merge_sorted_into(counts /* sorted leaves */, U, left_h, right_h, nl_h, &root, hscratch))
             return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
         host_trace().mark("delta: tree (host)");
         CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));

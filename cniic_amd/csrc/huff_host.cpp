@@ -40,27 +40,14 @@ void sort_leaves(std::vector<uint64_t> &a, std::vector<uint64_t> &tmp, uint32_t 
 }  // namespace
 
 // counts below 2^32 (every image this library takes has fewer pixels): leaves packed as count << 32 | leaf
+static void merge_sorted_u32(const uint64_t *leaf, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc);
 static void build_tree_u32(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc) {
-    std::vector<uint64_t> &leaf = sc.leaf, &bfreq = sc.bfreq;
+    std::vector<uint64_t> &leaf = sc.leaf;
     leaf.resize(n);
     uint32_t maxc = 0;
     for (uint64_t i = 0; i < n; i++) { leaf[i] = (counts[i] << 32) | i; maxc |= (uint32_t)counts[i]; }
     sort_leaves(leaf, sc.tmp, maxc);  // (count, key): the leaf ids are ascending keys and the sort is stable
-    bfreq.resize(n > 1 ? n - 1 : 0);
-    uint64_t li = 0, bi = 0, made = 0;
-    while (made + 1 < n) {
-        uint32_t node[2], leaves = 0;
-        uint64_t f[2];
-        for (int k = 0; k < 2; k++) {
-            if (li < n && (bi >= made || (leaf[li] >> 32) <= bfreq[bi])) { f[k] = leaf[li] >> 32; node[k] = (uint32_t)leaf[li]; li++; leaves += 1; }
-            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); if (nl) leaves += nl[bi]; bi++; }
-        }
-        left[made] = node[0];
-        right[made] = node[1];
-        if (nl) nl[made] = leaves;
-        bfreq[made] = f[0] + f[1];
-        made++;
-    }
+    merge_sorted_u32(leaf.data(), n, left, right, nl, sc);
 }
 
 // any counts: the same rule through a comparison sort
@@ -84,6 +71,35 @@ static void build_tree_u64(const uint64_t *counts, uint64_t n, uint32_t *left, u
         bfreq[made] = f[0] + f[1];
         made++;
     }
+}
+
+// the merge alone: leaf[] = count << 32 | leaf id, sorted by (count, id)
+static void merge_sorted_u32(const uint64_t *leaf, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc) {
+    std::vector<uint64_t> &bfreq = sc.bfreq;
+    bfreq.resize(n > 1 ? n - 1 : 0);
+    uint64_t li = 0, bi = 0, made = 0;
+    while (made + 1 < n) {
+        uint32_t node[2], leaves = 0;
+        uint64_t f[2];
+        for (int k = 0; k < 2; k++) {
+            if (li < n && (bi >= made || (leaf[li] >> 32) <= bfreq[bi])) { f[k] = leaf[li] >> 32; node[k] = (uint32_t)leaf[li]; li++; leaves += 1; }
+            else { f[k] = bfreq[bi]; node[k] = (uint32_t)(n + bi); if (nl) leaves += nl[bi]; bi++; }
+        }
+        left[made] = node[0];
+        right[made] = node[1];
+        if (nl) nl[made] = leaves;
+        bfreq[made] = f[0] + f[1];
+        made++;
+    }
+}
+
+bool huff_merge_sorted_into(const uint64_t *leaf_sorted, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root,
+                            HuffScratch *scratch) {
+    if (n == 0 || n > 0x7fffffffull) return false;
+    HuffScratch local;
+    merge_sorted_u32(leaf_sorted, n, left, right, nleaves, scratch ? *scratch : local);
+    *root = n > 1 ? (uint32_t)(2 * n - 2) : 0;
+    return true;
 }
 
 bool huff_build_tree_into(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root, HuffScratch *scratch) {

@@ -23,6 +23,9 @@ bool huff_build_tree(const uint64_t *counts, uint64_t n, HuffTree &t, HuffScratc
 // the same into arrays of the caller's (n - 1 entries each; pinned memory, say); nleaves (optional): leaves below every branch
 bool huff_build_tree_into(const uint64_t *counts, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root,
                           HuffScratch *scratch = nullptr);
+// the merge alone, from leaves count << 32 | id already sorted by (count, id) (counts below 2^32)
+bool huff_merge_sorted_into(const uint64_t *leaf_sorted, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nleaves, uint32_t *root,
+                            HuffScratch *scratch = nullptr);
 // Enc::from(&Dec) (huf.rs:125-135): code length and code bits (MSB-first in the low bits) per leaf.
 bool huff_codes(const HuffTree &t, std::vector<uint8_t> &len, std::vector<uint64_t> &code);
 bool huff_codes_into(const HuffTree &t, uint8_t *len, uint64_t *code);  // len / code: t.nleaf entries (pinned memory, say)

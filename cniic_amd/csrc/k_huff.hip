@@ -808,6 +808,91 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_write32(const uint32_t *_
     }
 }
 
+// ---------------------------------------------------------------- the leaves of a large alphabet, sorted by (count, key)
+// huf.rs:58-117 `build` takes the two rarest subtrees again and again; with the leaves sorted by count (ties: ascending key,
+// DESIGN.md 2 D1) that is a two-queue merge on the host, and the sort -- 26 ms of one core for 6.8 M colours -- is a stable
+// LSD radix sort here: 8 bits a pass over count << 32 | rank (the compaction's order is ascending key, so rank order = key
+// order and a stable sort by count keeps it inside equal counts).  A pass: digit counts per 4096-element block, one scan
+// over [digit][block], then every block places its elements -- 16 rounds of 256 in element order, the rank among equal
+// digits from ballots inside a wave, wave totals and running digit counters in LDS across waves and rounds.
+constexpr int kSortThreads = 256, kSortPer = 16, kSortBlock = kSortThreads * kSortPer;
+__global__ __launch_bounds__(256) void k_leaf_init(const uint64_t *__restrict__ counts, uint32_t n, uint64_t *__restrict__ leaf) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) leaf[i] = (counts[i] << 32) | i;
+}
+__global__ __launch_bounds__(kSortThreads) void k_sort_hist(const uint64_t *__restrict__ src, uint32_t n, uint32_t shift, uint32_t nblocks,
+                                                            uint32_t *__restrict__ blockhist /* [256][nblocks] */) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kSortPer; j++) {
+        const uint32_t i = blockIdx.x * kSortBlock + j * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(src[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *__restrict__ src, uint32_t n, uint32_t shift, uint32_t nblocks,
+                                                               const uint64_t *__restrict__ blockoff /* [256][nblocks], scanned */,
+                                                               uint64_t *__restrict__ dst) {
+    __shared__ uint32_t base[256];            // where the block's next element of a digit goes (the low 32 bits: n < 2^32)
+    __shared__ uint32_t wcnt[4][256];         // this round's elements per wave and digit
+    const uint32_t wave = threadIdx.x >> 6;
+    base[threadIdx.x] = (uint32_t)blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    for (int j = 0; j < kSortPer; j++) {
+        const uint32_t i = blockIdx.x * kSortBlock + j * kSortThreads + threadIdx.x;
+        const bool ok = i < n;
+        const uint64_t v = ok ? src[i] : 0;
+        const uint32_t dg = (uint32_t)(v >> shift) & 255u;
+        // the lanes of the wave with the same digit
+        unsigned long long peers = __builtin_amdgcn_ballot_w64(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        if (ok && before == 0) wcnt[wave][dg] = (uint32_t)__popcll(peers);  // (the first of its peers)
+        __syncthreads();
+        if (ok) {
+            uint32_t pos = base[dg] + before;
+            for (uint32_t w = 0; w < wave; w++) pos += wcnt[w][dg];
+            dst[pos] = v;
+        }
+        __syncthreads();
+        base[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; w++) wcnt[w][threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+
+// counts_d: n counts below 2^32 in ascending key order -> sorted_d: count << 32 | rank, ascending (count, rank); max_count: a
+// bound on the counts (the number of symbols).  tmp_d: n u64 of scratch.  The result may end in either buffer: *out_d tells.
+int huff_sort_leaves_dev(Ctx *c, const uint64_t *counts_d, uint32_t n, uint64_t max_count, uint64_t *buf_a, uint64_t *buf_b, uint64_t **out_d) {
+    const uint32_t nblocks = ceil_div(n, (uint32_t)kSortBlock);
+    DevBuf hist, off, tot;
+    CNIIC_HIP_TRY(c, hist.alloc((uint64_t)256 * nblocks * 4));
+    CNIIC_HIP_TRY(c, off.alloc((uint64_t)256 * nblocks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    hipLaunchKernelGGL(k_leaf_init, dim3(ceil_div(n, 256u)), dim3(256), 0, c->stream, counts_d, n, buf_a);
+    uint64_t *src = buf_a, *dst = buf_b;
+    for (uint32_t shift = 32; shift < 64 && (max_count >> (shift - 32)) != 0; shift += 8) {
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kSortThreads), 0, c->stream, (const uint64_t *)src, n, shift, nblocks, hist.as<uint32_t>());
+        CNIIC_TRY(pack_scan(c, hist.as<uint32_t>(), 256 * nblocks, off.as<uint64_t>(), tot.as<uint64_t>()));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kSortThreads), 0, c->stream, (const uint64_t *)src, n, shift, nblocks,
+                           (const uint64_t *)off.as<uint64_t>(), dst);
+        std::swap(src, dst);
+    }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    *out_d = src;
+    return CNIIC_OK;
+}
+
 // ---------------------------------------------------------------- codes and the serialised decoder of a large alphabet
 // The host makes the tree (a sequential merge); with 10^5 .. 10^7 leaves what follows is the GPU's: every leaf walks to the
 // root and collects its code (the side it hangs on at depth d is bit len - d), and its place in BinTrie::serialize's
