@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+# fuzz_codecs.py [seconds] -- random images (sizes, smooth / ramps / noise / flat patches) through `delta`, `hufman` and
+# `hilbert(rle)` on the GPU against the oracle (tests/oracle_lib.py), bytes and round trip; with the knobs that move the
+# routes (16-bit / 32-bit delta stream, tile / per-position gather and linearise, host / GPU Huffman codes).
+import os, sys, time
+root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import cniic_amd
+import oracle_lib as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+ctx = cniic_amd.Context(0)
+KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_HILBERT_MOVE": "any"}, {"CNIIC_HUF_GPU_CODES_MIN": "0"},
+         {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"}]
+
+
+def image():
+    if rng.random() < 0.5:
+        s = int(2 ** rng.integers(0, 10)); h = w = s
+    else:
+        h, w = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    y, x = np.mgrid[0:h, 0:w]
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, 3))
+    elif kind == 1:
+        img = np.stack([x // 2 + y // 3, x // 3 + y, (x + y) // 4], axis=2) + rng.integers(-3, 4, (h, w, 3))
+    elif kind == 2:
+        img = np.stack([x * 3, y * 5, x ^ y], axis=2)
+    elif kind == 3:
+        img = np.full((h, w, 3), rng.integers(0, 256)) + (rng.random((h, w, 1)) < 0.02) * rng.integers(0, 255, (h, w, 3))
+    else:
+        img = (np.stack([x, y, x + y], axis=2) // int(rng.integers(1, 40))) * int(rng.integers(1, 9))
+    return (img & 255).astype(np.uint8)
+
+
+t0, cases = time.time(), 0
+while time.time() - t0 < budget:
+    img = image()
+    knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
+    saved = {k: os.environ.get(k) for k in knob}
+    os.environ.update(knob)
+    try:
+        for expr in ("delta", "hufman", "hilbert(rle)"):
+            rc, data, _ = ctx.encode(expr, img)
+            erc, edata, _ = O.encode(expr, img)
+            assert rc == erc == 0 and data == edata, (expr, img.shape, knob, "encode")
+            rc, back = ctx.decode(expr, data)
+            assert rc == 0 and np.array_equal(back, img), (expr, img.shape, knob, "decode")
+            cases += 1
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+print("fuzz_codecs: %d cases in %.0f s, all equal to the oracle" % (cases, time.time() - t0))
