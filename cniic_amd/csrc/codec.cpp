@@ -1013,10 +1013,12 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
     case CODEC_DELTA: {          // hilbertc.rs:417-431
         const bool delta = d.kind == CODEC_DELTA;
         const int sym_kind = delta ? CNIIC_SYM_SIGNED : CNIIC_SYM_RGB;
+        host_trace().mark("decode: enter");
         std::vector<TrieNode> trie;
         if (!huff_parse_trie(sym_kind, bytes, nbytes, pos, trie))
             return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
         if (!n) return CNIIC_OK;
+        host_trace().mark("decode: parse the decoder (host)");
         const bool dst_dev = is_device_ptr(rgb_out);
         DevBuf keys_d, lin_d, img_d;
         CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
@@ -1035,6 +1037,7 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         }
         if (status == 1)
             return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
+        host_trace().mark("decode: symbols");
         uint8_t *dst = rgb_out;
         if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
         if (!delta) {
@@ -1047,8 +1050,11 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
             CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
         }
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (!dst_dev) return put_image(c, dst, true, n * 3, rgb_out);
-        return CNIIC_OK;
+        host_trace().mark("decode: pixels");
+        const int rc_put = dst_dev ? CNIIC_OK : put_image(c, dst, true, n * 3, rgb_out);
+        host_trace().mark("decode: image out");
+        host_trace().dump();
+        return rc_put;
     }
     case CODEC_HILBERT_RLE: {  // hilbertc.rs:53-79: RleDecoder (:304-337) zipped with hilbert::iter
         if (!n) return CNIIC_OK;
