@@ -312,23 +312,12 @@ __global__ void k_delta_fill_codes(const uint32_t *__restrict__ keys, const uint
     }
 }
 
-// the cold symbols' keys -> their len << 26 | code words, in place (32 chunks per block, eight entries per thread)
-__global__ __launch_bounds__(256) void k_delta_cold_codes(uint32_t *__restrict__ coldkeys, const uint8_t *__restrict__ chunk_cold, uint32_t nchunks,
-                                                          const uint32_t *__restrict__ dense) {
-    const uint32_t ch = blockIdx.x * 32 + (threadIdx.x >> 3);
-    if (ch >= nchunks) return;
-    const uint32_t cnt = min((uint32_t)chunk_cold[ch], kColdPerChunk);
-    for (uint32_t r = threadIdx.x & 7; r < cnt; r += 8) {
-        uint32_t *e = coldkeys + (uint64_t)ch * kColdPerChunk + r;
-        *e = dense[*e];
-    }
-}
-
 // ---------------------------------------------------------------- pass 3: bits per chunk
 constexpr int kCountBatch = 4;  // chunks whose reads a wave has in flight together
 __global__ __launch_bounds__(256) void k_delta_count16(const uint16_t *__restrict__ hot16, uint32_t nchunks, const uint8_t *__restrict__ hotlen,
-                                                       const uint32_t *__restrict__ coldcodes, const uint8_t *__restrict__ chunk_cold,
-                                                       const uint8_t *__restrict__ len, uint32_t *__restrict__ chunk_bits) {
+                                                       uint32_t *__restrict__ coldcodes /* in: keys */, const uint8_t *__restrict__ chunk_cold,
+                                                       const uint32_t *__restrict__ dense, const uint8_t *__restrict__ len,
+                                                       uint32_t *__restrict__ chunk_bits) {
     __shared__ __align__(16) uint8_t s_len[kHot];
     for (uint32_t i = threadIdx.x; i < kHot / 16; i += 256) reinterpret_cast<uint4 *>(s_len)[i] = reinterpret_cast<const uint4 *>(hotlen)[i];
     __syncthreads();
@@ -352,8 +341,10 @@ __global__ __launch_bounds__(256) void k_delta_count16(const uint16_t *__restric
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if (s[i] < kHot) bits += s_len[s[i]];
-            if (lane < ncold[b]) {  // the chunk's cold symbols: lane r takes the r-th (the sum does not care whose it is)
-                const uint32_t v = coldcodes[(uint64_t)ch * kColdPerChunk + lane];
+            if (lane < ncold[b]) {  // the chunk's cold symbols: lane r takes the r-th (the sum does not care whose it is) and
+                uint32_t *e = coldcodes + (uint64_t)ch * kColdPerChunk + lane;  // turns its key into the len << 26 | code word
+                const uint32_t v = dense[*e];                                    // the pack will want (a pass of its own: 31 us)
+                *e = v;
                 bits += (v >> 26) == kEscape ? (uint32_t)len[v & 0x3ffffffu] : v >> 26;
             }
             bits = wave_reduce_sum(bits);
@@ -625,9 +616,8 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
     const uint32_t inline_max = im ? std::min<uint32_t>((uint32_t)atoi(im), 26u) : 26u;
     hipLaunchKernelGGL(k_delta_fill_codes, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
                        dense_d, keep->hot.as<uint32_t>(), keep->hotlen.as<uint8_t>(), inline_max);
-    hipLaunchKernelGGL(k_delta_cold_codes, dim3(ceil_div(nchunks, 32u)), dim3(256), 0, c->stream, coldkeys_d, chunk_cold_d, nchunks, (const uint32_t *)dense_d);
     hipLaunchKernelGGL(k_delta_count16, dim3(std::min<uint32_t>(ceil_div(nchunks, 4u), 256 * 4)), dim3(256), 0, c->stream, hot16_d, nchunks,
-                       (const uint8_t *)keep->hotlen.as<uint8_t>(), (const uint32_t *)coldkeys_d, chunk_cold_d, len_d, keep->cb.as<uint32_t>());
+                       (const uint8_t *)keep->hotlen.as<uint8_t>(), coldkeys_d, chunk_cold_d, (const uint32_t *)dense_d, len_d, keep->cb.as<uint32_t>());
     CNIIC_TRY(pack_scan(c, keep->cb.as<uint32_t>(), nchunks, keep->co.as<uint64_t>(), total_d));
     hipLaunchKernelGGL(k_delta_write16, dim3(std::min<uint32_t>(ceil_div(nchunks, (uint32_t)kWriteWaves), 256)), dim3(kWriteWaves * 64), kWriteLds,
                        c->stream, hot16_d, nchunks, (const uint32_t *)keep->hot.as<uint32_t>(), len_d, code_d,
