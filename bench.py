@@ -11,6 +11,8 @@ Metric (BASELINE.json): Mpixels/sec encode, `cluster-colors` K=256.
                                 the colour occupancy is all-reduced once and the K partial centroid sums every iteration
                                 (RCCL, in-stream); each frame is then its own Hufman stream.  Weak scaling: per-GPU work is
                                 fixed, the palette is the union's.  A step = the whole batch encode.
+  --config c5                   configs[4]: `delta` on one 16384x16384 image per GPU (its own metric: Mpixels/sec encode
+                                (delta); roofline = the gather kernel, 3 B/px read).  Not the default anywhere.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -62,7 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["auto", "c2", "c4"], default="auto", help="auto: c2 on one GPU, c4 on several")
+    ap.add_argument("--config", choices=["auto", "c2", "c4", "c5"], default="auto", help="auto: c2 on one GPU, c4 on several; c5: `delta` 16384^2")
+    ap.add_argument("--c5-size", type=int, default=16384, help="c5: image side (default: configs[4], 16384)")
     ap.add_argument("--frames-per-gpu", type=int, default=128, help="c4: 1920x1080 frames per GPU (128 x 8 GPUs = the 1024 of configs[3])")
     ap.add_argument("--size", type=int, default=4096, help="c2: image side (default: configs[1], 4096)")
     ap.add_argument("--k", type=int, default=256)
@@ -187,6 +190,55 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu,
             }
         enc.close()
+    elif config == "c5":
+        # configs[4]: `delta` (Hilbert gather + neighbour differences + symbol histogram + Huffman) on one 16384^2 image per GPU
+        # (independent images: replicas, no collective).  roofline = the gather kernel, SURVEY 8(d): 3 B/px read.
+        W = H = args.c5_size
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 5 + rank, W, H, out=img)
+        out = torch.empty(W * H * 3 + (1 << 24), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            rc, ln, st = ctx.encode("delta", img, w=W, h=H, out=out)
+            return ln, st
+        dt, (nbytes, st) = timed(step, args.warmup, args.steps)
+        if rank == 0:
+            ctx.encode("delta", img, w=W, h=H, out=out, flags=_lib.KM_PROFILE)  # one more call with the stage timers (HIP events on the ctx stream)
+            stages = {}
+            for k in ("delta_gather", "delta_hist", "huff_pack"):
+                ms, n = ctx.kernel_time(k)
+                if n:
+                    stages[k + "_ms"] = round(ms / n, 4)
+            g_ms = stages.get("delta_gather_ms")
+            roofline = None
+            if g_ms:
+                algo = 3.0 * W * H
+                roofline = {"kernel": "k_delta_gather_p2", "bound": "hbm", "achieved": round(algo / (g_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": g_ms, "launches": 1,
+                            "algorithmic_bytes_per_launch": algo,
+                            "with_symbol_stream": {"bytes_per_launch": 5.0 * W * H, "GBps": round(5.0 * W * H / (g_ms * 1e-3) / 1e9, 2),
+                                                   "frac": round(5.0 * W * H / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                            "note": "HIP events around the gather launch of one more encode (stage timers); algorithmic bytes = 3 B/px read (SURVEY 8(d), "
+                                    "Hilbert gather + delta); the kernel also writes the 2 B/px symbol stream the later passes read: with_symbol_stream"}
+            cpu = None
+            if args.cpu_sample > 0:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                s = min(2048, W)
+                crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+                t0 = time.perf_counter()
+                rc, data, _ = O.encode("delta", crop)
+                cdt = time.perf_counter() - t0
+                cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                       "sample": "%dx%d crop of the same image, the CPU restatement of Delta::encode, %.1f s" % (s, s, cdt), "bytes_per_px": round(len(data) / (s * s), 4)}
+            line = {"metric": "Mpixels/sec encode (delta)", "value": round(W * H * world * args.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+                    "config": {"workload": "configs[4]: delta encode (Hilbert gather + differences + histogram + Huffman) of one %dx%d photo-like synthetic RGB "
+                                           "image per GPU (seed 0x636E696963+5+rank)" % (W, H), "pixels_per_gpu": W * H, "bytes_per_px": round(nbytes / (W * H), 4),
+                               "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
+                    "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
     else:
         W = H = args.size
         seed = synth.SEED0 + 2 + rank  # config 2 of SURVEY 8(d); one image per rank

@@ -564,7 +564,7 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     const HilbertLut *lut = nullptr;
     CNIIC_TRY(hilbert_lut(c, &lut));
     const uint64_t npad = delta_stream_len(n);
-    ScopedKernelTimer timer(c, "hilbert_delta");
+    ScopedKernelTimer timer(c, "delta_gather");  // (bench.py --config c5 takes the gather's roofline from this one)
     const uint32_t order = pow2_order(w, h);
     const char *force = getenv("CNIIC_DELTA_GATHER");  // "any": the per-position kernel on 2^n squares too (tests)
     if (order >= 6 && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(force && force[0] == 'a')) {
@@ -576,6 +576,9 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
         hipLaunchKernelGGL(k_delta_gather_any, dim3(grid), dim3(256), 0, c->stream, rgb_d, w, h, order, lut, hot16_d, table_d, pages_d, coldkeys_d,
                            chunk_cold_d, overflow_d);
     }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    timer.stop(1);
+    ScopedKernelTimer timer_h(c, "delta_hist");
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_delta_hist16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kHot * 4));
@@ -584,7 +587,7 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     const uint32_t hgrid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(npad >> 17, 1), 256);
     hipLaunchKernelGGL(k_delta_hist16, dim3(hgrid), dim3(1024), kHot * 4, c->stream, (const uint16_t *)hot16_d, npad / 8, table_d, pages_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
-    timer.stop(1);
+    timer_h.stop(1);
     return CNIIC_OK;
 }
 

@@ -55,7 +55,7 @@ for name, size in (("delta", 4096), ("hufman", 4096), ("delta16k", 16384), ("rle
     dt, (rc, ln, st) = timed(lambda: ctx.encode(expr, img, w=size, h=size, out=out), reps=2)
     ctx.encode(expr, img, w=size, h=size, out=out, flags=_lib.KM_PROFILE)  # one more call with the stage timers on
     extra = {}
-    for k in ("hilbert_delta", "huff_pack", "hist_rgb"):
+    for k in ("hilbert_delta", "delta_gather", "delta_hist", "huff_pack", "hist_rgb"):
         ms, n = ctx.kernel_time(k)
         if n:
             extra[k + "_ms"] = round(ms / n, 3)
