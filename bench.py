@@ -11,6 +11,8 @@ Metric (BASELINE.json): Mpixels/sec encode, `cluster-colors` K=256.
                                 the colour occupancy is all-reduced once and the K partial centroid sums every iteration
                                 (RCCL, in-stream); each frame is then its own Hufman stream.  Weak scaling: per-GPU work is
                                 fixed, the palette is the union's.  A step = the whole batch encode.
+  --config c3                   configs[2]: voronoi(2048) on one 4096x4096 image per GPU (its own metric; roofline = the 5-D
+                                assign per iteration, 7 B/px).  Not the default anywhere.
   --config c5                   configs[4]: `delta` on one 16384x16384 image per GPU (its own metric: Mpixels/sec encode
                                 (delta); roofline = the gather kernel, 3 B/px read).  Not the default anywhere.
 
@@ -64,7 +66,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["auto", "c2", "c4", "c5"], default="auto", help="auto: c2 on one GPU, c4 on several; c5: `delta` 16384^2")
+    ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
+                    help="auto: c2 on one GPU, c4 on several; c3: voronoi(2048) 4096^2; c5: `delta` 16384^2")
     ap.add_argument("--c5-size", type=int, default=16384, help="c5: image side (default: configs[4], 16384)")
     ap.add_argument("--frames-per-gpu", type=int, default=128, help="c4: 1920x1080 frames per GPU (128 x 8 GPUs = the 1024 of configs[3])")
     ap.add_argument("--size", type=int, default=4096, help="c2: image side (default: configs[1], 4096)")
@@ -190,6 +193,52 @@ def main():
                 "roofline": roof, "cpu_baseline": cpu,
             }
         enc.close()
+    elif config == "c3":
+        # configs[2]: voronoi(2048), 5-D position + colour K-means on one 4096^2 image per GPU (replicas), to convergence.
+        # roofline = k_xy_assign per iteration, SURVEY 8(d): 7 B/px/iteration (3 B pixel + u16 label read and written).
+        W = H = args.size
+        Kv = 2048
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 3 + rank, W, H, out=img)
+        out = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            rc, ln, st = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, allow=(_lib.FEW_ACTIVE,))
+            return ln, st
+        dt, (nbytes, st) = timed(step, args.warmup, args.steps)
+        if rank == 0:
+            rc, ln, stp = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE, allow=(_lib.FEW_ACTIVE,))
+            ms, n = ctx.kernel_time("kmeans_xyrgb_iter")
+            roofline = None
+            if n:
+                it_ms = ms / n
+                algo = 7.0 * W * H
+                roofline = {"kernel": "k_xy_assign (+ k_xy_update)", "bound": "hbm", "achieved": round(algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": round(it_ms, 5),
+                            "launches": int(n), "algorithmic_bytes_per_launch": algo,
+                            "note": "HIP events around the whole K-means loop of one more encode / its %d iterations (assign + update launches); "
+                                    "algorithmic bytes = 7 B/px/iteration (SURVEY 8(d)); tiles nothing changed for are skipped, so late iterations read less" % int(n)}
+            cpu = None
+            if args.cpu_sample > 0:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import oracle_lib as O
+                s = min(768, W)
+                crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+                t0 = time.perf_counter()
+                rc, data, ost = O.encode("voronoi(%d)" % Kv, crop, mode=O.MODE_R)
+                cdt = time.perf_counter() - t0
+                cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                       "sample": "%dx%d crop of the same image, voronoi(%d), oracle mode R, %d iterations, %.1f s (rc %d)" % (s, s, Kv, ost.get("iterations", 0), cdt, rc)}
+            line = {"metric": "Mpixels/sec encode (voronoi K=%d)" % Kv, "value": round(W * H * world * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "i32/u64", "data": "synthetic",
+                    "config": {"workload": "configs[2]: voronoi(%d) encode (5-D position + colour K-means to convergence) of one %dx%d photo-like synthetic RGB "
+                                           "image per GPU (seed 0x636E696963+3+rank)" % (Kv, W, H), "pixels_per_gpu": W * H,
+                               "kmeans_iterations": int(st["iterations"]),
+                               "centroids_tested_per_px_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / (W * H), 2) if "pair_evals" in st else None,
+                               "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
+                    "roofline": roofline, "cpu_baseline": cpu}
     elif config == "c5":
         # configs[4]: `delta` (Hilbert gather + neighbour differences + symbol histogram + Huffman) on one 16384^2 image per GPU
         # (independent images: replicas, no collective).  roofline = the gather kernel, SURVEY 8(d): 3 B/px read.

@@ -23,6 +23,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 python3 $R/tools/pmc_rows.py $O/pmc_sq k_rgbw_assign > $O/${TAG}_pmc_sq_assign_per_launch.txt
 python3 $R/tools/bench_others.py > $O/${TAG}_others.jsonl 2>> $O/bench.err
 python3 $R/bench.py --config c5 2>> $O/bench.err | tail -1 > $O/${TAG}_c5_bench.json
+python3 $R/bench.py --config c3 --steps 3 2>> $O/bench.err | tail -1 > $O/${TAG}_c3_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_d16 -o d -- python3 $R/tools/bench_others.py delta16k > /dev/null 2>&1
 cp $(find $O/stats_d16 -name '*kernel_stats.csv' | head -1) $O/${TAG}_delta16k_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_v -o v -- python3 $R/tools/bench_others.py voronoi > /dev/null 2>&1
