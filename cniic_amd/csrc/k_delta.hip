@@ -268,12 +268,14 @@ __global__ __launch_bounds__(1024) void k_delta_hist16(const uint16_t *__restric
         }
     };
     uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-    for (; i + stride < nvec; i += 2 * stride) {  // two reads in flight per thread
-        const uint4 a = v[i], b = v[i + stride];
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four reads in flight per thread (one block per CU: 64 KiB in flight)
+        const uint4 a = v[i], b = v[i + stride], c2 = v[i + 2 * stride], d = v[i + 3 * stride];
         count8(a);
         count8(b);
+        count8(c2);
+        count8(d);
     }
-    if (i < nvec) count8(v[i]);
+    for (; i < nvec; i += stride) count8(v[i]);
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kHot; b += 1024) {
         const uint32_t cnt = s_bins[b];
