@@ -1,17 +1,14 @@
 #!/usr/bin/env python3
-# fuzz_codecs.py [seconds] -- random images (sizes, smooth / ramps / noise / flat patches) through `delta`, `hufman` and
+# tests/fuzz_codecs.py [seconds] -- random images (sizes, smooth / ramps / noise / flat patches) through `delta`, `hufman` and
 # `hilbert(rle)` on the GPU against the oracle (tests/oracle_lib.py), bytes and round trip; with the knobs that move the
 # routes (16-bit / 32-bit delta stream, tile / per-position gather and linearise, host / GPU Huffman codes).
 import os, sys, time
-root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
-import cniic_amd
 import oracle_lib as O
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
-ctx = cniic_amd.Context(0)
 KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_HILBERT_MOVE": "any"}, {"CNIIC_HUF_GPU_CODES_MIN": "0"},
          {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"}]
 
@@ -36,22 +33,31 @@ def image():
     return (img & 255).astype(np.uint8)
 
 
-t0, cases = time.time(), 0
-while time.time() - t0 < budget:
-    img = image()
-    knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
-    saved = {k: os.environ.get(k) for k in knob}
-    os.environ.update(knob)
-    try:
-        for expr in ("delta", "hufman", "hilbert(rle)"):
-            rc, data, _ = ctx.encode(expr, img)
-            erc, edata, _ = O.encode(expr, img)
-            assert rc == erc == 0 and data == edata, (expr, img.shape, knob, "encode")
-            rc, back = ctx.decode(expr, data)
-            assert rc == 0 and np.array_equal(back, img), (expr, img.shape, knob, "decode")
-            cases += 1
-    finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-print("fuzz_codecs: %d cases in %.0f s, all equal to the oracle" % (cases, time.time() - t0))
+def run(ctx, budget):
+    """`budget` seconds of random cases on ctx; returns how many were checked (an assertion stops at the first difference)"""
+    t0, cases = time.time(), 0
+    while time.time() - t0 < budget:
+        img = image()
+        knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
+        saved = {k: os.environ.get(k) for k in knob}
+        os.environ.update(knob)
+        try:
+            for expr in ("delta", "hufman", "hilbert(rle)"):
+                rc, data, _ = ctx.encode(expr, img)
+                erc, edata, _ = O.encode(expr, img)
+                assert rc == erc == 0 and data == edata, (expr, img.shape, knob, "encode")
+                rc, back = ctx.decode(expr, data)
+                assert rc == 0 and np.array_equal(back, img), (expr, img.shape, knob, "decode")
+                cases += 1
+        finally:
+            for k, v in saved.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
+    return cases
+
+
+if __name__ == "__main__":
+    import cniic_amd
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    n = run(cniic_amd.Context(0), seconds)
+    print("fuzz_codecs: %d cases in %.0f s, all equal to the oracle" % (n, seconds))

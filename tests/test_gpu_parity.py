@@ -417,6 +417,14 @@ def test_delta_single_symbol_and_back_to_back_calls(ctx):
         rc, data, _ = ctx.encode("delta", img)
         assert rc == 0 and data == O.encode("delta", img)[1]
 
+def test_fuzz_lossless_codecs(ctx):
+    """a few seconds of tests/fuzz_codecs.py: random images x route knobs through delta / hufman / hilbert(rle), bytes and round
+    trip against the oracle (CNIIC_FUZZ_SECONDS for longer; `python tests/fuzz_codecs.py 150` ran 46 K cases)"""
+    import os
+    import fuzz_codecs
+    assert fuzz_codecs.run(ctx, float(os.environ.get("CNIIC_FUZZ_SECONDS", "6"))) > 0
+
+
 @pytest.mark.parametrize("case", ["flat", "stripes", "levels2", "long_runs", "wide", "tall"])
 def test_hilbert_rle_runs_equal_oracle(ctx, case):
     """run boundaries, the 255 cap across chunk borders (4096 positions per block) and ragged sizes"""
