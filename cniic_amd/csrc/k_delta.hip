@@ -12,11 +12,14 @@
 // replace (hilbert_delta + huff_pack_code32_hot) moved 3 + 4, 4 + 4 and 4 + payload.
 //   k_delta_gather_p2   2^n squares: a block stages one 64 x 64 tile of the image -- 4096 consecutive scan positions --
 //                       through LDS with 48-byte row reads and walks it in scan order from there
-//   k_delta_gather_any  any rectangle: four scan positions per thread, one pixel read each
+//   k_delta_gather_any  any rectangle: eight scan positions per thread (a wave = a chunk), one pixel read each
 //   k_delta_hist16      the cube's counts in LDS bins, added to the dense 2^27-bin table once per block
-//   k_delta_count16     bits per 512-symbol chunk from a table of code lengths in LDS
+//   k_delta_count16     bits per 512-symbol chunk from a table of code lengths in LDS; turns the chunk's cold keys into
+//                       their (length, code) words on the way
 //   k_delta_write16     the pack: (length, code) of the cube in LDS, one wave per chunk with a bit image of its own --
-//                       no block barrier in the loop
+//                       no block barrier in the loop; k_delta_edges joins the words neighbouring chunks share
+// Between histogram and code lengths the tree: compaction of the touched pages, leaves sorted on the GPU, merged on the
+// host, codes and the serialised decoder from huff_tree_codes (k_huff.hip) -- see encode_delta (codec.cpp).
 // The dense table is kept clean between calls and swept by 4096-entry pages that a flag marks as touched, so that an
 // image with few distinct differences does not pay for 2^27 entries three times per call.
 #include <mutex>
