@@ -1014,7 +1014,8 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         const bool delta = d.kind == CODEC_DELTA;
         const int sym_kind = delta ? CNIIC_SYM_SIGNED : CNIIC_SYM_RGB;
         host_trace().mark("decode: enter");
-        std::vector<TrieNode> trie;
+        if (!c->trie_scratch) c->trie_scratch = std::make_shared<std::vector<TrieNode>>();
+        std::vector<TrieNode> &trie = *static_cast<std::vector<TrieNode> *>(c->trie_scratch.get());
         if (!huff_parse_trie(sym_kind, bytes, nbytes, pos, trie))
             return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
         if (!n) return CNIIC_OK;

@@ -133,6 +133,7 @@ struct Ctx {
     uint64_t *pinned_u = nullptr;  // 64 KiB of pinned host memory: [0] sp_build's distinct-colour count, [1] the point list's length,
                                    // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
+    std::shared_ptr<void> trie_scratch; // the decoder's parsed trie (std::vector<TrieNode>, codec.cpp), kept between calls: 110 MB of fresh pages cost 30 ms
     std::shared_ptr<void> huf_scratch;  // host arrays of the Huffman tree build, kept between calls (HuffScratch, codec.cpp)
     void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
     uint64_t pinned_huf_bytes = 0;
