@@ -53,6 +53,7 @@ __device__ __forceinline__ bool hd_symbol(const uint32_t *__restrict__ w, uint64
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(const uint32_t *__restrict__ w, uint64_t nbits, const uint2 *__restrict__ nodes,
                                                         const uint2 *__restrict__ lut_g, uint64_t nsub,
                                                         const uint64_t *__restrict__ end_prev /* null: pass 0 */,
+                                                        const uint64_t *__restrict__ end_prev2 /* the pass before that; null: passes 0, 1 */,
                                                         uint64_t *__restrict__ end_out, uint32_t *__restrict__ count,
                                                         uint32_t *__restrict__ changed) {
     __shared__ uint2 lut[1 << kHdLut];
@@ -62,6 +63,13 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(const uint32_t *__restri
     if (t >= nsub) return;
     const uint64_t lo = t * kHdSub, hi = min(lo + kHdSub, nbits);
     uint64_t at = !end_prev ? lo : (t ? end_prev[t - 1] : 0);
+    // a thread whose start did not move since the pass before ends where it ended then (and counted what it counted): from
+    // the third pass on only the few subsequences still out of step decode again (every pass decoding everything made ten
+    // passes over a 6.8 M-leaf code cost 63 ms)
+    if (end_prev) {
+        const uint64_t before = end_prev2 ? (t ? end_prev2[t - 1] : 0) : lo;
+        if (before == at) { end_out[t] = end_prev[t]; return; }
+    }
     uint32_t cnt = 0, key;
     while (at < hi) {
         if (!hd_symbol(w, nbits, nodes, lut, at, key)) { at = nbits; break; }  // nothing decodable from here on
@@ -150,12 +158,13 @@ int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t 
     }
     const uint64_t nsub = ceil_div(nbits, kHdSub);
     const uint64_t words = ceil_div(payload_bytes, 4) + 4;  // zero padding: hd_peek reads one word ahead
-    DevBuf w_d, nodes_d, lut_d, end_a, end_b, count, off, tot, changed;
+    DevBuf w_d, nodes_d, lut_d, end_a, end_b, end_c, count, off, tot, changed;
     CNIIC_HIP_TRY(c, w_d.alloc(words * 4));
     CNIIC_HIP_TRY(c, nodes_d.alloc(nodes_h.size() * 8));
     CNIIC_HIP_TRY(c, lut_d.alloc(lut.size() * 8));
     CNIIC_HIP_TRY(c, end_a.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, end_b.alloc(nsub * 8));
+    CNIIC_HIP_TRY(c, end_c.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, count.alloc(nsub * 4));
     CNIIC_HIP_TRY(c, off.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, tot.alloc(8));
@@ -165,12 +174,13 @@ int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t 
     CNIIC_HIP_TRY(c, hipMemcpyAsync(nodes_d.p, nodes_h.data(), nodes_h.size() * 8, hipMemcpyHostToDevice, c->stream));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(lut_d.p, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream));
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
-    uint64_t *cur = end_a.as<uint64_t>(), *prev = nullptr;
+    uint64_t *bufs[3] = {end_a.as<uint64_t>(), end_b.as<uint64_t>(), end_c.as<uint64_t>()};
+    uint64_t *cur = bufs[0], *prev = nullptr, *prev2 = nullptr;
     bool settled = false;
     for (int pass = 0; pass < kHdMaxPasses; pass++) {
         if (prev) CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
         hipLaunchKernelGGL(k_hd_pass, dim3(grid), dim3(kHdThreads), 0, c->stream, w_d.as<uint32_t>(), nbits, nodes_d.as<uint2>(),
-                           lut_d.as<uint2>(), nsub, (const uint64_t *)prev, cur, count.as<uint32_t>(), changed.as<uint32_t>());
+                           lut_d.as<uint2>(), nsub, (const uint64_t *)prev, (const uint64_t *)prev2, cur, count.as<uint32_t>(), changed.as<uint32_t>());
         CNIIC_HIP_TRY(c, hipGetLastError());
         if (prev) {
             uint32_t ch = 1;
@@ -178,8 +188,9 @@ int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t 
             CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (!ch) { settled = true; break; }
         }
+        prev2 = prev;
         prev = cur;
-        cur = cur == end_a.as<uint64_t>() ? end_b.as<uint64_t>() : end_a.as<uint64_t>();
+        cur = bufs[(pass + 1) % 3];
     }
     if (!settled) { *status = 2; CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream)); return CNIIC_OK; }
     // `cur` holds the settled boundaries (equal to prev's)
