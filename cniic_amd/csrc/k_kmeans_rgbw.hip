@@ -2021,6 +2021,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, s->wide ? 1024 : 64), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
+        if (s->wide) s->nblocks = (s->nblocks + 7) & ~7u;  // (wide: a wave each; launch_assign groups them by up to eight)
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
@@ -2165,11 +2166,21 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : s->max_skip, getenv("CNIIC_DBG_TIMELINE") ? (uint32_t)atoi(getenv("CNIIC_DBG_TIMELINE")) + 1u : 0u};
-        if (s->wide) {  // K up to 2048: one wave per block so that the candidate strip fits the LDS
-            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)((s->K + 1) / 2 + s->K) * 8 + (size_t)((s->K + 63) / 64) * 8;
-            hipLaunchKernelGGL((k_rgbw_assign_cells<uint16_t, 12, 1>), dim3(s->nblocks), dim3(64), lds, c->stream,
-                               s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->ne_cell.as<uint32_t>(), s->ne_start.as<uint32_t>(),
-                               s->wfirst.as<uint32_t>(), s->shard, s->K, s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
+        if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
+            // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
+            // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.
+            auto lds_for = [&](uint32_t wv) {
+                return (size_t)s->K * (5 * 8 + 8) + (size_t)wv * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wv * ((s->K + 63) / 64) * 8;
+            };
+            uint32_t wv = 8;
+            while (wv > 1 && (lds_for(wv) > 150 * 1024 || s->nblocks % wv)) wv >>= 1;
+            const size_t lds = lds_for(wv);
+            auto kern = wv == 8 ? k_rgbw_assign_cells<uint16_t, 12, 8> : wv == 4 ? k_rgbw_assign_cells<uint16_t, 12, 4>
+                        : wv == 2 ? k_rgbw_assign_cells<uint16_t, 12, 2> : k_rgbw_assign_cells<uint16_t, 12, 1>;
+            hipLaunchKernelGGL(kern, dim3(s->nblocks / wv), dim3(64 * wv), lds, c->stream,
+                               (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
+                               (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
+                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
         } else if (s->sup) {
             SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
             if (const char *ds = getenv("CNIIC_SUP_STOP")) ss.no_skip |= ((uint32_t)atoi(ds) & 255u) << 8;
