@@ -2329,7 +2329,7 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
 
 static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
-    const int batch = getenv("CNIIC_KM_BATCH") ? atoi(getenv("CNIIC_KM_BATCH")) : cm ? 2 : 4;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
+    const int batch = getenv("CNIIC_KM_BATCH") ? atoi(getenv("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
                                    // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
     KmDevState h;
     LaunchTimer lt;
