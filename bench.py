@@ -3,14 +3,19 @@
 
 Metric (BASELINE.json): Mpixels/sec encode, `cluster-colors` K=256.
 
-  --config c2 (default at N=1)  configs[1]: one 4096x4096 synthetic photo-like RGB image per GPU, resident in HBM; a
+  --config c2 (default, EVERY N)  configs[1]: one 4096x4096 synthetic photo-like RGB image per GPU, resident in HBM; a
                                 "step" is one full Codec::encode (count_freqs dedup -> K-means to convergence -> remap ->
-                                Huffman), the stream landing in an HBM buffer.
-  --config c4 (default at N>1)  configs[3]: a batch of 1920x1080 frames, --frames-per-gpu F of them per GPU (128: 1024 frames
+                                Huffman), the stream landing in an HBM buffer.  At N > 1 the per-GPU workload is the same
+                                (weak scaling: one 4096^2 image per GPU) and the N images share ONE palette: the colour
+                                occupancy is all-reduced once and the K partial centroid sums every iteration (RCCL,
+                                in-stream) -- so the driver's 1/2/4/8 curve compares like with like.
+  --config c4                   configs[3]: a batch of 1920x1080 frames, --frames-per-gpu F of them per GPU (128: 1024 frames
                                 on 8 GPUs), ONE palette for the whole batch: every rank partitions its own frames' pixels,
                                 the colour occupancy is all-reduced once and the K partial centroid sums every iteration
                                 (RCCL, in-stream); each frame is then its own Hufman stream.  Weak scaling: per-GPU work is
-                                fixed, the palette is the union's.  A step = the whole batch encode.
+                                fixed, the palette is the union's.  A step = the whole batch encode.  EVERY default line also
+                                carries this workload as a block of its own (`c4_one_gpu` at N = 1, `c4` at N > 1 with the
+                                same run's one-rank timing of rank 0's frames and `efficiency_vs_one_gpu`).
   --config c3                   configs[2]: voronoi(2048) on one 4096x4096 image per GPU (its own metric; roofline = the 5-D
                                 assign per iteration, 7 B/px).  Not the default anywhere.
   --config c5                   configs[4]: `delta` on one 16384x16384 image per GPU (its own metric: Mpixels/sec encode
@@ -21,8 +26,7 @@ Metric (BASELINE.json): Mpixels/sec encode, `cluster-colors` K=256.
 
 Prints ONE JSON line (rank 0).  `roofline` is the K-means assign kernel (dominant kernel), timed live with HIP events
 attached to every dispatch on the stream it runs on; `cpu_baseline` is the CPU restatement of the reference algorithm
-(oracle mode R) on a bounded sample, rank 0, N=1 only.  At N=1 the c2 line also carries `c4_one_gpu`: the c4 workload on
-this one GPU, which is what the N>1 lines scale from.
+(oracle mode R) on a bounded sample, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -67,7 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
-                    help="auto: c2 on one GPU, c4 on several; c3: voronoi(2048) 4096^2; c5: `delta` 16384^2")
+                    help="auto = c2 at every N (same per-GPU workload, so the 1/2/4/8 curve is one workload); c4: the frame batch; c3: voronoi(2048) 4096^2; c5: `delta` 16384^2")
     ap.add_argument("--c5-size", type=int, default=16384, help="c5: image side (default: configs[4], 16384)")
     ap.add_argument("--frames-per-gpu", type=int, default=128, help="c4: 1920x1080 frames per GPU (128 x 8 GPUs = the 1024 of configs[3])")
     ap.add_argument("--size", type=int, default=4096, help="c2: image side (default: configs[1], 4096)")
@@ -95,7 +99,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knob: CNIIC_BENCH_FORCE_SHARDED=1 runs the multi-GPU code path (process group, collectives) with one rank
     sharded = world > 1 or os.environ.get("CNIIC_BENCH_FORCE_SHARDED") == "1"
-    config = args.config if args.config != "auto" else ("c4" if world > 1 else "c2")
+    config = args.config if args.config != "auto" else "c2"
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -126,16 +130,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, warmup, steps):
+    def timed(step, warmup, steps, reduce_max=True):
         for _ in range(warmup):
             step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             r = step()
-        barrier()
+        if reduce_max:
+            barrier()
+        else:
+            torch.cuda.synchronize()   # a rank timing work of its own: its own clock, nobody else's
         dt = time.perf_counter() - t0
-        if dist is not None:
+        if dist is not None and reduce_max:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -147,13 +154,13 @@ def main():
             ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 4 + first_frame + f, FRAME_W, FRAME_H, out=fr[f])
         return fr
 
-    def run_c4(enc, F, warmup, steps, profile):
+    def run_c4(enc, F, warmup, steps, profile, reduce_max=True):
         """-> (seconds for `steps` batch encodes, bytes of this rank's streams, stats, distinct colours of this rank, roofline)"""
         frames = make_frames(F, rank * F)
         stride = FRAME_W * FRAME_H  # 1 byte per pixel between streams: K = 256 labels need at most 8 bits each + the tree
         out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        dt, (lens, st) = timed(lambda: enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride), warmup, steps)
+        dt, (lens, st) = timed(lambda: enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride), warmup, steps, reduce_max)
         roof, U = None, 0
         if profile:
             keys, counts = ctx.hist_rgb24(frames, npx=F * FRAME_W * FRAME_H)
@@ -308,6 +315,10 @@ def main():
         dt, (nbytes, st) = timed(step, args.warmup, args.steps)
         npx_total = W * H * world
         roofline, cpu, extras, U = None, None, {}, 0
+        enc_collectives = enc.collectives if enc is not None else None
+        if enc is not None:
+            enc.close()
+            enc = None
         if rank == 0:
             keys, counts = ctx.hist_rgb24(img, npx=W * H)
             U = int(keys.size)
@@ -336,7 +347,7 @@ def main():
                     ctx.encode(expr, himg, out=hout)
                 extras["host_io_ms_per_step"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
                 del himg, hout
-                # configs[3] on this one GPU: what the N > 1 lines (128 frames per GPU, weak scaling) scale from
+                # configs[3] on this one GPU (the N > 1 lines carry the same block over N GPUs, with their own one-rank timing)
                 F = args.frames_per_gpu
                 e4 = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
                 d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=True)
@@ -360,6 +371,29 @@ def main():
                        "sample": "%dx%d crop of the same image, oracle mode R (reference algorithm incl. neighbour pruning), "
                                  "%d iterations, %.1f s" % (s, s, ost["iterations"], cdt),
                        "bytes_per_px": round(len(data) / (s * s), 4)}
+        if world > 1 and not args.no_extras:
+            # configs[3] over these N GPUs (128 frames per GPU, one palette for all N x 128), and -- in the same run -- every rank's
+            # own frames clustered by that rank ALONE (no collective; rank 0's is reported): the line is self-contained, its
+            # efficiency does not lean on another invocation's N = 1 figure.
+            F = args.frames_per_gpu
+            del img, out
+            e4 = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives=native)  # (its own communicator: the first one is closed)
+            d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=False)
+            coll4 = e4.collectives
+            e4.close()
+            solo = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
+            d1, nb1, st1, U1, roof1 = run_c4(solo, F, 1, 2, profile=(rank == 0), reduce_max=False)
+            solo.close()
+            if rank == 0:
+                vN = F * FRAME_W * FRAME_H * world * 2 / d4 / 1e6
+                v1 = F * FRAME_W * FRAME_H * 2 / d1 / 1e6
+                extras["c4"] = {"workload": "configs[3]: %d frames 1920x1080 (%d per GPU) over %d GPUs, one palette, one Hufman stream per frame" % (F * world, F, world),
+                                "value": round(vN, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3), "kmeans_iterations": int(st4["iterations"]),
+                                "collectives": coll4,
+                                "one_gpu_same_run": {"what": "rank 0's %d frames clustered by rank 0 alone (its own palette, no collective), timed in this run" % F,
+                                                     "value": round(v1, 3), "ms_per_step": round(d1 / 2 * 1e3, 3), "kmeans_iterations": int(st1["iterations"]),
+                                                     "unique_colours": U1, "roofline": roof1},
+                                "efficiency_vs_one_gpu": round(vN / (world * v1), 4)}
         if rank == 0:
             line = {
                 "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
@@ -372,7 +406,7 @@ def main():
                            "bytes_per_px": round(nbytes / (W * H), 4),
                            "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
                                                                        "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
-                                                                       % (world, "library communicator, in-stream" if enc.collectives == "native"
+                                                                       % (world, "library communicator, in-stream" if enc_collectives == "native"
                                                                           else "torch.distributed")},
                 "roofline": roofline, "cpu_baseline": cpu,
             }

@@ -581,6 +581,12 @@ int32_t cniic_comm_all_reduce(cniic_comm *cm, void *buf_dev, uint64_t count, int
     return comm_all_reduce(cm->m, buf_dev, count, kind);
 }
 
+int32_t cniic_comm_set_timeout(cniic_comm *cm, uint64_t milliseconds) {
+    if (!cm || !cm->m) return CNIIC_ERR_BAD_ARG;
+    comm_set_timeout_ms(cm->m, milliseconds);
+    return CNIIC_OK;
+}
+
 int32_t cniic_cc_run(cniic_cc *cc, cniic_comm *cm, cniic_kmeans_stats *stats) {
     if (!cc) return CNIIC_ERR_BAD_ARG;
     cniic_ctx *c = static_cast<cniic_ctx *>(cc->c);

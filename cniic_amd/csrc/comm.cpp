@@ -5,6 +5,7 @@
 // without RCCL; cniic_comm_* then returns CNIIC_ERR_UNSUPPORTED.  In a Python process torch has already
 // mapped its own librccl.so.1, and dlopen by soname returns that copy, so the process holds one RCCL.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -59,6 +60,11 @@ struct Comm {
     void *user = nullptr;
     std::vector<uint8_t> bounce;
     bool dead = false;  // aborted after a failure on this rank or a peer: every later collective fails at once
+    uint64_t timeout_ms = default_timeout_ms();  // how long a loop waits for a batch that contains collectives (0: for ever)
+    static uint64_t default_timeout_ms() {
+        const char *e = getenv("CNIIC_COLLECTIVE_TIMEOUT_MS");
+        return e ? strtoull(e, nullptr, 10) : 120000ull;
+    }
 };
 
 int comm_unique_id(uint8_t *id128) {
@@ -121,6 +127,9 @@ int comm_async_error(Comm *cm) {
     }
     return CNIIC_OK;
 }
+
+uint64_t comm_timeout_ms(const Comm *cm) { return cm ? cm->timeout_ms : 0; }
+void comm_set_timeout_ms(Comm *cm, uint64_t ms) { if (cm) cm->timeout_ms = ms; }
 
 Ctx *comm_ctx(Comm *cm) { return cm->c; }
 uint32_t comm_size(const Comm *cm) { return cm->nranks; }

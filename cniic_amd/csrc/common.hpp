@@ -261,6 +261,7 @@ constexpr uint32_t kPollRing = 16;
 struct Comm;
 void comm_abort(Comm *cm);
 int comm_async_error(Comm *cm);
+uint64_t comm_timeout_ms(const Comm *cm);
 
 // Lagged convergence polling.  The K-means loops enqueue batches of (assign, update) launches; every
 // kernel exits at once when the device-side `done` flag is set.  After each batch the state is copied to
@@ -312,11 +313,20 @@ struct LaggedPoll {
         *have = pending > 0;
         if (pending) {
             if (watch) {  // a loop with collectives: a peer that failed leaves this rank's stream stuck in an all-reduce -- look at the communicator while waiting
+                // A dead peer is not always reported through ncclCommGetAsyncError (intra-node P2P / SHM transports), so the wait has
+                // a deadline of its own: when a batch has not finished after watch_timeout_ms (cniic_comm_set_timeout /
+                // CNIIC_COLLECTIVE_TIMEOUT_MS, default 120 s; 0 = wait for ever) the communicator is aborted -- by km_rgbw_run, on any
+                // error return -- and the call ends with CNIIC_ERR_RCCL instead of hanging.
+                const uint64_t limit_ms = comm_timeout_ms(watch);
+                const auto t_wait = std::chrono::steady_clock::now();
                 for (;;) {
                     const hipError_t q = hipEventQuery(c->poll_ev[slot ^ 1]);
                     if (q == hipSuccess) break;
                     if (q != hipErrorNotReady) return c->fail(CNIIC_ERR_HIP, "kmeans: waiting for a batch: %s", hipGetErrorString(q));
                     CNIIC_TRY(comm_async_error(watch));
+                    if (limit_ms && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_wait).count() >= (long long)limit_ms)
+                        return c->fail(CNIIC_ERR_RCCL, "kmeans: a batch with collectives did not finish within %llu ms (a peer is gone?): communicator aborted",
+                                       (unsigned long long)limit_ms);
                     std::this_thread::sleep_for(std::chrono::microseconds(20));
                 }
             }
@@ -469,6 +479,8 @@ uint32_t comm_size(const Comm *cm);
 int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind);  // in place, sum; kind 0 = u8, 1 = u32, 2 = u64
 void comm_abort(Comm *cm);        // after a failure on this rank: the peers' collectives end with an error instead of hanging
 int comm_async_error(Comm *cm);   // CNIIC_OK while healthy; an error once this rank aborted or the transport reports a peer's failure
+uint64_t comm_timeout_ms(const Comm *cm);           // deadline of a loop's wait for a batch with collectives (0: none)
+void comm_set_timeout_ms(Comm *cm, uint64_t ms);
 
 int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs

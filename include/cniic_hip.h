@@ -252,9 +252,15 @@ int32_t  cniic_comm_all_reduce(cniic_comm *comm, void *buf_dev, uint64_t count, 
  * RCCL: ncclCommAbort here, ncclCommGetAsyncError polled by the peers while they wait for a batch; host transport: fn is
  * called once with (buf_host = NULL, count = 0, elem_bytes = -1) and should tear the caller's transport down (a peer
  * whose fn then fails returns non-zero, which ends that peer's loop the same way).  The communicator is unusable
- * afterwards (every call returns CNIIC_ERR_RCCL): destroy it. */
+ * afterwards (every call returns CNIIC_ERR_RCCL): destroy it.
+ * A peer that dies WITHOUT aborting (killed process, lost node) is not always reported by RCCL's asynchronous error state
+ * (intra-node P2P / SHM transports), so the wait for a batch of launches that contains collectives has a deadline of its own:
+ * cniic_comm_set_timeout (default 120 000 ms, or CNIIC_COLLECTIVE_TIMEOUT_MS at creation; 0 = wait for ever).  When it expires
+ * cniic_cc_run aborts the communicator and returns CNIIC_ERR_RCCL.  With a host transport every all-reduce is a blocking call
+ * of fn: there the transport's own timeout bounds the wait (gloo: the process group's `timeout`). */
 typedef int32_t (*cniic_host_sum_fn)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes);
 int32_t  cniic_comm_create_host(cniic_ctx *ctx, uint32_t rank, uint32_t nranks, cniic_host_sum_fn fn, void *user, cniic_comm **out);
+int32_t  cniic_comm_set_timeout(cniic_comm *comm, uint64_t milliseconds);
 int32_t  cniic_cc_run(cniic_cc *cc, cniic_comm *comm /* NULL: one rank */, cniic_kmeans_stats *stats);
 
 /* ------------------------------------------------------------------ cluster-colors remap */

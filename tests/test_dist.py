@@ -615,3 +615,41 @@ def test_native_loop_world2_empty_cluster_reseed(route):
     assert it == iters
     for r in (0, 1):
         assert res[r][0] == exp[r] and res[r][1] == iters
+
+
+# ------------------------------------------------------------------ the driver's N > 1 invocation of bench.py, rehearsed
+@pytest.mark.gpu
+def test_bench_two_ranks_same_workload_as_one_rank_and_self_contained_c4_block():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` as the driver launches it (two ranks sharing the test
+    box's one GPU, rendezvous over gloo): ONE JSON line on stdout; the top-level workload is configs[1] PER GPU -- the workload
+    of the N = 1 line, so the driver's 1/2/4/8 curve is one workload -- and the line carries configs[3] as a block of its own
+    with the same run's one-rank timing and an efficiency that needs no other invocation."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, CNIIC_BENCH_BACKEND="gloo", CNIIC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "1", "--warmup", "1", "--size", "1024", "--frames-per-gpu", "2", "--cpu-sample", "0"]
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    lines2 = [l for l in p2.stdout.splitlines() if l.strip()]
+    assert len(lines2) == 1, p2.stdout
+    two = json.loads(lines2[0])
+    p1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--no-extras"] + common, env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.strip()][0])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["metric"] == one["metric"] and two["unit"] == one["unit"] and two["scaling"] == one["scaling"] == "weak"
+    assert two["config"]["workload"] == one["config"]["workload"]            # the same per-GPU workload at every N
+    assert two["config"]["pixels_per_gpu"] == one["config"]["pixels_per_gpu"] == 1024 * 1024
+    assert two["value"] > 0 and two["cpu_baseline"] is None
+    c4 = two["c4"]
+    assert c4["value"] > 0 and c4["one_gpu_same_run"]["value"] > 0
+    assert abs(c4["efficiency_vs_one_gpu"] - c4["value"] / (2 * c4["one_gpu_same_run"]["value"])) < 1e-3
+    assert c4["one_gpu_same_run"]["roofline"]["frac"] > 0

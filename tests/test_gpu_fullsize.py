@@ -296,3 +296,48 @@ def test_config4_frame_batch_1080p(env):
         palette.update(pal.tolist())
         assert ctx.huf_size(_lib.SYM_RGB, cnt.astype(np.uint64)) + 8 == lens[f]
     assert len(palette) <= K
+
+
+def test_config4_frame_batch_128_frames_1080p(env):
+    """configs[3] exactly as one GPU of the 8-GPU job sees it: 128 frames 1920 x 1080 (265 Mpixels, 5 x 10^5 pixels per partition
+    bucket: k_sp_partlab runs sliced, k_frame_trees one block per frame), ONE palette.  The batch encode is deterministic; sampled
+    frames decode on their own to exactly the rows the plain encode of the stacked frames (one 1920 x 138240 image: the same union
+    clustering through the single-image path) decodes to; every stream is as long as its own label histogram predicts
+    (SURVEY 8(a) H2); all frames share one palette of at most K colours; the labels of ALL frames are checked through the stream
+    lengths (a wrong label in any frame changes that frame's histogram or its payload size)."""
+    ctx, torch, dev = env
+    from cniic_amd import _lib
+    from cniic_amd.dist import ShardedClusterColors
+    F, w, h, K = 128, 1920, 1080, 256
+    frames = torch.empty((F, h, w, 3), dtype=torch.uint8, device=dev)
+    for f in range(F):
+        ctx.synth_image(1, SEED + 4 + f, w, h, out=frames[f])
+    stride = w * h
+    out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
+    enc = ShardedClusterColors(ctx, K, None, dev)
+    lens, st = enc.encode_frames(frames, w, h, F, out, stride)
+    assert len(lens) == F and st["iterations"] > 1 and st["moved_last"] == 0
+    heads = [out[f * stride:f * stride + lens[f]].cpu().numpy().tobytes() for f in range(F)]
+    lens2, st2 = enc.encode_frames(frames, w, h, F, out, stride)
+    assert lens2 == lens and st2["iterations"] == st["iterations"]
+    for f in range(F):
+        assert out[f * stride:f * stride + lens[f]].cpu().numpy().tobytes() == heads[f], "frame %d differs between two batch encodes" % f
+    enc.close()
+    # the same union clustering through the single-image path
+    big = torch.empty(F * w * h + (1 << 20), dtype=torch.uint8, device=dev)
+    rc, nb, stb = ctx.encode("cluster-colors(%d)" % K, frames, w=w, h=F * h, out=big)
+    assert rc == 0 and stb["iterations"] == st["iterations"]
+    rc, whole = ctx.decode("cluster-colors(%d)" % K, big[:nb].cpu().numpy().tobytes())
+    assert rc == 0 and whole.shape == (F * h, w, 3)
+    del big
+    wkeys = (whole[..., 0].astype(np.uint32) << 16) | (whole[..., 1].astype(np.uint32) << 8) | whole[..., 2]
+    palette = set(np.unique(wkeys).tolist())
+    assert len(palette) <= K
+    for f in range(F):
+        # every frame: stream length = what the histogram of ITS rows of the union clustering predicts
+        cnt = np.unique(wkeys[f * h:(f + 1) * h], return_counts=True)[1]
+        assert ctx.huf_size(_lib.SYM_RGB, cnt.astype(np.uint64)) + 8 == lens[f], "frame %d" % f
+    for f in (0, 37, 90, 127):
+        rc, back = ctx.decode("cluster-colors(%d)" % K, heads[f])
+        assert rc == 0 and back.shape == (h, w, 3)
+        assert np.array_equal(back, whole[f * h:(f + 1) * h]), "frame %d" % f
