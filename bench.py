@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--max-iters", type=int, default=0, help="0 = to convergence, like the reference")
     ap.add_argument("--cpu-sample", type=int, default=2560, help="side of the crop timed on the CPU (0 = skip every CPU leg)")
     ap.add_argument("--no-extras", action="store_true", help="c2 at N=1: skip the c4_one_gpu and host-buffer legs")
+    ap.add_argument("--decode", action="store_true", help="c2 / c5: time Codec::decode of the stream the encode produced (stream and image resident in HBM) "
+                                                           "instead of the encode; its own metric (Mpixels/sec decode)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line: everything else a library prints there (RCCL's version banner when a communicator is made)
@@ -177,7 +179,9 @@ def main():
         return dt, int(sum(lens)), st, U, roof
 
     line = None
-    if config == "c4":
+    if args.decode:
+        line = bench_decode(args, ctx, torch, np, dev, rank, world, timed, config)
+    elif config == "c4":
         F = args.frames_per_gpu
         enc = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives=native)
         dt, nbytes, st, U, roof = run_c4(enc, F, args.warmup, args.steps, profile=(rank == 0))
@@ -420,6 +424,81 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bench_decode(args, ctx, torch, np, dev, rank, world, timed, config):
+    """The other half of the trait (bench.rs:45-46 decodes every image it encodes): Codec::decode of the stream Codec::encode made,
+    stream and image both resident in HBM (replicas: one image per GPU, no collective).  roofline = the kernel that decodes the
+    payload and writes the symbols (k_hd_write): payload bytes read + the bytes it writes, timed with HIP events around it."""
+    from cniic_amd import _lib, synth
+    if config == "c5":
+        W = H = args.c5_size
+        expr, seed, what = "delta", synth.SEED0 + 5 + rank, "configs[4]"
+    else:
+        W = H = args.size
+        expr, seed, what = "cluster-colors(%d)" % args.k, synth.SEED0 + 2 + rank, "configs[1]"
+    lossless = expr == "delta"
+    img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    ctx.synth_image(_lib.SYNTH_PHOTO, seed, W, H, out=img)
+    stream = torch.empty(W * H * 3 + (1 << 24), dtype=torch.uint8, device=dev)
+    rc, ln, st = ctx.encode(expr, img, w=W, h=H, out=stream, max_iters=args.max_iters)
+    back = torch.empty(W * H * 3, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return ctx.decode_into(expr, stream, ln, back)
+    dt, (rc, dw, dh) = timed(step, args.warmup, args.steps)
+    assert (dw, dh) == (W, H)
+    if lossless:
+        assert torch.equal(back.view(H, W, 3), img), "decode(encode(img)) != img"
+    if rank != 0:
+        return None
+    mse = float((img.view(-1).to(torch.float32) - back.to(torch.float32)).pow(2).mean().item())   # bench::compute_error (bench.rs:95-104)
+    ctx.set_opt(_lib.OPT_STAGE_TIMERS, 1)
+    ctx.decode_into(expr, stream, ln, back)
+    stages = {}
+    for k in ("hd_pass0", "hd_check", "hd_write", "undiff_scatter"):
+        ms, n = ctx.kernel_time(k)
+        if n:
+            stages[k + "_ms"] = round(ms / n, 4)
+    ctx.set_opt(_lib.OPT_STAGE_TIMERS, None)
+    himg = np.empty(W * H * 3, np.uint8)
+    hstream = stream[:ln].cpu().numpy()
+    ctx.decode_into(expr, hstream, ln, himg)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.decode_into(expr, hstream, ln, himg)
+    host_ms = (time.perf_counter() - t0) / 3 * 1e3
+    roofline = None
+    w_ms = stages.get("hd_write_ms")
+    if w_ms:
+        sym_bytes = 4 if lossless else 3       # delta: packed differences (u32) for the prefix sum; the RGB codecs: pixels
+        algo = float(ln) + float(sym_bytes) * W * H
+        roofline = {"kernel": "k_hd_write (+ the offsets scan in front of it)", "bound": "hbm", "achieved": round(algo / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(algo / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": w_ms, "launches": 1,
+                    "algorithmic_bytes_per_launch": algo,
+                    "note": "HIP events around the scan + write launches of one more decode (stage timers); algorithmic bytes = the %d-byte stream read once + "
+                            "%d B/symbol written; the boundary passes before it (hd_pass0, hd_check) read the stream again and write 20 B per 1024 bits" % (ln, sym_bytes)}
+    cpu = None
+    if args.cpu_sample > 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        s = min(2048, W)
+        crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+        rc, data, _ = ctx.encode(expr, crop, max_iters=args.max_iters)
+        t0 = time.perf_counter()
+        rco, dec = O.decode(expr, data)
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+               "sample": "the CPU restatement's decode of the %dx%d crop's stream (%d bytes), %.1f s (rc %d)" % (s, s, len(data), cdt, rco)}
+    return {"metric": "Mpixels/sec decode (%s)" % ("delta" if lossless else "cluster-colors K=%d" % args.k),
+            "value": round(W * H * world * args.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u64", "data": "synthetic",
+            "config": {"workload": "%s: %s DECODE of the stream its encode made of one %dx%d photo-like synthetic RGB image per GPU, stream (%d bytes) and image "
+                                   "resident in HBM" % (what, expr, W, H, ln), "pixels_per_gpu": W * H, "stream_bytes": int(ln), "mse_vs_source": round(mse, 3),
+                       "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "host_io_ms_per_step": round(host_ms, 3)}
 
 
 def cpu_all_cores(np, make_frames, expr):

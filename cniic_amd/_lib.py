@@ -16,11 +16,12 @@ BAD_ARG, TOO_FEW_POINTS, FEW_ACTIVE, HIP, RCCL, DECODE, NOMEM, CAPACITY, UNSUPPO
 SYM_RGB, SYM_SIGNED = 1, 2
 SYNTH_UNIFORM, SYNTH_PHOTO = 0, 1
 KM_BRUTE_FORCE, KM_PROFILE, KM_NO_SKIP = 1, 2, 4
+OPT_SP_MIN_PIXELS, OPT_HUF_GPU_CODES_MIN, OPT_GPU_DECODE_MIN, OPT_DELTA_ROUTE, OPT_STAGE_TIMERS, OPT_FRAME_TREES_HOST, OPT_BATCH_STREAMS = range(1, 8)
 
 # every symbol include/cniic_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cniic_ctx_create", "cniic_ctx_destroy", "cniic_last_error", "cniic_version", "cniic_sync", "cniic_dev_alloc",
-    "cniic_dev_free", "cniic_memcpy", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
+    "cniic_dev_free", "cniic_memcpy", "cniic_ctx_set_opt", "cniic_ctx_unset_opt", "cniic_ctx_get_opt", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
     "cniic_kmeans_rgbw", "cniic_kmeans_xyrgb", "cniic_kmeans_step_rgbw", "cniic_kmeans_step_xyrgb",
     "cniic_km_create_rgbw", "cniic_km_partial_words", "cniic_km_partials", "cniic_km_begin",
     "cniic_km_labels_internal", "cniic_km_assign", "cniic_km_update",
@@ -147,6 +148,18 @@ class Context:
         if rc != OK and rc not in allow:
             raise CniicError(rc, (self._L.cniic_last_error(self.h) or b"").decode())
         return rc
+
+    def set_opt(self, opt, value):
+        """cniic_ctx_set_opt: a route switch / threshold for this context (value None: back to the environment's / the default)"""
+        if value is None:
+            self._check(self._L.cniic_ctx_unset_opt(self.h, C.c_int32(opt)))
+        else:
+            self._check(self._L.cniic_ctx_set_opt(self.h, C.c_int32(opt), C.c_uint64(value)))
+
+    def get_opt(self, opt):
+        v = C.c_uint64(0)
+        self._check(self._L.cniic_ctx_get_opt(self.h, C.c_int32(opt), C.byref(v)))
+        return v.value
 
     def sync(self):
         self._check(self._L.cniic_sync(self.h))
@@ -330,6 +343,15 @@ class Context:
         if rc != OK:
             return rc, None
         return rc, out[:w * h].reshape(h, w, 3)
+
+    def decode_into(self, expr, data, nbytes, out, allow=()):
+        """Codec::decode with caller-owned buffers: data = the stream (device tensor / address / numpy array), nbytes of it;
+        out = a uint8 buffer (device tensor or numpy array) that receives the w x h x 3 image.  -> (rc, w, h)"""
+        cap = out.numel() if hasattr(out, "numel") else out.size
+        cw, ch = C.c_uint32(0), C.c_uint32(0)
+        rc = self._check(self._L.cniic_codec_decode(self.h, expr.encode(), _ptr(data), C.c_uint64(nbytes), _ptr(out), C.c_uint64(cap),
+                                                    C.byref(cw), C.byref(ch)), allow)
+        return rc, cw.value, ch.value
 
     def mse(self, a, b):
         a = np.ascontiguousarray(a, np.uint8)

@@ -122,6 +122,36 @@ int32_t cniic_memcpy(cniic_ctx *c, void *dst, const void *src, uint64_t bytes) {
     return CNIIC_OK;
 }
 
+int32_t cniic_ctx_set_opt(cniic_ctx *c, int32_t opt, uint64_t value) {
+    if (!c) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    if (opt <= 0 || opt >= CNIIC_OPT_COUNT) return c->fail(CNIIC_ERR_BAD_ARG, "ctx_set_opt: unknown option %d", opt);
+    c->opt_val[opt] = value;
+    c->opt_set |= 1u << opt;
+    if (opt == CNIIC_OPT_STAGE_TIMERS) c->timers = value != 0;
+    return CNIIC_OK;
+}
+
+int32_t cniic_ctx_unset_opt(cniic_ctx *c, int32_t opt) {
+    if (!c) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    if (opt <= 0 || opt >= CNIIC_OPT_COUNT) return c->fail(CNIIC_ERR_BAD_ARG, "ctx_unset_opt: unknown option %d", opt);
+    c->opt_set &= ~(1u << opt);
+    if (opt == CNIIC_OPT_STAGE_TIMERS) c->timers = getenv("CNIIC_KERNEL_TIMERS") != nullptr;
+    return CNIIC_OK;
+}
+
+int32_t cniic_ctx_get_opt(cniic_ctx *c, int32_t opt, uint64_t *value) {
+    if (!c || !value) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    static const struct { const char *env; uint64_t dflt; } k[CNIIC_OPT_COUNT] = {
+        {nullptr, 0}, {"CNIIC_SP_MIN_PIXELS", 1ull << 20}, {"CNIIC_HUF_GPU_CODES_MIN", 32768}, {"CNIIC_GPU_DECODE_MIN", 1ull << 14},
+        {"CNIIC_DELTA_ROUTE", 0}, {nullptr, 0}, {"CNIIC_FRAME_TREES_HOST", 0}, {nullptr, 8}};
+    if (opt <= 0 || opt >= CNIIC_OPT_COUNT) return c->fail(CNIIC_ERR_BAD_ARG, "ctx_get_opt: unknown option %d", opt);
+    *value = opt == CNIIC_OPT_STAGE_TIMERS ? (c->timers ? 1 : 0) : c->opt(opt, k[opt].env, k[opt].dflt);
+    return CNIIC_OK;
+}
+
 int32_t cniic_last_kernel_time(cniic_ctx *c, const char *which, double *ms, uint64_t *launches) {
     if (!c || !which) return CNIIC_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -843,14 +873,7 @@ int32_t cniic_codec_decode(cniic_ctx *c, const char *expr, const uint8_t *bytes,
     CodecDesc d;
     if (!parse_codec(expr, &d)) return c->fail(CNIIC_ERR_BAD_ARG, "Malformed codec argument: %s", expr ? expr : "(null)");
     if (!bytes || !w || !h) return c->fail(CNIIC_ERR_BAD_ARG, "codec_decode: null argument");
-    std::vector<uint8_t> host;
-    const uint8_t *b = bytes;
-    if (is_device_ptr(bytes)) {
-        host.resize(n);
-        CNIIC_HIP_TRY(c, hipMemcpy(host.data(), bytes, n, hipMemcpyDeviceToHost));
-        b = host.data();
-    }
-    return codec_decode(c, d, b, n, rgb, cap, w, h);
+    return codec_decode(c, d, bytes, n, rgb, cap, w, h);  // (the stream may be in host memory or in HBM)
 }
 
 int32_t cniic_mse(cniic_ctx *c, const uint8_t *a, const uint8_t *b, uint64_t npx, double *mse) {

@@ -161,8 +161,7 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     CNIIC_TRY(hist_compact_write(c, table_d, &plan, keys_d.as<uint32_t>(), counts_d.as<uint64_t>(), nullptr));
     // A large alphabet (a photograph's colours): the host only merges the tree; codes and the serialised decoder are the
     // GPU's (huff_tree_codes).  The counts land in pinned memory, the tree's arrays are written there, the keys stay put.
-    const char *gmin = getenv("CNIIC_HUF_GPU_CODES_MIN");  // (tests: 0)
-    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2 && U < (1ull << 30) && n < (1ull << 32);
+    const bool gpu_codes = U >= c->opt(CNIIC_OPT_HUF_GPU_CODES_MIN, "CNIIC_HUF_GPU_CODES_MIN", 32768) && U >= 2 && U < (1ull << 30) && n < (1ull << 32);
     std::vector<uint32_t> keys(gpu_codes ? 0 : U);
     std::vector<uint64_t> counts_v(gpu_codes ? 0 : U);
     uint64_t *counts = counts_v.data();
@@ -580,7 +579,7 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
     }
     CNIIC_HIP_TRY(c, cnt_d.alloc((uint64_t)F * K * 4));
     CNIIC_TRY(frame_label_hist(c, labs, npf, lab_stride, F, wide, K, cnt_d.as<uint32_t>()));
-    const bool gpu_trees = !wide && K <= 256 && getenv("CNIIC_FRAME_TREES_HOST") == nullptr;
+    const bool gpu_trees = !wide && K <= 256 && c->opt(CNIIC_OPT_FRAME_TREES_HOST, "CNIIC_FRAME_TREES_HOST", 0) == 0;
     std::vector<uint32_t> cnt(gpu_trees ? 0 : (size_t)F * K);
     if (!gpu_trees) CNIIC_HIP_TRY(c, hipMemcpyAsync(cnt.data(), cnt_d.p, cnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
     host_trace().mark("frames: hist enqueued");
@@ -720,17 +719,14 @@ int cc_finish_frames(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h,
 }
 
 // images of at least this many pixels take the super-cell partition (k_points.hip); CNIIC_SP_MIN_PIXELS overrides (tests: 0)
-static uint64_t sp_min_pixels() {
-    const char *e = getenv("CNIIC_SP_MIN_PIXELS");
-    return e ? strtoull(e, nullptr, 10) : (1ull << 20);
-}
+static uint64_t sp_min_pixels(const Ctx *c) { return c->opt(CNIIC_OPT_SP_MIN_PIXELS, "CNIIC_SP_MIN_PIXELS", 1ull << 20); }
 
 static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
                                  const cniic_kmeans_opts *opts, uint8_t *out, uint64_t cap, uint64_t *len,
                                  cniic_kmeans_stats *stats) {
     const uint64_t n = (uint64_t)w * h;
     host_trace().mark("enter");
-    if (n >= sp_min_pixels() && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))) {
+    if (n >= sp_min_pixels(c) && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))) {
         CcSession *raw = nullptr;
         CNIIC_TRY(cc_prepare_image(c, rgb_d, n, K, opts, &raw));
         std::unique_ptr<CcSession> s(raw);
@@ -810,8 +806,8 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     put_u32(header, w);
     put_u32(header, h);
     if (n == 0) return c->fail(CNIIC_ERR_BAD_ARG, "delta: empty image (src/huf.rs:99 asserts)");
-    const char *route = getenv("CNIIC_DELTA_ROUTE");  // "32": the 32-bit route whatever the image (tests)
-    if (route && atoi(route) == 32) return encode_delta_syms32(c, rgb_d, w, h, header, out, cap, len);
+    if (c->opt(CNIIC_OPT_DELTA_ROUTE, "CNIIC_DELTA_ROUTE", 0) == 32)  // the 32-bit route whatever the image (tests)
+        return encode_delta_syms32(c, rgb_d, w, h, header, out, cap, len);
     host_trace().mark("delta: enter");
     // 1. linearize + DiffStream + count_freqs (hilbertc.rs:408-410, huf.rs:30): the symbols as a 16-bit stream (k_delta.hip)
     uint32_t *table = nullptr;
@@ -850,8 +846,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     // the decoder in ordinary memory (the host reads the keys at random and writes the decoder byte by byte: 0.20 ms in pinned
     // memory, 0.12 there).
     const uint64_t decoder_bytes = huff_tree_bytes(CNIIC_SYM_SIGNED, U), header_bytes = header.size() + decoder_bytes;
-    const char *gmin = getenv("CNIIC_HUF_GPU_CODES_MIN");  // (tests: 0, or a large number for the host's way)
-    const bool gpu_codes = U >= (gmin ? strtoull(gmin, nullptr, 10) : 32768ull) && U >= 2;
+    const bool gpu_codes = U >= c->opt(CNIIC_OPT_HUF_GPU_CODES_MIN, "CNIIC_HUF_GPU_CODES_MIN", 32768) && U >= 2;
     const uint64_t off_code = U * 8, off_len = off_code + U * 8;
     CNIIC_HIP_TRY(c, ctx_pinned_huf(c, gpu_codes ? U * 8 + 3 * (U - 1) * 4 + 64 : off_len + U));
     uint8_t *const pin = static_cast<uint8_t *>(c->pinned_huf);
@@ -983,10 +978,7 @@ int codec_encode(Ctx *c, const CodecDesc &d, const uint8_t *rgb_d, uint32_t w, u
 
 // ------------------------------------------------------------------ decode
 // below this many symbols the parallel decoder's fixed cost is not worth it (CNIIC_GPU_DECODE_MIN overrides: tests)
-static uint64_t gpu_decode_min_symbols() {
-    const char *e = getenv("CNIIC_GPU_DECODE_MIN");
-    return e ? strtoull(e, nullptr, 10) : (1ull << 14);
-}
+static uint64_t gpu_decode_min_symbols(const Ctx *c) { return c->opt(CNIIC_OPT_GPU_DECODE_MIN, "CNIIC_GPU_DECODE_MIN", 1ull << 14); }
 
 static int put_image(Ctx *c, const uint8_t *src, bool src_dev, uint64_t bytes, uint8_t *dst) {
     if (!bytes) return CNIIC_OK;
@@ -998,10 +990,33 @@ static int put_image(Ctx *c, const uint8_t *src, bool src_dev, uint64_t bytes, u
     return CNIIC_OK;
 }
 
+// The stream may live in host memory or in HBM (bytes_dev).  Only the HEAD of a device-resident stream comes to the host -- the
+// dimensions and, for the Huffman codecs, the serialised decoder, which is parsed there (O(alphabet)); the payload is decoded
+// where it lies.  head_h / head_n: the part of the stream the host can read (all of it for a host stream).
+struct StreamHead {
+    std::vector<uint8_t> buf;
+    const uint8_t *p = nullptr;
+    uint64_t n = 0;
+};
+static int stream_head(Ctx *c, const uint8_t *bytes, bool bytes_dev, uint64_t nbytes, uint64_t want, StreamHead *h) {
+    if (!bytes_dev) { h->p = bytes; h->n = nbytes; return CNIIC_OK; }
+    want = std::min(want, nbytes);
+    if (h->n >= want) return CNIIC_OK;
+    h->buf.resize(want);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(h->buf.data() + h->n, bytes + h->n, want - h->n, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    h->p = h->buf.data();
+    h->n = want;
+    return CNIIC_OK;
+}
+
 int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
                  uint32_t *w, uint32_t *h) {
+    const bool bytes_dev = is_device_ptr(bytes);
+    StreamHead head;
+    CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, 1ull << 16, &head));
     uint64_t pos = 0;
-    if (!get_u32(bytes, nbytes, pos, *w) || !get_u32(bytes, nbytes, pos, *h))  // create_image_buffer_standard codec.rs:22-26
+    if (!get_u32(head.p, head.n, pos, *w) || !get_u32(head.p, head.n, pos, *h))  // create_image_buffer_standard codec.rs:22-26
         return c->fail(CNIIC_ERR_DECODE, "decode: truncated dimensions");
     const uint64_t n = (uint64_t)*w * *h;
     if (n >= (1ull << 32)) return c->fail(CNIIC_ERR_DECODE, "decode: image too large");
@@ -1013,46 +1028,62 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
     case CODEC_DELTA: {          // hilbertc.rs:417-431
         const bool delta = d.kind == CODEC_DELTA;
         const int sym_kind = delta ? CNIIC_SYM_SIGNED : CNIIC_SYM_RGB;
+        const char *bad_stream = delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol";
         host_trace().mark("decode: enter");
-        if (!c->trie_scratch) c->trie_scratch = std::make_shared<std::vector<TrieNode>>();
-        std::vector<TrieNode> &trie = *static_cast<std::vector<TrieNode> *>(c->trie_scratch.get());
-        if (!huff_parse_trie(sym_kind, bytes, nbytes, pos, trie))
-            return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
-        if (!n) return CNIIC_OK;
+        if (!c->trie_scratch) c->trie_scratch = std::make_shared<LeafTable>();
+        LeafTable &lt = *static_cast<LeafTable *>(c->trie_scratch.get());
+        // the decoder: parsed from what the host holds of the stream; a device-resident stream whose decoder is longer than
+        // that is fetched further (a failed parse of a TRUNCATED head says nothing: only the whole stream's verdict counts)
+        uint64_t tpos = pos;
+        bool parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
+        while (!parsed && head.n < nbytes) {
+            CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, head.n * 16, &head));
+            tpos = pos;
+            parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
+        }
+        if (!parsed) return c->fail(CNIIC_ERR_DECODE, bad_stream);
         host_trace().mark("decode: parse the decoder (host)");
         const bool dst_dev = is_device_ptr(rgb_out);
-        DevBuf keys_d, lin_d, img_d;
-        CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
-        // symbols on the GPU (parallel, self-synchronising); small inputs and codes that do not settle go through the
-        // host walk (same trie, same answers)
         int status = 2;
-        if (n >= gpu_decode_min_symbols()) CNIIC_TRY(huff_decode_dev(c, trie, bytes + pos, nbytes - pos, n, keys_d.as<uint32_t>(), &status));
-        if (status == 2) {
+        DevBuf keys_d, lin_d, img_d;
+        uint8_t *dst = rgb_out;
+        if (!lt.too_deep) {
+            if (!n) return CNIIC_OK;
+            if (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3)) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+            if (delta) CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
+            // symbols on the GPU (parallel, self-synchronising), straight from the stream where it lies; small inputs and codes
+            // that do not settle go through the host walk (same answers)
+            if (n >= gpu_decode_min_symbols(c))
+                CNIIC_TRY(huff_decode_dev(c, lt, bytes + tpos, bytes_dev, nbytes - tpos, n, delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+        }
+        if (status == 2) {  // the node walk on the host: needs the whole stream there
+            CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, nbytes, &head));
+            std::vector<TrieNode> trie;
+            if (!huff_parse_trie(sym_kind, head.p, head.n, pos, trie)) return c->fail(CNIIC_ERR_DECODE, bad_stream);
+            if (!n) return CNIIC_OK;
+            if (!img_d.p && (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3))) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+            CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
             std::vector<uint32_t> keys(n);
-            if (!huff_decode_host(trie, bytes + pos, nbytes - pos, n, keys.data(), nullptr)) status = 1;
+            if (!huff_decode_host(trie, head.p + pos, head.n - pos, n, keys.data(), nullptr)) status = 1;
             else {
                 status = 0;
                 CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_d.p, keys.data(), n * 4, hipMemcpyHostToDevice, c->stream));
                 CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (!delta) CNIIC_TRY(keys_to_rgb(c, keys_d.as<uint32_t>(), n, dst));
             }
         }
-        if (status == 1)
-            return c->fail(CNIIC_ERR_DECODE, delta ? "delta: cannot decode the difference stream" : "Failed to decode symbol");
+        if (status == 1) return c->fail(CNIIC_ERR_DECODE, bad_stream);
         host_trace().mark("decode: symbols");
-        uint8_t *dst = rgb_out;
-        if (!dst_dev) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
-        if (!delta) {
-            CNIIC_TRY(keys_to_rgb(c, keys_d.as<uint32_t>(), n, dst));
-        } else {
-            CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
-            uint32_t bad = 0;  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508)
-            CNIIC_TRY(delta_undiff_dev(c, keys_d.as<uint32_t>(), n, lin_d.as<uint8_t>(), &bad));
+        if (delta) {
+            uint32_t bad = 0;  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508); then follow the traversal (hilbertc.rs:426-428)
+            ScopedKernelTimer tu(c, "undiff_scatter");
+            CNIIC_TRY(delta_undiff_scatter_dev(c, keys_d.as<uint32_t>(), *w, *h, dst, &bad));
+            tu.stop();
             if (bad) return c->fail(CNIIC_ERR_DECODE, "delta: colour out of range (hilbertc.rs:505)");
-            CNIIC_TRY(hilbert_scatter(c, lin_d.as<uint8_t>(), *w, *h, dst));  // follow the traversal (hilbertc.rs:426-428)
         }
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         host_trace().mark("decode: pixels");
-        const int rc_put = dst_dev ? CNIIC_OK : put_image(c, dst, true, n * 3, rgb_out);
+        const int rc_put = dst == rgb_out ? CNIIC_OK : put_image(c, dst, true, n * 3, rgb_out);
         host_trace().mark("decode: image out");
         host_trace().dump();
         return rc_put;
@@ -1063,7 +1094,7 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         const uint64_t body = nbytes - pos, R = body / 12, tail = body % 12;
         DevBuf rec_d, lin_d, img_d;
         CNIIC_HIP_TRY(c, rec_d.alloc(std::max<uint64_t>(R * 12, 16)));
-        if (R) CNIIC_HIP_TRY(c, hipMemcpyAsync(rec_d.p, bytes + pos, R * 12, hipMemcpyHostToDevice, c->stream));
+        if (R) CNIIC_HIP_TRY(c, hipMemcpyAsync(rec_d.p, bytes + pos, R * 12, bytes_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
         CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
         int status = 0;
         CNIIC_TRY(rle_expand_dev(c, rec_d.as<uint8_t>(), R, tail, n, lin_d.as<uint8_t>(), &status));
@@ -1078,16 +1109,18 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         return CNIIC_OK;
     }
     case CODEC_VORONOI: {  // clusterc.rs:168-189
+        CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, nbytes, &head));  // 16 + 19 K bytes: parsed on the host
+        const uint8_t *hb = head.p;
         uint64_t K;
-        if (!get_u64(bytes, nbytes, pos, K)) return c->fail(CNIIC_ERR_DECODE, "voronoi: truncated");
+        if (!get_u64(hb, nbytes, pos, K)) return c->fail(CNIIC_ERR_DECODE, "voronoi: truncated");
         if (K > (nbytes - pos) / 19) return c->fail(CNIIC_ERR_DECODE, "voronoi: truncated centroid list");
         std::vector<cniic_colorpos> cent(K);
         for (uint64_t k = 0; k < K; k++) {
             uint64_t l;
-            if (!get_u32(bytes, nbytes, pos, cent[k].x) || !get_u32(bytes, nbytes, pos, cent[k].y) ||
-                !get_u64(bytes, nbytes, pos, l) || l != 3 || pos + 3 > nbytes)
+            if (!get_u32(hb, nbytes, pos, cent[k].x) || !get_u32(hb, nbytes, pos, cent[k].y) ||
+                !get_u64(hb, nbytes, pos, l) || l != 3 || pos + 3 > nbytes)
                 return c->fail(CNIIC_ERR_DECODE, "voronoi: bad centroid");
-            memcpy(cent[k].rgb, bytes + pos, 3);
+            memcpy(cent[k].rgb, hb + pos, 3);
             cent[k].pad = 0;
             pos += 3;
         }

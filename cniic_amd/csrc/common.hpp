@@ -119,6 +119,14 @@ struct Ctx {
     std::map<std::string, KernelTime> ktimes;  // per-call dominant-kernel timings (HIP events)
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     bool    timers = getenv("CNIIC_KERNEL_TIMERS") != nullptr;  // per-stage HIP-event timers (they synchronise)
+    // cniic_ctx_set_opt: values a host set for this context (bit i of opt_set); unset options read their environment variable per call
+    uint64_t opt_val[CNIIC_OPT_COUNT] = {};
+    uint32_t opt_set = 0;
+    uint64_t opt(int id, const char *env, uint64_t dflt) const {
+        if (id > 0 && id < CNIIC_OPT_COUNT && ((opt_set >> id) & 1u)) return opt_val[id];
+        const char *e = env ? getenv(env) : nullptr;
+        return e ? strtoull(e, nullptr, 10) : dflt;
+    }
     DevPool pool;           // recycled scratch HBM (all DevBufs created inside an ABI call)
     // persistent scratch: dense symbol tables (zeroed on demand), grown lazily
     DevBuf dense;           // u32[2^24] or u32[2^27]
@@ -133,7 +141,7 @@ struct Ctx {
     uint64_t *pinned_u = nullptr;  // 64 KiB of pinned host memory: [0] sp_build's distinct-colour count, [1] the point list's length,
                                    // [8 ..] this image's pixels per cluster (shared palette); u_ev: behind the copy of [0]
     hipEvent_t u_ev = nullptr;
-    std::shared_ptr<void> trie_scratch; // the decoder's parsed trie (std::vector<TrieNode>, codec.cpp), kept between calls: 110 MB of fresh pages cost 30 ms
+    std::shared_ptr<void> trie_scratch; // the decoder's parsed leaf table (LeafTable, codec.cpp), kept between calls: 90 MB of fresh pages cost 25 ms
     std::shared_ptr<void> huf_scratch;  // host arrays of the Huffman tree build, kept between calls (HuffScratch, codec.cpp)
     void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
     uint64_t pinned_huf_bytes = 0;
@@ -539,11 +547,14 @@ constexpr uint32_t kCellsPerDim = 256 >> kCellShift;           // 32
 constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 32768
 
 // ---- k_hdecode.hip: parallel Huffman decode (self-synchronising subsequences), keys -> pixels, FromDiff as a scan ----
-struct TrieNode;
-int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t *payload, uint64_t payload_bytes, uint64_t nsyms,
-                    uint32_t *keys_d, int *status);  // status: 0 ok, 1 stream ends early, 2 did not settle (decode on the host)
+struct LeafTable;
+// payload in host memory, or (payload_dev) anywhere in HBM; mode 0: out_d = nsyms packed keys (u32, 16-byte aligned), mode 1: nsyms RGB
+// triples (4-byte aligned).  status: 0 ok, 1 stream ends early, 2 did not settle (decode on the host)
+int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
+                    int mode, void *out_d, int *status);
 int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d);
 int delta_undiff_dev(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *lin_d, uint32_t *bad_h);
+int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h);  // + the walk along the scan
 
 // ---- k_rle.hip: exact run-length coding of a linearised image (hilbertc.rs:100-196) ----
 struct RlePlan { uint64_t n = 0, nruns = 0; uint32_t nchunks = 0; DevBuf flags, run_off; };
@@ -557,6 +568,7 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
 // gather + delta; syms_d (packed SIGNED keys, may be null) and/or histogram into table_d (u32[2^27], may be null)
 int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t *syms_d, uint32_t *table_d);
 int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d);
+int hilbert_undiff_scatter(Ctx *c, const uint32_t *keys_d, const int32_t *chunk_off_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_d, bool *fused);
 
 // ---- k_delta.hip: the `delta` encoder's passes over a 16-bit symbol stream ----
 constexpr uint32_t kPageShift = 12;  // a page of a dense table = the 4096 entries one block of the compaction reads

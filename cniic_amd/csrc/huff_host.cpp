@@ -290,6 +290,40 @@ bool huff_parse_trie(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64
     return true;
 }
 
+// Dec::deserialize again, keeping only what a table-driven decoder needs: the leaves in pre-order with their paths.  The parse
+// IS a depth-first walk, so path and depth are at hand when a leaf is met; pending right children wait on a stack.
+// Returns false exactly where huff_parse_trie does (truncated, a tag other than 0 / 1, a malformed symbol).
+bool huff_parse_leaves(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, LeafTable &t) {
+    t.code.clear(); t.key.clear(); t.len.clear();
+    t.max_len = 0; t.min_len = 0xffffffffu; t.too_deep = false;
+    struct Pend { uint64_t code; uint32_t depth; };
+    std::vector<Pend> stack;
+    const uint64_t pos0 = pos;
+    uint64_t code = 0;
+    uint32_t depth = 0;
+    for (;;) {
+        if (pos >= nbytes) return false;
+        const uint8_t tag = bytes[pos++];
+        if (tag == 1) {
+            if (depth >= kLeafMaxLen) { t.too_deep = true; pos = pos0; return true; }  // the caller parses nodes instead (huff_parse_trie)
+            stack.push_back({code | (1ull << (63 - depth)), depth + 1});  // right child: this path + a 1
+            depth++;                                                      // left child: this path + a 0
+        } else if (tag == 0) {
+            uint32_t key;
+            if (!get_symbol(bytes, nbytes, pos, sym_kind, key)) return false;
+            if (t.code.size() >= 0xfffffff0ull) return false;
+            t.code.push_back(code); t.key.push_back(key); t.len.push_back((uint8_t)depth);
+            t.max_len = std::max(t.max_len, depth); t.min_len = std::min(t.min_len, depth);
+            if (stack.empty()) break;
+            code = stack.back().code; depth = stack.back().depth;
+            stack.pop_back();
+        } else {
+            return false;  // huf.rs:343-345
+        }
+    }
+    return true;
+}
+
 // bit_reader MsbFirst (bit.rs:256-259) + BinTrie::lookup (huf.rs:187-206).  The walk is the reference's, taken
 // kLut bits at a time: lut[prefix] = the node reached from the root by those bits and how many of them were
 // used (a leaf may be reached early); a symbol longer than kLut bits goes on bit by bit from that node.

@@ -44,6 +44,23 @@ bool huff_parse_trie(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64
 bool huff_decode_host(const std::vector<TrieNode> &nodes, const uint8_t *payload, uint64_t payload_bytes, uint64_t nsyms,
                       uint32_t *keys_out, uint64_t *bytes_used);
 
+// The same deserialisation as a table of LEAVES in pre-order, which is ascending order of their codes read as left-aligned
+// binary fractions (a left child comes before its right sibling): code[i] = leaf i's path from the root in the TOP bits of a
+// u64 (left = 0, right = 1), len[i] its depth, key[i] its symbol.  That table is all a decoder needs -- the symbol at a bit
+// position is the last leaf whose code is <= the next 64 bits -- and the parallel decoder (k_hdecode.hip) searches it instead
+// of walking nodes.  too_deep: some leaf lies deeper than kLeafMaxLen (no encoder of fewer than 2^32 symbols makes one; such
+// a stream is decoded by the node walk instead).
+constexpr uint32_t kLeafMaxLen = 56;
+struct LeafTable {
+    std::vector<uint64_t> code;
+    std::vector<uint32_t> key;
+    std::vector<uint8_t> len;
+    uint32_t max_len = 0, min_len = 0;
+    bool too_deep = false;
+    uint64_t n() const { return code.size(); }
+};
+bool huff_parse_leaves(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, LeafTable &t);
+
 // Dec::deserialize + DecStream (huf.rs:323-348, 187-206, 366-374): read the trie at bytes[pos..],
 // then decode nsyms symbols into keys_out.  Returns false where the reference yields None.
 bool huff_decode_symbols(int sym_kind, const uint8_t *bytes, uint64_t nbytes, uint64_t &pos, uint64_t nsyms,

@@ -4,15 +4,23 @@
 // The stream has no markers, so where a symbol starts is only known by decoding everything before it.  Huffman
 // codes resynchronise: a decoder started at a wrong bit position falls into step with the true symbol
 // boundaries after a few symbols.  The payload is cut into subsequences of kHdSub bits, one per thread:
-//   pass 0      every thread decodes from the first bit of its subsequence (a guess, exact only for thread 0)
-//               to the first symbol boundary at or past its end, and reports that boundary and how many
-//               symbols started inside
-//   pass r > 0  thread t restarts from the boundary thread t-1 reported in pass r-1
-//   until no boundary changes.  Thread 0 is exact from the start and exactness moves at least one thread per
-//   pass, so an unchanged pass is the exact chain from bit 0; resynchronisation makes that 2-4 passes instead of
-//   one per thread.  Codes that refuse to settle within kHdMaxPasses fall back to the host decoder.
+//   pass 0      every thread starts kHdWarm bits BEFORE its subsequence (a guess; exact for thread 0), decodes up to the
+//               first symbol boundary inside it -- by then it has almost always fallen into step -- and notes that boundary
+//               (start[t]); then on to the first boundary at or past the subsequence's end (end[t]), counting the symbols
+//               that start in between
+//   pass r > 0  thread t compares the boundary thread t-1 reported (end[t-1]) with the start it assumed: equal -> nothing
+//               to do; different -> it decodes again from end[t-1]
+//   until a pass changes nothing.  Thread 0 is exact from the start, and a thread whose start equals its predecessor's
+//   end is exact if the predecessor is, so an unchanged pass is the exact chain from bit 0.  With the warm-up the first
+//   check already finds every thread in step on ordinary streams: 1.25 decodes of the payload instead of one per pass.
 //   Then: exclusive scan of the symbol counts -> every thread decodes once more and writes its symbols.
-// The walk itself is the reference's trie walk, kHdLut bits at a time through a table held in LDS.
+// Round 3: the walk is no longer the reference's node-by-node trie walk (one dependent random read per bit beyond the
+// first twelve: 6 ms per pass over a 6.8 M-leaf code).  The decoder is the table of leaves in pre-order = ascending code
+// order (huff_parse_leaves): the symbol at a bit position is the LAST leaf whose left-aligned code is <= the next 64 bits.
+// A 12-bit table in LDS answers directly when one leaf covers the whole prefix (every code of up to 12 bits), else with
+// the range of leaves to search; codes longer than that go through a second table on the top 20 bits (in L2) and a
+// binary search over a handful of neighbouring leaves.  The block's stretch of the stream is staged in LDS, byte-swapped
+// once, so a symbol costs two or three LDS reads and a shift.  Same symbols as the walk, bit for bit (tests).
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "huff_host.hpp"
@@ -20,107 +28,242 @@
 namespace cniic {
 
 constexpr int kHdLut = 12;
-constexpr uint32_t kHdSub = 1024;       // bits per thread
+constexpr uint32_t kHdSub = 512;        // bits per thread: short enough that a 4096^2 image fills the machine (2.6 x 10^5 threads for 16 MB)
+constexpr uint32_t kHdWarm = 128;       // bits of warm-up before the subsequence (a multiple of 32)
 constexpr int kHdThreads = 256;
 constexpr int kHdMaxPasses = 48;
-constexpr uint32_t kHdLeaf = 0xffffffffu;
+constexpr uint32_t kHdDirect = 0x80000000u;   // second-table entry: x = symbol key, y = kHdDirect | length; else x = first leaf, y = leaves after it
+constexpr uint32_t kHdTail = 4;               // words staged past the block's last subsequence (a symbol may run kLeafMaxLen bits over)
+constexpr uint32_t kHdStageWords = kHdThreads * (kHdSub / 32) + kHdWarm / 32 + kHdTail;
+// first table (LDS, 4 bytes an entry -- an 8-byte entry per lane is two LDS passes and twice the footprint): a code of up to
+// kHdLut bits answers key << 5 | length << 1 | 1 (keys have at most 27 bits); anything longer answers 0 and goes to the second table
+constexpr size_t kHdLds = (4u << kHdLut) + kHdStageWords * 4;   // 16 KiB + 16.5 KiB: four blocks per CU
 
-// n <= 32 bits starting at bit `at` of an MSB-first stream held as words (zero padded past the end)
-__device__ __forceinline__ uint32_t hd_peek(const uint32_t *__restrict__ w, uint64_t at, int n) {
-    const uint64_t i = at >> 5;
-    const uint64_t v = ((uint64_t)__builtin_bswap32(w[i]) << 32) | __builtin_bswap32(w[i + 1]);
-    return (uint32_t)((v << (at & 31)) >> (64 - n));
+struct HdTables {
+    const uint64_t *code;   // [n] left-aligned codes, ascending
+    const uint32_t *key;    // [n]
+    const uint8_t *len;     // [n]
+    const uint32_t *lut1;   // [1 << kHdLut]
+    const uint2 *lut2;      // [1 << bits2], or null when no code is longer than kHdLut bits
+    uint32_t bits2;
+    uint32_t n;
+};
+
+// the stream as the decoder sees it: 32-bit words from a 4-byte aligned address; the payload's first bit is bit `bit0`
+// of that word sequence and its last one bit `nbits` - 1 (positions below are in that frame)
+struct HdStream {
+    const uint32_t *w;
+    uint64_t nwords;   // words that may be read
+    uint64_t bit0, nbits;
+};
+
+// table entries for the `bits` top bits p: all 64-bit windows that begin with p lie between base and top
+__global__ void k_hd_build_lut(const uint64_t *__restrict__ code, const uint32_t *__restrict__ key, const uint8_t *__restrict__ len, uint32_t n,
+                               uint32_t bits, uint32_t *__restrict__ lut1, uint2 *__restrict__ lut2) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (1u << bits)) return;
+    const uint64_t base = (uint64_t)p << (64 - bits), top = base | ((1ull << (64 - bits)) - 1ull);
+    auto last_le = [&](uint64_t v) -> uint32_t {  // largest i with code[i] <= v (code[0] = 0: exists)
+        uint32_t a = 0, b = n;                    // invariant: code[a] <= v, (b == n or code[b] > v)
+        while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (code[m] <= v) a = m; else b = m; }
+        return a;
+    };
+    const uint32_t lo = last_le(base), hi = last_le(top);
+    if (lut1) lut1[p] = lo == hi ? (key[lo] << 5) | ((uint32_t)len[lo] << 1) | 1u : 0u;
+    else lut2[p] = lo == hi ? make_uint2(key[lo], kHdDirect | len[lo]) : make_uint2(lo, hi - lo);
 }
 
-// one symbol from bit `at`: false when the stream ends inside it (DecStream yields None)
-__device__ __forceinline__ bool hd_symbol(const uint32_t *__restrict__ w, uint64_t nbits, const uint2 *__restrict__ nodes,
-                                          const uint2 *lut, uint64_t &at, uint32_t &key) {
-    if (at >= nbits) return false;
-    const uint2 hop = lut[hd_peek(w, at, kHdLut)];
-    uint64_t p = at + hop.y;
-    if (p > nbits) return false;
-    uint2 node = nodes[hop.x];
-    while (node.x != kHdLeaf) {
-        if (p >= nbits) return false;
-        node = nodes[hd_peek(w, p, 1) ? node.y : node.x];
-        p++;
+struct HdSym { uint32_t key, len; };
+
+// the leaf of the 64-bit window `win` (its top 33 bits are stream bits, or all of it when WIDE)
+template <bool KEY>
+__device__ __forceinline__ HdSym hd_lookup(const HdTables &T, const uint32_t *lut_s, uint64_t win) {
+    const uint32_t e1 = lut_s[win >> (64 - kHdLut)];
+    if (e1) return HdSym{e1 >> 5, (e1 >> 1) & 15u};
+    const uint2 e = T.lut2[win >> (64 - T.bits2)];   // (a code longer than kHdLut bits exists, so the second table does)
+    if (e.y & kHdDirect) return HdSym{e.x, e.y & 0xffu};
+    uint32_t a = e.x, b = e.x + e.y + 1;  // code[a] <= win; the answer is in [a, b)
+    while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (T.code[m] <= win) a = m; else b = m; }
+    return HdSym{KEY ? T.key[a] : 0u, (uint32_t)T.len[a]};
+}
+
+// Block prologue: the first table and the block's stretch of the stream into LDS (stage[i] = word i of the stretch, MSB-first).
+// Returns the bit position (stream frame) of stage word 0.
+__device__ __forceinline__ uint64_t hd_stage(const HdStream &S, const uint32_t *__restrict__ lut_g, uint32_t *lut_s, uint32_t *stage) {
+    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut_s[i] = lut_g[i];
+    const uint64_t blk_bit = (uint64_t)blockIdx.x * kHdThreads * kHdSub;
+    const int64_t w0 = (int64_t)(blk_bit / 32) - (int64_t)(kHdWarm / 32);   // negative for block 0: those words read as zero
+    for (uint32_t i = threadIdx.x; i < kHdStageWords; i += kHdThreads) {
+        const int64_t wi = w0 + i;
+        stage[i] = (wi >= 0 && (uint64_t)wi < S.nwords) ? __builtin_bswap32(S.w[wi]) : 0u;
     }
-    key = node.y;
-    at = p;
-    return true;
-}
-
-__global__ __launch_bounds__(kHdThreads) void k_hd_pass(const uint32_t *__restrict__ w, uint64_t nbits, const uint2 *__restrict__ nodes,
-                                                        const uint2 *__restrict__ lut_g, uint64_t nsub,
-                                                        const uint64_t *__restrict__ end_prev /* null: pass 0 */,
-                                                        const uint64_t *__restrict__ end_prev2 /* the pass before that; null: passes 0, 1 */,
-                                                        uint64_t *__restrict__ end_out, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ changed) {
-    __shared__ uint2 lut[1 << kHdLut];
-    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut[i] = lut_g[i];
     __syncthreads();
+    return (uint64_t)(w0 * 32);  // (two's complement: position - base stays right for block 0)
+}
+
+// A thread's view of the staged stream: the next bits left-aligned in a register, topped up a word at a time -- one LDS read per
+// 32 bits consumed instead of two or three per symbol.  WIDE (codes of more than 32 bits): the window is rebuilt from three
+// words for every symbol, all 64 bits valid.
+template <bool WIDE>
+struct HdBits {
+    const uint32_t *stage;
+    uint64_t buf;      // !WIDE: bits from position `at`, the top nb of them valid
+    uint32_t nb, wi;
+    uint32_t rel;      // WIDE: at - base
+    __device__ __forceinline__ void seek(const uint32_t *st, uint32_t r) {
+        stage = st;
+        if (WIDE) { rel = r; return; }
+        const uint32_t i = r >> 5, s = r & 31;
+        buf = (((uint64_t)stage[i] << 32) | stage[i + 1]) << s;
+        nb = 64 - s;
+        wi = i + 2;
+    }
+    __device__ __forceinline__ uint64_t window() {
+        if (WIDE) {
+            const uint32_t i = rel >> 5, s = rel & 31;
+            const uint64_t hi = ((uint64_t)stage[i] << 32) | stage[i + 1];
+            return s ? (hi << s) | (stage[i + 2] >> (32 - s)) : hi;
+        }
+        if (nb < 33) { buf |= (uint64_t)stage[wi++] << (32 - nb); nb += 32; }
+        return buf;
+    }
+    __device__ __forceinline__ void skip(uint32_t len) {
+        if (WIDE) { rel += len; return; }
+        buf <<= len;
+        nb -= len;
+    }
+};
+
+// decode from `at` until the first symbol boundary at or past `until`; cnt (COUNT) = the symbols met on the way.
+// A symbol that would end past the stream's last bit ends the walk there (at = nbits): DecStream yields None.
+template <bool WIDE, bool COUNT>
+__device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s, const uint32_t *stage, uint64_t base, uint64_t nbits,
+                                       uint64_t &at, uint64_t until, uint32_t &cnt) {
+    if (at >= until) return;
+    HdBits<WIDE> B;
+    B.seek(stage, (uint32_t)(at - base));
+    while (at < until) {
+        if (at >= nbits) { at = nbits; return; }
+        const HdSym sy = hd_lookup<false>(T, lut_s, B.window());
+        if (at + sy.len > nbits) { at = nbits; return; }
+        if (COUNT) cnt++;
+        at += sy.len;
+        B.skip(sy.len);
+    }
+}
+
+// pass 0 (end_prev == null) and the checking passes
+template <bool WIDE>
+__global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
+                                                        uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
+                                                        uint32_t *__restrict__ changed) {
+    extern __shared__ __align__(16) uint32_t hd_lds[];
+    uint32_t *lut_s = hd_lds;
+    uint32_t *stage = hd_lds + (1u << kHdLut);
+    static_assert(kHdSub - kHdWarm >= 32, "a warm-up never starts before the stream's first bit");
     const uint64_t t = (uint64_t)blockIdx.x * kHdThreads + threadIdx.x;
-    if (t >= nsub) return;
-    const uint64_t lo = t * kHdSub, hi = min(lo + kHdSub, nbits);
-    uint64_t at = !end_prev ? lo : (t ? end_prev[t - 1] : 0);
-    // a thread whose start did not move since the pass before ends where it ended then (and counted what it counted): from
-    // the third pass on only the few subsequences still out of step decode again (every pass decoding everything made ten
-    // passes over a 6.8 M-leaf code cost 63 ms)
-    if (end_prev) {
-        const uint64_t before = end_prev2 ? (t ? end_prev2[t - 1] : 0) : lo;
-        if (before == at) { end_out[t] = end_prev[t]; return; }
+    const uint64_t lo = max(t * kHdSub, S.bit0), hi = min((t + 1) * kHdSub, S.nbits);
+    uint32_t cnt = 0;
+    if (!end_prev) {
+        const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
+        if (t >= nsub) return;
+        uint64_t at = S.bit0;
+        if (t) {       // warm-up: from kHdWarm bits before the subsequence to the first boundary inside it
+            at = t * kHdSub - kHdWarm;
+            uint32_t dummy = 0;
+            hd_run<WIDE, false>(T, lut_s, stage, base, S.nbits, at, lo, dummy);
+        }
+        start[t] = at;
+        hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, cnt);
+        end_out[t] = at;
+        count[t] = cnt;
+        return;
     }
-    uint32_t cnt = 0, key;
-    while (at < hi) {
-        if (!hd_symbol(w, nbits, nodes, lut, at, key)) { at = nbits; break; }  // nothing decodable from here on
-        cnt++;
+    // a check: who is out of step with the thread before?  Nobody, as a rule -- then the block is done without staging anything
+    uint64_t s = 0;
+    bool redo = false;
+    if (t < nsub) {
+        s = t ? end_prev[t - 1] : S.bit0;
+        redo = s != start[t];
+        if (!redo) end_out[t] = end_prev[t];   // in step with the thread before: what it found stands
     }
-    if (end_prev && end_prev[t] != at) *changed = 1u;
+    if (!__syncthreads_or(redo)) return;
+    const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
+    if (!redo) return;
+    uint64_t at = s;
+    hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, cnt);
+    start[t] = s;
     end_out[t] = at;
     count[t] = cnt;
+    // Only a moved END matters to anybody else.  If no end moves in a pass, every thread's start equals its predecessor's
+    // end (it was equal, or has just been set to it) and the chain from the first bit is exact.
+    if (at != end_prev[t]) *changed = 1u;
 }
 
-// single block: off[t] = symbols before subsequence t; *total = all symbols
-__global__ __launch_bounds__(1024) void k_hd_offsets(const uint32_t *__restrict__ count, uint64_t nsub, uint64_t *__restrict__ off,
-                                                     uint64_t *__restrict__ total) {
-    __shared__ uint64_t sh[1024];
-    const uint64_t per = (nsub + 1023) / 1024;
-    const uint64_t lo = threadIdx.x * per, hi = min(lo + per, nsub);
-    uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; i++) s += count[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint64_t v = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint64_t run = sh[threadIdx.x] - s;
-    for (uint64_t i = lo; i < hi; i++) { off[i] = run; run += count[i]; }
-    if (threadIdx.x == 1023) *total = sh[1023];
-}
-
-__global__ __launch_bounds__(kHdThreads) void k_hd_write(const uint32_t *__restrict__ w, uint64_t nbits, const uint2 *__restrict__ nodes,
-                                                         const uint2 *__restrict__ lut_g, uint64_t nsub, const uint64_t *__restrict__ end,
-                                                         const uint64_t *__restrict__ off, uint64_t nsyms, uint32_t *__restrict__ keys) {
-    __shared__ uint2 lut[1 << kHdLut];
-    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut[i] = lut_g[i];
-    __syncthreads();
+// every thread decodes its symbols once more and writes them: MODE 0 = packed keys (u32 each), 1 = RGB bytes (3 each).
+// Four symbols leave together (16 / 12 bytes at an aligned address) where the symbol index allows: a store per symbol is one
+// L2 request per lane, 16.7 M of them at 4096^2.
+template <bool WIDE, int MODE>
+__global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ start,
+                                                         const uint64_t *__restrict__ off, uint64_t nsyms, void *__restrict__ out) {
+    extern __shared__ __align__(16) uint32_t hd_lds[];
+    uint32_t *lut_s = hd_lds;
+    uint32_t *stage = hd_lds + (1u << kHdLut);
+    const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
     const uint64_t t = (uint64_t)blockIdx.x * kHdThreads + threadIdx.x;
     if (t >= nsub) return;
-    const uint64_t hi = min((t + 1) * kHdSub, nbits);
-    uint64_t at = t ? end[t - 1] : 0, idx = off[t];
-    uint32_t key;
-    while (at < hi && idx < nsyms) {  // the reference reads exactly nsyms symbols; what the padding decodes to is dropped
-        if (!hd_symbol(w, nbits, nodes, lut, at, key)) break;
-        keys[idx++] = key;
+    const uint64_t hi = min((t + 1) * kHdSub, S.nbits);
+    uint64_t at = start[t], idx = off[t], widx = idx;   // idx: next symbol to be stored, widx: next to be decoded
+    if (at >= hi) return;
+    uint32_t *keys = static_cast<uint32_t *>(out);
+    uint8_t *rgb = static_cast<uint8_t *>(out);
+    HdBits<WIDE> B;
+    B.seek(stage, (uint32_t)(at - base));
+    auto next = [&](uint32_t &key) -> bool {   // the reference reads exactly nsyms symbols; what the padding decodes to is dropped
+        if (at >= hi || widx >= nsyms) return false;
+        const HdSym sy = hd_lookup<true>(T, lut_s, B.window());
+        if (at + sy.len > S.nbits) { at = hi; return false; }
+        at += sy.len;
+        B.skip(sy.len);
+        widx++;
+        key = sy.key;
+        return true;
+    };
+    auto put1 = [&](uint32_t key) {
+        if (MODE == 0) keys[idx] = key;
+        else { rgb[3 * idx] = (uint8_t)(key >> 16); rgb[3 * idx + 1] = (uint8_t)(key >> 8); rgb[3 * idx + 2] = (uint8_t)key; }
+        idx++;
+    };
+    uint32_t k0, k1, k2, k3;
+    while ((idx & 3) && next(k0)) put1(k0);
+    for (;;) {
+        if (!next(k0)) break;
+        if (!next(k1)) { put1(k0); break; }
+        if (!next(k2)) { put1(k0); put1(k1); break; }
+        if (!next(k3)) { put1(k0); put1(k1); put1(k2); break; }
+        // (next() advanced `at` and widx only: idx is still the first of the four)
+        if (MODE == 0) {
+            *reinterpret_cast<uint4 *>(keys + idx) = make_uint4(k0, k1, k2, k3);
+        } else {  // r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3, little-endian words
+            uint32_t *dst = reinterpret_cast<uint32_t *>(rgb + 3 * idx);
+            const uint32_t w0 = ((k0 >> 16) & 255) | (((k0 >> 8) & 255) << 8) | ((k0 & 255) << 16) | (((k1 >> 16) & 255) << 24);
+            const uint32_t w1 = ((k1 >> 8) & 255) | ((k1 & 255) << 8) | (((k2 >> 16) & 255) << 16) | (((k2 >> 8) & 255) << 24);
+            const uint32_t w2 = (k2 & 255) | (((k3 >> 16) & 255) << 8) | (((k3 >> 8) & 255) << 16) | ((k3 & 255) << 24);
+            dst[0] = w0; dst[1] = w1; dst[2] = w2;
+        }
+        idx += 4;
     }
 }
 
 __global__ void k_hd_fill(uint32_t *__restrict__ keys, uint64_t n, uint32_t key) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keys[i] = key;
+}
+__global__ void k_hd_fill_rgb(uint8_t *__restrict__ rgb, uint64_t n, uint32_t key) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        rgb[3 * i] = (uint8_t)(key >> 16); rgb[3 * i + 1] = (uint8_t)(key >> 8); rgb[3 * i + 2] = (uint8_t)key;
+    }
 }
 
 // packed RGB keys -> interleaved bytes
@@ -132,77 +275,130 @@ __global__ void k_keys_to_rgb(const uint32_t *__restrict__ keys, uint64_t n, uin
     }
 }
 
-// nodes_h: (l, r) per node, leaves as (kHdLeaf, key); payload: host bytes.  keys_d receives nsyms symbols.
+// lt: the decoder as a table of leaves (huff_parse_leaves; not too_deep).  payload: the bit stream, in HOST memory or -- payload_dev
+// -- anywhere in HBM (any alignment: it is read as words from the 4-byte boundary below it).  mode 0: out_d receives nsyms packed
+// keys (u32, 16-byte aligned); mode 1: nsyms RGB triples (u8, 4-byte aligned).
 // *status: 0 = decoded, 1 = the stream ends early (None), 2 = did not settle (caller decodes on the host)
-int huff_decode_dev(Ctx *c, const std::vector<TrieNode> &nodes_h, const uint8_t *payload, uint64_t payload_bytes, uint64_t nsyms,
-                    uint32_t *keys_d, int *status) {
+int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
+                    int mode, void *out_d, int *status) {
     *status = 0;
     if (nsyms == 0) return CNIIC_OK;
-    static_assert(sizeof(TrieNode) == sizeof(uint2) && kTrieLeaf == kHdLeaf, "TrieNode is copied to the device as uint2");
-    if (nodes_h[0].l == kHdLeaf) {  // one symbol, zero-length code, no payload (huf.rs:140-142)
-        hipLaunchKernelGGL(k_hd_fill, dim3(1024), dim3(256), 0, c->stream, keys_d, nsyms, nodes_h[0].r);
+    const uint64_t n = lt.n();
+    if (n == 0 || lt.too_deep) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
+    if (n == 1) {  // one symbol, zero-length code, no payload (huf.rs:140-142)
+        if (mode == 0) hipLaunchKernelGGL(k_hd_fill, dim3(1024), dim3(256), 0, c->stream, static_cast<uint32_t *>(out_d), nsyms, lt.key[0]);
+        else hipLaunchKernelGGL(k_hd_fill_rgb, dim3(1024), dim3(256), 0, c->stream, static_cast<uint8_t *>(out_d), nsyms, lt.key[0]);
         CNIIC_HIP_TRY(c, hipGetLastError());
         return CNIIC_OK;
     }
-    const uint64_t nbits = payload_bytes * 8;
-    if (nbits == 0) { *status = 1; return CNIIC_OK; }
-    // the reference's walk, kHdLut bits at a time: node reached from the root and bits used
-    std::vector<uint2> lut(1u << kHdLut);
-    for (uint32_t pre = 0; pre < (1u << kHdLut); pre++) {
-        uint32_t nd = 0, used = 0;
-        while (used < (uint32_t)kHdLut && nodes_h[nd].l != kHdLeaf) {
-            nd = ((pre >> (kHdLut - 1 - used)) & 1) ? nodes_h[nd].r : nodes_h[nd].l;
-            used++;
-        }
-        lut[pre] = make_uint2(nd, used);
+    if (payload_bytes == 0) { *status = 1; return CNIIC_OK; }
+    if ((reinterpret_cast<uintptr_t>(out_d) & (mode == 0 ? 15u : 3u)) != 0) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: misaligned output");
+    // ---- the stream as aligned words
+    DevBuf w_d;
+    HdStream S{};
+    if (payload_dev) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(payload);
+        S.w = reinterpret_cast<const uint32_t *>(a & ~uintptr_t(3));
+        S.bit0 = (a & 3) * 8;
+    } else {
+        CNIIC_HIP_TRY(c, w_d.alloc((payload_bytes + 3) & ~3ull));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(w_d.p, payload, payload_bytes, hipMemcpyHostToDevice, c->stream));
+        S.w = w_d.as<uint32_t>();
+        S.bit0 = 0;
     }
-    const uint64_t nsub = ceil_div(nbits, kHdSub);
-    const uint64_t words = ceil_div(payload_bytes, 4) + 4;  // zero padding: hd_peek reads one word ahead
-    DevBuf w_d, nodes_d, lut_d, end_a, end_b, end_c, count, off, tot, changed;
-    CNIIC_HIP_TRY(c, w_d.alloc(words * 4));
-    CNIIC_HIP_TRY(c, nodes_d.alloc(nodes_h.size() * 8));
-    CNIIC_HIP_TRY(c, lut_d.alloc(lut.size() * 8));
+    S.nbits = S.bit0 + payload_bytes * 8;
+    S.nwords = ceil_div(S.nbits, 32);
+    // ---- the tables
+    const uint32_t bits2 = lt.max_len > (uint32_t)kHdLut ? std::min<uint32_t>(lt.max_len, 20u) : 0u;
+    DevBuf code_d, key_d, len_d, lut1_d, lut2_d;
+    CNIIC_HIP_TRY(c, code_d.alloc(n * 8));
+    CNIIC_HIP_TRY(c, key_d.alloc(n * 4));
+    CNIIC_HIP_TRY(c, len_d.alloc(n));
+    CNIIC_HIP_TRY(c, lut1_d.alloc((4ull << kHdLut)));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, lt.code.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(key_d.p, lt.key.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, lt.len.data(), n, hipMemcpyHostToDevice, c->stream));
+    HdTables T{code_d.as<uint64_t>(), key_d.as<uint32_t>(), len_d.as<uint8_t>(), lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
+    hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << kHdLut) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, (uint32_t)kHdLut, lut1_d.as<uint32_t>(),
+                       (uint2 *)nullptr);
+    if (bits2) {
+        CNIIC_HIP_TRY(c, lut2_d.alloc(8ull << bits2));
+        hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << bits2) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, bits2, (uint32_t *)nullptr,
+                           lut2_d.as<uint2>());
+        T.lut2 = lut2_d.as<uint2>();
+    }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    // ---- boundaries
+    const uint64_t nsub = ceil_div(S.nbits, kHdSub);
+    if (nsub > 0xffffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: payload too long");
+    DevBuf start_d, end_a, end_b, count, off, tot, changed;
+    CNIIC_HIP_TRY(c, start_d.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, end_a.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, end_b.alloc(nsub * 8));
-    CNIIC_HIP_TRY(c, end_c.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, count.alloc(nsub * 4));
     CNIIC_HIP_TRY(c, off.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, tot.alloc(8));
     CNIIC_HIP_TRY(c, changed.alloc(4));
-    CNIIC_HIP_TRY(c, hipMemsetAsync(static_cast<uint8_t *>(w_d.p) + (words - 5) * 4, 0, 20, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(w_d.p, payload, payload_bytes, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(nodes_d.p, nodes_h.data(), nodes_h.size() * 8, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(lut_d.p, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+    volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4096;   // (slots of this function's own) [0] total symbols, [1] did the last pass move an end?
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
-    uint64_t *bufs[3] = {end_a.as<uint64_t>(), end_b.as<uint64_t>(), end_c.as<uint64_t>()};
-    uint64_t *cur = bufs[0], *prev = nullptr, *prev2 = nullptr;
-    bool settled = false;
-    for (int pass = 0; pass < kHdMaxPasses; pass++) {
-        if (prev) CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
-        hipLaunchKernelGGL(k_hd_pass, dim3(grid), dim3(kHdThreads), 0, c->stream, w_d.as<uint32_t>(), nbits, nodes_d.as<uint2>(),
-                           lut_d.as<uint2>(), nsub, (const uint64_t *)prev, (const uint64_t *)prev2, cur, count.as<uint32_t>(), changed.as<uint32_t>());
-        CNIIC_HIP_TRY(c, hipGetLastError());
-        if (prev) {
-            uint32_t ch = 1;
-            CNIIC_HIP_TRY(c, hipMemcpyAsync(&ch, changed.p, 4, hipMemcpyDeviceToHost, c->stream));
-            CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (!ch) { settled = true; break; }
+    const size_t lds = kHdLds;
+    const bool wide = lt.max_len > 32;
+    auto pass = [&](const uint64_t *prev, uint64_t *cur) {
+        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>());
+        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>());
+    };
+    auto write = [&]() -> int {
+        CNIIC_TRY(pack_scan(c, count.as<uint32_t>(), (uint32_t)nsub, off.as<uint64_t>(), tot.as<uint64_t>()));
+        const uint64_t *st = start_d.as<uint64_t>(), *of = off.as<uint64_t>();
+        if (wide) {
+            if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
+            else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
+            else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
         }
-        prev2 = prev;
-        prev = cur;
-        cur = bufs[(pass + 1) % 3];
+        CNIIC_HIP_TRY(c, hipGetLastError());
+        return CNIIC_OK;
+    };
+    auto look = [&]() -> int {   // total and flag to the host
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin), tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin) + 1, changed.p, 4, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return CNIIC_OK;
+    };
+    // Pass 0, one check, and -- taking that check to find everybody in step, as it does on ordinary streams -- offsets and
+    // symbols straight behind it: one look at the result for the whole decode.  A check that did move an end is followed by
+    // further checks, one look each, and the symbols are written again.
+    uint64_t *cur = end_a.as<uint64_t>(), *nxt = end_b.as<uint64_t>();
+    pin[1] = 0;
+    {
+        ScopedKernelTimer t0(c, "hd_pass0");   // (stage timers: CNIIC_OPT_STAGE_TIMERS; they synchronise)
+        pass(nullptr, cur);
+        t0.stop();
+        CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
+        ScopedKernelTimer t1(c, "hd_check");
+        pass(cur, nxt);
+        t1.stop();
+        ScopedKernelTimer t2(c, "hd_write");
+        CNIIC_TRY(write());
+        t2.stop();
     }
-    if (!settled) { *status = 2; CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream)); return CNIIC_OK; }
-    // `cur` holds the settled boundaries (equal to prev's)
-    hipLaunchKernelGGL(k_hd_offsets, dim3(1), dim3(1024), 0, c->stream, count.as<uint32_t>(), nsub, off.as<uint64_t>(), tot.as<uint64_t>());
-    uint64_t total = 0;
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (total < nsyms) { *status = 1; return CNIIC_OK; }
-    hipLaunchKernelGGL(k_hd_write, dim3(grid), dim3(kHdThreads), 0, c->stream, w_d.as<uint32_t>(), nbits, nodes_d.as<uint2>(),
-                       lut_d.as<uint2>(), nsub, (const uint64_t *)cur, off.as<uint64_t>(), nsyms, keys_d);
-    CNIIC_HIP_TRY(c, hipGetLastError());
-    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // the scratch buffers go back to the pool
+    CNIIC_TRY(look());
+    if ((uint32_t)pin[1]) {
+        bool settled = false;
+        for (int r = 2; r < kHdMaxPasses; r++) {
+            std::swap(cur, nxt);
+            CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
+            pass(cur, nxt);
+            CNIIC_TRY(look());
+            if (!(uint32_t)pin[1]) { settled = true; break; }
+        }
+        if (!settled) { *status = 2; return CNIIC_OK; }
+        CNIIC_TRY(write());
+        CNIIC_TRY(look());
+    }
+    if (pin[0] < nsyms) { *status = 1; return CNIIC_OK; }
     return CNIIC_OK;
 }
 
@@ -301,6 +497,44 @@ __global__ __launch_bounds__(kUdThreads) void k_ud_apply(const uint32_t *__restr
         }
     }
     if (oob) *bad = 1u;
+}
+
+// exclusive channel sums of the differences before every chunk of kUdChunk symbols (sums_d: 3 x int32 per chunk)
+int delta_undiff_prefix(Ctx *c, const uint32_t *keys_d, uint64_t n, DevBuf *sums) {
+    const uint64_t nchunks64 = ceil_div(n, kUdChunk);
+    if (nchunks64 > 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "undiff: too many symbols");
+    const uint32_t nchunks = (uint32_t)nchunks64;
+    CNIIC_HIP_TRY(c, sums->alloc((uint64_t)nchunks * 12));
+    hipLaunchKernelGGL(k_ud_sums, dim3(nchunks), dim3(kUdThreads), 0, c->stream, keys_d, n, sums->as<int32_t>());
+    hipLaunchKernelGGL(k_ud_scan, dim3(1), dim3(1024), 0, c->stream, sums->as<int32_t>(), nchunks);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// FromDiff (hilbertc.rs:482-509) and the walk along the scan (hilbertc.rs:426-428): keys_d = the w x h decoded symbols in scan
+// order -> rgb_out_d.  2^n squares: one fused pass by tiles (k_hilbert_move_p2<true, true>); other rectangles: the linearised
+// colours first, then the per-position scatter.  *bad_h != 0: a colour left 0..255 (the reference's unwrap, hilbertc.rs:505).
+int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h) {
+    *bad_h = 0;
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return CNIIC_OK;
+    static_assert(kUdChunk == 4096, "a chunk of the prefix sums is a 64 x 64 tile of the scan");
+    DevBuf sums, bad, lin;
+    CNIIC_HIP_TRY(c, bad.alloc(4));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
+    CNIIC_TRY(delta_undiff_prefix(c, keys_d, n, &sums));
+    bool fused = false;
+    CNIIC_TRY(hilbert_undiff_scatter(c, keys_d, sums.as<int32_t>(), w, h, rgb_out_d, bad.as<uint32_t>(), &fused));
+    if (!fused) {
+        CNIIC_HIP_TRY(c, lin.alloc(n * 3));
+        hipLaunchKernelGGL(k_ud_apply, dim3((uint32_t)ceil_div(n, kUdChunk)), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(),
+                           lin.as<uint8_t>(), bad.as<uint32_t>());
+        CNIIC_HIP_TRY(c, hipGetLastError());
+        CNIIC_TRY(hilbert_scatter(c, lin.as<uint8_t>(), w, h, rgb_out_d));
+    }
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(bad_h, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CNIIC_OK;
 }
 
 // keys_d: n packed SignedColor symbols in scan order -> lin_d: n colours (3 B each); *bad_h != 0: a colour left 0..255

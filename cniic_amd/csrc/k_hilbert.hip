@@ -123,10 +123,17 @@ __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict_
 // (k_delta_gather_p2's scheme): the image side of a tile is read or written as rows of 48-byte pieces, the scan side as
 // 48-byte pieces of 16 positions, and the permutation happens in LDS -- one word per pixel, stored 8 x 8 block by block
 // (a block is 64 consecutive positions) with the rows of a block XOR-ed so that neither side's accesses pile up on a bank.
-template <bool SCATTER>
+// UNDIFF (with SCATTER): the scan side is not colours but the decoded `delta` symbols (packed SignedColor keys, 4 bytes each),
+// turned into colours on the way -- FromDiff (hilbertc.rs:482-509) as a prefix sum: a tile is 4096 consecutive positions = one
+// chunk of k_ud_sums, whose exclusive channel sums chunk_off holds; a colour outside 0..255 is reported through *bad.  Saves
+// writing and re-reading the linearised image (6 of 17 bytes per pixel) and a launch.
+template <bool SCATTER, bool UNDIFF = false>
 __global__ __launch_bounds__(256) void k_hilbert_move_p2(const uint8_t *__restrict__ src, uint32_t order, const HilbertLut *__restrict__ lut,
-                                                         uint8_t *__restrict__ dst) {
+                                                         uint8_t *__restrict__ dst, const int32_t *__restrict__ chunk_off = nullptr,
+                                                         uint32_t *__restrict__ bad = nullptr) {
+    static_assert(!UNDIFF || SCATTER, "undiff feeds the scatter");
     __shared__ __align__(16) uint32_t s_tile[64 * 64];
+    __shared__ int32_t s_wsum[3][4];
     __shared__ uint16_t s_l4[1024];
     __shared__ uint8_t s_l1[16];
     __shared__ uint8_t s_l3[4 * 64];  // three levels from state s for six bits q: x:3 | y:3 << 3 | end state << 6
@@ -164,10 +171,28 @@ __global__ __launch_bounds__(256) void k_hilbert_move_p2(const uint8_t *__restri
         }
         // the image side: row `row` of the tile, pixels 16 seg ..; the scan side: positions 16 t .. of the tile
         uint8_t *const img_piece = const_cast<uint8_t *>(SCATTER ? dst : src) + ((uint64_t)((ty << 6) + row) * w + (tx << 6) + seg * 16) * 3;
-        uint8_t *const lin_piece = const_cast<uint8_t *>(SCATTER ? src : dst) + ((uint64_t)tile * 4096 + threadIdx.x * 16) * 3;
+        uint8_t *const lin_piece = const_cast<uint8_t *>(SCATTER ? src : dst) + ((uint64_t)tile * 4096 + threadIdx.x * 16) * (UNDIFF ? 4 : 3);
         const uint4 *in = reinterpret_cast<const uint4 *>(SCATTER ? lin_piece : img_piece);
         const uint4 q0 = in[0], q1 = in[1], q2 = in[2];
         const uint32_t q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        uint32_t kq[4] = {0, 0, 0, 0};
+        int32_t run[3] = {0, 0, 0};
+        if (UNDIFF) {  // 16 symbols: three words more; this thread's channel sums, scanned over the block (the tile) below
+            const uint4 q3 = in[3];
+            kq[0] = q3.x; kq[1] = q3.y; kq[2] = q3.z; kq[3] = q3.w;
+            int32_t sm[3] = {0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t key = i < 12 ? q[i] : kq[i - 12];
+                sm[0] += (int32_t)((key >> 18) & 511) - 255; sm[1] += (int32_t)((key >> 9) & 511) - 255; sm[2] += (int32_t)(key & 511) - 255;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const int32_t inc = (int32_t)wave_inclusive_scan((uint32_t)sm[ch]);
+                if ((threadIdx.x & 63) == 63) s_wsum[ch][threadIdx.x >> 6] = inc;
+                run[ch] = inc - sm[ch];
+            }
+        }
         // this thread's 16 positions lie in one block: block number threadIdx.x / 4 of the tile's 64, places 16 (t & 3) ..
         const uint32_t eb = s_l3[st * 64 + (threadIdx.x >> 2)];
         const uint32_t yhi = row >> 3, y3 = row & 7;
@@ -179,6 +204,26 @@ __global__ __launch_bounds__(256) void k_hilbert_move_p2(const uint8_t *__restri
                 *reinterpret_cast<uint4 *>(&s_tile[blk_base(e) + (((y3 << 3) ^ blk_xor(e)) | ((g & 1) << 2))]) = unpack4(q[3 * g], q[3 * g + 1], q[3 * g + 2]);
             }
         } else {
+            if (UNDIFF) {
+                bool oob = false;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    for (uint32_t i = 0; i < (threadIdx.x >> 6); i++) run[ch] += s_wsum[ch][i];
+                    run[ch] += chunk_off[3 * (size_t)tile + ch];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t key = 4 * g + i < 12 ? q[4 * g + i] : kq[4 * g + i - 12];
+                        run[0] += (int32_t)((key >> 18) & 511) - 255; run[1] += (int32_t)((key >> 9) & 511) - 255; run[2] += (int32_t)(key & 511) - 255;
+                        oob |= ((uint32_t)run[0] | (uint32_t)run[1] | (uint32_t)run[2]) > 255u;   // (a negative value has its top bits set)
+                        const uint32_t place = s_l3[(eb >> 6) * 64 + (threadIdx.x & 3) * 16 + 4 * g + i] & 63u;
+                        s_tile[blk_base(eb) + (place ^ blk_xor(eb))] = ((uint32_t)run[0] & 255u) | (((uint32_t)run[1] & 255u) << 8) | (((uint32_t)run[2] & 255u) << 16);
+                    }
+                }
+                if (oob) *bad = 1u;
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const uint4 p4 = unpack4(q[3 * g], q[3 * g + 1], q[3 * g + 2]);
@@ -188,6 +233,7 @@ __global__ __launch_bounds__(256) void k_hilbert_move_p2(const uint8_t *__restri
                     const uint32_t place = s_l3[(eb >> 6) * 64 + (threadIdx.x & 3) * 16 + 4 * g + i] & 63u;
                     s_tile[blk_base(eb) + (place ^ blk_xor(eb))] = p[i];
                 }
+            }
             }
         }
         __syncthreads();
@@ -470,6 +516,24 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     else
         hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// FromDiff + the scatter along the scan in one pass over the decoded symbols (2^n squares from 64 x 64, 16-byte aligned buffers;
+// chunk_off_d: delta_undiff_prefix's exclusive channel sums per 4096 symbols).  *fused = false: not this image -- the caller
+// goes through the linearised colours (delta_undiff_dev + hilbert_scatter).
+int hilbert_undiff_scatter(Ctx *c, const uint32_t *keys_d, const int32_t *chunk_off_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_d,
+                           bool *fused) {
+    *fused = false;
+    CNIIC_TRY(check_dims(c, w, h));
+    const uint64_t n = (uint64_t)w * h;
+    if (!n || !move_by_tiles(w, h, keys_d, rgb_out_d)) return CNIIC_OK;
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(hilbert_lut(c, &lut));
+    hipLaunchKernelGGL((k_hilbert_move_p2<true, true>), dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const uint8_t *>(keys_d), pow2_order(w, h), lut, rgb_out_d, chunk_off_d, bad_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    *fused = true;
     return CNIIC_OK;
 }
 

@@ -54,6 +54,26 @@ int32_t     cniic_sync(cniic_ctx *ctx);
 int32_t     cniic_dev_alloc(cniic_ctx *ctx, uint64_t bytes, void **dptr);
 int32_t     cniic_dev_free(cniic_ctx *ctx, void *dptr);
 int32_t     cniic_memcpy(cniic_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* Route switches and thresholds a host can set per context (a Rust caller has no other way: the CNIIC_* environment variables
+ * named beside them are read per call ONLY while an option is unset, and exist for the test-suite).  value semantics per option;
+ * cniic_ctx_get_opt returns the effective value (set, or the environment's, or the default). */
+#define CNIIC_OPT_SP_MIN_PIXELS      1  /* cluster-colors: images of at least this many pixels take the pixel partition by colour        */
+                                        /* super-cell (k_points.hip), smaller ones the dense 2^24 table.  Default 2^20. CNIIC_SP_MIN_PIXELS */
+#define CNIIC_OPT_HUF_GPU_CODES_MIN  2  /* huf::encode_all: alphabets of at least this many symbols sort their leaves and derive codes  */
+                                        /* and decoder on the GPU (the host only merges).  Default 32768.  CNIIC_HUF_GPU_CODES_MIN        */
+#define CNIIC_OPT_GPU_DECODE_MIN     3  /* decode: streams of at least this many symbols use the parallel decoder, shorter ones the host  */
+                                        /* walk.  Default 16384.  CNIIC_GPU_DECODE_MIN                                                      */
+#define CNIIC_OPT_DELTA_ROUTE        4  /* delta: 0 = 16-bit symbol stream where the image allows (default), 32 = always the 32-bit route. */
+                                        /* CNIIC_DELTA_ROUTE                                                                                */
+#define CNIIC_OPT_STAGE_TIMERS       5  /* 1: HIP-event timers around the stages of every call (they synchronise; read with              */
+                                        /* cniic_last_kernel_time).  Default 0.  CNIIC_KERNEL_TIMERS                                       */
+#define CNIIC_OPT_FRAME_TREES_HOST   6  /* cniic_cc_finish_frames: 1 = the frames' Huffman trees on host threads instead of the GPU.       */
+                                        /* Default 0.  CNIIC_FRAME_TREES_HOST                                                               */
+#define CNIIC_OPT_BATCH_STREAMS      7  /* cniic_codec_encode_batch: images in flight at once (worker streams).  Default 8.               */
+#define CNIIC_OPT_COUNT              8
+int32_t     cniic_ctx_set_opt(cniic_ctx *ctx, int32_t opt, uint64_t value);
+int32_t     cniic_ctx_unset_opt(cniic_ctx *ctx, int32_t opt);
+int32_t     cniic_ctx_get_opt(cniic_ctx *ctx, int32_t opt, uint64_t *value);
 /* dominant-kernel timing of the most recent call on this ctx, measured with HIP events on the
  * ctx stream: *ms = summed duration, *launches = number of launches of that kernel. */
 int32_t     cniic_last_kernel_time(cniic_ctx *ctx, const char *which, double *ms, uint64_t *launches);

@@ -1,0 +1,109 @@
+"""Codec::decode with the stream (and the image) resident in HBM: the payload is decoded where it lies -- at whatever byte
+alignment the serialised decoder leaves it -- and only the head of the stream (dimensions + decoder) visits the host.  Same
+pixels as the host-buffer call and as the oracle; the context options that replace the route environment variables."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import cniic_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield ctx, torch, dev
+    ctx.close()
+
+
+@pytest.mark.parametrize("expr", ["hufman", "delta", "cluster-colors(8)", "ccol(200)", "hilbert(rle)", "voronoi(12)"])
+@pytest.mark.parametrize("shape", [(3, 5), (64, 64), (97, 131), (256, 320)])
+def test_device_resident_decode_equals_oracle(env, expr, shape):
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    h, w = shape
+    img = synth.photo(w, h, synth.SEED0 + 77 + h)
+    rc, data, _ = ctx.encode(expr, img, allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE))
+    if rc != 0:
+        pytest.skip("fewer colours than clusters")
+    rco, exp = O.decode(expr, data)
+    assert rco == 0
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)          # the parallel decoder whatever the size
+    try:
+        for shift in (0, 1, 2, 3):                  # the stream at every byte alignment (the payload's own varies with the decoder's size)
+            buf = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+            buf[shift:shift + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+            out = torch.zeros(h * w * 3 + 16, dtype=torch.uint8, device=dev)
+            rc, dw, dh = ctx.decode_into(expr, buf[shift:], len(data), out)
+            assert rc == 0 and (dw, dh) == (w, h)
+            assert np.array_equal(out[:h * w * 3].cpu().numpy().reshape(h, w, 3), exp), (expr, shape, shift)
+            assert not out[h * w * 3:].any()
+        # a host stream into a device image, and a device stream into a host image
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+        rc, _, _ = ctx.decode_into(expr, np.frombuffer(data, np.uint8), len(data), out)
+        assert rc == 0 and np.array_equal(out.cpu().numpy().reshape(h, w, 3), exp)
+        hout = np.zeros(h * w * 3, np.uint8)
+        rc, _, _ = ctx.decode_into(expr, buf[3:], len(data), hout)
+        assert rc == 0 and np.array_equal(hout.reshape(h, w, 3), exp)
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
+def test_device_resident_truncated_streams_fail_like_the_oracle(env):
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    img = synth.photo(120, 90, synth.SEED0 + 5)
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        for expr in ("hufman", "delta", "cluster-colors(16)"):
+            rc, data, _ = ctx.encode(expr, img)
+            full = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+            out = torch.zeros(120 * 90 * 3, dtype=torch.uint8, device=dev)
+            for cut in (1, 5, 200, len(data) // 2, len(data) - 9, len(data) - 8):
+                rc, _, _ = ctx.decode_into(expr, full, len(data) - cut, out, allow=(_lib.DECODE,))
+                rco, _ = O.decode(expr, data[:len(data) - cut])
+                assert (rc == 0) == (rco == 0), (expr, cut)
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
+def test_decoder_longer_than_the_first_head_fetch(env):
+    """a decoder of more than 64 KiB (the first piece of a device-resident stream the host looks at): the head is fetched further"""
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    img = synth.uniform(300, 200, synth.SEED0 + 9)                     # ~60000 distinct colours: 12 bytes each in the decoder
+    rc, data, _ = ctx.encode("hufman", img)
+    assert len(data) > 300 * 200 * 9
+    out = torch.zeros(300 * 200 * 3, dtype=torch.uint8, device=dev)
+    rc, dw, dh = ctx.decode_into("hufman", torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev), len(data), out)
+    assert rc == 0 and np.array_equal(out.cpu().numpy().reshape(200, 300, 3), img)
+
+
+def test_context_options_replace_the_environment(env, monkeypatch):
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    monkeypatch.delenv("CNIIC_SP_MIN_PIXELS", raising=False)
+    assert ctx.get_opt(_lib.OPT_SP_MIN_PIXELS) == 1 << 20
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", "123")
+    assert ctx.get_opt(_lib.OPT_SP_MIN_PIXELS) == 123                 # unset option: the environment, read per call
+    ctx.set_opt(_lib.OPT_SP_MIN_PIXELS, 0)
+    assert ctx.get_opt(_lib.OPT_SP_MIN_PIXELS) == 0                   # a set option wins
+    img = synth.photo(96, 64, synth.SEED0 + 1)
+    rc, a, _ = ctx.encode("cluster-colors(16)", img)                   # through the pixel partition
+    ctx.set_opt(_lib.OPT_SP_MIN_PIXELS, 1 << 40)
+    rc, b, _ = ctx.encode("cluster-colors(16)", img)                   # through the dense table
+    ctx.set_opt(_lib.OPT_SP_MIN_PIXELS, None)
+    assert ctx.get_opt(_lib.OPT_SP_MIN_PIXELS) == 123
+    rco, e, _ = O.encode("cluster-colors(16)", img, mode=O.MODE_L)
+    assert a == b == e
+    ctx.set_opt(_lib.OPT_DELTA_ROUTE, 32)
+    rc, d32, _ = ctx.encode("delta", img)
+    ctx.set_opt(_lib.OPT_DELTA_ROUTE, None)
+    rc, d16, _ = ctx.encode("delta", img)
+    assert d32 == d16 == O.encode("delta", img)[1]
+    with pytest.raises(Exception):
+        ctx.set_opt(99, 1)
