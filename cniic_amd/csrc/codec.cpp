@@ -994,18 +994,21 @@ static int put_image(Ctx *c, const uint8_t *src, bool src_dev, uint64_t bytes, u
 // dimensions and, for the Huffman codecs, the serialised decoder, which is parsed there (O(alphabet)); the payload is decoded
 // where it lies.  head_h / head_n: the part of the stream the host can read (all of it for a host stream).
 struct StreamHead {
-    std::vector<uint8_t> buf;
     const uint8_t *p = nullptr;
     uint64_t n = 0;
 };
+// the first `want` bytes of the stream where the host can read them: the stream itself, or (device-resident) a copy in the
+// context's pinned block (a pageable landing buffer costs the copy a staging pass and ~40 us)
 static int stream_head(Ctx *c, const uint8_t *bytes, bool bytes_dev, uint64_t nbytes, uint64_t want, StreamHead *h) {
-    if (!bytes_dev) { h->p = bytes; h->n = nbytes; return CNIIC_OK; }
     want = std::min(want, nbytes);
+    // (a host stream is all there, but the decoder is looked for in its head only, like a device stream's: one that does not end
+    // there has hundreds of thousands of leaves and is parsed faster on the GPU than by this core)
+    if (!bytes_dev) { h->p = bytes; h->n = std::max(h->n, want); return CNIIC_OK; }
     if (h->n >= want) return CNIIC_OK;
-    h->buf.resize(want);
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(h->buf.data() + h->n, bytes + h->n, want - h->n, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, ctx_pinned_huf(c, want));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(c->pinned_huf, bytes, want, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    h->p = h->buf.data();
+    h->p = static_cast<const uint8_t *>(c->pinned_huf);
     h->n = want;
     return CNIIC_OK;
 }
@@ -1014,7 +1017,8 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
                  uint32_t *w, uint32_t *h) {
     const bool bytes_dev = is_device_ptr(bytes);
     StreamHead head;
-    CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, 1ull << 16, &head));
+    // (the serialised decoder of a Huffman stream is at most a few per cent of it, for the images these codecs are meant for)
+    CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, std::min<uint64_t>(std::max<uint64_t>(nbytes / 48, 8192), 4ull << 20), &head));
     uint64_t pos = 0;
     if (!get_u32(head.p, head.n, pos, *w) || !get_u32(head.p, head.n, pos, *h))  // create_image_buffer_standard codec.rs:22-26
         return c->fail(CNIIC_ERR_DECODE, "decode: truncated dimensions");
@@ -1036,32 +1040,69 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         // that is fetched further (a failed parse of a TRUNCATED head says nothing: only the whole stream's verdict counts)
         uint64_t tpos = pos;
         bool parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
-        while (!parsed && head.n < nbytes) {
-            CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, head.n * 16, &head));
-            tpos = pos;
-            parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
-        }
-        if (!parsed) return c->fail(CNIIC_ERR_DECODE, bad_stream);
-        host_trace().mark("decode: parse the decoder (host)");
         const bool dst_dev = is_device_ptr(rgb_out);
         int status = 2;
-        DevBuf keys_d, lin_d, img_d;
+        DevBuf keys_d, lin_d, img_d, stream_up, tab_big;
         uint8_t *dst = rgb_out;
-        if (!lt.too_deep) {
-            if (!n) return CNIIC_OK;
-            if (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3)) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
-            if (delta) CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
-            // symbols on the GPU (parallel, self-synchronising), straight from the stream where it lies; small inputs and codes
-            // that do not settle go through the host walk (same answers)
-            if (n >= gpu_decode_min_symbols(c))
-                CNIIC_TRY(huff_decode_dev(c, lt, bytes + tpos, bytes_dev, nbytes - tpos, n, delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+        auto need_image = [&]() -> int {   // where the pixels are produced: the caller's image if it is in HBM and word-aligned
+            if (!img_d.p && (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3))) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+            return CNIIC_OK;
+        };
+        const bool force_gpu_parse = getenv("CNIIC_TEST_TRIE_GPU") != nullptr;   // tests: every decoder through k_trieparse.hip
+        if (force_gpu_parse || (!parsed && head.n < nbytes)) {
+            // The decoder is longer than the head of the stream that was looked at (4 MiB at most): an alphabet of hundreds of
+            // thousands of symbols -- `hufman` on a photograph.  Parsed on the GPU (k_trieparse.hip), from the stream in HBM.
+            bool done_dev = false;
+            if (n >= gpu_decode_min_symbols(c)) {
+                const uint8_t *sd = bytes;
+                if (!bytes_dev) {
+                    CNIIC_HIP_TRY(c, stream_up.alloc(nbytes + 16));
+                    CNIIC_HIP_TRY(c, hipMemcpyAsync(stream_up.p, bytes, nbytes, hipMemcpyHostToDevice, c->stream));
+                    sd = stream_up.as<uint8_t>();
+                }
+                uint64_t nl = 0, off_key = 0, off_len = 0, ppos = 0;
+                uint32_t max_len = 0;
+                int pst = 1;
+                CNIIC_TRY(huff_parse_leaves_dev(c, sym_kind, sd, nbytes, pos, &tab_big, &nl, &off_key, &off_len, &max_len, &ppos, &pst));
+                host_trace().mark("decode: parse the decoder (GPU)");
+                if (pst == 1) return c->fail(CNIIC_ERR_DECODE, bad_stream);
+                if (pst == 0) {
+                    if (!n) return CNIIC_OK;
+                    CNIIC_TRY(need_image());
+                    if (delta) CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
+                    CNIIC_TRY(huff_decode_tables_dev(c, tab_big.as<uint8_t>(), nl, off_key, off_len, max_len, 0u, sd + ppos, true, nbytes - ppos, n,
+                                                     delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+                    done_dev = status != 2;
+                }
+            }
+            if (!done_dev) {  // the host's way: the whole stream there
+                if (bytes_dev) head.n = 0;
+                CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, nbytes, &head));
+                tpos = pos;
+                parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
+                if (!parsed) return c->fail(CNIIC_ERR_DECODE, bad_stream);
+                lt.too_deep = true;   // (whatever was tried on the GPU did not work out: the node walk below)
+            }
+        } else {
+            if (!parsed) return c->fail(CNIIC_ERR_DECODE, bad_stream);
+            host_trace().mark("decode: parse the decoder (host)");
+            if (!lt.too_deep) {
+                if (!n) return CNIIC_OK;
+                CNIIC_TRY(need_image());
+                if (delta) CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
+                // symbols on the GPU (parallel, self-synchronising), straight from the stream where it lies; small inputs and codes
+                // that do not settle go through the host walk (same answers)
+                if (n >= gpu_decode_min_symbols(c))
+                    CNIIC_TRY(huff_decode_dev(c, lt, bytes + tpos, bytes_dev, nbytes - tpos, n, delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+            }
         }
         if (status == 2) {  // the node walk on the host: needs the whole stream there
+            if (bytes_dev) head.n = 0;  // (the pinned block the head was fetched into has served other purposes since: fetch again)
             CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, nbytes, &head));
             std::vector<TrieNode> trie;
             if (!huff_parse_trie(sym_kind, head.p, head.n, pos, trie)) return c->fail(CNIIC_ERR_DECODE, bad_stream);
             if (!n) return CNIIC_OK;
-            if (!img_d.p && (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3))) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
+            CNIIC_TRY(need_image());
             CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
             std::vector<uint32_t> keys(n);
             if (!huff_decode_host(trie, head.p + pos, head.n - pos, n, keys.data(), nullptr)) status = 1;

@@ -32,6 +32,7 @@ constexpr uint32_t kHdSub = 512;        // bits per thread: short enough that a 
 constexpr uint32_t kHdWarm = 128;       // bits of warm-up before the subsequence (a multiple of 32)
 constexpr int kHdThreads = 256;
 constexpr int kHdMaxPasses = 48;
+constexpr int kHdBlindChecks = 2;
 constexpr uint32_t kHdDirect = 0x80000000u;   // second-table entry: x = symbol key, y = kHdDirect | length; else x = first leaf, y = leaves after it
 constexpr uint32_t kHdTail = 4;               // words staged past the block's last subsequence (a symbol may run kLeafMaxLen bits over)
 constexpr uint32_t kHdStageWords = kHdThreads * (kHdSub / 32) + kHdWarm / 32 + kHdTail;
@@ -152,52 +153,100 @@ __device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s,
     }
 }
 
-// pass 0 (end_prev == null) and the checking passes
+// pass 0 (end_prev == null) and the checking passes.
+//
+// How fast a decoder that starts at a wrong bit falls into step depends on the code: the differences of a photograph (14 bits a
+// symbol) need ~300 bits, the near-fixed-length code of 256 equally popular cluster colours far longer -- after a 128-bit
+// warm-up 59 % of the `delta` subsequences are still out of step, and each further 512 bits cures 4 in 5 of them.  A pass per
+// cure (every block staging again, a whole wave decoding for one lane) cost eight checks and seven decodes' worth of time.  So
+// the BLOCK settles itself before it leaves: its threads' ends sit in LDS, whoever starts elsewhere than its predecessor ended
+// goes on a work list, the list is decoded by as many threads as it has entries (dense waves, the stream still staged), and so
+// on until the list is empty.  What remains between launches is the first thread of a block against the block before it.
+constexpr int kHdMaxRounds = 320;   // (a cure moves at least one thread forward for good: 256 rounds settle any block)
 template <bool WIDE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
                                                         uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
                                                         uint32_t *__restrict__ changed) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
+    __shared__ unsigned long long s_end[kHdThreads], s_nstart[kHdThreads], s_nend[kHdThreads];
+    __shared__ uint32_t s_ncnt[kHdThreads];
+    __shared__ uint16_t s_list[kHdThreads];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_pred0;
     uint32_t *lut_s = hd_lds;
     uint32_t *stage = hd_lds + (1u << kHdLut);
     static_assert(kHdSub - kHdWarm >= 32, "a warm-up never starts before the stream's first bit");
-    const uint64_t t = (uint64_t)blockIdx.x * kHdThreads + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kHdThreads, t = t0 + tid;
+    const bool live = t < nsub;
     const uint64_t lo = max(t * kHdSub, S.bit0), hi = min((t + 1) * kHdSub, S.nbits);
-    uint32_t cnt = 0;
+    uint64_t my_start = 0, my_end = 0, base = 0;
+    uint32_t my_cnt = 0;
+    uint64_t pred0 = 0;      // where the thread before the block's first one ended (pass 0: not known yet -- the first thread trusts its warm-up)
     if (!end_prev) {
-        const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
-        if (t >= nsub) return;
-        uint64_t at = S.bit0;
-        if (t) {       // warm-up: from kHdWarm bits before the subsequence to the first boundary inside it
-            at = t * kHdSub - kHdWarm;
-            uint32_t dummy = 0;
-            hd_run<WIDE, false>(T, lut_s, stage, base, S.nbits, at, lo, dummy);
+        base = hd_stage(S, T.lut1, lut_s, stage);
+        if (live) {
+            uint64_t at = S.bit0;
+            if (t) {       // warm-up: from kHdWarm bits before the subsequence to the first boundary inside it
+                at = t * kHdSub - kHdWarm;
+                uint32_t dummy = 0;
+                hd_run<WIDE, false>(T, lut_s, stage, base, S.nbits, at, lo, dummy);
+            }
+            my_start = at;
+            hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, my_cnt);
+            my_end = at;
         }
-        start[t] = at;
-        hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, cnt);
-        end_out[t] = at;
-        count[t] = cnt;
-        return;
+        pred0 = my_start;    // (read by thread 0 only)
+    } else {
+        // a check: who is out of step with the thread before?  Nobody, as a rule -- then the block is done without staging anything
+        bool redo = false;
+        if (live) {
+            const uint64_t s = t ? end_prev[t - 1] : S.bit0;
+            my_start = start[t]; my_end = end_prev[t]; my_cnt = count[t];
+            redo = s != my_start;
+            if (tid == 0) pred0 = s;
+            if (!redo) end_out[t] = my_end;   // in step with the thread before: what it found stands (rewritten below if a cure moves it)
+        }
+        if (changed[2]) {  // measuring runs (CNIIC_HD_STATS): threads out of step / blocks that stage, per check
+            const int nredo = __syncthreads_count(redo);
+            if (tid == 0 && nredo) { atomicAdd(&changed[3], (uint32_t)nredo); atomicAdd(&changed[4], 1u); }
+            if (!nredo) return;
+        } else if (!__syncthreads_or(redo)) return;
+        base = hd_stage(S, T.lut1, lut_s, stage);
     }
-    // a check: who is out of step with the thread before?  Nobody, as a rule -- then the block is done without staging anything
-    uint64_t s = 0;
-    bool redo = false;
-    if (t < nsub) {
-        s = t ? end_prev[t - 1] : S.bit0;
-        redo = s != start[t];
-        if (!redo) end_out[t] = end_prev[t];   // in step with the thread before: what it found stands
+    // ---- the block settles itself
+    s_end[tid] = live ? my_end : ~0ull;
+    if (tid == 0) s_pred0 = pred0;
+    const uint64_t end_at_entry = my_end;
+    for (int round = 0; round < kHdMaxRounds; round++) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();                                   // s_end of the round before is in place
+        const uint64_t pred = tid ? s_end[tid - 1] : s_pred0;
+        const bool redo = live && pred != my_start;
+        if (redo) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)tid;
+        __syncthreads();
+        const uint32_t nl = s_n;
+        if (nl == 0) break;
+        if (tid < nl) {                                    // entry tid of the list: subsequence j again, from where its predecessor ended
+            const uint32_t j = s_list[tid];
+            const uint64_t tj = t0 + j, hj = min((tj + 1) * kHdSub, S.nbits);
+            uint64_t at = j ? s_end[j - 1] : s_pred0;
+            uint32_t cn = 0;
+            s_nstart[j] = at;
+            hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hj, cn);
+            s_nend[j] = at;
+            s_ncnt[j] = cn;
+        }
+        __syncthreads();                                   // every s_end[j - 1] has been read
+        if (redo) { my_start = s_nstart[tid]; my_end = s_nend[tid]; my_cnt = s_ncnt[tid]; s_end[tid] = my_end; }
     }
-    if (!__syncthreads_or(redo)) return;
-    const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
-    if (!redo) return;
-    uint64_t at = s;
-    hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, cnt);
-    start[t] = s;
-    end_out[t] = at;
-    count[t] = cnt;
-    // Only a moved END matters to anybody else.  If no end moves in a pass, every thread's start equals its predecessor's
-    // end (it was equal, or has just been set to it) and the chain from the first bit is exact.
-    if (at != end_prev[t]) *changed = 1u;
+    if (!live) return;
+    start[t] = my_start;
+    end_out[t] = my_end;
+    count[t] = my_cnt;
+    // Only a moved END matters to anybody outside the block.  If no end moves in a pass, every thread's start equals its
+    // predecessor's end and the chain from the first bit is exact.
+    if (end_prev && my_end != end_at_entry) *changed = 1u;
 }
 
 // every thread decodes its symbols once more and writes them: MODE 0 = packed keys (u32 each), 1 = RGB bytes (3 each).
@@ -275,19 +324,20 @@ __global__ void k_keys_to_rgb(const uint32_t *__restrict__ keys, uint64_t n, uin
     }
 }
 
-// lt: the decoder as a table of leaves (huff_parse_leaves; not too_deep).  payload: the bit stream, in HOST memory or -- payload_dev
-// -- anywhere in HBM (any alignment: it is read as words from the 4-byte boundary below it).  mode 0: out_d receives nsyms packed
-// keys (u32, 16-byte aligned); mode 1: nsyms RGB triples (u8, 4-byte aligned).
+struct LeafMeta { uint32_t max_len; };
+
+// The decoder as a table of leaves already in HBM (tab_d: code u64[n] | key u32[n] at off_key | len u8[n] at off_len).
+// payload: the bit stream, in HOST memory or -- payload_dev -- anywhere in HBM (any alignment: it is read as words from the 4-byte
+// boundary below it).  mode 0: out_d receives nsyms packed keys (u32, 16-byte aligned); mode 1: nsyms RGB triples (u8, 4-byte aligned).
 // *status: 0 = decoded, 1 = the stream ends early (None), 2 = did not settle (caller decodes on the host)
-int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
-                    int mode, void *out_d, int *status) {
+int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t off_key, uint64_t off_len, uint32_t max_len, uint32_t first_key,
+                           const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms, int mode, void *out_d, int *status) {
     *status = 0;
     if (nsyms == 0) return CNIIC_OK;
-    const uint64_t n = lt.n();
-    if (n == 0 || lt.too_deep) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
+    if (n == 0 || max_len > kLeafMaxLen) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
     if (n == 1) {  // one symbol, zero-length code, no payload (huf.rs:140-142)
-        if (mode == 0) hipLaunchKernelGGL(k_hd_fill, dim3(1024), dim3(256), 0, c->stream, static_cast<uint32_t *>(out_d), nsyms, lt.key[0]);
-        else hipLaunchKernelGGL(k_hd_fill_rgb, dim3(1024), dim3(256), 0, c->stream, static_cast<uint8_t *>(out_d), nsyms, lt.key[0]);
+        if (mode == 0) hipLaunchKernelGGL(k_hd_fill, dim3(1024), dim3(256), 0, c->stream, static_cast<uint32_t *>(out_d), nsyms, first_key);
+        else hipLaunchKernelGGL(k_hd_fill_rgb, dim3(1024), dim3(256), 0, c->stream, static_cast<uint8_t *>(out_d), nsyms, first_key);
         CNIIC_HIP_TRY(c, hipGetLastError());
         return CNIIC_OK;
     }
@@ -308,17 +358,11 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
     }
     S.nbits = S.bit0 + payload_bytes * 8;
     S.nwords = ceil_div(S.nbits, 32);
-    // ---- the tables
-    const uint32_t bits2 = lt.max_len > (uint32_t)kHdLut ? std::min<uint32_t>(lt.max_len, 20u) : 0u;
-    DevBuf code_d, key_d, len_d, lut1_d, lut2_d;
-    CNIIC_HIP_TRY(c, code_d.alloc(n * 8));
-    CNIIC_HIP_TRY(c, key_d.alloc(n * 4));
-    CNIIC_HIP_TRY(c, len_d.alloc(n));
+    // ---- the look-up tables
+    const uint32_t bits2 = max_len > (uint32_t)kHdLut ? std::min<uint32_t>(max_len, 20u) : 0u;
+    DevBuf lut1_d, lut2_d;
     CNIIC_HIP_TRY(c, lut1_d.alloc((4ull << kHdLut)));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(code_d.p, lt.code.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(key_d.p, lt.key.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(len_d.p, lt.len.data(), n, hipMemcpyHostToDevice, c->stream));
-    HdTables T{code_d.as<uint64_t>(), key_d.as<uint32_t>(), len_d.as<uint8_t>(), lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
+    HdTables T{reinterpret_cast<const uint64_t *>(tab_d), reinterpret_cast<const uint32_t *>(tab_d + off_key), tab_d + off_len, lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
     hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << kHdLut) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, (uint32_t)kHdLut, lut1_d.as<uint32_t>(),
                        (uint2 *)nullptr);
     if (bits2) {
@@ -328,6 +372,7 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
         T.lut2 = lut2_d.as<uint2>();
     }
     CNIIC_HIP_TRY(c, hipGetLastError());
+    const LeafMeta lt{max_len};
     // ---- boundaries
     const uint64_t nsub = ceil_div(S.nbits, kHdSub);
     if (nsub > 0xffffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: payload too long");
@@ -338,7 +383,10 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
     CNIIC_HIP_TRY(c, count.alloc(nsub * 4));
     CNIIC_HIP_TRY(c, off.alloc(nsub * 8));
     CNIIC_HIP_TRY(c, tot.alloc(8));
-    CNIIC_HIP_TRY(c, changed.alloc(4));
+    CNIIC_HIP_TRY(c, changed.alloc(32));   // [0] an end moved in this check; [2] statistics wanted, [3] threads out of step, [4] blocks that staged
+    CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 32, c->stream));
+    const bool hd_stats = getenv("CNIIC_HD_STATS") != nullptr;
+    if (hd_stats) { const uint32_t one = 1; CNIIC_HIP_TRY(c, hipMemcpyAsync(changed.as<uint32_t>() + 2, &one, 4, hipMemcpyHostToDevice, c->stream)); }
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4096;   // (slots of this function's own) [0] total symbols, [1] did the last pass move an end?
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
@@ -367,18 +415,30 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         return CNIIC_OK;
     };
-    // Pass 0, one check, and -- taking that check to find everybody in step, as it does on ordinary streams -- offsets and
-    // symbols straight behind it: one look at the result for the whole decode.  A check that did move an end is followed by
-    // further checks, one look each, and the symbols are written again.
+    // Pass 0, then kHdBlindChecks checks and -- taking the last of them to find everybody in step, as it does on ordinary streams --
+    // offsets and symbols straight behind: ONE look at the result for the whole decode.  (The first check re-decodes the few per
+    // cent of subsequences whose warm-up had not fallen into step; that can move an end and put a neighbour out of step, which the
+    // next check repairs; a check that finds its whole block in step stages nothing and costs next to nothing.)  Should the last
+    // blind check still have moved an end, checks go on one look at a time and the symbols are written again.
     uint64_t *cur = end_a.as<uint64_t>(), *nxt = end_b.as<uint64_t>();
     pin[1] = 0;
     {
         ScopedKernelTimer t0(c, "hd_pass0");   // (stage timers: CNIIC_OPT_STAGE_TIMERS; they synchronise)
         pass(nullptr, cur);
         t0.stop();
-        CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
         ScopedKernelTimer t1(c, "hd_check");
-        pass(cur, nxt);
+        for (int r = 0; r < kHdBlindChecks; r++) {
+            CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
+            pass(cur, nxt);
+            std::swap(cur, nxt);
+            if (hd_stats) {
+                uint32_t st[5];
+                CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                CNIIC_HIP_TRY(c, hipMemcpy(st, changed.p, 20, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[hd] check %d: %u of %llu threads out of step, %u of %u blocks staged, an end moved: %u\n", r + 1, st[3], (unsigned long long)nsub, st[4], grid, st[0]);
+                CNIIC_HIP_TRY(c, hipMemsetAsync(changed.as<uint32_t>() + 3, 0, 8, c->stream));
+            }
+        }
         t1.stop();
         ScopedKernelTimer t2(c, "hd_write");
         CNIIC_TRY(write());
@@ -387,11 +447,12 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
     CNIIC_TRY(look());
     if ((uint32_t)pin[1]) {
         bool settled = false;
-        for (int r = 2; r < kHdMaxPasses; r++) {
-            std::swap(cur, nxt);
+        for (int r = kHdBlindChecks; r < kHdMaxPasses; r++) {
             CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
             pass(cur, nxt);
+            std::swap(cur, nxt);
             CNIIC_TRY(look());
+            if (hd_stats) fprintf(stderr, "[hd] check %d (after a look): an end moved: %u\n", r + 1, (uint32_t)pin[1]);
             if (!(uint32_t)pin[1]) { settled = true; break; }
         }
         if (!settled) { *status = 2; return CNIIC_OK; }
@@ -400,6 +461,26 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
     }
     if (pin[0] < nsyms) { *status = 1; return CNIIC_OK; }
     return CNIIC_OK;
+}
+
+// the same from the host's table of leaves (huff_parse_leaves; not too_deep): one pinned block, one copy up (three copies out of
+// pageable vectors were ~100 us of a 0.5 ms decode)
+int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
+                    int mode, void *out_d, int *status) {
+    *status = 0;
+    if (nsyms == 0) return CNIIC_OK;
+    const uint64_t n = lt.n();
+    if (n == 0 || lt.too_deep) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
+    const uint64_t off_key = n * 8, off_len = off_key + n * 4, tab_bytes = off_len + n;
+    DevBuf tab_d;
+    CNIIC_HIP_TRY(c, tab_d.alloc(tab_bytes));
+    CNIIC_HIP_TRY(c, ctx_pinned_huf(c, tab_bytes));   // (the stream's head, if it was fetched there, has been parsed: lt owns what it said)
+    uint8_t *ph = static_cast<uint8_t *>(c->pinned_huf);
+    memcpy(ph, lt.code.data(), n * 8);
+    memcpy(ph + off_key, lt.key.data(), n * 4);
+    memcpy(ph + off_len, lt.len.data(), n);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(tab_d.p, c->pinned_huf, tab_bytes, hipMemcpyHostToDevice, c->stream));
+    return huff_decode_tables_dev(c, tab_d.as<uint8_t>(), n, off_key, off_len, lt.max_len, lt.key[0], payload, payload_dev, payload_bytes, nsyms, mode, out_d, status);
 }
 
 int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d) {

@@ -107,3 +107,48 @@ def test_context_options_replace_the_environment(env, monkeypatch):
     assert d32 == d16 == O.encode("delta", img)[1]
     with pytest.raises(Exception):
         ctx.set_opt(99, 1)
+
+
+@pytest.mark.parametrize("expr", ["hufman", "delta", "cluster-colors(8)", "ccol(200)"])
+@pytest.mark.parametrize("shape,kind", [((5, 7), "photo"), ((64, 64), "photo"), ((130, 97), "photo"), ((200, 300), "uniform"), ((512, 512), "uniform")])
+def test_decoder_parsed_on_the_gpu_equals_oracle(env, monkeypatch, expr, shape, kind):
+    """Dec::deserialize on the GPU (k_trieparse.hip: chunk maps -> composition -> node records -> right children -> leaf codes),
+    forced for every decoder whatever its size: same pixels as the oracle; host and device streams; every cut of the stream fails
+    or succeeds as the oracle's decoder does"""
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    h, w = shape
+    img = getattr(synth, kind)(w, h, synth.SEED0 + 31 + h)
+    rc, data, _ = ctx.encode(expr, img, allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE))
+    if rc != 0:
+        pytest.skip("fewer colours than clusters")
+    rco, exp = O.decode(expr, data)
+    assert rco == 0
+    monkeypatch.setenv("CNIIC_TEST_TRIE_GPU", "1")
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        rc, back = ctx.decode(expr, data)
+        assert rc == 0 and np.array_equal(back, exp)
+        full = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+        rc, _, _ = ctx.decode_into(expr, full, len(data), out)
+        assert rc == 0 and np.array_equal(out.cpu().numpy().reshape(h, w, 3), exp)
+        rng = np.random.default_rng(h * w)
+        cuts = [1, 2, 9, len(data) // 3, len(data) - 9, len(data) - 12] + rng.integers(1, max(2, len(data) - 8), 6).tolist()
+        for cut in cuts:
+            if not 0 < cut < len(data) - 7:
+                continue
+            rc, _, _ = ctx.decode_into(expr, full, len(data) - cut, out, allow=(_lib.DECODE,))
+            rco, _ = O.decode(expr, data[:len(data) - cut])
+            assert (rc == 0) == (rco == 0), (expr, shape, cut)
+        # a corrupted tag / symbol inside the decoder: both refuse, or both decode the same pixels
+        for at in rng.integers(8, min(len(data), 8 + 2000), 8).tolist():
+            bad = bytearray(data)
+            bad[at] ^= 0x5A
+            rc, b2 = ctx.decode(expr, bytes(bad), allow=(_lib.DECODE,))
+            rco, e2 = O.decode(expr, bytes(bad))
+            assert (rc == 0) == (rco == 0), (expr, shape, at)
+            if rc == 0:
+                assert np.array_equal(b2, e2)
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
