@@ -21,7 +21,7 @@ OPT_SP_MIN_PIXELS, OPT_HUF_GPU_CODES_MIN, OPT_GPU_DECODE_MIN, OPT_DELTA_ROUTE, O
 # every symbol include/cniic_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cniic_ctx_create", "cniic_ctx_destroy", "cniic_last_error", "cniic_version", "cniic_sync", "cniic_dev_alloc",
-    "cniic_dev_free", "cniic_memcpy", "cniic_ctx_set_opt", "cniic_ctx_unset_opt", "cniic_ctx_get_opt", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
+    "cniic_dev_free", "cniic_memcpy", "cniic_ctx_set_opt", "cniic_ctx_unset_opt", "cniic_ctx_get_opt", "cniic_ctx_set_scan", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
     "cniic_kmeans_rgbw", "cniic_kmeans_xyrgb", "cniic_kmeans_step_rgbw", "cniic_kmeans_step_xyrgb",
     "cniic_km_create_rgbw", "cniic_km_partial_words", "cniic_km_partials", "cniic_km_begin",
     "cniic_km_labels_internal", "cniic_km_assign", "cniic_km_update",
@@ -32,7 +32,7 @@ SYMBOLS = [
     "cniic_cc_create_local", "cniic_cc_image_begin", "cniic_cc_image_occupancy", "cniic_cc_image_create", "cniic_remap_rgb", "cniic_hilbert_xy",
     "cniic_hilbert_linearize", "cniic_hilbert_delta", "cniic_hilbert_delta_hist", "cniic_huf_encode_all",
     "cniic_huf_size", "cniic_codec_parse", "cniic_codec_name", "cniic_codec_is_lossless", "cniic_codec_encode",
-    "cniic_codec_encode_opts", "cniic_codec_decode", "cniic_mse", "cniic_synth_image",
+    "cniic_codec_encode_opts", "cniic_codec_encode_batch", "cniic_codec_decode", "cniic_mse", "cniic_synth_image",
 ]
 
 
@@ -155,6 +155,12 @@ class Context:
             self._check(self._L.cniic_ctx_unset_opt(self.h, C.c_int32(opt)))
         else:
             self._check(self._L.cniic_ctx_set_opt(self.h, C.c_int32(opt), C.c_uint64(value)))
+
+    def set_scan(self, w, h, xy):
+        """cniic_ctx_set_scan: inject the scan of w x h images (xy: (w h, 2) uint32 positions, or None for the built-in one)"""
+        if xy is not None and isinstance(xy, np.ndarray):
+            xy = np.ascontiguousarray(xy, np.uint32)
+        self._check(self._L.cniic_ctx_set_scan(self.h, C.c_uint32(w), C.c_uint32(h), _ptr(xy)))
 
     def get_opt(self, opt):
         v = C.c_uint64(0)
@@ -327,6 +333,17 @@ class Context:
         if own:
             return rc, (out[:ln.value].tobytes() if rc == OK else b""), st.as_dict()
         return rc, ln.value, st.as_dict()
+
+    def encode_batch(self, expr, frames, w, h, F, out, stride, seed=0, max_iters=0, flags=0, allow=()):
+        """cniic_codec_encode_batch: F images (one contiguous [F][h][w][3] buffer), each encoded on its own (its own palette), image f's
+        stream at out[f * stride:].  -> (rc, list of F lengths, list of F per-image status codes, list of F stats dicts)"""
+        lens = (C.c_uint64 * F)()
+        rcs = (C.c_int32 * F)()
+        sts = (KmStats * F)()
+        o = self._opts(seed, max_iters, flags)
+        rc = self._check(self._L.cniic_codec_encode_batch(self.h, expr.encode(), C.byref(o), _ptr(frames), C.c_uint32(w), C.c_uint32(h), C.c_uint32(F),
+                                                          _ptr(out), C.c_uint64(stride), lens, rcs, sts), allow)
+        return rc, [int(x) for x in lens], [int(x) for x in rcs], [s.as_dict() for s in sts]
 
     def decode(self, expr, data, allow=()):
         raw = np.frombuffer(bytes(data), np.uint8)

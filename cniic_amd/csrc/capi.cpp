@@ -6,6 +6,9 @@
 #include <memory>
 
 #include "codec.hpp"
+#include <atomic>
+#include <thread>
+
 #include "common.hpp"
 #include "huff_host.hpp"
 
@@ -74,9 +77,12 @@ int32_t cniic_ctx_create(int32_t device, void *stream, cniic_ctx **out) {
 
 void cniic_ctx_destroy(cniic_ctx *c) {
     if (!c) return;
+    for (void *w : c->batch_workers) cniic_ctx_destroy(static_cast<cniic_ctx *>(w));
+    c->batch_workers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->dense.release();
+    c->scan_xy.release();
     c->pool.trim();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -139,6 +145,11 @@ int32_t cniic_ctx_unset_opt(cniic_ctx *c, int32_t opt) {
     c->opt_set &= ~(1u << opt);
     if (opt == CNIIC_OPT_STAGE_TIMERS) c->timers = getenv("CNIIC_KERNEL_TIMERS") != nullptr;
     return CNIIC_OK;
+}
+
+int32_t cniic_ctx_set_scan(cniic_ctx *c, uint32_t w, uint32_t h, const uint32_t *xy) {
+    LOCK(c);
+    return scan_inject(c, w, h, xy, xy && is_device_ptr(xy));
 }
 
 int32_t cniic_ctx_get_opt(cniic_ctx *c, int32_t opt, uint64_t *value) {
@@ -864,6 +875,61 @@ int32_t cniic_codec_encode_opts(cniic_ctx *c, const char *expr, const cniic_kmea
     In<uint8_t> in;
     CNIIC_TRY(in.bind(c, rgb, (uint64_t)w * h * 3));
     return codec_encode(c, d, in.d, w, h, opts, out, cap, len, stats);
+}
+
+int32_t cniic_codec_encode_batch(cniic_ctx *c, const char *expr, const cniic_kmeans_opts *opts, const uint8_t *rgb, uint32_t w, uint32_t h,
+                                 uint32_t frames, uint8_t *out, uint64_t stride, uint64_t *lens, int32_t *rcs, cniic_kmeans_stats *stats) {
+    LOCK(c);
+    c->ktimes.clear();
+    CodecDesc d;
+    if (!parse_codec(expr, &d)) return c->fail(CNIIC_ERR_BAD_ARG, "Malformed codec argument: %s", expr ? expr : "(null)");
+    if (!frames) return CNIIC_OK;
+    if (!rgb || !out || !lens) return c->fail(CNIIC_ERR_BAD_ARG, "codec_encode_batch: null argument");
+    const uint64_t img_bytes = (uint64_t)w * h * 3;
+    const uint32_t S = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, c->opt(CNIIC_OPT_BATCH_STREAMS, nullptr, 8)));
+    while (c->batch_workers.size() < S) {
+        cniic_ctx *wk = nullptr;
+        const int32_t rc = cniic_ctx_create(c->device, nullptr, &wk);
+        if (rc != CNIIC_OK) return c->fail(rc, "codec_encode_batch: cannot create worker context %zu", c->batch_workers.size());
+        c->batch_workers.push_back(wk);
+    }
+    for (uint32_t i = 0; i < S; i++) {  // the workers take this context's route switches
+        cniic_ctx *wk = static_cast<cniic_ctx *>(c->batch_workers[i]);
+        memcpy(wk->opt_val, c->opt_val, sizeof c->opt_val);
+        wk->opt_set = c->opt_set;
+        wk->scan_xy.release();                 // ... and its injected scan, as a view of this context's table
+        wk->scan_w = wk->scan_h = 0;
+        if (c->scan_xy.p) { wk->scan_xy.view(c->scan_xy.p, c->scan_xy.bytes); wk->scan_w = c->scan_w; wk->scan_h = c->scan_h; }
+    }
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));   // whatever produced the images on this context's stream is done
+    std::atomic<uint32_t> next{0};
+    std::vector<int32_t> status(frames, CNIIC_OK);
+    auto run = [&](uint32_t i) {
+        cniic_ctx *wk = static_cast<cniic_ctx *>(c->batch_workers[i]);
+        for (;;) {
+            const uint32_t f = next.fetch_add(1);
+            if (f >= frames) break;
+            cniic_kmeans_stats st{};
+            status[f] = cniic_codec_encode_opts(wk, expr, opts, rgb + (uint64_t)f * img_bytes, w, h, out + (uint64_t)f * stride, stride, &lens[f], &st);
+            if (stats) stats[f] = st;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < S; i++) th.emplace_back(run, i);
+    run(0);
+    for (auto &t : th) t.join();
+    int32_t first = CNIIC_OK;
+    for (uint32_t f = 0; f < frames; f++) {
+        if (rcs) rcs[f] = status[f];
+        if (status[f] != CNIIC_OK && first == CNIIC_OK) first = status[f];
+    }
+    if (first != CNIIC_OK) {
+        for (uint32_t i = 0; i < S; i++) {
+            cniic_ctx *wk = static_cast<cniic_ctx *>(c->batch_workers[i]);
+            if (!wk->err.empty()) { c->err = wk->err; break; }
+        }
+    }
+    return first;
 }
 
 int32_t cniic_codec_decode(cniic_ctx *c, const char *expr, const uint8_t *bytes, uint64_t n, uint8_t *rgb, uint64_t cap, uint32_t *w,

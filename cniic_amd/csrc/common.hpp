@@ -146,6 +146,9 @@ struct Ctx {
     void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
     uint64_t pinned_huf_bytes = 0;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
+    DevBuf scan_xy;         // cniic_ctx_set_scan: an injected scan of scan_w x scan_h images, (x, y) per position (uint2[w h])
+    uint32_t scan_w = 0, scan_h = 0;
+    std::vector<void *> batch_workers;  // cniic_codec_encode_batch: worker contexts (cniic_ctx *), created on first use
     const void *poll_owner = nullptr;  // the K-means state whose lagged polls own `pinned` / poll_ev (one loop at a time per context)
 
     int fail(int code, const char *fmt, ...) {
@@ -574,6 +577,7 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
 // gather + delta; syms_d (packed SIGNED keys, may be null) and/or histogram into table_d (u32[2^27], may be null)
 int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t *syms_d, uint32_t *table_d);
 int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d);
+int scan_inject(Ctx *c, uint32_t w, uint32_t h, const uint32_t *xy, bool xy_dev);   // cniic_ctx_set_scan (xy == null: the built-in scan again)
 int hilbert_undiff_scatter(Ctx *c, const uint32_t *keys_d, const int32_t *chunk_off_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_d, bool *fused);
 
 // ---- k_delta.hip: the `delta` encoder's passes over a 16-bit symbol stream ----

@@ -70,23 +70,28 @@ __device__ __forceinline__ void pow2_d2xy(const uint16_t *l4, const uint8_t *l1,
 }
 
 // scan position -> pixel; order > 0 selects the table-driven path (w == h == 1 << order)
+// ... or an order the caller injected (cniic_ctx_set_scan): position d -> custom[d] = (x, y)
 struct Scan {
     uint32_t w, h, order;
     const uint16_t *l4;
     const uint8_t *l1;
+    const uint2 *custom;
     __device__ __forceinline__ void xy(uint64_t d, uint32_t &x, uint32_t &y) const {
         if (order) pow2_d2xy(l4, l1, order, (uint32_t)d, x, y);
+        else if (custom) { const uint2 v = custom[d]; x = v.x; y = v.y; }
         else gilbert_d2xy(w, h, d, x, y);
     }
 };
 
+// `lut`: the state-machine tables when order > 0; with order == 0 it is either null (the generalised curve is computed) or the
+// injected table of positions (scan_select below hands the kernels one or the other)
 __device__ __forceinline__ Scan load_scan(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *lut, uint16_t *s_l4, uint8_t *s_l1) {
     if (order) {
         for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) s_l4[i] = lut->l4[i];
         if (threadIdx.x < 16) s_l1[threadIdx.x] = lut->l1[threadIdx.x];
         __syncthreads();
     }
-    return Scan{w, h, order, s_l4, s_l1};
+    return Scan{w, h, order, s_l4, s_l1, order ? nullptr : reinterpret_cast<const uint2 *>(lut)};
 }
 
 // pixel idx as r | g << 8 | b << 16 (bits 24..31 unspecified) with one load; the buffer's last pixel by bytes
@@ -103,5 +108,9 @@ __device__ __forceinline__ uint32_t px_le24(const uint8_t *__restrict__ rgb, uin
 // the context's copy of the tables (built and self-checked once per process); order of a 2^n square (n >= 1), else 0
 int hilbert_lut(Ctx *c, const HilbertLut **lut_d);
 uint32_t pow2_order(uint32_t w, uint32_t h);
+// what the scan kernels of a w x h image are launched with: (order, tables) of the built-in scan, or (0, the injected positions)
+// when the context holds an order for exactly these dimensions (cniic_ctx_set_scan); the tile kernels want sel.order >= 6
+struct ScanSel { uint32_t order; const HilbertLut *arg; };
+int scan_select(Ctx *c, uint32_t w, uint32_t h, ScanSel *sel);
 
 }  // namespace cniic

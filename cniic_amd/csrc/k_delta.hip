@@ -566,11 +566,12 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
     if (w >= (1u << 30) || h >= (1u << 30) || n >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "hilbert: image %ux%u too large", w, h);
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    const HilbertLut *lut = sel.arg;
     const uint64_t npad = delta_stream_len(n);
     ScopedKernelTimer timer(c, "delta_gather");  // (bench.py --config c5 takes the gather's roofline from this one)
-    const uint32_t order = pow2_order(w, h);
+    const uint32_t order = sel.order;
     const char *force = getenv("CNIIC_DELTA_GATHER");  // "any": the per-position kernel on 2^n squares too (tests)
     if (order >= 6 && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(force && force[0] == 'a')) {
         const uint32_t ntiles = (uint32_t)(n >> 12);

@@ -473,18 +473,67 @@ int hilbert_lut(Ctx *c, const HilbertLut **lut_d) {
 }
 
 // 2^n squares from 64 x 64 with 16-byte aligned buffers go by tiles (CNIIC_HILBERT_MOVE=any: the per-position kernel; tests)
-static bool move_by_tiles(uint32_t w, uint32_t h, const void *a, const void *b) {
+static bool move_by_tiles(uint32_t order, const void *a, const void *b) {
     const char *e = getenv("CNIIC_HILBERT_MOVE");
-    return pow2_order(w, h) >= 6 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !(e && e[0] == 'a');
+    return order >= 6 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !(e && e[0] == 'a');
+}
+
+int scan_select(Ctx *c, uint32_t w, uint32_t h, ScanSel *sel) {
+    if (c->scan_xy.p && c->scan_w == w && c->scan_h == h) { *sel = ScanSel{0u, reinterpret_cast<const HilbertLut *>(c->scan_xy.p)}; return CNIIC_OK; }
+    const HilbertLut *lut = nullptr;
+    CNIIC_TRY(hilbert_lut(c, &lut));
+    const uint32_t order = pow2_order(w, h);
+    *sel = ScanSel{order, order ? lut : nullptr};
+    return CNIIC_OK;
+}
+
+// cniic_ctx_set_scan: xy_d = w h positions (x, y); every pixel exactly once, or the scan is refused
+__global__ void k_scan_mark(const uint2 *__restrict__ xy, uint64_t n, uint32_t w, uint32_t h, uint32_t *__restrict__ seen, uint32_t *__restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += stride) {
+        const uint2 v = xy[d];
+        if (v.x >= w || v.y >= h) { *bad = 1u; continue; }
+        const uint64_t p = (uint64_t)v.y * w + v.x;
+        if (atomicOr(&seen[p >> 5], 1u << (p & 31)) & (1u << (p & 31))) *bad = 1u;   // visited twice (so another pixel never)
+    }
+}
+int scan_inject(Ctx *c, uint32_t w, uint32_t h, const uint32_t *xy, bool xy_dev) {
+    c->scan_xy.release();
+    c->scan_w = c->scan_h = 0;
+    if (!xy) return CNIIC_OK;
+    CNIIC_TRY(check_dims(c, w, h));
+    const uint64_t n = (uint64_t)w * h;
+    if (!n) return c->fail(CNIIC_ERR_BAD_ARG, "set_scan: empty image");
+    DevBuf buf, seen, bad;
+    {
+        // (a buffer of the context's own: it outlives the call's scratch pool scope because the context keeps it)
+        void *p = nullptr;
+        CNIIC_HIP_TRY(c, hipMalloc(&p, n * 8));
+        buf.p = p; buf.bytes = buf.cap = n * 8; buf.pool = nullptr; buf.owned = true;
+    }
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(buf.p, xy, n * 8, xy_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, seen.alloc(((n + 31) / 32) * 4));
+    CNIIC_HIP_TRY(c, bad.alloc(4));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(seen.p, 0, ((n + 31) / 32) * 4, c->stream));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_scan_mark, dim3(hgrid(n)), dim3(256), 0, c->stream, (const uint2 *)buf.as<uint2>(), n, w, h, seen.as<uint32_t>(), bad.as<uint32_t>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint32_t b = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&b, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (b) return c->fail(CNIIC_ERR_BAD_ARG, "set_scan: not a scan of the %u x %u image (a position outside it, or a pixel visited twice)", w, h);
+    c->scan_xy = std::move(buf);
+    c->scan_w = w; c->scan_h = h;
+    return CNIIC_OK;
 }
 
 int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d) {
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
-    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, pow2_order(w, h), lut, xy_d);
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, sel.order, sel.arg, xy_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -493,13 +542,13 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
-    if (move_by_tiles(w, h, rgb_d, out_d))
-        hipLaunchKernelGGL(k_hilbert_move_p2<false>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, rgb_d, pow2_order(w, h), lut,
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    if (move_by_tiles(sel.order, rgb_d, out_d))
+        hipLaunchKernelGGL(k_hilbert_move_p2<false>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, rgb_d, sel.order, sel.arg,
                            out_d);
     else
-        hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, pow2_order(w, h), lut, out_d);
+        hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, sel.order, sel.arg, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -508,13 +557,13 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
-    if (move_by_tiles(w, h, lin_d, rgb_out_d))
-        hipLaunchKernelGGL(k_hilbert_move_p2<true>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, lin_d, pow2_order(w, h), lut,
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    if (move_by_tiles(sel.order, lin_d, rgb_out_d))
+        hipLaunchKernelGGL(k_hilbert_move_p2<true>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, lin_d, sel.order, sel.arg,
                            rgb_out_d);
     else
-        hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, pow2_order(w, h), lut, rgb_out_d);
+        hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, sel.order, sel.arg, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -527,11 +576,11 @@ int hilbert_undiff_scatter(Ctx *c, const uint32_t *keys_d, const int32_t *chunk_
     *fused = false;
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
-    if (!n || !move_by_tiles(w, h, keys_d, rgb_out_d)) return CNIIC_OK;
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    if (!n || !move_by_tiles(sel.order, keys_d, rgb_out_d)) return CNIIC_OK;
     hipLaunchKernelGGL((k_hilbert_move_p2<true, true>), dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream,
-                       reinterpret_cast<const uint8_t *>(keys_d), pow2_order(w, h), lut, rgb_out_d, chunk_off_d, bad_d);
+                       reinterpret_cast<const uint8_t *>(keys_d), sel.order, sel.arg, rgb_out_d, chunk_off_d, bad_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     *fused = true;
     return CNIIC_OK;
@@ -541,8 +590,9 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
     CNIIC_TRY(check_dims(c, w, h));
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
-    const HilbertLut *lut = nullptr;
-    CNIIC_TRY(hilbert_lut(c, &lut));
+    ScanSel sel;
+    CNIIC_TRY(scan_select(c, w, h, &sel));
+    const HilbertLut *lut = sel.arg;
     const uint64_t nruns = ceil_div(n, kDeltaRun);
     // persistent blocks: one 1024-thread block per CU keeps the LDS bins private for as long as possible
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(nruns, kDeltaThreads), 1), 256);
@@ -552,7 +602,7 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
                                   (int)(kHotBins * 4));
     });
     ScopedKernelTimer timer(c, "hilbert_delta");
-    const uint32_t order = pow2_order(w, h);
+    const uint32_t order = sel.order;
     // Measured at 16384^2: without the histogram the lane-per-position kernel takes 0.75 ms against 0.89 ms; with it 1.30 against
     // 1.14 ms (one block per CU for the 128 KiB of bins either way), so the fused encode keeps the 4-positions-per-thread kernel.
     // CNIIC_HILBERT_LANE_SCAN=1 / 0 forces one or the other (tests run both).
@@ -570,11 +620,11 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
         else
             hipLaunchKernelGGL(k_hilbert_delta_p2<false>, dim3(g2), dim3(kDeltaThreads), 0, c->stream, rgb_d, order, lut, syms_d, table_d);
     } else if (table_d)
-        hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, pow2_order(w, h), lut,
+        hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, order, lut,
                            syms_d, table_d);
     else
         hipLaunchKernelGGL(k_hilbert_delta<false>, dim3(std::min<uint32_t>(grid * 4, 1024)), dim3(kDeltaThreads), 0, c->stream, rgb_d, w, h,
-                           pow2_order(w, h), lut, syms_d, table_d);
+                           order, lut, syms_d, table_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     timer.stop(1);
     return CNIIC_OK;

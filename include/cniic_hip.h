@@ -294,6 +294,13 @@ int32_t cniic_remap_rgb(cniic_ctx *ctx, const uint8_t *rgb, uint64_t npx, const 
 /* hilbert::iter(w,h) (src/hilbert.rs:40-43): xy[2*d], xy[2*d+1] for d in 0..w*h.
  * The scan is the one frozen by this build (see DESIGN.md "Hilbert scan: parity unpinned"). */
 int32_t cniic_hilbert_xy(cniic_ctx *ctx, uint32_t w, uint32_t h, uint32_t *xy);
+/* The reference's scan is the un-vendored crate zhang_hilbert 0.1.1 (src/hilbert.rs:40-43, Cargo.toml:15), which this build
+ * cannot reproduce (parity unpinned).  A host that HAS the crate injects its order: xy = w * h pairs (x, y), entry d =
+ * where ArbHilbertScan32::new([w, h]) is at step d (host or device memory).  From then on every scan-dependent path of this
+ * context -- cniic_hilbert_*, `delta`, `hilbert(rle)`, encode and decode -- follows that order for images of exactly w x h
+ * (per-position kernels instead of the tile kernels of the built-in 2^n scan), and its streams are the reference's.  The order
+ * must visit every pixel exactly once (CNIIC_ERR_BAD_ARG otherwise).  xy == NULL: back to the built-in scan. */
+int32_t cniic_ctx_set_scan(cniic_ctx *ctx, uint32_t w, uint32_t h, const uint32_t *xy);
 /* hilbert::linearize (src/hilbert.rs:10-12): pixels gathered in scan order. */
 int32_t cniic_hilbert_linearize(cniic_ctx *ctx, const uint8_t *rgb, uint32_t w, uint32_t h, uint8_t *out_rgb);
 /* DiffStream over the Hilbert-ordered pixels (src/codec/hilbertc.rs:449-477): N packed
@@ -327,6 +334,15 @@ int32_t cniic_codec_encode(cniic_ctx *ctx, const char *expr, const uint8_t *rgb,
 int32_t cniic_codec_encode_opts(cniic_ctx *ctx, const char *expr, const cniic_kmeans_opts *opts, const uint8_t *rgb,
                                 uint32_t w, uint32_t h, uint8_t *out, uint64_t cap, uint64_t *len,
                                 cniic_kmeans_stats *stats);
+/* The harness's many-images loop (src/bench.rs:24-35: `paths.into_par_iter()`, one Codec::encode per rayon worker) as ONE call:
+ * `frames` images of w x h, contiguous in memory (image f at rgb + f * w * h * 3), each encoded on its own exactly as
+ * cniic_codec_encode would -- its own histogram, its own palette, its own stream (byte for byte; tests) -- written at
+ * out + f * stride with its length in lens[f].  The images are dealt to CNIIC_OPT_BATCH_STREAMS worker contexts of this context
+ * (own HIP streams, own scratch; created on first use, destroyed with the context), so that the dependent launches of one
+ * image's K-means fill the gaps between another's.  rcs (may be NULL): per-image status; the call returns the first failure.
+ * stats (may be NULL): `frames` entries. */
+int32_t cniic_codec_encode_batch(cniic_ctx *ctx, const char *expr, const cniic_kmeans_opts *opts, const uint8_t *rgb, uint32_t w, uint32_t h,
+                                 uint32_t frames, uint8_t *out, uint64_t stride, uint64_t *lens, int32_t *rcs, cniic_kmeans_stats *stats);
 /* Codec::decode: CNIIC_ERR_DECODE where the reference returns None / panics. */
 int32_t cniic_codec_decode(cniic_ctx *ctx, const char *expr, const uint8_t *bytes, uint64_t n,
                            uint8_t *rgb, uint64_t cap, uint32_t *w, uint32_t *h);

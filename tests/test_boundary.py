@@ -94,3 +94,38 @@ def test_harness_program_two_images_on_worker_threads(tmp_path):
         assert abs(float(rows[spec][2]) - O.mse(img, back)) <= 1e-6 * max(1.0, O.mse(img, back))
     r = subprocess.run([exe, "--codec=nonsense(3)", specs[0]], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "Malformed codec argument" in r.stderr                # codec.rs:41-59
+
+
+@pytest.mark.gpu
+def test_encode_batch_equals_separate_encodes():
+    """cniic_codec_encode_batch = the harness's many-images loop (bench.rs:24-35) in one call: every image on its own -- its own
+    palette, its own stream -- byte for byte what cniic_codec_encode gives for it, whatever the number of worker streams; a frame
+    that fails (fewer colours than clusters) fails alone."""
+    import torch
+    import cniic_amd
+    from cniic_amd import _lib, synth
+    dev = torch.device("cuda", 0)
+    F, w, h = 11, 160, 96
+    frames = np.stack([synth.photo(w, h, synth.SEED0 + 200 + f) for f in range(F)])
+    frames[7] = 33                                          # one colour: cluster-colors(16) cannot cluster it
+    fr_d = torch.from_numpy(frames).to(dev)
+    with cniic_amd.Context(0) as ctx:
+        for expr in ("cluster-colors(16)", "delta", "hufman", "voronoi(8)"):
+            single = [ctx.encode(expr, frames[f], allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE)) for f in range(F)]
+            stride = w * h * 16 + 4096
+            for streams in (1, 3, 8):
+                ctx.set_opt(_lib.OPT_BATCH_STREAMS, streams)
+                out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
+                rc, lens, rcs, sts = ctx.encode_batch(expr, fr_d, w, h, F, out, stride, allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE))
+                host = out.cpu().numpy()
+                for f in range(F):
+                    assert rcs[f] == single[f][0], (expr, f)
+                    if rcs[f] == 0:
+                        assert host[f * stride:f * stride + lens[f]].tobytes() == single[f][1], (expr, streams, f)
+                        assert sts[f]["iterations"] == single[f][2]["iterations"]
+                assert rc == next((r for r in rcs if r != 0), 0)
+            ctx.set_opt(_lib.OPT_BATCH_STREAMS, None)
+        # host buffers in and out
+        hout = np.zeros(stride * F, np.uint8)
+        rc, lens, rcs, _ = ctx.encode_batch("delta", frames, w, h, F, hout, stride)
+        assert rc == 0 and all(hout[f * stride:f * stride + lens[f]].tobytes() == ctx.encode("delta", frames[f])[1] for f in range(F))
