@@ -286,7 +286,11 @@ struct LaggedPoll {
     bool ring = false;    // ... or every launch into its own slot of the ring behind the three slots (deterministic per launch)
     uint32_t last_prev = 0;
     Comm *watch = nullptr;  // set by loops with collectives
+    bool owner = false;     // this poll holds the context's slots (Ctx::poll_owner)
     LaggedPoll(Ctx *ctx, const void *dstate_d) : c(ctx), dstate(dstate_d) {}
+    LaggedPoll(const LaggedPoll &) = delete;
+    LaggedPoll &operator=(const LaggedPoll &) = delete;
+    ~LaggedPoll() { if (owner && c->poll_owner == dstate) c->poll_owner = nullptr; }
     static constexpr size_t ring_offset() { return (3 * sizeof(KmDevState) + 63) & ~size_t(63); }
     int ring_slot(PollRec **dev_ptr) {
         static_assert(ring_offset() + kPollRing * sizeof(PollRec) <= 4096, "the poll ring must fit the pinned page");
@@ -310,6 +314,13 @@ struct LaggedPoll {
     }
     int prepare() {
         static_assert(3 * sizeof(KmDevState) <= 4096, "the poll slots must fit the pinned page");
+        // The slots, the ring and the two events are the CONTEXT's: one K-means loop at a time polls through them.  A second
+        // state that starts polling while another still holds them would read the first one's records -- refused instead.
+        if (c->poll_owner && c->poll_owner != dstate)
+            return c->fail(CNIIC_ERR_BAD_ARG, "kmeans: another K-means state of this context is polling (one lagged-poll loop per context at a time; "
+                                              "destroy it, or give the second session its own context)");
+        c->poll_owner = dstate;
+        owner = true;
         if (!c->pinned) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
         for (int i = 0; i < 2; i++)
             if (!c->poll_ev[i]) CNIIC_HIP_TRY(c, hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));

@@ -90,6 +90,8 @@ struct KmRgbwState {
     uint32_t big_blocks_from = 10;  // launches from this one on run in blocks of kCellWavesBig waves (CNIIC_KM_BIG_BLOCKS_FROM; a huge value: never)
     uint32_t agg_launches = 3;  // launches 1 .. agg_launches book their movers round by round (CNIIC_KM_AGG_LAUNCHES)
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
+    uint32_t dbg_timeline = 0, dbg_sup_bits = 0;  // measuring knobs (CNIIC_DBG_TIMELINE, CNIIC_SUP_STOP, CNIIC_DBG_LAUNCH), read ONCE when the state is made
+    long fail_at = -1;           // fault injection for the multi-rank tests (CNIIC_TEST_FAIL_AT_LAUNCH), read once as well
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
     DevBuf sup_rec, sup_agg;     // per cell: candidate mask + state word; aggregate of its points
@@ -1972,6 +1974,11 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (const char *al = getenv("CNIIC_KM_AGG_LAUNCHES")) s->agg_launches = (uint32_t)atoi(al);
     if (const char *bb = getenv("CNIIC_KM_BIG_BLOCKS_FROM")) s->big_blocks_from = (uint32_t)atoi(bb);
     if (const char *ms = getenv("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
+    // (every knob of the loop is read here, once: getenv() per launch raced with tools that set variables between contexts)
+    if (const char *tl = getenv("CNIIC_DBG_TIMELINE")) s->dbg_timeline = (uint32_t)atoi(tl) + 1u;
+    if (const char *ds = getenv("CNIIC_SUP_STOP")) s->dbg_sup_bits |= ((uint32_t)atoi(ds) & 255u) << 8;
+    if (const char *ds = getenv("CNIIC_DBG_LAUNCH")) s->dbg_sup_bits |= (uint32_t)atoi(ds) << 16;
+    if (const char *fa = getenv("CNIIC_TEST_FAIL_AT_LAUNCH")) s->fail_at = atol(fa);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
     const uint64_t n = hi - lo;
@@ -2021,6 +2028,12 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (s->cells) {
         // cell-major copy of the whole point list (every rank keeps all U points and works on [lo,hi))
         s->nblocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ceil_div(U / nshards, s->wide ? 1024 : 64), 1), s->wide ? 4096u : kCellBlocks);  // same on every shard
+        // (CNIIC_OPT_KM_MAX_BLOCKS; batch encodes: a smaller grid per image so that several images' launches share the machine -- a multiple of 3,
+        // which the regrouping into 12-wave blocks wants)
+        if (const uint64_t mb = c->opt(CNIIC_OPT_KM_MAX_BLOCKS, "CNIIC_KM_MAX_BLOCKS", 0)) {
+            const uint32_t cap = std::max(3u, (uint32_t)std::min<uint64_t>(mb, kCellBlocks) / 3 * 3);
+            if (!s->wide && nshards == 1 && s->nblocks > cap) s->nblocks = cap;
+        }
         if (s->wide) s->nblocks = (s->nblocks + 7) & ~7u;  // (wide: a wave each; launch_assign groups them by up to eight)
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
         KM_ALLOC(s->ckeys, U * 4);
@@ -2165,7 +2178,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
-                     s->no_skip ? 0u : s->max_skip, getenv("CNIIC_DBG_TIMELINE") ? (uint32_t)atoi(getenv("CNIIC_DBG_TIMELINE")) + 1u : 0u};
+                     s->no_skip ? 0u : s->max_skip, s->dbg_timeline};
         if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
             // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
             // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.
@@ -2183,8 +2196,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
                                (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
         } else if (s->sup) {
             SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
-            if (const char *ds = getenv("CNIIC_SUP_STOP")) ss.no_skip |= ((uint32_t)atoi(ds) & 255u) << 8;
-            if (const char *ds = getenv("CNIIC_DBG_LAUNCH")) ss.no_skip |= (uint32_t)atoi(ds) << 16;
+            ss.no_skip |= s->dbg_sup_bits;
             s->labels_stale = true;
             s->sup_force = false;
             const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
@@ -2329,15 +2341,15 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
 
 static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
-    const int batch = getenv("CNIIC_KM_BATCH") ? atoi(getenv("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
+    int batch = getenv("CNIIC_KM_BATCH") ? atoi(getenv("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
                                    // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
+    const bool batch_fixed = getenv("CNIIC_KM_BATCH") != nullptr || cm != nullptr;
     KmDevState h;
     LaunchTimer lt;
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
     poll.watch = cm;
-    const char *fail_at_env = getenv("CNIIC_TEST_FAIL_AT_LAUNCH");  // fault injection (tests): this rank fails before enqueuing launch n
-    const long fail_at = fail_at_env ? atol(fail_at_env) : -1;
+    const long fail_at = s->fail_at;  // fault injection (tests): this rank fails before enqueuing launch n
     KmDevState *st_host = nullptr;
     // The mapped slot shows the host a state AT LEAST as new as the batch it asks about -- how much newer depends on timing.
     // Alone that only ends the loop a little earlier; with collectives every rank must leave after the SAME batch (a rank
@@ -2404,6 +2416,9 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         bool have = false;
         CNIIC_TRY(poll.after_batch(&h, &have, launch_no ? launch_no - 1 : 0));
         if (have && h.done) break;
+        // The tail of a run (a few thousand points still moving) is launches of ~11 us that do little: four in flight keep the GPU fed
+        // as well as eight, and up to eight fewer launches past convergence (4 us each) are paid at the end.
+        if (have && !batch_fixed && h.iter > 8) batch = h.moved_last < 20000 ? 4 : 8;
     }
     // (the state the loop ended on is final -- launches past convergence change nothing: callers that only want the statistics
     // need not wait for those launches, km_rgbw_run_stats)

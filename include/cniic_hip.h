@@ -70,7 +70,10 @@ int32_t     cniic_memcpy(cniic_ctx *ctx, void *dst, const void *src, uint64_t by
 #define CNIIC_OPT_FRAME_TREES_HOST   6  /* cniic_cc_finish_frames: 1 = the frames' Huffman trees on host threads instead of the GPU.       */
                                         /* Default 0.  CNIIC_FRAME_TREES_HOST                                                               */
 #define CNIIC_OPT_BATCH_STREAMS      7  /* cniic_codec_encode_batch: images in flight at once (worker streams).  Default 8.               */
-#define CNIIC_OPT_COUNT              8
+#define CNIIC_OPT_KM_MAX_BLOCKS      8  /* cluster-colors: cap on the K-means assign kernel's grid (a multiple of 3; 0 = none, 768 blocks  */
+                                        /* on large inputs).  A smaller grid lets the launches of several contexts share the machine:     */
+                                        /* cniic_codec_encode_batch gives its workers 384 unless this is set.  CNIIC_KM_MAX_BLOCKS          */
+#define CNIIC_OPT_COUNT              9
 int32_t     cniic_ctx_set_opt(cniic_ctx *ctx, int32_t opt, uint64_t value);
 int32_t     cniic_ctx_unset_opt(cniic_ctx *ctx, int32_t opt);
 int32_t     cniic_ctx_get_opt(cniic_ctx *ctx, int32_t opt, uint64_t *value);

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Everything under profiles/ for one round, on one MI355X:  tools/make_profiles.sh r02   (writes gpurun_out/prof_<tag>/, copy what is wanted)
 set -e
-TAG=${1:-r02}
+set -x
+TAG=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -26,9 +27,24 @@ python3 $R/bench.py --config c5 2>> $O/bench.err | tail -1 > $O/${TAG}_c5_bench.
 python3 $R/bench.py --config c3 --steps 3 2>> $O/bench.err | tail -1 > $O/${TAG}_c3_bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_d16 -o d -- python3 $R/tools/bench_others.py delta16k > /dev/null 2>&1
 cp $(find $O/stats_d16 -name '*kernel_stats.csv' | head -1) $O/${TAG}_delta16k_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_v -o v -- python3 $R/tools/bench_others.py voronoi > /dev/null 2>&1
+# voronoi: the FULL run (configs[2], to convergence), per-kernel stats and one PMC pass each for traffic and for what the waves do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_v -o v -- python3 $R/bench.py --config c3 --steps 2 --warmup 1 --cpu-sample 0 > $O/${TAG}_c3_bench_profiled.json 2>> $O/bench.err
 cp $(find $O/stats_v -name '*kernel_stats.csv' | head -1) $O/${TAG}_voronoi_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_v1 -o p -- python3 $R/bench.py --config c3 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_v3 -o p -- python3 $R/bench.py --config c3 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_v2 -o p -- python3 $R/bench.py --config c3 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+python3 $R/tools/pmc_kernel_mean.py $O/pmc_v1 k_xy_assign > $O/${TAG}_voronoi_pmc_traffic.txt 2>&1
+python3 $R/tools/pmc_kernel_mean.py $O/pmc_v3 k_xy_assign >> $O/${TAG}_voronoi_pmc_traffic.txt 2>&1
+python3 $R/tools/pmc_kernel_mean.py $O/pmc_v2 k_xy_assign > $O/${TAG}_voronoi_pmc_sq.txt 2>&1
+# decode (the other half of the trait): bench lines and per-kernel stats
+python3 $R/bench.py --decode 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_c2_bench.json
+python3 $R/bench.py --decode --config c5 --c5-size 4096 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_delta4096_bench.json
+python3 $R/bench.py --decode --config c5 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_c5_bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec -o d -- python3 $R/tools/decode_dev_probe.py 4096 "cluster-colors(256)" delta hufman > $O/${TAG}_decode_probe.txt 2>&1
+cp $(find $O/stats_dec -name '*kernel_stats.csv' | head -1) $O/${TAG}_decode_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec16 -o d -- python3 $R/tools/decode_dev_probe.py 16384 delta >> $O/${TAG}_decode_probe.txt 2>&1
+cp $(find $O/stats_dec16 -name '*kernel_stats.csv' | head -1) $O/${TAG}_decode_delta16k_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -o c -- python3 $R/bench.py --config c4 --steps 2 --cpu-sample 0 > $O/${TAG}_c4_bench_profiled.json 2>> $O/bench.err
 cp $(find $O/stats_c4 -name '*kernel_stats.csv' | head -1) $O/${TAG}_c4_kernel_stats.csv
-rm -rf $O/stats $O/stats_d16 $O/stats_v $O/stats_c4 $O/pmc_f $O/pmc_w $O/pmc_sq
+rm -rf $O/stats $O/stats_d16 $O/stats_v $O/stats_c4 $O/pmc_f $O/pmc_w $O/pmc_sq $O/pmc_v1 $O/pmc_v2 $O/pmc_v3 $O/stats_dec $O/stats_dec16
 ls -la $O $O/out
