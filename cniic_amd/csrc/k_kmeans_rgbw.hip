@@ -900,6 +900,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
     __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
+    __shared__ uint32_t s_nS[WAVES];        // full schedule: lengths of the block's shared super-cell lists
     __shared__ unsigned long long s_mm[4];  // K <= 256: bit k <=> centroid k moved in the last update
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
@@ -1030,6 +1031,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         // static split predicts (with one fixed range per wave the slowest wave ran 2x the mean).
         const uint32_t bg = gw0 + blockIdx.x * WAVES;
         const uint32_t mb0 = wfirst[bg], mb1 = wfirst[bg + WAVES];
+        // The super-cell lists S of the block's range, ONCE per block: its cells are consecutive in super-cell-major order, so they
+        // lie in one to three super-cells; wave w builds the list of super-cell sup_first + w into its own strip and every wave
+        // reads the strip it needs.  (Until round 3 every wave built S for every super-cell it touched: 8 K builds a launch for 512
+        // super-cells, ~15 % of the full schedule's VALU instructions -- and the launch is bound by those)  A range
+        // that spans more super-cells than the block has waves (a sparse image) keeps the private builds.
+        uint32_t sup_first = 0, nsl = 0;
+        if (mb1 > mb0) {
+            const uint32_t cf = ne_cell[mb0] >> kSuperShift, cl = ne_cell[mb1 - 1] >> kSuperShift;
+            sup_first = cf;
+            if (cl - cf < (uint32_t)WAVES) nsl = cl - cf + 1;
+        }
+        if ((uint32_t)wid < nsl) {
+            const uint32_t n = build_super(tab, K, sup_first + wid, lane, lt_mask, S, scap);
+            if (lane == 0) s_nS[wid] = n;
+        }
         if (threadIdx.x == 0) s_cell = mb0;
         __syncthreads();
         auto draw = [&]() -> uint32_t {
@@ -1058,9 +1074,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             uint32_t s_next = 0, e_next = 0, c_next = 0;
             if (mn < mb1) { s_next = ne_start[mn]; e_next = ne_start[mn + 1]; c_next = ne_cell[mn]; }
             RG_PHASE(1);
-            if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
+            const uint2 *Sl = S;
+            if (nsl) {
+                const uint32_t slot = (c >> kSuperShift) - sup_first;
+                Sl = tab + K + (size_t)slot * (scap + K);
+                nSup = s_nS[slot];
+            } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
             RG_PHASE(2);
-            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(S, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
+            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
                                                 : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
             RG_PHASE(3);
             RG_COUNT(9, 1);
