@@ -54,7 +54,10 @@ struct KmXyState {
     uint64_t N = 0, seed = 0, max_iters = 0;
     bool brute = false, no_skip = false;
     DevBuf labels, cent, partials, running, dstate, members_last, tile_box, super_box, tile_piv, tile_mask, moved_list;
-    bool use_tab = false;
+    DevBuf sup_piv, sup_mask;              // super-tile filter of the skip schedule
+    DevBuf f_partials, f_running, f_cent;  // the loop with the update folded into the assign launches: 3 / 2 / 2 buffers (XyFused)
+    bool use_tab = false, fused = false;
+    uint32_t launch_no = 0;
 };
 
 __device__ __forceinline__ uint32_t xdot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
@@ -178,6 +181,8 @@ struct TileState {              // per tile, carried between iterations
     unsigned long long *mask;   // [ntiles][K/64 rounded up] candidate bitmask of the last build
     const uint32_t *moved;      // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;         // skip schedule when moved[0] <= max_moved (0 disables it)
+    uint32_t *spiv;             // per super-tile: id of the pivot of its last list build (0xffffffff: none yet)
+    unsigned long long *smask;  // per super-tile: union of its tiles' candidate masks
 };
 
 // -DCNIIC_XY_PHASES: wave-clock totals per phase of k_xy_assign (a measuring build, never the shipped one)
@@ -192,6 +197,26 @@ __device__ unsigned long long g_xy_phase[12];
 
 __host__ __device__ constexpr uint32_t xy_acc_words(uint32_t K) { return (6 * K + 3) & ~3u; }  // keeps the int4 arrays aligned
 
+// Centroid update folded into the next assign launch (round 3; the colour kernel has had it since round 1): launch j first finishes
+// iteration j - 1 -- every block turns (running sums + the deltas of launch j - 1) into the K centroids it loads into LDS anyway,
+// two per thread, and block 0 also writes the global state -- and then assigns.  One dependent kernel less per iteration (8.5 us +
+// the gap in front of it, x 188 launches of the configs[2] run).  The deltas are triple-buffered (launch j adds into buffer j % 3,
+// reads (j - 1) % 3, block 0 clears (j + 1) % 3); running sums and the centroids to compare with ping-pong.  Only with the table
+// in LDS (K <= 2048): without it other blocks would read centroids from memory while block 0 writes them.
+struct XyFused {
+    uint32_t on, launch_no;
+    uint64_t seed, max_iters, N;
+    const unsigned long long *partials_prev;   // deltas of launch j - 1
+    unsigned long long *partials_clear;        // the buffer launch j + 1 adds into
+    const unsigned long long *running_prev;
+    unsigned long long *running_new;
+    const int4 *cent_prev;                     // centroids launch j - 1 assigned with
+    int4 *cent_new;                            // block 0: this launch's, for launch j + 1 to start from
+    int4 *cent_g;                              // ... and the result copy
+    uint64_t *members_out;
+    KmDevState *st_rw;
+};
+
 // LDS (dynamic): acc[K][6] u32 | S_c[kSCap] int4 | W_c[16][wcap] int4 | M_c[512] int4 | W_mask[16][MW] u64 |
 //                S_k[kSCap] u16 | W_k[16][wcap] u16 | (use_tab) tab[K] int4: the centroid table itself
 __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                                                          uint16_t *__restrict__ labels,
                                                          unsigned long long *__restrict__ partials,
                                                          const KmDevState *__restrict__ st, uint32_t wcap, int use_tab,
-                                                         int brute, TileState ts) {
+                                                         int brute, TileState ts, XyFused fz) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t MW = (K + 63) >> 6;
     uint32_t *acc = lds;
@@ -215,6 +240,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     __shared__ unsigned long long s_key, s_evals;
     __shared__ uint32_t s_n;
     __shared__ uint32_t wsum[kXWaves], s_dirty[2][kXWaves], s_ncand[kXWaves];
+    __shared__ uint16_t s_rel[3][kXMaxMovedSkip];   // skip schedule: the moved centroids that matter to the super-tile (indices into M_c)
+    __shared__ uint32_t s_nrel[3];
+    __shared__ unsigned long long s_smask[64];      // union of the super-tile's tiles' candidate masks, being collected
     const uint32_t done = st->done;  // acted on once the set-up loads are out
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -225,40 +253,132 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
 #endif
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const bool first = st->iter == 0;
-    const uint32_t nS = ts.moved[0];
-    const bool skip_mode = !first && !brute && nS <= ts.max_moved;
+    const bool first = fz.on ? fz.launch_no == 0 : st->iter == 0;
+    uint32_t nS = fz.on ? K : ts.moved[0];
+    const bool upd = fz.on && !first;
+    __shared__ uint32_t s_nmoved, s_reseed, s_active;
     for (uint32_t i = threadIdx.x; i < 6 * K; i += kXThreads) acc[i] = 0;
-    if (skip_mode)
-        for (uint32_t j = threadIdx.x; j < nS; j += kXThreads) {
-            const uint32_t k = ts.moved[1 + j];
-            int4 c = cent[k];
-            c.w = (int32_t)k;
-            M_c[j] = c;
-        }
-    if (threadIdx.x == 0) { s_key = ~0ull; s_evals = 0; }
-    if (use_tab)
-        for (uint32_t k = threadIdx.x; k < K; k += kXThreads) tab[k] = cent[k];
+    if (threadIdx.x == 0) { s_key = ~0ull; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_nrel[0] = s_nrel[1] = s_nrel[2] = 0; }
     // this thread's slice of the centroid table, for the whole launch: [t R, (t+1) R) so lists come out ascending
     const uint32_t R = (K + kXThreads - 1) / kXThreads;
     int4 mine[kXMaxR];
-#pragma unroll
-    for (int i = 0; i < kXMaxR; i++) {
-        const uint32_t k = threadIdx.x * R + i;
-        mine[i] = ((uint32_t)i < R && k < K) ? cent[k] : make_int4(0, 0, 0, 0);
-    }
     int4 *const my_c = W_c + (size_t)wv * wcap;
     uint16_t *const my_k = W_k + (size_t)wv * wcap;
     unsigned long long *const my_mask = W_mask + (size_t)wv * MW;
     uint32_t moved = 0;
     unsigned long long evals = 0;
-    if (done) return;
-    __syncthreads();
+    if (!upd) {
+        if (!fz.on && !first && !brute && nS <= ts.max_moved)
+            for (uint32_t j = threadIdx.x; j < nS; j += kXThreads) {
+                const uint32_t k = ts.moved[1 + j];
+                int4 c = cent[k];
+                c.w = (int32_t)k;
+                M_c[j] = c;
+            }
+        if (use_tab)
+            for (uint32_t k = threadIdx.x; k < K; k += kXThreads) tab[k] = cent[k];
+#pragma unroll
+        for (int i = 0; i < kXMaxR; i++) {
+            const uint32_t k = threadIdx.x * R + i;
+            mine[i] = ((uint32_t)i < R && k < K) ? cent[k] : make_int4(0, 0, 0, 0);
+        }
+        if (done) return;
+        if (fz.on && blockIdx.x == 0)
+            for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += kXThreads) fz.partials_clear[i] = 0ull;
+        __syncthreads();
+    } else {
+        // ---- finish iteration j - 1: Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137),
+        // two clusters per thread, everything requested before anything is looked at
+        const uint32_t j = fz.launch_no;
+        const unsigned long long changed = fz.partials_prev[6 * (size_t)K], pev = fz.partials_prev[6 * (size_t)K + 1];
+        unsigned long long r[kXMaxR][6];   // running sums + the deltas (kept apart they were 96 registers and spilled)
+        bool anyd[kXMaxR];
+        int4 oc[kXMaxR];
+#pragma unroll
+        for (int i = 0; i < kXMaxR; i++) {
+            const uint32_t k = threadIdx.x * R + i;
+            oc[i] = make_int4(0, 0, 0, 0);
+            anyd[i] = false;
+#pragma unroll
+            for (int q = 0; q < 6; q++) r[i][q] = 0;
+            if ((uint32_t)i < R && k < K) {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const size_t at = q < 5 ? 5 * (size_t)k + q : 5 * (size_t)K + k;
+                    const unsigned long long dd = fz.partials_prev[at];
+                    anyd[i] |= dd != 0;
+                    r[i][q] = fz.running_prev[at] + dd;
+                }
+                oc[i] = fz.cent_prev[k];
+            }
+        }
+        if (done) return;   // a launch past convergence
+        __syncthreads();    // (the accumulators and counters above are in place)
+#pragma unroll
+        for (int i = 0; i < kXMaxR; i++) {
+            const uint32_t k = threadIdx.x * R + i;
+            mine[i] = make_int4(0, 0, 0, 0);
+            if ((uint32_t)i < R && k < K) {
+                const bool any = anyd[i];
+                const unsigned long long m = r[i][5];
+                int4 nc = oc[i];
+                if (m == 0) {  // reseeded every iteration it stays empty (the index depends on the iteration)
+                    const uint64_t idx = reseed_index(fz.seed, (uint64_t)j - 1, k, fz.N);  // fake_clone of the stolen pixel
+                    nc = make_cent((int32_t)(idx % w), (int32_t)(idx / w), rgb_key(rgb + 3 * idx));
+                    atomicAdd(&s_reseed, 1u);
+                } else {
+                    atomicAdd(&s_active, 1u);
+                    if (any) {  // floor(sum / m) with sum < 2^42 and m < 2^28: a double quotient is within one of it
+                        uint32_t q5[5];
+                        const double md = (double)m;
+#pragma unroll
+                        for (int q = 0; q < 5; q++) {
+                            unsigned long long e = (unsigned long long)((double)r[i][q] / md);
+                            if (e * m > r[i][q]) e--;
+                            else if ((e + 1) * m <= r[i][q]) e++;
+                            q5[q] = (uint32_t)e;
+                        }
+                        nc = make_cent((int32_t)q5[0], (int32_t)q5[1], ((q5[2] & 255) << 16) | ((q5[3] & 255) << 8) | (q5[4] & 255));
+                    }
+                }
+                mine[i] = nc;
+                tab[k] = nc;
+                if (oc[i].x != nc.x || oc[i].y != nc.y || oc[i].z != nc.z) {
+                    const uint32_t pos = atomicAdd(&s_nmoved, 1u);
+                    if (pos < kXMaxMovedSkip) { int4 mc = nc; mc.w = (int32_t)k; M_c[pos] = mc; }
+                }
+                if (blockIdx.x == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) fz.running_new[q < 5 ? 5 * (size_t)k + q : 5 * (size_t)K + k] = r[i][q];
+                    fz.cent_new[k] = nc;
+                    fz.cent_g[k] = nc;
+                    fz.members_out[k] = m;
+                }
+            }
+        }
+        if (blockIdx.x == 0)
+            for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += kXThreads) fz.partials_clear[i] = 0ull;
+        __syncthreads();
+        const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            KmDevState *sw = fz.st_rw;
+            sw->changed_ring[(j - 1) % kHistRing] = changed;
+            sw->moved_last = changed;
+            sw->reseeds += s_reseed;
+            sw->active = s_active;
+            sw->pair_evals += pev;
+            sw->iter = j;
+            if (fin) sw->done = 1;
+        }
+        if (fin) return;  // converged (or the iteration cap): nothing to assign
+        nS = s_nmoved;
+    }
+    const bool skip_mode = !first && !brute && nS <= ts.max_moved;
     XY_PHASE(0);
 
     const uint64_t npix = (uint64_t)w * h;
-    uint32_t par = 0;
-    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x, par ^= 1) {
+    uint32_t par = 0, sit = 0;
+    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x, par ^= 1, sit++) {
         const uint32_t stx = (sup % super_x) * kSTX, sty = (sup / super_x) * kSTY;
         const uint32_t tix = stx + (wv & (kSTX - 1)), tiy = sty + wv / kSTX;
         const bool has_tile = tix < tiles_x && tiy < tiles_y;
@@ -269,18 +389,51 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         tb.lo[0] = (int32_t)tx0; tb.hi[0] = (int32_t)(tx0 + tw) - 1; tb.lo[1] = (int32_t)ty0; tb.hi[1] = (int32_t)(ty0 + th) - 1;
         box_colours(tb, has_tile ? ts.box[tile] : make_uint2(0, 0));
 
+        // ---- skip schedule, first the whole super-tile (round 3): of the centroids that moved, which matter here at all?  One per
+        // thread: a moved centroid that no tile of the super-tile has as a candidate (the union of their masks) and that the
+        // super-tile's pivot -- any centroid will do for the argument; the pivot of its last list build is a good one -- strictly
+        // dominates over the super-tile's whole box cannot be nearest or tied for any pixel of it, before or after its move: no
+        // tile's decisions depend on it.  The tiles then test what is left, typically a handful of the up to 512 (every tile
+        // against every moved centroid was a quarter of the kernel's instructions in mid-run), and a super-tile nothing
+        // matters to is done without reading a tile record.
+        const uint32_t it3 = sit % 3;
+        uint32_t nrel = nS;
+        if (skip_mode) {
+            if (threadIdx.x == 0) s_nrel[(sit + 1) % 3] = 0;   // (the counter of the NEXT super-tile; its last readers are two barriers back)
+            const uint32_t pid = ts.spiv[sup];
+            if (threadIdx.x < nS) {
+                const int4 m = M_c[threadIdx.x];
+                bool rel = true;
+                if (pid < K) {
+                    Box5 sb;
+                    sb.lo[0] = (int32_t)(stx * kTW); sb.hi[0] = (int32_t)min(w, (stx + kSTX) * kTW) - 1;
+                    sb.lo[1] = (int32_t)(sty * kTH); sb.hi[1] = (int32_t)min(h, (sty + kSTY) * kTH) - 1;
+                    box_colours(sb, ts.sbox[sup]);
+                    Dominance ds;
+                    ds.set(sb, use_tab ? tab[pid] : cent[pid]);
+                    const unsigned long long uw = ts.smask[(size_t)sup * MW + ((uint32_t)m.w >> 6)];
+                    rel = ((uw >> (m.w & 63)) & 1ull) || ds.worst(m) >= 0;
+                }
+                if (rel) s_rel[it3][atomicAdd(&s_nrel[it3], 1u)] = (uint16_t)threadIdx.x;
+            }
+            __syncthreads();
+            nrel = s_nrel[it3];
+            if (nrel == 0) continue;   // nothing that moved matters to any tile here (block-uniform)
+        }
+        if (wv == 0 && lane < MW) s_smask[lane] = 0ull;   // (collected below, between the two barriers of a super-tile that has dirty tiles)
         // ---- skip test (per wave): did anything that matters to this tile change?
         bool dirty = has_tile;
+        unsigned long long mword = 0ull;
         if (skip_mode && has_tile) {
             Dominance dm;
             dm.set(tb, ts.piv[tile]);
-            const unsigned long long mword = lane < MW ? ts.mask[(size_t)tile * MW + lane] : 0ull;
+            mword = lane < MW ? ts.mask[(size_t)tile * MW + lane] : 0ull;
             bool d = false;
-            for (uint32_t j0 = 0; j0 < nS; j0 += 64) {  // wave-uniform trip count: the shuffle needs every lane
+            for (uint32_t j0 = 0; j0 < nrel; j0 += 64) {  // wave-uniform trip count: the shuffle needs every lane
                 const uint32_t j = j0 + lane;
-                const int4 m = M_c[min(j, nS - 1)];
+                const int4 m = M_c[s_rel[it3][min(j, nrel - 1)]];
                 const unsigned long long wd = __shfl(mword, (m.w >> 6) & 63, 64);
-                d |= j < nS && (((wd >> (m.w & 63)) & 1ull) || dm.worst(m) >= 0);
+                d |= j < nrel && (((wd >> (m.w & 63)) & 1ull) || dm.worst(m) >= 0);
             }
             dirty = __ballot(d) != 0ull;
         }
@@ -331,6 +484,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             if (lane == 0) atomicMin(&s_key, key);
             __syncthreads();
             const uint32_t pk = (uint32_t)(s_key & 4095ull);
+            if (threadIdx.x == 0) ts.spiv[sup] = pk;
             Dominance dm;
             dm.set(sb, use_tab ? tab[pk] : cent[pk]);
             bool keep[kXMaxR];
@@ -391,13 +545,19 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             if (lane == 0) ts.piv[tile] = pv;
             for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = my_mask[i];
         } else if (dirty) {
-            if (lane == 0) ts.piv[tile] = cent[0];                      // every centroid is a candidate:
+            if (lane == 0) ts.piv[tile] = use_tab ? tab[0] : cent[0];   // every centroid is a candidate:
             for (uint32_t i = lane; i < MW; i += 64) ts.mask[(size_t)tile * MW + i] = ~0ull;  // any move makes the tile dirty
         }
 
+        // the union of the tiles' masks, for the super-tile filter of later launches: a dirty tile's new mask, a clean tile's old one
+        if (has_tile && lane < MW) {
+            const unsigned long long v = !dirty ? mword : s_over ? ~0ull : my_mask[lane];
+            if (v) atomicOr(&s_smask[lane], v);
+        }
         XY_PHASE(4);
         __syncthreads();  // every dirty tile's strip is in LDS
         XY_PHASE(2);
+        if (wv == 0 && lane < MW) ts.smask[(size_t)sup * MW + lane] = s_smask[lane];
 
         // ---- assign, one unit at a time; the next unit's pixels and labels are in flight meanwhile
 #pragma unroll
@@ -444,8 +604,8 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     }
                 }
             } else {
-                for (uint32_t q = 0; q < K; q++) {  // q wave-uniform: scalar loads
-                    const int4 cc = cent[q];
+                for (uint32_t q = 0; q < K; q++) {  // q wave-uniform: scalar loads (an LDS broadcast with the table there)
+                    const int4 cc = use_tab ? tab[q] : cent[q];
                     const int32_t ax = xmad24(2 * x, cc.x, cc.w);
 #pragma unroll
                     for (int j = 0; j < kXRows; j++) {
@@ -644,9 +804,9 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     const uint64_t per_block_max = std::max<uint64_t>(((1ull << 31) - 1) / ((uint64_t)std::max(w, h) * kSuperPx), 1);
     s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256), ceil_div(nsuper, per_block_max));
     const uint32_t MW = (K + 63) / 64;
-    // LDS budget (159 KiB): accumulators, S, the moved list, the masks, then the centroid table if it fits next
+    // LDS budget (155 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
     // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
-    const size_t lds_max = 159 * 1024;
+    const size_t lds_max = 155 * 1024;  // (160 KiB less the kernel's static arrays: 4 KiB since the super-tile filter's lists)
     size_t fixed = (size_t)xy_acc_words(K) * 4 + (size_t)kSCap * 18 + (size_t)kXMaxMovedSkip * 16 + (size_t)kXWaves * MW * 8;
     s.use_tab = fixed + (size_t)K * 16 + (size_t)kXWaves * 64 * 18 <= lds_max;
     if (s.use_tab) fixed += (size_t)K * 16;
@@ -663,7 +823,20 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, s.tile_piv.alloc((uint64_t)ntiles * 16));
     CNIIC_HIP_TRY(c, s.tile_mask.alloc((uint64_t)ntiles * MW * 8));
     CNIIC_HIP_TRY(c, s.moved_list.alloc(((uint64_t)K + 1) * 4));
+    CNIIC_HIP_TRY(c, s.sup_piv.alloc((uint64_t)nsuper * 4));
+    CNIIC_HIP_TRY(c, s.sup_mask.alloc((uint64_t)nsuper * MW * 8));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(s.sup_piv.p, 0xff, (uint64_t)nsuper * 4, c->stream));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(s.sup_mask.p, 0xff, (uint64_t)nsuper * MW * 8, c->stream));
     s.no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
+    s.fused = s.use_tab && !s.brute && !(getenv("CNIIC_XY_UNFUSED") && atoi(getenv("CNIIC_XY_UNFUSED")));
+    if (s.fused) {
+        const uint64_t Wb = (6 * (uint64_t)K + 2) * 8;
+        CNIIC_HIP_TRY(c, s.f_partials.alloc(3 * Wb));
+        CNIIC_HIP_TRY(c, s.f_running.alloc(2 * Wb));
+        CNIIC_HIP_TRY(c, s.f_cent.alloc(2 * (uint64_t)K * 16));
+        CNIIC_HIP_TRY(c, hipMemsetAsync(s.f_partials.p, 0, 3 * Wb, c->stream));
+        CNIIC_HIP_TRY(c, hipMemsetAsync(s.f_running.p, 0, 2 * Wb, c->stream));
+    }
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.partials.p, 0, (6 * (uint64_t)K + 2) * 8, c->stream));
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.running.p, 0, (6 * (uint64_t)K + 2) * 8, c->stream));
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.dstate.p, 0, sizeof(KmDevState), c->stream));
@@ -674,20 +847,42 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     hipLaunchKernelGGL(k_xy_super_boxes, dim3((uint32_t)ceil_div(nsuper, 256)), dim3(256), 0, c->stream, s.tile_box.as<uint2>(),
                        s.tiles_x, s.tiles_y, s.super_x, nsuper, s.super_box.as<uint2>());
     CNIIC_HIP_TRY(c, hipGetLastError());
-    // the assign kernel carves up to ~150 KiB of the CU's 160 KiB LDS
+    // the assign kernel carves up to 155 KiB of the CU's 160 KiB LDS
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         159 * 1024));
+                                         155 * 1024));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
 
-static int xy_assign(KmXyState &s) {
+static int xy_assign(KmXyState &s, bool fused = false) {
     Ctx *c = s.c;
+    XyFused fz{};
+    unsigned long long *part = s.partials.as<unsigned long long>();
+    if (fused) {
+        const uint64_t W = 6 * (uint64_t)s.K + 2;
+        const uint32_t j = s.launch_no++;
+        auto *P = s.f_partials.as<unsigned long long>();
+        auto *Rn = s.f_running.as<unsigned long long>();
+        int4 *Cn = s.f_cent.as<int4>();
+        fz.on = 1; fz.launch_no = j; fz.seed = s.seed; fz.max_iters = s.max_iters; fz.N = s.N;
+        fz.partials_prev = P + ((j + 2) % 3) * W;
+        fz.partials_clear = P + ((j + 1) % 3) * W;
+        fz.running_prev = Rn + ((j + 1) % 2) * W;
+        fz.running_new = Rn + (j % 2) * W;
+        fz.cent_prev = Cn + ((j + 1) % 2) * (size_t)s.K;
+        fz.cent_new = Cn + (j % 2) * (size_t)s.K;
+        fz.cent_g = s.cent.as<int4>();
+        fz.members_out = s.members_last.as<uint64_t>();
+        fz.st_rw = s.dstate.as<KmDevState>();
+        part = P + (j % 3) * W;
+    }
+    // (launch 0 of the fused loop reads the initial centroids from s.cent; every later one computes its table from the sums)
     hipLaunchKernelGGL(k_xy_assign, dim3(s.nblocks), dim3(kXThreads), s.lds, c->stream, s.rgb, s.w, s.h, s.tiles_x, s.tiles_y,
                        s.super_x, s.super_x * s.super_y, s.K, s.cent.as<int4>(), s.labels.as<uint16_t>(),
-                       s.partials.as<unsigned long long>(), s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
+                       part, s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
                        TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),
-                                 s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip});
+                                 s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip, s.sup_piv.as<uint32_t>(),
+                                 s.sup_mask.as<unsigned long long>()}, fz);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -714,8 +909,11 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
     LaggedPoll poll(c, s.dstate.p);
     CNIIC_TRY(poll.prepare());
     ScopedKernelTimer timer(c, "kmeans_xyrgb_iter", opts && (opts->flags & CNIIC_KM_PROFILE));  // (stop() synchronises)
+    if (s.fused)  // the centroids launch 0 assigns with are what launch 1 compares its new ones with (cent_prev of launch 1 = buffer 0)
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(s.f_cent.p, s.cent.p, (size_t)K * 16, hipMemcpyDeviceToDevice, c->stream));
     for (;;) {
         for (int b = 0; b < 4; b++) {
+            if (s.fused) { CNIIC_TRY(xy_assign(s, true)); continue; }
             CNIIC_TRY(xy_assign(s));
             CNIIC_TRY(xy_update(s));
         }
