@@ -1070,7 +1070,12 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
                     if (!n) return CNIIC_OK;
                     CNIIC_TRY(need_image());
                     if (delta) CNIIC_HIP_TRY(c, keys_d.alloc(n * 4));
-                    CNIIC_TRY(huff_decode_tables_dev(c, tab_big.as<uint8_t>(), nl, off_key, off_len, max_len, 0u, sd + ppos, true, nbytes - ppos, n,
+                    uint32_t key0 = 0;   // (a one-symbol alphabet is filled in, not decoded: its key is wanted here)
+                    if (nl == 1) {
+                        CNIIC_HIP_TRY(c, hipMemcpyAsync(&key0, tab_big.as<uint8_t>() + off_key, 4, hipMemcpyDeviceToHost, c->stream));
+                        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    }
+                    CNIIC_TRY(huff_decode_tables_dev(c, tab_big.as<uint8_t>(), nl, off_key, off_len, max_len, key0, sd + ppos, true, nbytes - ppos, n,
                                                      delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
                     done_dev = status != 2;
                 }

@@ -552,6 +552,16 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
                                              LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    if (!first && !ALLWRITE && ncand == 1) {
+        // More than half of the cells lie inside one cluster's region: ONE candidate, and every point already carries its label.
+        // Nothing can move then (the lone candidate beats every other centroid for every colour of the cube): the sweep is over
+        // after four compares and a ballot instead of ~90 instructions of scores and label checks.
+        const uint32_t only = IDMASK - (cand[0].y & IDMASK);
+        bool same = true;
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) same = same && (base + u * 64 + lane >= e || cur[u] == only);
+        if (__ballot(!same) == 0ull) return;
+    }
     uint32_t best[kSweep];
 #pragma unroll
     for (int u = 0; u < kSweep; u++) best[u] = 0;

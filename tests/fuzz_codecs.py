@@ -10,7 +10,9 @@ import oracle_lib as O
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_HILBERT_MOVE": "any"}, {"CNIIC_HUF_GPU_CODES_MIN": "0"},
-         {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"}]
+         {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"},
+         {"CNIIC_GPU_DECODE_MIN": "0"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1"},   # round 3: the parallel decoder / the GPU trie parse whatever the size
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HILBERT_MOVE": "any"}]
 
 
 def image():
@@ -33,6 +35,14 @@ def image():
     return (img & 255).astype(np.uint8)
 
 
+try:
+    import torch as TORCH
+    if not TORCH.cuda.is_available():
+        TORCH = None
+except Exception:
+    TORCH = None
+
+
 def run(ctx, budget):
     """`budget` seconds of random cases on ctx; returns how many were checked (an assertion stops at the first difference)"""
     t0, cases = time.time(), 0
@@ -42,13 +52,29 @@ def run(ctx, budget):
         saved = {k: os.environ.get(k) for k in knob}
         os.environ.update(knob)
         try:
+          try:
             for expr in ("delta", "hufman", "hilbert(rle)"):
                 rc, data, _ = ctx.encode(expr, img)
                 erc, edata, _ = O.encode(expr, img)
                 assert rc == erc == 0 and data == edata, (expr, img.shape, knob, "encode")
                 rc, back = ctx.decode(expr, data)
                 assert rc == 0 and np.array_equal(back, img), (expr, img.shape, knob, "decode")
+                if TORCH is not None:   # the stream in HBM at a random byte alignment, the image into HBM; and a random cut of it
+                    shift = int(rng.integers(0, 4))
+                    buf = TORCH.zeros(len(data) + 8, dtype=TORCH.uint8, device="cuda")
+                    buf[shift:shift + len(data)] = TORCH.frombuffer(bytearray(data), dtype=TORCH.uint8).cuda()
+                    out = TORCH.zeros(max(img.size, 1), dtype=TORCH.uint8, device="cuda")
+                    rc, dw, dh = ctx.decode_into(expr, buf[shift:], len(data), out)
+                    assert rc == 0 and np.array_equal(out[:img.size].cpu().numpy().reshape(img.shape), img), (expr, img.shape, knob, "decode (HBM)")
+                    cut = int(rng.integers(1, max(2, len(data))))
+                    rc, _, _ = ctx.decode_into(expr, buf[shift:], len(data) - cut, out, allow=(-6, -8))
+                    erc, _ = O.decode(expr, data[:len(data) - cut])
+                    assert (rc == 0) == (erc == 0), (expr, img.shape, knob, "cut", cut)
                 cases += 1
+          except Exception:
+            sys.stderr.write("fuzz_codecs: failing case: codec %s, image %s kind-independent seed state, knobs %s\n" % (expr, img.shape, knob))
+            np.save("/tmp/fuzz_fail.npy", img)
+            raise
         finally:
             for k, v in saved.items():
                 if v is None: os.environ.pop(k, None)
