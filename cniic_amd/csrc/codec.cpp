@@ -176,13 +176,21 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
         CNIIC_HIP_TRY(c, hipMemcpyAsync(keys.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
     }
     // (large alphabet: the leaves come back sorted by (count, key) -- huff_sort_leaves_dev -- and the host only merges)
-    DevBuf sort_a, sort_b;
+    DevBuf sort_a, sort_b, len_d, code_d, off_run_d;
+    uint64_t nbits_runs = 0;
+    bool tree_built = false;
     if (gpu_codes) {
         uint64_t *sorted_d = nullptr;
         CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
         CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
         CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
+        // (round 3) the tree, the codes and the leaves' places in the decoder without the host's merge, when the counts come in runs
+        CNIIC_HIP_TRY(c, len_d.alloc(U));
+        CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+        CNIIC_HIP_TRY(c, off_run_d.alloc(U * 8));
+        CNIIC_TRY(huff_tree_from_runs(c, sorted_d, counts_d.as<uint64_t>(), (uint32_t)U, sym_kind, len_d.as<uint8_t>(), code_d.as<uint64_t>(),
+                                      off_run_d.as<uint64_t>(), &nbits_runs, &tree_built));
+        if (!tree_built) CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
     } else {
         CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
     }
@@ -206,34 +214,39 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
     // build() (huf.rs:31) and the serialised decoder (huf.rs:34)
     if (!c->huf_scratch) c->huf_scratch = std::make_shared<HuffScratch>();
     HuffScratch *scratch = static_cast<HuffScratch *>(c->huf_scratch.get());
-    DevBuf len_d, code_d;
-    CNIIC_HIP_TRY(c, len_d.alloc(U));
-    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    if (!len_d.p) CNIIC_HIP_TRY(c, len_d.alloc(U));
+    if (!code_d.p) CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
     uint64_t nbits = 0, header_bytes = 0;
     StreamOut so(c, out, cap, len);
     if (gpu_codes) {
-        uint32_t root = 0;
-        if (!huff_merge_sorted_into(counts /* sorted leaves */, U, left_h, right_h, nl_h, &root, scratch))
-            return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
-        host_trace().mark("huf: tree (host)");
         DevBuf tree_d, off_d, totals_d;
-        CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));
-        CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
-        CNIIC_HIP_TRY(c, totals_d.alloc(16));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(tree_d.p, left_h, 3 * (U - 1) * 4, hipMemcpyHostToDevice, c->stream));
-        const uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (U - 1), *nl_d = right_d + (U - 1);
-        CNIIC_TRY(huff_tree_codes(c, left_d, right_d, nl_d, counts_d.as<uint64_t>(), (uint32_t)U, root, sym_kind, len_d.as<uint8_t>(),
-                                  code_d.as<uint64_t>(), off_d.as<uint64_t>(), totals_d.as<uint64_t>()));
-        CNIIC_HIP_TRY(c, ctx_pinned_u(c));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], totals_d.p, 16, hipMemcpyDeviceToHost, c->stream));
-        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->pinned_u[3]) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
-        nbits = c->pinned_u[2];
+        const uint64_t *off_use = off_run_d.as<uint64_t>();
+        if (tree_built) {
+            nbits = nbits_runs;
+        } else {
+            uint32_t root = 0;
+            if (!huff_merge_sorted_into(counts /* sorted leaves */, U, left_h, right_h, nl_h, &root, scratch))
+                return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+            host_trace().mark("huf: tree (host)");
+            CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));
+            CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
+            CNIIC_HIP_TRY(c, totals_d.alloc(16));
+            CNIIC_HIP_TRY(c, hipMemcpyAsync(tree_d.p, left_h, 3 * (U - 1) * 4, hipMemcpyHostToDevice, c->stream));
+            const uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (U - 1), *nl_d = right_d + (U - 1);
+            CNIIC_TRY(huff_tree_codes(c, left_d, right_d, nl_d, counts_d.as<uint64_t>(), (uint32_t)U, root, sym_kind, len_d.as<uint8_t>(),
+                                      code_d.as<uint64_t>(), off_d.as<uint64_t>(), totals_d.as<uint64_t>()));
+            CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+            CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], totals_d.p, 16, hipMemcpyDeviceToHost, c->stream));
+            CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->pinned_u[3]) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
+            nbits = c->pinned_u[2];
+            off_use = off_d.as<uint64_t>();
+        }
         host_trace().mark("huf: codes (GPU)");
         const uint64_t trie_bytes = huff_tree_bytes(sym_kind, U), head = header.size();
         CNIIC_TRY(so.begin_sized(head + trie_bytes, (nbits + 7) / 8));
         CNIIC_TRY(so.put_header(header));
-        CNIIC_TRY(huff_tree_serialize_dev(c, keys_d.as<uint32_t>(), off_d.as<uint64_t>(), (uint32_t)U, sym_kind, so.dev + head, trie_bytes));
+        CNIIC_TRY(huff_tree_serialize_dev(c, keys_d.as<uint32_t>(), off_use, (uint32_t)U, sym_kind, so.dev + head, trie_bytes));
         header_bytes = head + trie_bytes;  // (what the pack below starts behind; the decoder's bytes are on the device)
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));  // tree_d / off_d go back to the pool
         host_trace().mark("huf: serialise trie (GPU)");
@@ -852,13 +865,21 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     uint8_t *const pin = static_cast<uint8_t *>(c->pinned_huf);
     uint64_t *const counts = reinterpret_cast<uint64_t *>(pin);
     std::vector<uint32_t> keys_v(gpu_codes ? 0 : U);
-    DevBuf sort_a, sort_b;
+    DevBuf sort_a, sort_b, len_d, code_d, tree_d, off_d;
+    uint64_t nbits = 0;
+    bool tree_built = false;
     if (gpu_codes) {  // the leaves come back sorted by (count, key): the host only merges
         uint64_t *sorted_d = nullptr;
         CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
         CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
         CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
-        CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
+        // (round 3) the tree, the codes and the leaves' places in the decoder without the host's merge, when the counts come in runs
+        CNIIC_HIP_TRY(c, len_d.alloc(U));
+        CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+        CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
+        CNIIC_TRY(huff_tree_from_runs(c, sorted_d, counts_d.as<uint64_t>(), (uint32_t)U, CNIIC_SYM_SIGNED, len_d.as<uint8_t>(), code_d.as<uint64_t>(),
+                                      off_d.as<uint64_t>(), &nbits, &tree_built));
+        if (!tree_built) CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, sorted_d, U * 8, hipMemcpyDeviceToHost, c->stream));
     } else {
         CNIIC_HIP_TRY(c, hipMemcpyAsync(keys_v.data(), keys_d.p, U * 4, hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipMemcpyAsync(counts, counts_d.p, U * 8, hipMemcpyDeviceToHost, c->stream));
@@ -869,18 +890,16 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     //    from U alone: U leaves of 1 + 6 bytes and U - 1 branch tags
     if (!c->huf_scratch) c->huf_scratch = std::make_shared<HuffScratch>();
     HuffScratch *hscratch = static_cast<HuffScratch *>(c->huf_scratch.get());
-    DevBuf len_d, code_d, tree_d, off_d;
-    CNIIC_HIP_TRY(c, len_d.alloc(U));
-    CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
+    if (!len_d.p) CNIIC_HIP_TRY(c, len_d.alloc(U));
+    if (!code_d.p) CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
     HuffTree tree;
-    uint64_t nbits = 0;
-    if (gpu_codes) {
+    if (gpu_codes && !tree_built) {
         uint32_t *left_h = reinterpret_cast<uint32_t *>(counts + U), *right_h = left_h + (U - 1), *nl_h = right_h + (U - 1), root = 0;
         if (!huff_merge_sorted_into(counts /* sorted leaves */, U, left_h, right_h, nl_h, &root, hscratch))
             return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
         host_trace().mark("delta: tree (host)");
         CNIIC_HIP_TRY(c, tree_d.alloc(3 * (U - 1) * 4));
-        CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
+        if (!off_d.p) CNIIC_HIP_TRY(c, off_d.alloc(U * 8));
         CNIIC_HIP_TRY(c, hipMemcpyAsync(tree_d.p, left_h, 3 * (U - 1) * 4, hipMemcpyHostToDevice, c->stream));
         const uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (U - 1), *nl_d = right_d + (U - 1);
         CNIIC_TRY(huff_tree_codes(c, left_d, right_d, nl_d, counts_d.as<uint64_t>(), (uint32_t)U, root, CNIIC_SYM_SIGNED, len_d.as<uint8_t>(),
@@ -890,7 +909,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
         if (c->pinned_u[5]) return c->fail(CNIIC_ERR_BAD_ARG, "huffman: cannot build code (alphabet %llu)", (unsigned long long)U);
         nbits = c->pinned_u[4];
         host_trace().mark("delta: codes (GPU)");
-    } else {
+    } else if (!gpu_codes) {
         uint64_t *const code = reinterpret_cast<uint64_t *>(pin + off_code);
         uint8_t *const clen = pin + off_len;
         if (!huff_build_tree(counts, U, tree, hscratch) || !huff_codes_into(tree, clen, code))

@@ -606,6 +606,10 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
 // ---- k_huff.hip ----
 // the leaves count << 32 | rank sorted by (count, rank): stable radix sort (see k_huff.hip); the result is in *out_d = buf_a or buf_b
 int huff_sort_leaves_dev(Ctx *c, const uint64_t *counts_d, uint32_t n, uint64_t max_count, uint64_t *buf_a, uint64_t *buf_b, uint64_t **out_d);
+int huff_sort_u64(Ctx *c, uint64_t *buf_a, uint64_t *buf_b, uint32_t n, uint32_t lo_bit, uint64_t **out_d);
+// the tree, the codes and every leaf's place in the serialised decoder from the sorted leaves, the host merging RUNS of equal count only
+int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts_d, uint32_t n, int sym_kind, uint8_t *len_d, uint64_t *code_d,
+                        uint64_t *off_d, uint64_t *nbits_h, bool *built);
 // codes and the serialised decoder of a tree the host built, for large alphabets (see k_huff.hip)
 int huff_tree_codes(Ctx *c, const uint32_t *left_d, const uint32_t *right_d, const uint32_t *nleaves_d, const uint64_t *counts_d, uint32_t n,
                     uint32_t root, int sym_kind, uint8_t *len_d, uint64_t *code_d, uint64_t *off_d, uint64_t *totals_d);

@@ -12,6 +12,9 @@
 // (key -> rank+1), then len[rank] / code[rank].
 #include <mutex>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -873,6 +876,26 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_scatter(const uint64_t *_
 
 // counts_d: n counts below 2^32 in ascending key order -> sorted_d: count << 32 | rank, ascending (count, rank); max_count: a
 // bound on the counts (the number of symbols).  tmp_d: n u64 of scratch.  The result may end in either buffer: *out_d tells.
+// stable LSD radix sort of n u64 values in buf_a by their bits lo_bit .. 63 (8 bits a pass); the result ends in either buffer: *out_d
+int huff_sort_u64(Ctx *c, uint64_t *buf_a, uint64_t *buf_b, uint32_t n, uint32_t lo_bit, uint64_t **out_d) {
+    const uint32_t nblocks = ceil_div(n, (uint32_t)kSortBlock);
+    DevBuf hist, off, tot;
+    CNIIC_HIP_TRY(c, hist.alloc((uint64_t)256 * nblocks * 4));
+    CNIIC_HIP_TRY(c, off.alloc((uint64_t)256 * nblocks * 8));
+    CNIIC_HIP_TRY(c, tot.alloc(8));
+    uint64_t *src = buf_a, *dst = buf_b;
+    for (uint32_t shift = lo_bit & ~7u; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks), dim3(kSortThreads), 0, c->stream, (const uint64_t *)src, n, shift, nblocks, hist.as<uint32_t>());
+        CNIIC_TRY(pack_scan(c, hist.as<uint32_t>(), 256 * nblocks, off.as<uint64_t>(), tot.as<uint64_t>()));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks), dim3(kSortThreads), 0, c->stream, (const uint64_t *)src, n, shift, nblocks,
+                           (const uint64_t *)off.as<uint64_t>(), dst);
+        std::swap(src, dst);
+    }
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    *out_d = src;
+    return CNIIC_OK;
+}
+
 int huff_sort_leaves_dev(Ctx *c, const uint64_t *counts_d, uint32_t n, uint64_t max_count, uint64_t *buf_a, uint64_t *buf_b, uint64_t **out_d) {
     const uint32_t nblocks = ceil_div(n, (uint32_t)kSortBlock);
     DevBuf hist, off, tot;
@@ -982,6 +1005,217 @@ int huff_tree_serialize_dev(Ctx *c, const uint32_t *keys_d, const uint64_t *off_
     CNIIC_HIP_TRY(c, hipMemsetAsync(trie_d, 1, trie_bytes, c->stream));  // SER_ENUM_BRANCH huf.rs:297
     hipLaunchKernelGGL(k_tree_leaf_records, dim3(ceil_div(n, 256u)), dim3(256), 0, c->stream, keys_d, off_d, n, sym_kind == CNIIC_SYM_RGB ? 1 : 0, trie_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+// ---------------------------------------------------------------- the tree of a large alphabet without the host's merge (round 3)
+// The two-queue merge (huff_host.cpp) is sequential -- 8.8 ms for the 6.8 M colours of a photograph, most of what `hufman`
+// still cost there -- but its INPUT is not 6.8 M different things: the leaves come sorted by count, and a photograph's counts
+// are a few thousand values, each shared by a long run of leaves.  A run merges with itself: its elements are taken two by two,
+// in order, and become a run of branches of twice the count, which queues up behind the branches made before (branches are
+// made in non-decreasing order of count, so their queue stays sorted).  Only where a run has an odd element left does the next
+// run's first element pair with it.  So the host merges RUNS -- leaf runs in count order, branch runs in the order they were
+// made, a leaf run before a branch run of the same count -- and emits one descriptor per run ("pairs k0 ..
+// k0 + m - 1 are the consecutive elements of this run") or straddling pair: tens of thousands of steps instead of millions,
+// and the GPU expands the descriptors into the left / right arrays (pair k IS branch k).
+// What the merge also gave the old code, the number of leaves below every branch (a leaf's place in the serialised decoder was
+// summed from them along its path), is not needed: in pre-order the leaves appear in ascending order of their codes, and in
+// front of the leaf of rank r lie r leaf records and as many branch tags as the leaves up to and including it are the LEFTMOST
+// leaf of -- a leaf is the leftmost of one branch per trailing 0 of its code.  So: sort the leaves by code, scan the trailing
+// zeros.
+struct TreeDesc { uint32_t k0, kind, a, b; };   // kind 0: leaf run from sorted position a; 1: branch run from branch a; 2: one pair (refs a, b)
+constexpr uint32_t kRefBranch = 0x80000000u;    // a node reference: a sorted leaf position, or kRefBranch | branch number
+constexpr uint32_t kMaxLeafRuns = 1u << 16;     // more runs of equal count than this: the plain merge on the host
+
+__global__ __launch_bounds__(256) void k_leaf_run_count(const uint64_t *__restrict__ sorted, uint32_t n, uint32_t *__restrict__ nruns) {
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        mine += i == 0 || (sorted[i] >> 32) != (sorted[i - 1] >> 32);
+    mine = block_reduce_sum<256>(mine);
+    if (threadIdx.x == 0 && mine) atomicAdd(nruns, mine);
+}
+__global__ __launch_bounds__(256) void k_leaf_run_list(const uint64_t *__restrict__ sorted, uint32_t n, uint2 *__restrict__ runs, uint32_t *__restrict__ cursor) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        if (i == 0 || (sorted[i] >> 32) != (sorted[i - 1] >> 32)) runs[atomicAdd(cursor, 1u)] = make_uint2(i, (uint32_t)(sorted[i] >> 32));  // (start, count): any order
+}
+// pair k = branch k: its children
+__global__ __launch_bounds__(256) void k_tree_expand(const TreeDesc *__restrict__ desc, uint32_t ndesc, const uint64_t *__restrict__ sorted, uint32_t n,
+                                                     uint32_t *__restrict__ left, uint32_t *__restrict__ right) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k + 1 >= n) return;
+    uint32_t a = 0, b = ndesc;   // last descriptor with k0 <= k
+    while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (desc[m].k0 <= k) a = m; else b = m; }
+    const TreeDesc d = desc[a];
+    const uint32_t i = k - d.k0;
+    auto node = [&](uint32_t ref) { return (ref & kRefBranch) ? n + (ref & ~kRefBranch) : (uint32_t)sorted[ref]; };
+    uint32_t l, r;
+    if (d.kind == 0) { l = (uint32_t)sorted[d.a + 2 * i]; r = (uint32_t)sorted[d.a + 2 * i + 1]; }
+    else if (d.kind == 1) { l = n + d.a + 2 * i; r = n + d.a + 2 * i + 1; }
+    else { l = node(d.a); r = node(d.b); }
+    left[k] = l;
+    right[k] = r;
+}
+// every leaf walks to the root: length, code (the deepest bit last), count x length; totals: [0] payload bits, [1] codes longer
+// than 64 bits, [2] the longest code.  (Grid-stride, one set of atomics per block: per wave they are 10^5 on the same words.)
+__global__ __launch_bounds__(256) void k_tree_leaf_walk(const uint32_t *__restrict__ par, const uint64_t *__restrict__ counts, uint32_t n, uint32_t root,
+                                                        uint8_t *__restrict__ len, uint64_t *__restrict__ code, unsigned long long *__restrict__ totals) {
+    __shared__ unsigned long long s_bits[4];
+    __shared__ uint32_t s_mx[4], s_long[4];
+    unsigned long long bits = 0;
+    uint32_t mx = 0, toolong = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        uint32_t node = i, d = 0;
+        uint64_t cd = 0;
+        while (node != root) {
+            const uint32_t p = par[node];
+            if (d < 64) cd |= (uint64_t)(p & 1u) << d;
+            d++;
+            node = p >> 1;
+        }
+        if (d > 64) { toolong++; d = 0; cd = 0; }
+        len[i] = (uint8_t)d;
+        code[i] = cd;
+        bits += counts[i] * d;
+        mx = max(mx, d);
+    }
+    bits = wave_reduce_sum64(bits); mx = wave_reduce_max(mx); toolong = wave_reduce_sum(toolong);
+    if ((threadIdx.x & 63) == 0) { s_bits[threadIdx.x >> 6] = bits; s_mx[threadIdx.x >> 6] = mx; s_long[threadIdx.x >> 6] = toolong; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long bt = s_bits[0] + s_bits[1] + s_bits[2] + s_bits[3];
+        const uint32_t lg = s_long[0] + s_long[1] + s_long[2] + s_long[3];
+        if (bt) atomicAdd(&totals[0], bt);
+        if (lg) atomicAdd(&totals[1], (unsigned long long)lg);
+        atomicMax(&totals[2], (unsigned long long)max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])));
+    }
+}
+// code order: key = the code left-aligned in 32 bits << 32 | leaf (codes of up to 32 bits)
+__global__ __launch_bounds__(256) void k_code_keys(const uint64_t *__restrict__ code, const uint8_t *__restrict__ len, uint32_t n, uint64_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = len[i];
+    keys[i] = ((l ? (uint64_t)((uint32_t)code[i] << (32 - l)) : 0ull) << 32) | i;
+}
+// in code order: how many branches the leaf is the leftmost leaf of = the trailing zeros of its code
+__global__ __launch_bounds__(256) void k_code_tz(const uint64_t *__restrict__ sorted_keys, const uint64_t *__restrict__ code, const uint8_t *__restrict__ len, uint32_t n,
+                                                 uint32_t *__restrict__ z) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t i = (uint32_t)sorted_keys[r], l = len[i], cd = (uint32_t)code[i];
+    z[r] = cd ? min((uint32_t)__builtin_ctz(cd), l) : l;
+}
+// where the leaf's record starts in the serialised decoder: rank records of rec bytes + the branch tags in front of it
+__global__ __launch_bounds__(256) void k_code_off(const uint64_t *__restrict__ sorted_keys, const uint32_t *__restrict__ z, const uint64_t *__restrict__ zex, uint32_t n,
+                                                  uint32_t rec, uint64_t *__restrict__ off) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    off[(uint32_t)sorted_keys[r]] = (uint64_t)r * rec + zex[r] + z[r];
+}
+
+// the host's part: runs[] = the R runs of equal count among the n sorted leaves as (first sorted position, count), in order
+static bool merge_runs(const uint2 *runs, uint32_t R, uint32_t n, std::vector<TreeDesc> &desc) {
+    struct Run { uint64_t v; uint32_t first, cnt; };
+    std::vector<Run> br;   // branch runs in the order they were made (their counts never decrease)
+    size_t bh = 0;
+    uint32_t lh = 0, made = 0;
+    bool carry = false;
+    uint32_t carry_ref = 0;
+    uint64_t carry_v = 0;
+    desc.clear();
+    auto new_branches = [&](uint64_t v, uint32_t cnt) {   // branches made .. made + cnt - 1 have count v
+        if (!br.empty() && br.back().v == v && br.back().first + br.back().cnt == made) br.back().cnt += cnt;
+        else br.push_back({v, made, cnt});
+        made += cnt;
+    };
+    while (made + 1 < n) {
+        const bool leaf = lh < R && (bh >= br.size() || (uint64_t)runs[lh].y <= br[bh].v);   // among equally rare: a leaf before a branch
+        if (!leaf && bh >= br.size()) return false;   // (cannot happen: something is left to pair)
+        uint64_t v;
+        uint32_t pos, rem;
+        if (leaf) { v = runs[lh].y; pos = runs[lh].x; rem = (lh + 1 < R ? runs[lh + 1].x : n) - pos; lh++; }
+        else { v = br[bh].v; pos = br[bh].first; rem = br[bh].cnt; bh++; }
+        const uint32_t flag = leaf ? 0u : kRefBranch;
+        if (carry && rem) {
+            desc.push_back({made, 2u, carry_ref, flag | pos});
+            new_branches(carry_v + v, 1);
+            pos++; rem--; carry = false;
+        }
+        const uint32_t m = rem / 2;
+        if (m) {
+            desc.push_back({made, leaf ? 0u : 1u, pos, 0u});
+            new_branches(2 * v, m);
+            pos += 2 * m; rem -= 2 * m;
+        }
+        if (rem) { carry = true; carry_ref = flag | pos; carry_v = v; }
+    }
+    return true;
+}
+
+// sorted_d: the n >= 2 leaves as count << 32 | leaf, ascending (huff_sort_leaves_dev); counts_d: per leaf.  On *built: len_d / code_d /
+// off_d hold every leaf's code length, code and place in the serialised decoder, *nbits_h the payload's bits.  !*built: the counts
+// come in too many runs, or a code is longer than 32 bits -- the caller takes the host's merge (which handles everything).
+int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts_d, uint32_t n, int sym_kind, uint8_t *len_d, uint64_t *code_d,
+                        uint64_t *off_d, uint64_t *nbits_h, bool *built) {
+    *built = false;
+    if (n < 2 || getenv("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
+    DevBuf small, runs_d, desc_d, tree_d, par, keys_a, keys_b, z_d, zex_d, tot_d;
+    CNIIC_HIP_TRY(c, small.alloc(64));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(small.p, 0, 64, c->stream));
+    uint32_t *nruns_d = small.as<uint32_t>(), *cursor_d = nruns_d + 1;
+    unsigned long long *totals = reinterpret_cast<unsigned long long *>(small.as<uint8_t>() + 16);   // [0] bits, [1] too long, [2] longest
+    const uint32_t g = std::min<uint32_t>(ceil_div(n, 256u), 2048u);
+    hipLaunchKernelGGL(k_leaf_run_count, dim3(g), dim3(256), 0, c->stream, sorted_d, n, nruns_d);
+    CNIIC_HIP_TRY(c, ctx_pinned_u(c));
+    volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4300;   // (slots of this function's own)
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin), nruns_d, 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t R = (uint32_t)pin[0];
+    if (R == 0 || R > kMaxLeafRuns) return CNIIC_OK;
+    CNIIC_HIP_TRY(c, runs_d.alloc((uint64_t)R * 8));
+    hipLaunchKernelGGL(k_leaf_run_list, dim3(g), dim3(256), 0, c->stream, sorted_d, n, runs_d.as<uint2>(), cursor_d);
+    // (pinned_huf is the caller's: used as it is when large enough, never grown here -- the caller holds pointers into it)
+    std::vector<uint2> runs(R);
+    const bool pinned_runs = c->pinned_huf && c->pinned_huf_bytes >= (uint64_t)R * 8;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(pinned_runs ? c->pinned_huf : (void *)runs.data(), runs_d.p, (uint64_t)R * 8, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (pinned_runs) memcpy(runs.data(), c->pinned_huf, (uint64_t)R * 8);
+    std::sort(runs.begin(), runs.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
+    std::vector<TreeDesc> desc;
+    if (!merge_runs(runs.data(), R, n, desc)) return CNIIC_OK;
+    host_trace().mark("huf: tree by runs (host)");
+    const uint64_t dbytes = desc.size() * sizeof(TreeDesc);
+    CNIIC_HIP_TRY(c, desc_d.alloc(dbytes));
+    const bool pinned_desc = c->pinned_huf && c->pinned_huf_bytes >= dbytes;
+    if (pinned_desc) memcpy(c->pinned_huf, desc.data(), dbytes);
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(desc_d.p, pinned_desc ? c->pinned_huf : (const void *)desc.data(), dbytes, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, tree_d.alloc(2ull * (n - 1) * 4));
+    CNIIC_HIP_TRY(c, par.alloc(2ull * n * 4));
+    uint32_t *left_d = tree_d.as<uint32_t>(), *right_d = left_d + (n - 1);
+    hipLaunchKernelGGL(k_tree_expand, dim3(ceil_div(n - 1, 256u)), dim3(256), 0, c->stream, (const TreeDesc *)desc_d.as<TreeDesc>(), (uint32_t)desc.size(), sorted_d, n,
+                       left_d, right_d);
+    hipLaunchKernelGGL(k_tree_parents, dim3(ceil_div(n - 1, 256u)), dim3(256), 0, c->stream, (const uint32_t *)left_d, (const uint32_t *)right_d, n, par.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_leaf_walk, dim3(g), dim3(256), 0, c->stream, (const uint32_t *)par.as<uint32_t>(), counts_d, n, 2 * n - 2, len_d, code_d, totals);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin), totals, 24, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t nbits = pin[0], toolong = pin[1], longest = pin[2];
+    if (toolong || longest > 32) return CNIIC_OK;   // (the sort below keys on 32 bits of code)
+    // the leaves in code order
+    CNIIC_HIP_TRY(c, keys_a.alloc((uint64_t)n * 8));
+    CNIIC_HIP_TRY(c, keys_b.alloc((uint64_t)n * 8));
+    CNIIC_HIP_TRY(c, z_d.alloc((uint64_t)n * 4));
+    CNIIC_HIP_TRY(c, zex_d.alloc((uint64_t)n * 8));
+    CNIIC_HIP_TRY(c, tot_d.alloc(8));
+    hipLaunchKernelGGL(k_code_keys, dim3(ceil_div(n, 256u)), dim3(256), 0, c->stream, (const uint64_t *)code_d, (const uint8_t *)len_d, n, keys_a.as<uint64_t>());
+    uint64_t *srt = nullptr;
+    CNIIC_TRY(huff_sort_u64(c, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), n, 64 - (uint32_t)std::max<uint64_t>(longest, 1), &srt));
+    hipLaunchKernelGGL(k_code_tz, dim3(ceil_div(n, 256u)), dim3(256), 0, c->stream, (const uint64_t *)srt, (const uint64_t *)code_d, (const uint8_t *)len_d, n, z_d.as<uint32_t>());
+    CNIIC_TRY(pack_scan(c, z_d.as<uint32_t>(), n, zex_d.as<uint64_t>(), tot_d.as<uint64_t>()));
+    hipLaunchKernelGGL(k_code_off, dim3(ceil_div(n, 256u)), dim3(256), 0, c->stream, (const uint64_t *)srt, (const uint32_t *)z_d.as<uint32_t>(), (const uint64_t *)zex_d.as<uint64_t>(), n,
+                       (uint32_t)(1 + (sym_kind == CNIIC_SYM_RGB ? 11 : 6)), off_d);
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    *nbits_h = nbits;
+    *built = true;
     return CNIIC_OK;
 }
 
