@@ -1026,6 +1026,7 @@ int huff_tree_serialize_dev(Ctx *c, const uint32_t *keys_d, const uint64_t *off_
 struct TreeDesc { uint32_t k0, kind, a, b; };   // kind 0: leaf run from sorted position a; 1: branch run from branch a; 2: one pair (refs a, b)
 constexpr uint32_t kRefBranch = 0x80000000u;    // a node reference: a sorted leaf position, or kRefBranch | branch number
 constexpr uint32_t kMaxLeafRuns = 1u << 16;     // more runs of equal count than this: the plain merge on the host
+constexpr uint32_t kRunsMinLeaves = 1u << 18;   // fewer leaves than this: the plain merge on the host
 
 __global__ __launch_bounds__(256) void k_leaf_run_count(const uint64_t *__restrict__ sorted, uint32_t n, uint32_t *__restrict__ nruns) {
     uint32_t mine = 0;
@@ -1157,7 +1158,10 @@ static bool merge_runs(const uint2 *runs, uint32_t R, uint32_t n, std::vector<Tr
 int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts_d, uint32_t n, int sym_kind, uint8_t *len_d, uint64_t *code_d,
                         uint64_t *off_d, uint64_t *nbits_h, bool *built) {
     *built = false;
-    if (n < 2 || getenv("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
+    // (below ~3 10^5 leaves the host's merge is the faster one: this path has three waits for the stream and a sort by code in it,
+    // ~0.4 ms whatever n is -- `delta` at 16384^2, 54 K leaves: 2.06 ms against 1.68; CNIIC_HUF_RUNS_MIN moves the line, tests set 0)
+    const char *rm = getenv("CNIIC_HUF_RUNS_MIN");
+    if (n < 2 || n < (rm ? (uint32_t)atoi(rm) : kRunsMinLeaves) || getenv("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
     DevBuf small, runs_d, desc_d, tree_d, par, keys_a, keys_b, z_d, zex_d, tot_d;
     CNIIC_HIP_TRY(c, small.alloc(64));
     CNIIC_HIP_TRY(c, hipMemsetAsync(small.p, 0, 64, c->stream));

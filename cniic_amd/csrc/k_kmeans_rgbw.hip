@@ -95,6 +95,7 @@ struct KmRgbwState {
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
     bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
     DevBuf sup_rec, sup_agg;     // per cell: candidate mask + state word; aggregate of its points
+    bool no_block_build = true;   // the block-wide candidate build is opt-in (CNIIC_KM_BLOCK_BUILD=1): 30 % fewer VALU instructions, 0.3-0.8 us SLOWER per launch
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
 };
@@ -537,6 +538,82 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     return ncand;
 }
 
+// The same strip, mask and record from a verdict the BLOCK reached for all of its cells at once (full schedule, K <= 256: one LANE
+// per cell, the members of S dealt to the waves -- k_rgbw_assign_cells): pe = the pivot's position in `list`, cm = bit e <=> member
+// e of `list` is a candidate.  The mask IS the ballot: nothing is tested here.
+constexpr uint32_t kBlkCells = 128;  // cells of a block's range that get the block-wide build (the rest: one wave per cell)
+template <int IDBITS>
+__device__ __forceinline__ uint32_t expand_candidates(const uint2 *list, uint32_t pe, unsigned long long cm0, unsigned long long cm1, uint32_t c, int lane,
+                                                      uint2 *cand, unsigned long long *wmask, uint32_t *cell_rec, uint32_t m, uint32_t MW) {
+    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
+    const uint2 pvc = list[pe];
+    const uint32_t pv = pvc.x, pid = IDMASK - (pvc.y & IDMASK);
+    for (uint32_t i = lane; i < MW; i += 64) wmask[i] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t ncand = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned long long bm = h ? cm1 : cm0;
+        if (!bm) continue;
+        if ((bm >> lane) & 1ull) {
+            const uint2 cc = list[64 * h + lane];
+            cand[ncand + lanes_below(bm)] = cc;
+            const uint32_t k = IDMASK - (cc.y & IDMASK);
+            atomicOr(&wmask[k >> 6], 1ull << (k & 63));
+        }
+        ncand += (uint32_t)__popcll(bm);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
+    uint32_t i_first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(i_first));
+    for (uint32_t i = i_first; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
+    if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c | (pid << 16));
+    return ncand;
+}
+
+// The candidates of all the cells of a block's range at once (k_rgbw_assign_cells, full schedule): lane = cell, the members of the
+// cell's list S dealt to the waves; s_piv / s_cm as cleared by the caller.
+template <int WAVES>
+__device__ __forceinline__ void block_candidates(const uint2 *tab, uint32_t K, uint32_t scap, const uint32_t *cells, uint32_t nbc, uint32_t sup_first, uint32_t nsl,
+                                              const uint32_t *s_nS, uint32_t *s_piv, unsigned long long (*s_cm)[2], int wid, int lane) {
+    constexpr int32_t cext = (1 << kCellShift) - 1;
+    uint32_t nmax = 0;
+    for (uint32_t t = 0; t < nsl; t++) { const uint32_t n = s_nS[t]; if (n <= scap) nmax = max(nmax, n); }
+#pragma unroll 1
+    for (int phase = 0; phase < 2; phase++) {
+#pragma unroll 1
+        for (uint32_t r0 = 0; r0 < nbc; r0 += 64) {
+            const uint32_t i = r0 + lane;
+            const bool act = i < nbc;
+            const uint32_t ci = act ? cells[i] : cells[0];
+            const uint32_t slot = (ci >> kSuperShift) - sup_first;
+            uint32_t ni = act ? s_nS[slot] : 0u;
+            if (ni > scap) ni = 0u;  // (a list that did not fit: the cell keeps the wave-per-cell build from the whole table)
+            const uint2 *Sl = tab + K + (size_t)slot * (scap + K);
+            const CellBox bx = cell_box(ci);
+            if (phase == 0) {
+                uint32_t best = 0xffffffffu;
+                for (uint32_t e = wid; e < nmax; e += WAVES)
+                    if (e < ni) best = min(best, (centre_dist(Sl[e].x, bx, cext) << 8) | e);
+                if (best != 0xffffffffu) atomicMin(&s_piv[i], best);
+            } else if (ni) {
+                Dominance dm;
+                dm.set(bx, cext, Sl[s_piv[i] & 255u].x);
+                unsigned long long lo = 0, hi = 0;
+                for (uint32_t e = wid; e < nmax; e += WAVES) {
+                    const bool keep = e < ni && dm.worst(Sl[e].x) >= 0;
+                    if (e < 64) lo |= keep ? 1ull << e : 0ull;
+                    else hi |= keep ? 1ull << (e - 64) : 0ull;
+                }
+                if (lo) atomicOr(&s_cm[i][0], lo);
+                if (hi) atomicOr(&s_cm[i][1], hi);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip.
 // AGG (the full schedule, where centroids still travel): when a centroid shifts, whole cells change hands -- every lane of the
 // sweep moves from the same old cluster to the same new one, and ten LDS atomics per point on the same ten words run one lane
@@ -841,6 +918,7 @@ struct CellState {
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
     uint32_t dbg;           // measuring builds (-DCNIIC_RGBW_PHASES): 1 + the launch whose waves write their timeline (CNIIC_DBG_TIMELINE)
+    uint32_t opts;          // bit 0: no block-wide candidate build (the default: see block_candidates)
 };
 
 // Centroid update folded into the next assign launch (km_rgbw_run, K <= 256): launch j first finishes iteration
@@ -911,6 +989,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ uint32_t s_nS[WAVES];        // full schedule: lengths of the block's shared super-cell lists
+    __shared__ uint32_t s_piv[kBlkCells];   // ... the block-wide candidate build: per cell of the range (distance to the cube's centre << 8 | position in S) of its pivot,
+    __shared__ unsigned long long s_cm[kBlkCells][2];  // ... and the members of S its pivot does not dominate
     __shared__ unsigned long long s_mm[4];  // K <= 256: bit k <=> centroid k moved in the last update
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
@@ -1044,7 +1124,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
         // The super-cell lists S of the block's range, ONCE per block: its cells are consecutive in super-cell-major order, so they
         // lie in one to three super-cells; wave w builds the list of super-cell sup_first + w into its own strip and every wave
         // reads the strip it needs.  (Until round 3 every wave built S for every super-cell it touched: 8 K builds a launch for 512
-        // super-cells, ~15 % of the full schedule's VALU instructions -- and the launch is bound by those)  A range
+        // super-cells, ~15 % of the full schedule's VALU instructions.)  A range
         // that spans more super-cells than the block has waves (a sparse image) keeps the private builds.
         uint32_t sup_first = 0, nsl = 0;
         if (mb1 > mb0) {
@@ -1057,7 +1137,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             if (lane == 0) s_nS[wid] = n;
         }
         if (threadIdx.x == 0) s_cell = mb0;
+        // The candidates of ALL the block's cells at once (round 3; K <= 256): lane = cell, the members of the cell's list S dealt to
+        // the waves.  The wave-per-cell build below costs ~300 wave-instructions a cell whatever |S| is (two wave reductions for the
+        // pivot, a ballot per 64 members) and was 47 % of what a full-schedule launch issued; here a block's ~27 cells cost 8 waves x
+        // (|S| / 8 members x ~25 + ~50) together.  Same pivot (nearest the cube's centre, lowest position on ties: the minimum of
+        // distance << 8 | position), same test, so the same candidates.  Measured: a full-schedule launch issues 9.1 M VALU
+        // wave-instructions instead of 12.8 M -- and takes 36.6 us instead of 36.3 (NOTES.md C: it never was bound by issue, and
+        // the two block barriers cost what the instructions saved).  So it is OFF unless CNIIC_KM_BLOCK_BUILD=1.
+        const uint32_t nbc = (FIRSTK != 2 && nsl && scap <= 128u && !(cs.opts & 1u)) ? min(mb1 - mb0, kBlkCells) : 0u;  // (FIRSTK 2: the rounds' code has no register to spare)
+        for (uint32_t i = threadIdx.x; i < nbc; i += THREADS) { s_piv[i] = 0xffffffffu; s_cm[i][0] = 0ull; s_cm[i][1] = 0ull; }
         __syncthreads();
+        if (nbc) block_candidates<WAVES>(tab, K, scap, ne_cell + mb0, nbc, sup_first, nsl, s_nS, s_piv, s_cm, wid, lane);
         auto draw = [&]() -> uint32_t {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&s_cell, 1u);
@@ -1091,8 +1181,17 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
                 nSup = s_nS[slot];
             } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
             RG_PHASE(2);
-            const uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
-                                                : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+            uint32_t ncand;
+            const uint32_t ib = m - mb0;
+            const uint32_t pvw = ib < nbc ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_piv[ib]) : 0xffffffffu;
+            if (pvw != 0xffffffffu) {
+                const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cm[ib][0]);  // (wave-uniform: kept on the scalar side)
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]), c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[1]);
+                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]), c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
+                ncand = expand_candidates<IDBITS>(Sl, pvw & 255u, ((unsigned long long)c1 << 32) | c0, ((unsigned long long)c3 << 32) | c2, c, lane, cand, wmask, cs.rec, m, MW);
+            }
+            else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
+                                      : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
             RG_PHASE(3);
             RG_COUNT(9, 1);
             RG_TL1(2);
@@ -2078,6 +2177,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
+        s->no_block_build = !(getenv("CNIIC_KM_BLOCK_BUILD") && atoi(getenv("CNIIC_KM_BLOCK_BUILD")));
         // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
         // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
         s->sup = !s->wide && nshards == 1 && getenv("CNIIC_KM_SUP") && atoi(getenv("CNIIC_KM_SUP"));
@@ -2209,7 +2309,8 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
-                     s->no_skip ? 0u : s->max_skip, s->dbg_timeline};
+                     s->no_skip ? 0u : s->max_skip, s->dbg_timeline,
+                     s->no_block_build ? 1u : 0u};
         if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
             // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
             // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.

@@ -10,6 +10,7 @@ import oracle_lib as O
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_HILBERT_MOVE": "any"}, {"CNIIC_HUF_GPU_CODES_MIN": "0"},
+         {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_HUF_RUNS_MIN": "0"},   # round 3: the tree from runs of equal count whatever the alphabet's size
          {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"},
          {"CNIIC_GPU_DECODE_MIN": "0"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1"},   # round 3: the parallel decoder / the GPU trie parse whatever the size
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HILBERT_MOVE": "any"}]

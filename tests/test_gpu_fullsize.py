@@ -48,6 +48,12 @@ def test_config2_cluster_colors_4096(env):
     finally:
         del os.environ["CNIIC_KM_SUP"]
     assert out[:n3].cpu().numpy().tobytes() == data1 and st3["iterations"] == st1["iterations"]
+    os.environ["CNIIC_KM_BLOCK_BUILD"] = "1"                                    # the block-wide candidate build (opt-in): same bytes, same work counted
+    try:
+        rc, n4, st4 = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out)
+    finally:
+        del os.environ["CNIIC_KM_BLOCK_BUILD"]
+    assert out[:n4].cpu().numpy().tobytes() == data1 and st4["iterations"] == st1["iterations"] and st4["pair_evals"] == st1["pair_evals"]
     rc, back = ctx.decode("ccol(%d)" % K, data1)
     assert rc == 0 and back.shape == (size, size, 3)
     keys = (back[..., 0].astype(np.uint32) << 16) | (back[..., 1].astype(np.uint32) << 8) | back[..., 2]

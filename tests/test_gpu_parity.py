@@ -97,8 +97,11 @@ def test_kmeans_step_rgbw_ties_stay(ctx):
         assert got["labels"].tolist() == [0, 1, lab] and got["changed"] == 0
 
 
-@pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (300, (128, 160))])
-def test_kmeans_rgbw_run(ctx, K, shape):
+@pytest.mark.parametrize("block_build", ["0", "1"])
+@pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (300, (128, 160)), (200, (300, 260))])
+def test_kmeans_rgbw_run(ctx, monkeypatch, K, shape, block_build):
+    """`block_build`: the candidates of all of a block's cells built at once, one lane per cell (opt-in, CNIIC_KM_BLOCK_BUILD)"""
+    monkeypatch.setenv("CNIIC_KM_BLOCK_BUILD", block_build)
     img = synth_img(*shape, seed=7 + K)
     keys, counts = O.count_freqs(keys_of(img))
     w = counts.astype(np.uint32)
@@ -300,13 +303,17 @@ def test_huf_encode_all_long_codes(ctx):
     assert ctx.huf_encode_all(2, syms) == O.huf_encode_all(O.SYM_SIGNED, syms)
 
 
+@pytest.mark.parametrize("runs", [False, True])
 @pytest.mark.parametrize("kind", [1, 2])
 @pytest.mark.parametrize("n", [2, 3, 17, 4097, 60000])
-def test_huf_codes_and_decoder_on_the_gpu(ctx, monkeypatch, kind, n):
-    """large alphabets: the host merges the tree, every leaf's code and its place in the serialised decoder come from a walk to
-    the root on the GPU (CNIIC_HUF_GPU_CODES_MIN=0: for these small ones too) -- the oracle's bytes for both symbol kinds, skewed
-    and flat histograms, and through the `hufman` codec and the 32-bit route of `delta` on a noisy image"""
+def test_huf_codes_and_decoder_on_the_gpu(ctx, monkeypatch, kind, n, runs):
+    """large alphabets: the host merges the tree (`runs`: merges RUNS of equally frequent leaves and the GPU expands them, as it
+    does from 2^18 leaves on), every leaf's code and its place in the serialised decoder come from a walk to the root on the GPU
+    (CNIIC_HUF_GPU_CODES_MIN=0: for these small ones too) -- the oracle's bytes for both symbol kinds, skewed and flat
+    histograms, and through the `hufman` codec and the 32-bit route of `delta` on a noisy image"""
     monkeypatch.setenv("CNIIC_HUF_GPU_CODES_MIN", "0")
+    if runs:
+        monkeypatch.setenv("CNIIC_HUF_RUNS_MIN", "0")
     rng = np.random.default_rng(n * 3 + kind)
     top = (1 << 24) if kind == 1 else (1 << 27)
     distinct = rng.choice(top, size=min(n, 5000), replace=False).astype(np.uint32)
@@ -325,9 +332,13 @@ def test_huf_codes_and_decoder_on_the_gpu(ctx, monkeypatch, kind, n):
             assert rc == 0 and np.array_equal(back, img)
 
 
-def test_huf_long_codes_on_the_gpu(ctx, monkeypatch):
-    """Fibonacci-like counts: codes of up to 39 bits through the GPU's walk"""
+@pytest.mark.parametrize("runs", [False, True])
+def test_huf_long_codes_on_the_gpu(ctx, monkeypatch, runs):
+    """Fibonacci-like counts: codes of up to 39 bits through the GPU's walk (`runs`: the tree from runs gives way to the host's
+    merge when a code outgrows the 32 bits its sort by code keys on)"""
     monkeypatch.setenv("CNIIC_HUF_GPU_CODES_MIN", "0")
+    if runs:
+        monkeypatch.setenv("CNIIC_HUF_RUNS_MIN", "0")
     fib = [1, 1]
     while len(fib) < 40:
         fib.append(fib[-1] + fib[-2])

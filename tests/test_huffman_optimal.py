@@ -95,11 +95,15 @@ def test_product_host_builder_is_optimal(name, counts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("runs", [False, True])
 @pytest.mark.parametrize("distinct,n", [(300, 50000), (40000, 400000), (150000, 600000)])
-def test_gpu_encode_all_is_optimal_and_decodes_with_the_reference_faithful_decoder(distinct, n):
+def test_gpu_encode_all_is_optimal_and_decodes_with_the_reference_faithful_decoder(distinct, n, runs, monkeypatch):
     """huf::encode_all on the GPU -- small alphabets (host tree) and >= 32768 distinct symbols (GPU (count, key) radix sort,
-    host merge, GPU codes + decoder): stream length = the heap's cost, and the oracle's trie-walk decoder reads it back"""
+    host merge -- `runs`: of runs of equally frequent leaves, expanded on the GPU --, GPU codes + decoder): stream length = the
+    heap's cost, and the oracle's trie-walk decoder reads it back"""
     import cniic_amd
+    if runs:
+        monkeypatch.setenv("CNIIC_HUF_RUNS_MIN", "0")
     rng = np.random.default_rng(distinct)
     z = np.minimum(rng.zipf(1.2, n), distinct).astype(np.uint32)           # heavy ties among the rare symbols
     syms = (z * np.uint32(2654435761)) & np.uint32(0xFFFFFF)               # spread over the 24-bit key space
