@@ -56,6 +56,7 @@ struct KmXyState {
     DevBuf labels, cent, partials, running, dstate, members_last, tile_box, super_box, tile_piv, tile_mask, moved_list;
     DevBuf sup_piv, sup_mask;              // super-tile filter of the skip schedule
     DevBuf f_partials, f_running, f_cent;  // the loop with the update folded into the assign launches: 3 / 2 / 2 buffers (XyFused)
+    uint32_t dyn = 64;                     // ... which draws its super-tiles from a counter while at least this many centroids move (CNIIC_XY_DYN; 0: a block takes every gridDim-th)
     bool use_tab = false, fused = false;
     uint32_t launch_no = 0;
 };
@@ -170,6 +171,17 @@ __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, uint32_t i) {
     for (uint32_t t = 0; t < i; t++) m &= m - 1;
     return (uint32_t)__ffs((int)m) - 1u;
 }
+// the same for a 64-bit word held by one lane: six halvings
+__device__ __forceinline__ uint32_t select64(unsigned long long m, uint32_t r) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int wd = 32; wd >= 1; wd >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(m & ((1ull << wd) - 1ull));
+        if (r >= c) { r -= c; m >>= wd; pos += wd; }
+    }
+    return pos;
+}
+constexpr uint32_t kXHeavyWords = 64;   // super-tiles whose order of issue follows the launch before: 64 x 64 (a 8192 x 8192 image); more: index order
 
 // partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
 // [6K] moved ; [6K+1] pair evaluations.  At iteration 0 the partials are the full sums of the new
@@ -183,6 +195,8 @@ struct TileState {              // per tile, carried between iterations
     uint32_t max_moved;         // skip schedule when moved[0] <= max_moved (0 disables it)
     uint32_t *spiv;             // per super-tile: id of the pivot of its last list build (0xffffffff: none yet)
     unsigned long long *smask;  // per super-tile: union of its tiles' candidate masks
+    uint32_t dyn;               // the loop with the folded-in update: while at least this many centroids move (0: never), super-tiles beyond a block's first are
+                                // drawn from a counter (word 6 K + 2 of the launch's sums)
 };
 
 // -DCNIIC_XY_PHASES: wave-clock totals per phase of k_xy_assign (a measuring build, never the shipped one)
@@ -246,6 +260,24 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     const uint32_t done = st->done;  // acted on once the set-up loads are out
 
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the order of issue of the super-tiles (see the loop below): the bitmap of the launch before, its complement, and how many bits lie
+    // before each word of either; this block's first draw
+    __shared__ unsigned long long s_hw[64], s_lw[64];
+    __shared__ uint32_t s_hpre[2][65];
+    unsigned long long drawn = 0;
+    if (fz.on && ts.dyn) {
+        if (threadIdx.x == 0) drawn = atomicAdd(&partials[6 * (size_t)K + 2], 1ull);
+        const uint32_t nw = (nsuper + 63) >> 6;
+        if (wv == 0 && fz.launch_no && nw <= kXHeavyWords) {
+            const unsigned long long valid = lane + 1 < nw ? ~0ull : lane + 1 == nw ? ((nsuper & 63) ? (1ull << (nsuper & 63)) - 1ull : ~0ull) : 0ull;
+            const unsigned long long hw = lane < nw ? fz.partials_prev[6 * (size_t)K + 4 + lane] & valid : 0ull, lw = ~hw & valid;
+            const uint32_t ph = (uint32_t)__popcll(hw), pl = (uint32_t)__popcll(lw);
+            const uint32_t ih = wave_inclusive_scan(ph), il = wave_inclusive_scan(pl);
+            s_hw[lane] = hw; s_lw[lane] = lw;
+            s_hpre[0][lane] = ih - ph; s_hpre[1][lane] = il - pl;
+            if (lane == 63) { s_hpre[0][64] = ih; s_hpre[1][64] = il; }
+        }
+    }
 #ifdef CNIIC_XY_PHASES
     long long t_ph = clock64();
     unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -284,7 +316,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
         if (done) return;
         if (fz.on && blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += kXThreads) fz.partials_clear[i] = 0ull;
+            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
         __syncthreads();
     } else {
         // ---- finish iteration j - 1: Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137),
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             }
         }
         if (blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 6 * K + 2; i += kXThreads) fz.partials_clear[i] = 0ull;
+            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
         __syncthreads();
         const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -378,7 +410,43 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
 
     const uint64_t npix = (uint64_t)w * h;
     uint32_t par = 0, sit = 0;
-    for (uint32_t sup = blockIdx.x; sup < nsuper; sup += gridDim.x, par ^= 1, sit++) {
+    // Which super-tiles a block takes.  Statically: every gridDim-th.  The loop with the folded-in update, while centroids still move
+    // (dyn): whatever the launch's counter hands out next -- the dirty tiles lie in patches of the image, and a block that met four
+    // busy super-tiles kept the launch waiting: the waves were alive for 0.63-0.68 of a launch's duration (SQ_WAVE_CYCLES).  The
+    // draws are handed out in the order "busy in the launch before, then the rest" (a bit per super-tile, set by whoever found a
+    // dirty tile in it): what is still out when the blocks run dry is then the super-tiles that take a microsecond.  The draw for
+    // the NEXT super-tile is asked for before this one is worked on (a round trip to the L2).
+    __shared__ uint32_t s_sup[2];
+    const bool dyn = fz.on && ts.dyn && (!skip_mode || nS >= ts.dyn);   // (late in a run most super-tiles are passed over in a microsecond: nothing to balance)
+    const uint32_t hNW = (nsuper + 63) >> 6;
+    const bool ordered = dyn && !first && hNW <= kXHeavyWords;
+    unsigned long long *const heavy_cur = fz.on && hNW <= kXHeavyWords ? partials + 6 * (size_t)K + 4 : nullptr;
+    auto resolve = [&]() -> uint32_t {   // the draw thread 0 holds -> a super-tile, for every thread
+        if (wv == 0) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)drawn);
+            uint32_t v = d;
+            if (ordered) {
+                const uint32_t nheavy = s_hpre[0][64];
+                const bool cls = d < nheavy;
+                const uint32_t r = cls ? d : d - nheavy;
+                const uint32_t e0 = s_hpre[cls ? 0 : 1][lane], e1 = lane < 63 ? s_hpre[cls ? 0 : 1][lane + 1] : s_hpre[cls ? 0 : 1][64];
+                const unsigned long long bm = __ballot(r >= e0 && r < e1);
+                v = 0xffffffffu;
+                if (bm) {
+                    const int src = __builtin_ctzll(bm);
+                    const unsigned long long word = cls ? s_hw[lane] : s_lw[lane];
+                    v = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 64u + select64(word, r - e0)), src);
+                }
+            }
+            if (lane == 0) s_sup[sit & 1] = v;
+        }
+        __syncthreads();
+        return s_sup[sit & 1];
+    };
+    uint32_t sup = blockIdx.x;
+    if (dyn) { sit = 1; sup = resolve(); sit = 0; }
+    for (; sup < nsuper; sup = dyn ? resolve() : sup + gridDim.x, par ^= 1, sit++) {
+        if (dyn && threadIdx.x == 0) drawn = atomicAdd(&partials[6 * (size_t)K + 2], 1ull);
         const uint32_t stx = (sup % super_x) * kSTX, sty = (sup / super_x) * kSTY;
         const uint32_t tix = stx + (wv & (kSTX - 1)), tiy = sty + wv / kSTX;
         const bool has_tile = tix < tiles_x && tiy < tiles_y;
@@ -448,6 +516,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         const uint32_t dm16 = (uint32_t)__ballot(s_dirty[par][lane & (kXWaves - 1)] != 0u) & 0xffffu;  // wave-uniform
         const uint32_t nd = (uint32_t)__popc(dm16);
         if (nd == 0) continue;
+        if (heavy_cur && threadIdx.x == 0) atomicOr(&heavy_cur[sup >> 6], 1ull << (sup & 63));   // busy: among the first to be handed out next time
         const uint32_t g4 = (wv & 3) * kXRows;  // this wave's rows within a tile
         uint32_t px[2][kXRows], cur[2][kXRows];
         // pixel (lane, row j) of the unit: x = first column of the tile + lane, y = first row of the tile + g4 + j
@@ -806,7 +875,7 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     const uint32_t MW = (K + 63) / 64;
     // LDS budget (155 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
     // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
-    const size_t lds_max = 155 * 1024;  // (160 KiB less the kernel's static arrays: 4 KiB since the super-tile filter's lists)
+    const size_t lds_max = 154 * 1024;  // (160 KiB less the kernel's static arrays: 5.4 KiB with the super-tile filter's lists and the order of issue)
     size_t fixed = (size_t)xy_acc_words(K) * 4 + (size_t)kSCap * 18 + (size_t)kXMaxMovedSkip * 16 + (size_t)kXWaves * MW * 8;
     s.use_tab = fixed + (size_t)K * 16 + (size_t)kXWaves * 64 * 18 <= lds_max;
     if (s.use_tab) fixed += (size_t)K * 16;
@@ -829,8 +898,9 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.sup_mask.p, 0xff, (uint64_t)nsuper * MW * 8, c->stream));
     s.no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
     s.fused = s.use_tab && !s.brute && !(getenv("CNIIC_XY_UNFUSED") && atoi(getenv("CNIIC_XY_UNFUSED")));
+    if (const char *e = getenv("CNIIC_XY_DYN")) s.dyn = (uint32_t)atoi(e);
     if (s.fused) {
-        const uint64_t Wb = (6 * (uint64_t)K + 2) * 8;
+        const uint64_t Wb = (6 * (uint64_t)K + 4 + kXHeavyWords) * 8;   // (+ the launch's super-tile counter, a word of padding, the bitmap of its busy super-tiles)
         CNIIC_HIP_TRY(c, s.f_partials.alloc(3 * Wb));
         CNIIC_HIP_TRY(c, s.f_running.alloc(2 * Wb));
         CNIIC_HIP_TRY(c, s.f_cent.alloc(2 * (uint64_t)K * 16));
@@ -849,7 +919,7 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, hipGetLastError());
     // the assign kernel carves up to 155 KiB of the CU's 160 KiB LDS
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         155 * 1024));
+                                         154 * 1024));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
@@ -859,7 +929,7 @@ static int xy_assign(KmXyState &s, bool fused = false) {
     XyFused fz{};
     unsigned long long *part = s.partials.as<unsigned long long>();
     if (fused) {
-        const uint64_t W = 6 * (uint64_t)s.K + 2;
+        const uint64_t W = 6 * (uint64_t)s.K + 4 + kXHeavyWords;
         const uint32_t j = s.launch_no++;
         auto *P = s.f_partials.as<unsigned long long>();
         auto *Rn = s.f_running.as<unsigned long long>();
@@ -882,7 +952,7 @@ static int xy_assign(KmXyState &s, bool fused = false) {
                        part, s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
                        TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),
                                  s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip, s.sup_piv.as<uint32_t>(),
-                                 s.sup_mask.as<unsigned long long>()}, fz);
+                                 s.sup_mask.as<unsigned long long>(), s.dyn}, fz);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
