@@ -181,6 +181,8 @@ __device__ __forceinline__ uint32_t select64(unsigned long long m, uint32_t r) {
     }
     return pos;
 }
+constexpr uint32_t kXGroupLaunches = 3;  // launches 1 .. this book a row's movers label by label (wave reductions) when at least kXGroupMin of the row move
+constexpr uint32_t kXGroupMin = 8;
 constexpr uint32_t kXHeavyWords = 64;   // super-tiles whose order of issue follows the launch before: 64 x 64 (a 8192 x 8192 image); more: index order
 
 // partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
@@ -233,6 +235,9 @@ struct XyFused {
 
 // LDS (dynamic): acc[K][6] u32 | S_c[kSCap] int4 | W_c[16][wcap] int4 | M_c[512] int4 | W_mask[16][MW] u64 |
 //                S_k[kSCap] u16 | W_k[16][wcap] u16 | (use_tab) tab[K] int4: the centroid table itself
+// GROUP: the instance for the launches right after the first (the loop with the folded-in update knows which launch it enqueues):
+// the same body plus the label-by-label booking of a row's movers -- whose mere presence costs the other 180 launches 6 us each.
+template <bool GROUP>
 __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
                                                          uint32_t tiles_x, uint32_t tiles_y, uint32_t super_x, uint32_t nsuper,
                                                          uint32_t K, const int4 *__restrict__ cent,
@@ -702,24 +707,33 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     moved++;
                 }
                 const uint32_t r8 = (p[j] >> 16) & 255, gg = (p[j] >> 8) & 255, b = p[j] & 255;
-                if (first) {
-                    // vector_add clusterc.rs:221-228 for every pixel.  A row of 64 pixels holds few distinct
-                    // labels: one wave reduction per label instead of 64 colliding LDS atomics.
-                    unsigned long long todo = __ballot(ok);
+                // A row of 64 pixels holds few distinct labels: one wave reduction per label instead of 64 colliding LDS atomics
+                // (sgn: 0 adds the pixels, ~0 subtracts them -- the sums are u32 that wrap).
+                auto book_row = [&](bool sel, uint32_t lab, uint32_t sgn) {
+                    unsigned long long todo = __ballot(sel);
                     while (todo) {
-                        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)nl, __ffsll((long long)todo) - 1);
-                        const bool in = ok && nl == lk;
+                        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)lab, __ffsll((long long)todo) - 1);
+                        const bool in = sel && lab == lk;
                         const unsigned long long grp = __ballot(in);
                         const uint32_t cn = (uint32_t)__popcll(grp);
                         const uint32_t sx = wave_reduce_sum(in ? (uint32_t)x : 0u), sr = wave_reduce_sum(in ? r8 : 0u);
                         const uint32_t sg = wave_reduce_sum(in ? gg : 0u), sbb = wave_reduce_sum(in ? b : 0u);
                         if (lane == 0) {
                             uint32_t *a = acc + 6 * lk;
-                            atomicAdd(a + 0, sx); atomicAdd(a + 1, (uint32_t)y * cn); atomicAdd(a + 2, sr);
-                            atomicAdd(a + 3, sg); atomicAdd(a + 4, sbb); atomicAdd(a + 5, cn);
+                            atomicAdd(a + 0, (sx ^ sgn) - sgn); atomicAdd(a + 1, (((uint32_t)y * cn) ^ sgn) - sgn); atomicAdd(a + 2, (sr ^ sgn) - sgn);
+                            atomicAdd(a + 3, (sg ^ sgn) - sgn); atomicAdd(a + 4, (sbb ^ sgn) - sgn); atomicAdd(a + 5, (cn ^ sgn) - sgn);
                         }
                         todo &= ~grp;
                     }
+                };
+                if (first) {
+                    book_row(ok, nl, 0u);  // vector_add clusterc.rs:221-228 for every pixel
+                } else if (GROUP && __popcll(__ballot(mv)) >= (int)kXGroupMin) {
+                    // the launches after the first, where most pixels change hands again (16.1 M, 6.6 M, 2.5 M of 16.8 M in launches
+                    // 1-3 at configs[2]): twelve atomics per mover, 64 movers a row on the same few words, kept every CU's LDS busy
+                    // for 0.36 ms in launch 1
+                    book_row(mv, nl, 0u);
+                    book_row(mv, c[j], ~0u);
                 } else if (mv) {  // +pixel to its new cluster, -pixel from its old one
                     uint32_t *a = acc + 6 * nl, *o = acc + 6 * c[j];
                     atomicAdd(a + 0, (uint32_t)x); atomicAdd(a + 1, (uint32_t)y); atomicAdd(a + 2, r8);
@@ -918,7 +932,9 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
                        s.tiles_x, s.tiles_y, s.super_x, nsuper, s.super_box.as<uint2>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     // the assign kernel carves up to 155 KiB of the CU's 160 KiB LDS
-    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         154 * 1024));
+    CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          154 * 1024));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
@@ -947,7 +963,8 @@ static int xy_assign(KmXyState &s, bool fused = false) {
         part = P + (j % 3) * W;
     }
     // (launch 0 of the fused loop reads the initial centroids from s.cent; every later one computes its table from the sums)
-    hipLaunchKernelGGL(k_xy_assign, dim3(s.nblocks), dim3(kXThreads), s.lds, c->stream, s.rgb, s.w, s.h, s.tiles_x, s.tiles_y,
+    const bool group = fused && fz.launch_no >= 1 && fz.launch_no <= kXGroupLaunches;
+    hipLaunchKernelGGL(group ? k_xy_assign<true> : k_xy_assign<false>, dim3(s.nblocks), dim3(kXThreads), s.lds, c->stream, s.rgb, s.w, s.h, s.tiles_x, s.tiles_y,
                        s.super_x, s.super_x * s.super_y, s.K, s.cent.as<int4>(), s.labels.as<uint16_t>(),
                        part, s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
                        TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),

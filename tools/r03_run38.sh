@@ -1,0 +1,10 @@
+#!/bin/bash
+set -e
+mkdir -p gpurun_out
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_rare_branches.py -m gpu -x -q -k "xy or voronoi or pos" > gpurun_out/r38_tests.log 2>&1 || { tail -30 gpurun_out/r38_tests.log; exit 1; }
+tail -2 gpurun_out/r38_tests.log
+timeout -k 10 300 python -m pytest tests/test_gpu_fullsize.py -m gpu -x -q -k "voronoi or config3" 2>&1 | tail -2
+timeout -k 10 300 python bench.py --config c3 --steps 3 --cpu-sample 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3', d['ms_per_step'])"
+for cap in 1 2 3 4 6 10; do timeout -k 10 120 python tools/voronoi_probe.py 4096 2048 $cap 2>/dev/null | tail -1 | cut -c1-140; done
