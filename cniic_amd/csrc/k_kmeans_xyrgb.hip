@@ -665,7 +665,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             // maximise 2 p.c - |c|^2; ascending k and a strict compare: first maximum = lowest id
             if (!s_over) {
                 const int32_t x2 = 2 * x, y20 = 2 * (int32_t)uy0;
-                for (uint32_t q = 0; q < ncand; q++) {
+                const uint32_t ncu = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncand);  // (wave-uniform, which the compiler cannot see: a scalar loop counter instead of an exec-mask loop)
+#pragma unroll 2   // (two candidates' reads together; costs two spilled registers and is still 0.5 % faster than one at a time)
+                for (uint32_t q = 0; q < ncu; q++) {
                     const int4 cc = list_c[q];  // LDS broadcast
                     // 2 (x cx + y cy) - |c|^2 for the unit's first row; each further row adds 2 cy
                     int32_t t = xmad24(x2, cc.x, xmad24(y20, cc.y, cc.w));
