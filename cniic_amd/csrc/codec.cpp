@@ -183,7 +183,7 @@ int huf_encode_all_dev(Ctx *c, int sym_kind, const uint8_t *rgb_d, uint32_t *sym
         uint64_t *sorted_d = nullptr;
         CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
         CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
-        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
+        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, plan.max_count ? plan.max_count : n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
         // (round 3) the tree, the codes and the leaves' places in the decoder without the host's merge, when the counts come in runs
         CNIIC_HIP_TRY(c, len_d.alloc(U));
         CNIIC_HIP_TRY(c, code_d.alloc(U * 8));
@@ -872,7 +872,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
         uint64_t *sorted_d = nullptr;
         CNIIC_HIP_TRY(c, sort_a.alloc(U * 8));
         CNIIC_HIP_TRY(c, sort_b.alloc(U * 8));
-        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
+        CNIIC_TRY(huff_sort_leaves_dev(c, counts_d.as<uint64_t>(), (uint32_t)U, plan.max_count ? plan.max_count : n, sort_a.as<uint64_t>(), sort_b.as<uint64_t>(), &sorted_d));
         // (round 3) the tree, the codes and the leaves' places in the decoder without the host's merge, when the counts come in runs
         CNIIC_HIP_TRY(c, len_d.alloc(U));
         CNIIC_HIP_TRY(c, code_d.alloc(U * 8));

@@ -434,8 +434,9 @@ int hist_rgb_dense(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *table_d
 int hist_syms_dense(Ctx *c, const uint32_t *syms_d, uint64_t n, uint32_t *table_d, uint32_t bits);
 // Compaction of a dense count table into ascending (key,count) pairs (3-phase scan).
 struct CompactPlan {
-    DevBuf   blockoff;
+    DevBuf   blockoff, blockmax;
     uint64_t n_unique = 0;
+    uint64_t max_count = 0;          // the largest count in the table (how many radix passes the leaves' sort by count needs)
     uint32_t bits = 0;
     const uint8_t *pages = nullptr;  // (optional) a flag per 4096-entry page: pages without one are skipped
 };

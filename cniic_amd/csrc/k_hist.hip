@@ -215,30 +215,37 @@ constexpr int kScanChunk = kScanThreads * kScanPerThread;  // 4096 table entries
 // cell_count (24-bit RGB tables only, may be null): occupied bins per colour-space cell of the K-means that
 // follows.  A 4096-key chunk is one r, 16 g and all 256 b values: 2 x 32 cells, counted in LDS first.
 __global__ __launch_bounds__(kScanThreads) void k_compact_count(const uint32_t *__restrict__ table,
-                                                                uint32_t *__restrict__ blocksum,
-                                                                uint32_t *__restrict__ cell_count, const uint8_t *__restrict__ pages) {
+                                                                uint32_t *__restrict__ blocksum, uint32_t *__restrict__ blockmax,
+                                                                uint32_t *__restrict__ cell_count, const uint8_t *__restrict__ pages, uint64_t *__restrict__ total) {
     __shared__ uint32_t s_cell[64];
+    __shared__ uint32_t s_max;
+    if (blockIdx.x == 0 && threadIdx.x == 0) total[1] = 0;   // (the scan after this kernel collects the largest count there)
     if (pages && !pages[blockIdx.x]) {  // a page nothing was counted into
-        if (threadIdx.x == 0) blocksum[blockIdx.x] = 0;
+        if (threadIdx.x == 0) { blocksum[blockIdx.x] = 0; blockmax[blockIdx.x] = 0; }
         return;
     }
+    if (threadIdx.x == 0) s_max = 0;
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
     const uint4 *v = reinterpret_cast<const uint4 *>(table + base);
     if (cell_count) {
         if (threadIdx.x < 64) s_cell[threadIdx.x] = 0;
         __syncthreads();
     }
-    uint32_t nz = 0;
+    uint32_t nz = 0, mx = 0;
 #pragma unroll
     for (int j = 0; j < kScanPerThread / 4; j++) {
         const uint32_t quad = j * kScanThreads + threadIdx.x;  // keys base + 4 quad .. + 3: one cell
         const uint4 q = v[quad];
         const uint32_t c4 = (q.x != 0) + (q.y != 0) + (q.z != 0) + (q.w != 0);
         nz += c4;
+        mx = max(max(mx, max(q.x, q.y)), max(q.z, q.w));
         if (cell_count && c4) atomicAdd(&s_cell[((quad >> 6) >> kCellShift) * 32 + (((4 * quad) & 255) >> kCellShift)], c4);
     }
-    nz = block_reduce_sum<kScanThreads>(nz);  // (its barriers also complete s_cell)
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = nz;
+    mx = wave_reduce_max(mx);
+    if (!cell_count) __syncthreads();   // (s_max = 0 above; with cell_count the barrier after s_cell's clearing did it)
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_max, mx);
+    nz = block_reduce_sum<kScanThreads>(nz);  // (its barriers also complete s_cell and s_max)
+    if (threadIdx.x == 0) { blocksum[blockIdx.x] = nz; blockmax[blockIdx.x] = s_max; }
     if (cell_count && threadIdx.x < 64 && s_cell[threadIdx.x]) {
         const uint32_t g = (threadIdx.x >> 5) << kCellShift, b = (threadIdx.x & 31) << kCellShift;
         atomicAdd(&cell_count[cell_of((uint32_t)base + (g << 8) + b)], s_cell[threadIdx.x]);
@@ -247,11 +254,15 @@ __global__ __launch_bounds__(kScanThreads) void k_compact_count(const uint32_t *
 
 // exclusive scan of nblocks sums in place; total -> *total.  Blocks of 1024 sums scan their own part and leave their
 // total, then every block adds the totals before it (one block over the 32768 sums of a 2^27-bin table took 54 us).
-__global__ __launch_bounds__(1024) void k_compact_scan_local(uint32_t *__restrict__ blocksum, uint32_t nblocks,
+__global__ __launch_bounds__(1024) void k_compact_scan_local(uint32_t *__restrict__ blocksum, const uint32_t *__restrict__ blockmax, uint32_t nblocks,
                                                              uint32_t *__restrict__ parttot, uint64_t *__restrict__ total) {
     __shared__ uint32_t wsum[1024 / 64];
     const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
     const uint32_t v = i < nblocks ? blocksum[i] : 0u;
+    {   // the largest count of the table: total[1] (zeroed by the caller); one atomic per wave that has something to say, 16 per block
+        const uint32_t m = wave_reduce_max(i < nblocks ? blockmax[i] : 0u);
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned long long *>(total + 1), (unsigned long long)m);
+    }
     const uint32_t ex = block_exclusive_scan<1024>(v, wsum);
     if (i < nblocks) blocksum[i] = ex;
     if (threadIdx.x == 1023) {
@@ -321,24 +332,26 @@ int hist_compact_count(Ctx *c, const uint32_t *table_d, uint32_t bits, CompactPl
     const uint32_t nblocks = (uint32_t)(entries / kScanChunk);
     DevBuf tot;
     CNIIC_HIP_TRY(c, plan->blockoff.alloc((uint64_t)nblocks * 4));
-    CNIIC_HIP_TRY(c, tot.alloc(8));
-    hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>(),
-                       bits == 24 ? cell_count_d : nullptr, pages_d);
+    CNIIC_HIP_TRY(c, plan->blockmax.alloc((uint64_t)nblocks * 4));
+    CNIIC_HIP_TRY(c, tot.alloc(16));
+    hipLaunchKernelGGL(k_compact_count, dim3(nblocks), dim3(kScanThreads), 0, c->stream, table_d, plan->blockoff.as<uint32_t>(), plan->blockmax.as<uint32_t>(),
+                       bits == 24 ? cell_count_d : nullptr, pages_d, tot.as<uint64_t>());
     {
         const uint32_t nparts = (nblocks + 1023) / 1024;
         DevBuf parttot;
         CNIIC_HIP_TRY(c, parttot.alloc((uint64_t)nparts * 4));
-        hipLaunchKernelGGL(k_compact_scan_local, dim3(nparts), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks,
+        hipLaunchKernelGGL(k_compact_scan_local, dim3(nparts), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), (const uint32_t *)plan->blockmax.as<uint32_t>(), nblocks,
                            parttot.as<uint32_t>(), tot.as<uint64_t>());
         if (nparts > 1)
             hipLaunchKernelGGL(k_compact_scan_add, dim3(nparts), dim3(1024), 0, c->stream, plan->blockoff.as<uint32_t>(), nblocks,
                                (const uint32_t *)parttot.as<uint32_t>(), tot.as<uint64_t>());
     }
     CNIIC_HIP_TRY(c, hipGetLastError());
-    uint64_t total = 0;
-    CNIIC_HIP_TRY(c, hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+    uint64_t total[2] = {0, 0};
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(total, tot.p, 16, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, pages_d ? ctx_spin_sync(c) : hipStreamSynchronize(c->stream));
-    plan->n_unique = total;
+    plan->n_unique = total[0];
+    plan->max_count = total[1];
     plan->bits = bits;
     return CNIIC_OK;
 }
