@@ -116,6 +116,7 @@ def test_encode_batch_equals_separate_encodes():
             for streams in (1, 3, 8):
                 ctx.set_opt(_lib.OPT_BATCH_STREAMS, streams)
                 out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()   # (the context runs on a stream of its own: torch's fill must have landed)
                 rc, lens, rcs, sts = ctx.encode_batch(expr, fr_d, w, h, F, out, stride, allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE))
                 host = out.cpu().numpy()
                 for f in range(F):

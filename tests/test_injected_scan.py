@@ -83,7 +83,9 @@ def test_injected_scan_in_a_batch_and_from_device_memory():
         ctx.set_scan(w, h, torch.from_numpy(s.astype(np.int64)).to(torch.int32).to(dev))   # (u32 values as an int32 tensor)
         stride = w * h * 16 + 4096
         out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
-        rc, lens, rcs, _ = ctx.encode_batch("delta", torch.from_numpy(frames).to(dev), w, h, F, out, stride)
+        fr_d = torch.from_numpy(frames).to(dev)
+        torch.cuda.synchronize()   # (the context runs on a stream of its own: torch's fills must have landed)
+        rc, lens, rcs, _ = ctx.encode_batch("delta", fr_d, w, h, F, out, stride)
         host = out.cpu().numpy()
         for f in range(F):
             perm = np.empty_like(frames[f])
