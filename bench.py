@@ -225,8 +225,16 @@ def main():
             if n:
                 it_ms = ms / n
                 algo = 7.0 * W * H
+                traffic3 = None   # PMC passes over a whole run (tools/make_profiles.sh): mean HBM bytes per k_xy_assign launch, 2 * FETCH_SIZE + WRITE_SIZE
+                try:
+                    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                        t3 = json.load(f).get("c3")
+                    if t3 and t3.get("size") == W and t3.get("K") == Kv:
+                        traffic3 = t3.get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
                 roofline = {"kernel": "k_xy_assign (+ k_xy_update)", "bound": "hbm", "achieved": round(algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": round(it_ms, 5),
+                            "unit": "GB/s", "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic3, "launch_ms": round(it_ms, 5),
                             "launches": int(n), "algorithmic_bytes_per_launch": algo,
                             "note": "HIP events around the whole K-means loop of one more encode / its %d iterations (assign + update launches); "
                                     "algorithmic bytes = 7 B/px/iteration (SURVEY 8(d)); tiles nothing changed for are skipped, so late iterations read less" % int(n)}
@@ -398,6 +406,9 @@ def main():
                        "sample": "%dx%d crop of the same image, oracle mode R (reference algorithm incl. neighbour pruning), "
                                  "%d iterations, %.1f s" % (s, s, ost["iterations"], cdt),
                        "bytes_per_px": round(len(data) / (s * s), 4)}
+                # the HIP path on the SAME crop (the two bytes/px figures were of different images)
+                rcg, ng, stg = ctx.encode(expr, crop, max_iters=args.max_iters)
+                cpu["hip_same_crop"] = {"bytes_per_px": round(len(ng) / (s * s), 4) if rcg == 0 else None, "iterations": int(stg["iterations"]) if rcg == 0 else None}
         if world > 1 and not args.no_extras:
             try:
                 # configs[3] over these N GPUs (128 frames per GPU, one palette for all N x 128), and -- in the same run -- every rank's

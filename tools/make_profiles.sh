@@ -36,6 +36,20 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 python3 $R/tools/pmc_kernel_mean.py $O/pmc_v1 k_xy_assign > $O/${TAG}_voronoi_pmc_traffic.txt 2>&1
 python3 $R/tools/pmc_kernel_mean.py $O/pmc_v3 k_xy_assign >> $O/${TAG}_voronoi_pmc_traffic.txt 2>&1
 python3 $R/tools/pmc_kernel_mean.py $O/pmc_v2 k_xy_assign > $O/${TAG}_voronoi_pmc_sq.txt 2>&1
+# ... its mean HBM bytes per launch into traffic.json (key "c3"; bench.py --config c3: roofline.traffic); per-launch durations of the run
+python3 - "$O/${TAG}_voronoi_pmc_traffic.txt" "$O/out/traffic.json" <<'PY'
+import json, re, sys
+t = open(sys.argv[1]).read()
+f = float(re.search(r"FETCH_SIZE\s+dispatches\s+\d+\s+total\s+\S+\s+per dispatch\s+(\S+)", t).group(1))
+w = float(re.search(r"WRITE_SIZE\s+dispatches\s+\d+\s+total\s+\S+\s+per dispatch\s+(\S+)", t).group(1))
+j = json.load(open(sys.argv[2]))
+j["c3"] = {"kernel": "k_xy_assign", "size": 4096, "K": 2048, "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+           "note": "mean over the launches of two whole runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB; reads doubled: gfx950)"}
+json.dump(j, open(sys.argv[2], "w"), indent=1)
+PY
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_v -o t -- python3 $R/bench.py --config c3 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+python3 $R/tools/trace_iters.py $(find $O/trace_v -name '*kernel_trace.csv' | head -1) k_xy_assign > $O/${TAG}_voronoi_per_launch_final_us.txt
+rm -rf $O/trace_v
 # decode (the other half of the trait): bench lines and per-kernel stats
 python3 $R/bench.py --decode 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_c2_bench.json
 python3 $R/bench.py --decode --config c5 --c5-size 4096 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_delta4096_bench.json
