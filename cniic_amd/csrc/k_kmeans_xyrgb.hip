@@ -267,20 +267,24 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the order of issue of the super-tiles (see the loop below): the bitmap of the launch before, its complement, and how many bits lie
     // before each word of either; this block's first draw
-    __shared__ unsigned long long s_hw[64], s_lw[64];
-    __shared__ uint32_t s_hpre[2][65];
+    __shared__ unsigned long long s_cw[3][64];   // class 0: at least half of the tiles were dirty in the launch before, 1: some were, 2: none
+    __shared__ uint32_t s_hpre[3][65];
     unsigned long long drawn = 0;
     if (fz.on && ts.dyn) {
         if (threadIdx.x == 0) drawn = atomicAdd(&partials[6 * (size_t)K + 2], 1ull);
         const uint32_t nw = (nsuper + 63) >> 6;
         if (wv == 0 && fz.launch_no && nw <= kXHeavyWords) {
             const unsigned long long valid = lane + 1 < nw ? ~0ull : lane + 1 == nw ? ((nsuper & 63) ? (1ull << (nsuper & 63)) - 1ull : ~0ull) : 0ull;
-            const unsigned long long hw = lane < nw ? fz.partials_prev[6 * (size_t)K + 4 + lane] & valid : 0ull, lw = ~hw & valid;
-            const uint32_t ph = (uint32_t)__popcll(hw), pl = (uint32_t)__popcll(lw);
-            const uint32_t ih = wave_inclusive_scan(ph), il = wave_inclusive_scan(pl);
-            s_hw[lane] = hw; s_lw[lane] = lw;
-            s_hpre[0][lane] = ih - ph; s_hpre[1][lane] = il - pl;
-            if (lane == 63) { s_hpre[0][64] = ih; s_hpre[1][64] = il; }
+            const unsigned long long any = lane < nw ? fz.partials_prev[6 * (size_t)K + 4 + lane] & valid : 0ull;
+            const unsigned long long many = lane < nw ? fz.partials_prev[6 * (size_t)K + 4 + kXHeavyWords + lane] & any : 0ull;
+            const unsigned long long cw[3] = {many, any & ~many, ~any & valid};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const uint32_t pc = (uint32_t)__popcll(cw[q]), inc = wave_inclusive_scan(pc);
+                s_cw[q][lane] = cw[q];
+                s_hpre[q][lane] = inc - pc;
+                if (lane == 63) s_hpre[q][64] = inc;
+            }
         }
     }
 #ifdef CNIIC_XY_PHASES
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
         if (done) return;
         if (fz.on && blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
+            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + 2 * kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
         __syncthreads();
     } else {
         // ---- finish iteration j - 1: Point::mean for ColorPos (clusterc.rs:215-247) + empty-cluster reseed (kmeans.rs:110-137),
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             }
         }
         if (blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
+            for (uint32_t i = threadIdx.x; i < 6 * K + 4 + 2 * kXHeavyWords; i += kXThreads) fz.partials_clear[i] = 0ull;
         __syncthreads();
         const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -418,8 +422,8 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     // Which super-tiles a block takes.  Statically: every gridDim-th.  The loop with the folded-in update, while centroids still move
     // (dyn): whatever the launch's counter hands out next -- the dirty tiles lie in patches of the image, and a block that met four
     // busy super-tiles kept the launch waiting: the waves were alive for 0.63-0.68 of a launch's duration (SQ_WAVE_CYCLES).  The
-    // draws are handed out in the order "busy in the launch before, then the rest" (a bit per super-tile, set by whoever found a
-    // dirty tile in it): what is still out when the blocks run dry is then the super-tiles that take a microsecond.  The draw for
+    // draws are handed out in the order "at least half of its tiles dirty in the launch before, some dirty, none" (two bits per
+    // super-tile, set by whoever worked on it): what is still out when the blocks run dry is then the super-tiles that take a microsecond.  The draw for
     // the NEXT super-tile is asked for before this one is worked on (a round trip to the L2).
     __shared__ uint32_t s_sup[2];
     const bool dyn = fz.on && ts.dyn && (!skip_mode || nS >= ts.dyn);   // (late in a run most super-tiles are passed over in a microsecond: nothing to balance)
@@ -431,15 +435,15 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)drawn);
             uint32_t v = d;
             if (ordered) {
-                const uint32_t nheavy = s_hpre[0][64];
-                const bool cls = d < nheavy;
-                const uint32_t r = cls ? d : d - nheavy;
-                const uint32_t e0 = s_hpre[cls ? 0 : 1][lane], e1 = lane < 63 ? s_hpre[cls ? 0 : 1][lane + 1] : s_hpre[cls ? 0 : 1][64];
+                const uint32_t n0 = s_hpre[0][64], n1 = s_hpre[1][64];
+                const uint32_t cls = d < n0 ? 0u : d < n0 + n1 ? 1u : 2u;   // (wave-uniform)
+                const uint32_t r = d - (cls == 0 ? 0u : cls == 1 ? n0 : n0 + n1);
+                const uint32_t e0 = s_hpre[cls][lane], e1 = s_hpre[cls][lane + 1];
                 const unsigned long long bm = __ballot(r >= e0 && r < e1);
                 v = 0xffffffffu;
                 if (bm) {
                     const int src = __builtin_ctzll(bm);
-                    const unsigned long long word = cls ? s_hw[lane] : s_lw[lane];
+                    const unsigned long long word = s_cw[cls][lane];
                     v = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)lane * 64u + select64(word, r - e0)), src);
                 }
             }
@@ -521,7 +525,10 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         const uint32_t dm16 = (uint32_t)__ballot(s_dirty[par][lane & (kXWaves - 1)] != 0u) & 0xffffu;  // wave-uniform
         const uint32_t nd = (uint32_t)__popc(dm16);
         if (nd == 0) continue;
-        if (heavy_cur && threadIdx.x == 0) atomicOr(&heavy_cur[sup >> 6], 1ull << (sup & 63));   // busy: among the first to be handed out next time
+        if (heavy_cur && threadIdx.x == 0) {   // busy: among the first to be handed out next time, the busiest before the others
+            atomicOr(&heavy_cur[sup >> 6], 1ull << (sup & 63));
+            if (nd >= 8) atomicOr(&heavy_cur[kXHeavyWords + (sup >> 6)], 1ull << (sup & 63));
+        }
         const uint32_t g4 = (wv & 3) * kXRows;  // this wave's rows within a tile
         uint32_t px[2][kXRows], cur[2][kXRows];
         // pixel (lane, row j) of the unit: x = first column of the tile + lane, y = first row of the tile + g4 + j
@@ -889,9 +896,9 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     const uint64_t per_block_max = std::max<uint64_t>(((1ull << 31) - 1) / ((uint64_t)std::max(w, h) * kSuperPx), 1);
     s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256), ceil_div(nsuper, per_block_max));
     const uint32_t MW = (K + 63) / 64;
-    // LDS budget (155 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
+    // LDS budget (153 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
     // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
-    const size_t lds_max = 154 * 1024;  // (160 KiB less the kernel's static arrays: 5.4 KiB with the super-tile filter's lists and the order of issue)
+    const size_t lds_max = 153 * 1024;  // (160 KiB less the kernel's static arrays: 6.2 KiB with the super-tile filter's lists and the order of issue)
     size_t fixed = (size_t)xy_acc_words(K) * 4 + (size_t)kSCap * 18 + (size_t)kXMaxMovedSkip * 16 + (size_t)kXWaves * MW * 8;
     s.use_tab = fixed + (size_t)K * 16 + (size_t)kXWaves * 64 * 18 <= lds_max;
     if (s.use_tab) fixed += (size_t)K * 16;
@@ -916,7 +923,7 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     s.fused = s.use_tab && !s.brute && !(getenv("CNIIC_XY_UNFUSED") && atoi(getenv("CNIIC_XY_UNFUSED")));
     if (const char *e = getenv("CNIIC_XY_DYN")) s.dyn = (uint32_t)atoi(e);
     if (s.fused) {
-        const uint64_t Wb = (6 * (uint64_t)K + 4 + kXHeavyWords) * 8;   // (+ the launch's super-tile counter, a word of padding, the bitmap of its busy super-tiles)
+        const uint64_t Wb = (6 * (uint64_t)K + 4 + 2 * kXHeavyWords) * 8;   // (+ the launch's super-tile counter, a word of padding, the two bitmaps of its busy super-tiles)
         CNIIC_HIP_TRY(c, s.f_partials.alloc(3 * Wb));
         CNIIC_HIP_TRY(c, s.f_running.alloc(2 * Wb));
         CNIIC_HIP_TRY(c, s.f_cent.alloc(2 * (uint64_t)K * 16));
@@ -933,11 +940,11 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     hipLaunchKernelGGL(k_xy_super_boxes, dim3((uint32_t)ceil_div(nsuper, 256)), dim3(256), 0, c->stream, s.tile_box.as<uint2>(),
                        s.tiles_x, s.tiles_y, s.super_x, nsuper, s.super_box.as<uint2>());
     CNIIC_HIP_TRY(c, hipGetLastError());
-    // the assign kernel carves up to 155 KiB of the CU's 160 KiB LDS
+    // the assign kernel carves up to 153 KiB of the CU's 160 KiB LDS
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         154 * 1024));
+                                         153 * 1024));
     CNIIC_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_xy_assign<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         154 * 1024));
+                                         153 * 1024));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CNIIC_OK;
 }
@@ -947,7 +954,7 @@ static int xy_assign(KmXyState &s, bool fused = false) {
     XyFused fz{};
     unsigned long long *part = s.partials.as<unsigned long long>();
     if (fused) {
-        const uint64_t W = 6 * (uint64_t)s.K + 4 + kXHeavyWords;
+        const uint64_t W = 6 * (uint64_t)s.K + 4 + 2 * kXHeavyWords;
         const uint32_t j = s.launch_no++;
         auto *P = s.f_partials.as<unsigned long long>();
         auto *Rn = s.f_running.as<unsigned long long>();
