@@ -56,7 +56,7 @@ struct KmXyState {
     DevBuf labels, cent, partials, running, dstate, members_last, tile_box, super_box, tile_piv, tile_mask, moved_list;
     DevBuf sup_piv, sup_mask;              // super-tile filter of the skip schedule
     DevBuf f_partials, f_running, f_cent;  // the loop with the update folded into the assign launches: 3 / 2 / 2 buffers (XyFused)
-    uint32_t dyn = 64;                     // ... which draws its super-tiles from a counter while at least this many centroids move (CNIIC_XY_DYN; 0: a block takes every gridDim-th)
+    uint32_t dyn = 16;                     // ... which draws its super-tiles from a counter while at least this many centroids move (CNIIC_XY_DYN; 0: a block takes every gridDim-th)
     bool use_tab = false, fused = false;
     uint32_t launch_no = 0;
 };
