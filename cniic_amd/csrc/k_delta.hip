@@ -337,21 +337,36 @@ __global__ __launch_bounds__(256) void k_delta_count16(const uint16_t *__restric
             q[b] = ch < nchunks ? reinterpret_cast<const uint4 *>(hot16)[(uint64_t)ch * 64 + lane] : make_uint4(kPad16, kPad16, kPad16, kPad16);
             ncold[b] = ch < nchunks ? chunk_cold[ch] : 0;
         }
+        // the chunks' cold symbols: lane r takes the r-th (the sum does not care whose it is) and turns its key into the len << 26 | code
+        // word the pack will want (a pass of its own: 31 us).  Key -> word -> (escaped) length is three dependent reads: asked for the
+        // whole batch at a time -- chunk by chunk they were 8-12 round trips to memory per batch and held the kernel at 2 TB/s.
+        uint32_t ck[kCountBatch], cv[kCountBatch], cl[kCountBatch];
+#pragma unroll
+        for (int b = 0; b < kCountBatch; b++) {
+            const uint32_t ch = ch0 + b * nw;
+            ck[b] = (ch < nchunks && lane < ncold[b]) ? coldcodes[(uint64_t)ch * kColdPerChunk + lane] : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < kCountBatch; b++) {
+            const uint32_t ch = ch0 + b * nw;
+            cv[b] = (ch < nchunks && lane < ncold[b]) ? dense[ck[b]] : 0u;
+        }
+#pragma unroll
+        for (int b = 0; b < kCountBatch; b++) {
+            const uint32_t ch = ch0 + b * nw;
+            const bool cold = ch < nchunks && lane < ncold[b];
+            cl[b] = cold ? ((cv[b] >> 26) == kEscape ? (uint32_t)len[cv[b] & 0x3ffffffu] : cv[b] >> 26) : 0u;
+            if (cold) coldcodes[(uint64_t)ch * kColdPerChunk + lane] = cv[b];
+        }
 #pragma unroll
         for (int b = 0; b < kCountBatch; b++) {
             const uint32_t ch = ch0 + b * nw;
             if (ch >= nchunks) break;
             const uint32_t s[8] = {q[b].x & 0xffffu, q[b].x >> 16, q[b].y & 0xffffu, q[b].y >> 16, q[b].z & 0xffffu, q[b].z >> 16, q[b].w & 0xffffu, q[b].w >> 16};
-            uint32_t bits = 0;
+            uint32_t bits = cl[b];
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if (s[i] < kHot) bits += s_len[s[i]];
-            if (lane < ncold[b]) {  // the chunk's cold symbols: lane r takes the r-th (the sum does not care whose it is) and
-                uint32_t *e = coldcodes + (uint64_t)ch * kColdPerChunk + lane;  // turns its key into the len << 26 | code word
-                const uint32_t v = dense[*e];                                    // the pack will want (a pass of its own: 31 us)
-                *e = v;
-                bits += (v >> 26) == kEscape ? (uint32_t)len[v & 0x3ffffffu] : v >> 26;
-            }
             bits = wave_reduce_sum(bits);
             if (lane == 0) chunk_bits[ch] = bits;
         }

@@ -89,6 +89,8 @@ if __name__ == "__main__":
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     # (on torch's stream: the HBM decodes read buffers torch has just filled -- a context with a stream of its own raced with that copy
     # once in ~40 000 cases: "delta: colour out of range" on a stream that was fine)
+    if TORCH is not None:
+        TORCH.cuda.set_stream(TORCH.cuda.Stream())   # (a context does not share the NULL stream)
     ctx = cniic_amd.Context(0, stream=TORCH.cuda.current_stream().cuda_stream) if TORCH is not None else cniic_amd.Context(0)
     n = run(ctx, seconds)
     print("fuzz_codecs: %d cases in %.0f s, all equal to the oracle" % (n, seconds))
