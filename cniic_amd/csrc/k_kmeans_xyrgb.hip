@@ -56,6 +56,7 @@ struct KmXyState {
     DevBuf labels, cent, partials, running, dstate, members_last, tile_box, super_box, tile_piv, tile_mask, moved_list;
     DevBuf sup_piv, sup_mask;              // super-tile filter of the skip schedule
     DevBuf f_partials, f_running, f_cent;  // the loop with the update folded into the assign launches: 3 / 2 / 2 buffers (XyFused)
+    uint32_t sup_cap = 1;                  // super-tiles a block may take in one launch (its u32 accumulators)
     uint32_t dyn = 16;                     // ... which draws its super-tiles from a counter while at least this many centroids move (CNIIC_XY_DYN; 0: a block takes every gridDim-th)
     bool use_tab = false, fused = false;
     uint32_t launch_no = 0;
@@ -199,6 +200,7 @@ struct TileState {              // per tile, carried between iterations
     unsigned long long *smask;  // per super-tile: union of its tiles' candidate masks
     uint32_t dyn;               // the loop with the folded-in update: while at least this many centroids move (0: never), super-tiles beyond a block's first are
                                 // drawn from a counter (word 6 K + 2 of the launch's sums)
+    uint32_t sup_cap;           // ... at most this many per block: its u32 accumulators hold what that many super-tiles can add (xy_create: per_block_max)
 };
 
 // -DCNIIC_XY_PHASES: wave-clock totals per phase of k_xy_assign (a measuring build, never the shipped one)
@@ -454,8 +456,10 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     };
     uint32_t sup = blockIdx.x;
     if (dyn) { sit = 1; sup = resolve(); sit = 0; }
-    for (; sup < nsuper; sup = dyn ? resolve() : sup + gridDim.x, par ^= 1, sit++) {
-        if (dyn && threadIdx.x == 0) drawn = atomicAdd(&partials[6 * (size_t)K + 2], 1ull);
+    // (a block that has taken sup_cap super-tiles stops: the grid is sized so that every block taking that many covers the image, and
+    // the blocks that start later -- a large image has more blocks than fit the machine -- draw what it leaves)
+    for (; sup < nsuper && (!dyn || sit < ts.sup_cap); sup = dyn ? resolve() : sup + gridDim.x, par ^= 1, sit++) {
+        if (dyn && threadIdx.x == 0 && sit + 1 < ts.sup_cap) drawn = atomicAdd(&partials[6 * (size_t)K + 2], 1ull);
         const uint32_t stx = (sup % super_x) * kSTX, sty = (sup / super_x) * kSTY;
         const uint32_t tix = stx + (wv & (kSTX - 1)), tiy = sty + wv / kSTX;
         const bool has_tile = tix < tiles_x && tiy < tiles_y;
@@ -895,6 +899,7 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     // more blocks than CUs and the surplus queues behind the resident ones.
     const uint64_t per_block_max = std::max<uint64_t>(((1ull << 31) - 1) / ((uint64_t)std::max(w, h) * kSuperPx), 1);
     s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256), ceil_div(nsuper, per_block_max));
+    s.sup_cap = (uint32_t)std::min<uint64_t>(per_block_max, 0x7fffffffull);
     const uint32_t MW = (K + 63) / 64;
     // LDS budget (153 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
     // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
@@ -978,7 +983,7 @@ static int xy_assign(KmXyState &s, bool fused = false) {
                        part, s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
                        TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),
                                  s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip, s.sup_piv.as<uint32_t>(),
-                                 s.sup_mask.as<unsigned long long>(), s.dyn}, fz);
+                                 s.sup_mask.as<unsigned long long>(), s.dyn, s.sup_cap}, fz);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }

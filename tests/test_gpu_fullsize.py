@@ -190,6 +190,22 @@ def test_config3_voronoi_2048(env):
     assert int(a["members"].sum()) == 512 * 512
 
 
+def test_voronoi_dealing_8192(env, monkeypatch):
+    """voronoi(2048) on 8192 x 8192: the size at which every block has to take exactly as many super-tiles as its u32 accumulators
+    allow (16).  Drawn from the launch's counter, busy ones first (the default), or every 256th (CNIIC_XY_DYN=0): the same stream."""
+    ctx, torch, dev = env
+    from cniic_amd import _lib
+    size, K = 8192, 2048
+    img = synth(ctx, torch, dev, 1, SEED + 9, size)
+    out = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    res = []
+    for dyn in ("16", "0"):
+        monkeypatch.setenv("CNIIC_XY_DYN", dyn)
+        rc, n, st = ctx.encode("voronoi(%d)" % K, img, w=size, h=size, out=out, allow=(_lib.FEW_ACTIVE,))
+        res.append((rc, out[:n].cpu().numpy().tobytes(), st["iterations"], st["moved_last"]))
+    assert res[0] == res[1] and res[0][0] == 0 and res[0][3] == 0
+
+
 def test_hufman_lossless_2048_uniform(env):
     """Hufman on uniform noise (largest alphabet): lossless, size = histogram prediction"""
     ctx, torch, dev = env
