@@ -9,7 +9,7 @@
 //                   them one thread walks the chunk and notes where the walk leaves it (the first-tag offset of the next chunk),
 //                   how many nodes and leaves it met, and the lowest value its count of open subtrees reached.  A chunk is a map
 //                   offset -> offset of R nibbles.
-//   2. k_tp_chain   one block composes the maps (a scan over function composition) -> every chunk's true first-tag offset, its
+//   2. k_tp_chain_* one block composes the maps (a scan over function composition) -> every chunk's true first-tag offset, its
 //                   first node and leaf number, the number P of subtrees still open in front of it (the parser's stack depth),
 //                   and the chunk in which P reaches 0: the end of the trie.
 //   3. k_tp_emit    every chunk is walked once more from its true offset: per node P and leaf / branch, per leaf its symbol;
@@ -78,72 +78,103 @@ __global__ __launch_bounds__(kTpThreads) void k_tp_maps(const uint8_t *__restric
 
 __device__ __forceinline__ uint32_t tp_nib(unsigned long long m, uint32_t o) { return (uint32_t)(m >> (4 * o)) & 15u; }
 
-// one block: the chunks' maps composed in order
+// The chunks' maps composed in order -- in three kernels since round 3.  As ONE block it took 1.17 ms for the 133 K chunks of a
+// 6.8 M-leaf decoder, and 1.0 ms of that was the block's CU pulling 17 MB of cache lines through its own memory pipe to pick one 16-byte
+// record per chunk out of R (twice); picked by a grid of threads, one per chunk, the same records are 2 MB of consecutive memory.
+//   k_tp_chain_entries  (one block) the maps composed per group of chunks, the groups' entries by one thread, every chunk's entry offset
+//   k_tp_pick           (grid) picked[c] = info[c][entry[c]]
+//   k_tp_bases_*        (grid) exclusive sums over the chunks: every chunk's first node / leaf number and P; the trie's end
+constexpr uint32_t kTpB = 8;   // loads asked for eight at a time: a lone block has nobody else to hide a round trip to memory behind
 template <int R>
-__global__ __launch_bounds__(1024) void k_tp_chain(const unsigned long long *__restrict__ maps, const TpInfo *__restrict__ info, uint32_t nchunks,
-                                                   uint8_t *__restrict__ entry, uint32_t *__restrict__ nodebase, uint32_t *__restrict__ leafbase,
-                                                   int32_t *__restrict__ pbase, TpTotals *__restrict__ tot) {
+__global__ __launch_bounds__(1024) void k_tp_chain_entries(const unsigned long long *__restrict__ maps, uint32_t nchunks, uint8_t *__restrict__ entry) {
     __shared__ unsigned long long s_gmap[1024];
     __shared__ uint8_t s_gentry[1025];
-    __shared__ uint32_t s_nodes[1024], s_leaves[1024];
-    __shared__ int32_t s_dp[1024], s_gmin[1024];
-    __shared__ uint32_t s_endgroup;
     const uint32_t j = threadIdx.x;
     const uint32_t G = (nchunks + 1023) / 1024;
     const uint32_t c_lo = min(j * G, nchunks), c_hi = min(c_lo + G, nchunks);
     unsigned long long f = 0;
 #pragma unroll
     for (int k = 0; k < R; k++) f |= (unsigned long long)k << (4 * k);  // identity
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        const unsigned long long m = maps[c];
-        unsigned long long g = 0;
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += kTpB) {
+        unsigned long long mm[kTpB];
 #pragma unroll
-        for (int k = 0; k < R; k++) g |= (unsigned long long)tp_nib(m, tp_nib(f, k)) << (4 * k);
-        f = g;
+        for (uint32_t u = 0; u < kTpB; u++) mm[u] = c0 + u < c_hi ? maps[c0 + u] : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < kTpB; u++)
+            if (c0 + u < c_hi) {
+                unsigned long long g = 0;
+#pragma unroll
+                for (int k = 0; k < R; k++) g |= (unsigned long long)tp_nib(mm[u], tp_nib(f, k)) << (4 * k);
+                f = g;
+            }
     }
     s_gmap[j] = f;
-    if (j == 0) s_endgroup = 0xffffffffu;
     __syncthreads();
     if (j == 0) {
         uint32_t e = 0;  // the trie's first tag is the first byte of chunk 0
         for (uint32_t g = 0; g < 1024; g++) { s_gentry[g] = (uint8_t)e; e = tp_nib(s_gmap[g], e); }
     }
     __syncthreads();
-    uint32_t e = s_gentry[j], gn = 0, gl = 0;
-    int32_t gp = 0, gmin = 1 << 30;
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        const TpInfo in = info[(size_t)c * R + e];
-        gmin = min(gmin, in.minP == (1 << 30) ? (1 << 30) : gp + in.minP);
-        gn += in.nodes; gl += in.leaves; gp += in.dP;
-        e = tp_nib(maps[c], e);
+    uint32_t e = s_gentry[j];
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += kTpB) {
+        unsigned long long mm[kTpB];
+#pragma unroll
+        for (uint32_t u = 0; u < kTpB; u++) mm[u] = c0 + u < c_hi ? maps[c0 + u] : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < kTpB; u++)
+            if (c0 + u < c_hi) { entry[c0 + u] = (uint8_t)e; e = tp_nib(mm[u], e); }
     }
-    s_nodes[j] = gn; s_leaves[j] = gl; s_dp[j] = gp; s_gmin[j] = gmin;
-    __syncthreads();
-    // exclusive scans over the 1024 groups (Hillis-Steele on three arrays)
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t a = j >= o ? s_nodes[j - o] : 0, b2 = j >= o ? s_leaves[j - o] : 0;
-        const int32_t d = j >= o ? s_dp[j - o] : 0;
-        __syncthreads();
-        s_nodes[j] += a; s_leaves[j] += b2; s_dp[j] += d;
-        __syncthreads();
-    }
-    uint32_t nb = s_nodes[j] - gn, lb = s_leaves[j] - gl;
-    int32_t P = 1 + s_dp[j] - gp;   // one subtree -- the whole trie -- is open in front of the first tag
-    if (gmin != (1 << 30) && P + gmin <= 0) atomicMin(&s_endgroup, j);
-    __syncthreads();
-    const uint32_t eg = s_endgroup;
-    e = s_gentry[j];
-    for (uint32_t c = c_lo; c < c_hi; c++) {
-        const TpInfo in = info[(size_t)c * R + e];
-        entry[c] = (uint8_t)e; nodebase[c] = nb; leafbase[c] = lb; pbase[c] = P;
-        if (j == eg && in.minP != (1 << 30) && P + in.minP <= 0 && tot->end_chunk == 0xffffffffu) {
-            tot->end_chunk = c;   // (only this thread writes it, in chunk order: the first such chunk)
-            tot->nodes_upper = nb + in.nodes;
-            tot->leaves_upper = lb + in.leaves;
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_tp_pick(const TpInfo *__restrict__ info, const uint8_t *__restrict__ entry, uint32_t nchunks, TpInfo *__restrict__ picked) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < nchunks) picked[c] = info[(size_t)c * R + entry[c]];
+}
+// every chunk's first node / leaf number and P = exclusive sums over the chunks of (nodes, leaves, dP): a grid-wide scan in three steps
+// (as one block -- one CU storing 400 K scattered words -- this was 0.37 ms)
+__global__ __launch_bounds__(1024) void k_tp_bases_local(const TpInfo *__restrict__ picked, uint32_t nchunks, uint32_t *__restrict__ nodebase, uint32_t *__restrict__ leafbase,
+                                                         int32_t *__restrict__ pbase, uint32_t *__restrict__ blk /* [3][nblk] */, uint32_t nblk) {
+    __shared__ uint32_t wsum[1024 / 64];
+    const uint32_t c = blockIdx.x * 1024 + threadIdx.x;
+    TpInfo in = {0, 1 << 30, 0, 0};
+    if (c < nchunks) in = picked[c];
+    const uint32_t en = block_exclusive_scan<1024>(in.nodes, wsum), el = block_exclusive_scan<1024>(in.leaves, wsum);
+    const uint32_t ep = block_exclusive_scan<1024>((uint32_t)in.dP, wsum);   // (two's complement: the sum of signed values)
+    if (c < nchunks) { nodebase[c] = en; leafbase[c] = el; pbase[c] = (int32_t)ep; }
+    if (threadIdx.x == 1023) { blk[blockIdx.x] = en + in.nodes; blk[nblk + blockIdx.x] = el + in.leaves; blk[2 * nblk + blockIdx.x] = ep + (uint32_t)in.dP; }
+}
+__global__ __launch_bounds__(1024) void k_tp_bases_blocks(uint32_t *__restrict__ blk, uint32_t nblk) {   // exclusive sums over the blocks, in place (one block)
+    __shared__ uint32_t wsum[1024 / 64];
+    for (uint32_t q = 0; q < 3; q++) {
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nblk; b0 += 1024) {
+            const uint32_t i = b0 + threadIdx.x;
+            const uint32_t v = i < nblk ? blk[q * nblk + i] : 0u;
+            const uint32_t ex = block_exclusive_scan<1024>(v, wsum);
+            if (i < nblk) blk[q * nblk + i] = carry + ex;
+            __shared__ uint32_t s_tot;
+            if (threadIdx.x == 1023) s_tot = ex + v;
+            __syncthreads();
+            carry += s_tot;
+            __syncthreads();
         }
-        nb += in.nodes; lb += in.leaves; P += in.dP;
-        e = tp_nib(maps[c], e);
     }
+}
+__global__ __launch_bounds__(1024) void k_tp_bases_add(const TpInfo *__restrict__ picked, uint32_t nchunks, const uint32_t *__restrict__ blk, uint32_t nblk,
+                                                       uint32_t *__restrict__ nodebase, uint32_t *__restrict__ leafbase, int32_t *__restrict__ pbase, TpTotals *__restrict__ tot) {
+    const uint32_t c = blockIdx.x * 1024 + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint32_t nb = nodebase[c] + blk[blockIdx.x], lb = leafbase[c] + blk[nblk + blockIdx.x];
+    const int32_t P = 1 + pbase[c] + (int32_t)blk[2 * nblk + blockIdx.x];   // one subtree -- the whole trie -- is open in front of the first tag
+    nodebase[c] = nb; leafbase[c] = lb; pbase[c] = P;
+    const int32_t mp = picked[c].minP;
+    if (mp != (1 << 30) && P + mp <= 0) atomicMin(&tot->end_chunk, c);   // the first chunk in which the count of open subtrees reaches 0: the trie ends there
+}
+__global__ void k_tp_bases_end(const TpInfo *__restrict__ picked, const uint32_t *__restrict__ nodebase, const uint32_t *__restrict__ leafbase, TpTotals *__restrict__ tot) {
+    const uint32_t c = tot->end_chunk;
+    if (c == 0xffffffffu) return;
+    tot->nodes_upper = nodebase[c] + picked[c].nodes;
+    tot->leaves_upper = leafbase[c] + picked[c].leaves;
 }
 
 __device__ __forceinline__ bool tp_symbol(const uint8_t *__restrict__ b, uint64_t nbytes, uint64_t at, int sym_kind, uint32_t &key) {
@@ -301,13 +332,14 @@ int huff_parse_leaves_dev(Ctx *c, int sym_kind, const uint8_t *stream_d, uint64_
     const uint64_t span = nbytes - pos0;
     if (span / kTpChunk >= 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "trie parse: stream too long");
     const uint32_t nchunks = (uint32_t)ceil_div(span, kTpChunk);
-    DevBuf maps, info, entry, nodebase, leafbase, pbase, tot_d;
+    DevBuf maps, info, entry, nodebase, leafbase, pbase, tot_d, picked;
     CNIIC_HIP_TRY(c, maps.alloc((uint64_t)nchunks * 8));
     CNIIC_HIP_TRY(c, info.alloc((uint64_t)nchunks * R * sizeof(TpInfo)));
     CNIIC_HIP_TRY(c, entry.alloc(nchunks));
     CNIIC_HIP_TRY(c, nodebase.alloc((uint64_t)nchunks * 4));
     CNIIC_HIP_TRY(c, leafbase.alloc((uint64_t)nchunks * 4));
     CNIIC_HIP_TRY(c, pbase.alloc((uint64_t)nchunks * 4));
+    CNIIC_HIP_TRY(c, picked.alloc((uint64_t)nchunks * sizeof(TpInfo)));
     CNIIC_HIP_TRY(c, tot_d.alloc(sizeof(TpTotals)));
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     TpTotals *th = reinterpret_cast<TpTotals *>(c->pinned_u + 4200);   // (slots of this function's own)
@@ -318,12 +350,24 @@ int huff_parse_leaves_dev(Ctx *c, int sym_kind, const uint8_t *stream_d, uint64_
     const uint32_t g16 = (nchunks + 15) / 16;
     if (R == 12) {
         hipLaunchKernelGGL(k_tp_maps<12>, dim3(g16), dim3(kTpThreads), 0, c->stream, stream_d, nbytes, pos0, nchunks, maps.as<unsigned long long>(), info.as<TpInfo>());
-        hipLaunchKernelGGL(k_tp_chain<12>, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)maps.as<unsigned long long>(), (const TpInfo *)info.as<TpInfo>(), nchunks,
-                           entry.as<uint8_t>(), nodebase.as<uint32_t>(), leafbase.as<uint32_t>(), pbase.as<int32_t>(), tot_d.as<TpTotals>());
+        hipLaunchKernelGGL(k_tp_chain_entries<12>, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)maps.as<unsigned long long>(), nchunks, entry.as<uint8_t>());
+        hipLaunchKernelGGL(k_tp_pick<12>, dim3(ceil_div(nchunks, 256u)), dim3(256), 0, c->stream, (const TpInfo *)info.as<TpInfo>(), (const uint8_t *)entry.as<uint8_t>(), nchunks, picked.as<TpInfo>());
     } else {
         hipLaunchKernelGGL(k_tp_maps<7>, dim3(g16), dim3(kTpThreads), 0, c->stream, stream_d, nbytes, pos0, nchunks, maps.as<unsigned long long>(), info.as<TpInfo>());
-        hipLaunchKernelGGL(k_tp_chain<7>, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)maps.as<unsigned long long>(), (const TpInfo *)info.as<TpInfo>(), nchunks,
-                           entry.as<uint8_t>(), nodebase.as<uint32_t>(), leafbase.as<uint32_t>(), pbase.as<int32_t>(), tot_d.as<TpTotals>());
+        hipLaunchKernelGGL(k_tp_chain_entries<7>, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long *)maps.as<unsigned long long>(), nchunks, entry.as<uint8_t>());
+        hipLaunchKernelGGL(k_tp_pick<7>, dim3(ceil_div(nchunks, 256u)), dim3(256), 0, c->stream, (const TpInfo *)info.as<TpInfo>(), (const uint8_t *)entry.as<uint8_t>(), nchunks, picked.as<TpInfo>());
+    }
+    {
+        const uint32_t nblk = ceil_div(nchunks, 1024u);
+        DevBuf blk;
+        CNIIC_HIP_TRY(c, blk.alloc((uint64_t)3 * nblk * 4));
+        hipLaunchKernelGGL(k_tp_bases_local, dim3(nblk), dim3(1024), 0, c->stream, (const TpInfo *)picked.as<TpInfo>(), nchunks, nodebase.as<uint32_t>(), leafbase.as<uint32_t>(),
+                           pbase.as<int32_t>(), blk.as<uint32_t>(), nblk);
+        hipLaunchKernelGGL(k_tp_bases_blocks, dim3(1), dim3(1024), 0, c->stream, blk.as<uint32_t>(), nblk);
+        hipLaunchKernelGGL(k_tp_bases_add, dim3(nblk), dim3(1024), 0, c->stream, (const TpInfo *)picked.as<TpInfo>(), nchunks, (const uint32_t *)blk.as<uint32_t>(), nblk,
+                           nodebase.as<uint32_t>(), leafbase.as<uint32_t>(), pbase.as<int32_t>(), tot_d.as<TpTotals>());
+        hipLaunchKernelGGL(k_tp_bases_end, dim3(1), dim3(1), 0, c->stream, (const TpInfo *)picked.as<TpInfo>(), (const uint32_t *)nodebase.as<uint32_t>(),
+                           (const uint32_t *)leafbase.as<uint32_t>(), tot_d.as<TpTotals>());
     }
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(th, tot_d.p, sizeof(TpTotals), hipMemcpyDeviceToHost, c->stream));
