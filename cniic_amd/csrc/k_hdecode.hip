@@ -69,7 +69,11 @@ __global__ void k_hd_build_lut(const uint64_t *__restrict__ code, const uint32_t
         while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (code[m] <= v) a = m; else b = m; }
         return a;
     };
-    const uint32_t lo = last_le(base), hi = last_le(top);
+    // (the end of this entry's range from the start of the next one's: the lane above has it -- one search per entry instead of two)
+    const uint32_t lo = last_le(base);
+    uint32_t lo_next = (uint32_t)__shfl_down((int)lo, 1, 64);
+    if ((threadIdx.x & 63) == 63 || p + 1 == (1u << bits)) lo_next = p + 1 == (1u << bits) ? n - 1 : last_le(top + 1);
+    const uint32_t hi = p + 1 == (1u << bits) ? n - 1 : (code[lo_next] == top + 1 ? lo_next - 1 : lo_next);
     if (lut1) lut1[p] = lo == hi ? (key[lo] << 5) | ((uint32_t)len[lo] << 1) | 1u : 0u;
     else lut2[p] = lo == hi ? make_uint2(key[lo], kHdDirect | len[lo]) : make_uint2(lo, hi - lo);
 }
@@ -359,7 +363,12 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     S.nbits = S.bit0 + payload_bytes * 8;
     S.nwords = ceil_div(S.nbits, 32);
     // ---- the look-up tables
-    const uint32_t bits2 = max_len > (uint32_t)kHdLut ? std::min<uint32_t>(max_len, 20u) : 0u;
+    // The second table, measured (round 3): 2^18 entries = 2 MiB, which stays in an XCD's L2 -- `delta` 16384^2 (54 K leaves, 14.5 bits a
+    // symbol) decodes in 12.3 / 10.0 / 8.8 / 11.0 / 17.9 ms with 14 / 16 / 18 / 20 / 24 bits; for a decoder of a million leaves and more
+    // 2^24 entries = 128 MiB -- there even 20 bits leave half a dozen leaves per entry, i.e. a few more dependent reads for EVERY symbol:
+    // `hufman` 4096^2 (6.8 M leaves) 7.0 / 5.3 / 4.6 / 4.6 ms with 20 / 22 / 24 / 26.  CNIIC_HD_LUT2_BITS: the cap, for measurements.
+    const uint32_t cap2 = getenv("CNIIC_HD_LUT2_BITS") ? (uint32_t)atoi(getenv("CNIIC_HD_LUT2_BITS")) : (n >= (1u << 20) ? 24u : 18u);
+    const uint32_t bits2 = max_len > (uint32_t)kHdLut ? std::min<uint32_t>(max_len, std::max(cap2, (uint32_t)kHdLut + 1)) : 0u;
     DevBuf lut1_d, lut2_d;
     CNIIC_HIP_TRY(c, lut1_d.alloc((4ull << kHdLut)));
     HdTables T{reinterpret_cast<const uint64_t *>(tab_d), reinterpret_cast<const uint32_t *>(tab_d + off_key), tab_d + off_len, lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
