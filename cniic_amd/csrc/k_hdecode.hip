@@ -511,10 +511,15 @@ __device__ __forceinline__ void ud_unpack(uint32_t key, int32_t d[3]) {
 
 __global__ __launch_bounds__(kUdThreads) void k_ud_sums(const uint32_t *__restrict__ keys, uint64_t n, int32_t *__restrict__ chunk_sum) {
     __shared__ int32_t sh[3][kUdThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kUdChunk + (uint64_t)threadIdx.x * kUdPer;
+    // (a sum does not care about the order: neighbouring lanes read neighbouring words -- with 16 consecutive words per thread a load
+    // touched 64 cache lines and the kernel ran at 1.8 TB/s)
+    const uint64_t base = (uint64_t)blockIdx.x * kUdChunk + threadIdx.x;
     int32_t s[3] = {0, 0, 0};
-    for (int j = 0; j < kUdPer; j++)
-        if (base + j < n) { int32_t d[3]; ud_unpack(keys[base + j], d); s[0] += d[0]; s[1] += d[1]; s[2] += d[2]; }
+#pragma unroll
+    for (int j = 0; j < kUdPer; j++) {
+        const uint64_t i = base + (uint64_t)j * kUdThreads;
+        if (i < n) { int32_t d[3]; ud_unpack(keys[i], d); s[0] += d[0]; s[1] += d[1]; s[2] += d[2]; }
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         int32_t v = s[ch];
