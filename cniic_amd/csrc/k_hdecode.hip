@@ -78,6 +78,45 @@ __global__ void k_hd_build_lut(const uint64_t *__restrict__ code, const uint32_t
     else lut2[p] = lo == hi ? make_uint2(key[lo], kHdDirect | len[lo]) : make_uint2(lo, hi - lo);
 }
 
+// The same second table for a decoder of a million leaves, built from the LEAVES' side (round 3: 2^24 entries by binary search were
+// 0.5 ms of a 4.5 ms decode).  Prefix p's first leaf lo(p) = the last leaf whose code is <= p's first window: leaf i owns the prefixes
+// whose first window lies in its span [code[i], code[i + 1]), i.e. p in [ceil(code[i] / 2^S), ceil(code[i + 1] / 2^S)) -- every prefix
+// has exactly one owner.  k_hd_lut_owner: leaf i writes itself into lo[] for its prefixes (a leaf that owns more than kHdOwnMax of
+// them -- a short code -- leaves the rest to k_hd_lut_owner_big, a block per such leaf); k_hd_lut_entries: hi(p) from lo(p + 1) as above.
+constexpr uint32_t kHdOwnMax = 64;
+__device__ __forceinline__ uint64_t hd_first_prefix(uint64_t code, uint32_t S) { return (code >> S) + ((code & ((1ull << S) - 1ull)) ? 1ull : 0ull); }
+__global__ __launch_bounds__(256) void k_hd_lut_owner(const uint64_t *__restrict__ code, uint32_t n, uint32_t bits, uint32_t *__restrict__ lo,
+                                                      uint32_t *__restrict__ big, uint32_t *__restrict__ nbig, uint32_t big_cap) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t S = 64 - bits;
+    const uint64_t a = hd_first_prefix(code[i], S), b = i + 1 < n ? hd_first_prefix(code[i + 1], S) : (1ull << bits);
+    const uint64_t m = min(b, a + kHdOwnMax);
+    for (uint64_t p = a; p < m; p++) lo[p] = i;
+    if (b > m) { const uint32_t at = atomicAdd(nbig, 1u); if (at < big_cap) big[at] = i; }
+}
+__global__ __launch_bounds__(256) void k_hd_lut_owner_big(const uint64_t *__restrict__ code, uint32_t n, uint32_t bits, uint32_t *__restrict__ lo,
+                                                          const uint32_t *__restrict__ big, const uint32_t *__restrict__ nbig, uint32_t big_cap) {
+    const uint32_t nb = min(*nbig, big_cap), S = 64 - bits;
+    for (uint32_t q = blockIdx.x; q < nb; q += gridDim.x) {
+        const uint32_t i = big[q];
+        const uint64_t a = hd_first_prefix(code[i], S) + kHdOwnMax, b = i + 1 < n ? hd_first_prefix(code[i + 1], S) : (1ull << bits);
+        for (uint64_t p = a + threadIdx.x; p < b; p += 256) lo[p] = i;
+    }
+}
+__global__ __launch_bounds__(256) void k_hd_lut_entries(const uint64_t *__restrict__ code, const uint32_t *__restrict__ key, const uint8_t *__restrict__ len, uint32_t n,
+                                                        uint32_t bits, const uint32_t *__restrict__ lo_of, uint2 *__restrict__ lut2) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= (1u << bits)) return;
+    const uint32_t lo = lo_of[p];
+    uint32_t hi = n - 1;
+    if (p + 1 < (1u << bits)) {
+        const uint32_t ln = lo_of[p + 1];
+        hi = code[ln] == ((uint64_t)(p + 1) << (64 - bits)) ? ln - 1 : ln;
+    }
+    lut2[p] = lo == hi ? make_uint2(key[lo], kHdDirect | len[lo]) : make_uint2(lo, hi - lo);
+}
+
 struct HdSym { uint32_t key, len; };
 
 // the leaf of the 64-bit window `win` (its top 33 bits are stream bits, or all of it when WIDE)
@@ -374,10 +413,24 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     HdTables T{reinterpret_cast<const uint64_t *>(tab_d), reinterpret_cast<const uint32_t *>(tab_d + off_key), tab_d + off_len, lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
     hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << kHdLut) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, (uint32_t)kHdLut, lut1_d.as<uint32_t>(),
                        (uint2 *)nullptr);
+    DevBuf lo_d, big_d;
     if (bits2) {
         CNIIC_HIP_TRY(c, lut2_d.alloc(8ull << bits2));
-        hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << bits2) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, bits2, (uint32_t *)nullptr,
-                           lut2_d.as<uint2>());
+        if (bits2 > 20 && !getenv("CNIIC_HD_LUT2_SEARCH")) {   // a large table: from the leaves' side (see k_hd_lut_owner)
+            const uint32_t big_cap = (1u << bits2) / kHdOwnMax + 1;   // (leaves that own more than kHdOwnMax prefixes: at most this many)
+            CNIIC_HIP_TRY(c, lo_d.alloc(4ull << bits2));
+            CNIIC_HIP_TRY(c, big_d.alloc(((uint64_t)big_cap + 1) * 4));
+            CNIIC_HIP_TRY(c, hipMemsetAsync(big_d.p, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_hd_lut_owner, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, c->stream, T.code, T.n, bits2, lo_d.as<uint32_t>(), big_d.as<uint32_t>() + 1,
+                               big_d.as<uint32_t>(), big_cap);
+            hipLaunchKernelGGL(k_hd_lut_owner_big, dim3(512), dim3(256), 0, c->stream, T.code, T.n, bits2, lo_d.as<uint32_t>(), (const uint32_t *)big_d.as<uint32_t>() + 1,
+                               (const uint32_t *)big_d.as<uint32_t>(), big_cap);
+            hipLaunchKernelGGL(k_hd_lut_entries, dim3((1u << bits2) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, bits2, (const uint32_t *)lo_d.as<uint32_t>(),
+                               lut2_d.as<uint2>());
+        } else {
+            hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << bits2) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, bits2, (uint32_t *)nullptr,
+                               lut2_d.as<uint2>());
+        }
         T.lut2 = lut2_d.as<uint2>();
     }
     CNIIC_HIP_TRY(c, hipGetLastError());
