@@ -1164,11 +1164,15 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         // pixels the stream does not reach stay zero (ImageBuffer::new); RepCount::deserialize(..)? ends it quietly
         const uint64_t body = nbytes - pos, R = body / 12, tail = body % 12;
         DevBuf rec_d, lin_d, img_d;
-        CNIIC_HIP_TRY(c, rec_d.alloc(std::max<uint64_t>(R * 12, 16)));
-        if (R) CNIIC_HIP_TRY(c, hipMemcpyAsync(rec_d.p, bytes + pos, R * 12, bytes_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        const uint8_t *recs = bytes + pos;   // (a stream in HBM whose records are 4-byte aligned is read where it lies: 3.2 GB at 16384^2)
+        if (!bytes_dev || (reinterpret_cast<uintptr_t>(recs) & 3)) {
+            CNIIC_HIP_TRY(c, rec_d.alloc(std::max<uint64_t>(R * 12, 16)));
+            if (R) CNIIC_HIP_TRY(c, hipMemcpyAsync(rec_d.p, bytes + pos, R * 12, bytes_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+            recs = rec_d.as<uint8_t>();
+        }
         CNIIC_HIP_TRY(c, lin_d.alloc(n * 3));
         int status = 0;
-        CNIIC_TRY(rle_expand_dev(c, rec_d.as<uint8_t>(), R, tail, n, lin_d.as<uint8_t>(), &status));
+        CNIIC_TRY(rle_expand_dev(c, recs, R, tail, n, lin_d.as<uint8_t>(), &status));
         if (status)
             return c->fail(CNIIC_ERR_DECODE, "hilbert-rle: bad run record (assert!(count > 0) / unwrap, hilbertc.rs:327-328)");
         uint8_t *dst = rgb_out;

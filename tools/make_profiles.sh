@@ -54,9 +54,9 @@ rm -rf $O/trace_v
 python3 $R/bench.py --decode 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_c2_bench.json
 python3 $R/bench.py --decode --config c5 --c5-size 4096 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_delta4096_bench.json
 python3 $R/bench.py --decode --config c5 2>> $O/bench.err | tail -1 > $O/${TAG}_decode_c5_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec -o d -- python3 $R/tools/decode_dev_probe.py 4096 "cluster-colors(256)" delta hufman > $O/${TAG}_decode_probe.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec -o d -- python3 $R/tools/decode_dev_probe.py 4096 "cluster-colors(256)" delta hufman "hilbert(rle)" > $O/${TAG}_decode_probe.txt 2>&1
 cp $(find $O/stats_dec -name '*kernel_stats.csv' | head -1) $O/${TAG}_decode_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec16 -o d -- python3 $R/tools/decode_dev_probe.py 16384 delta >> $O/${TAG}_decode_probe.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dec16 -o d -- python3 $R/tools/decode_dev_probe.py 16384 delta "hilbert(rle)" >> $O/${TAG}_decode_probe.txt 2>&1
 cp $(find $O/stats_dec16 -name '*kernel_stats.csv' | head -1) $O/${TAG}_decode_delta16k_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -o c -- python3 $R/bench.py --config c4 --steps 2 --cpu-sample 0 > $O/${TAG}_c4_bench_profiled.json 2>> $O/bench.err
 cp $(find $O/stats_c4 -name '*kernel_stats.csv' | head -1) $O/${TAG}_c4_kernel_stats.csv
