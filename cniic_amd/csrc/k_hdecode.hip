@@ -206,10 +206,12 @@ __device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s,
 // goes on a work list, the list is decoded by as many threads as it has entries (dense waves, the stream still staged), and so
 // on until the list is empty.  What remains between launches is the first thread of a block against the block before it.
 constexpr int kHdMaxRounds = 320;   // (a cure moves at least one thread forward for good: 256 rounds settle any block)
+constexpr int kHdRoundsShort = 24;
+constexpr uint64_t kHdPhasesMaxSub = 1ull << 16;   // streams of up to this many subsequences (4 MiB) go to k_hd_phase_maps when the blind checks have not settled them
 template <bool WIDE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
                                                         uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ changed) {
+                                                        uint32_t *__restrict__ changed, int max_rounds) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
     __shared__ unsigned long long s_end[kHdThreads], s_nstart[kHdThreads], s_nend[kHdThreads];
     __shared__ uint32_t s_ncnt[kHdThreads];
@@ -261,7 +263,11 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
     s_end[tid] = live ? my_end : ~0ull;
     if (tid == 0) s_pred0 = pred0;
     const uint64_t end_at_entry = my_end;
-    for (int round = 0; round < kHdMaxRounds; round++) {
+    // (max_rounds < kHdMaxRounds -- a short stream of codes of at most 32 bits: a block that is not in step after kHdRoundsShort rounds, where
+    // an ordinary stream needs a handful, belongs to a stream that does not fall into step at all; it stops curing one subsequence per
+    // round and says so, and the host takes k_hd_phase_maps.  Such a block used to spend its 256 rounds, 2 ms, in each of three passes.)
+    bool gave_up = true;
+    for (int round = 0; round < max_rounds; round++) {
         if (tid == 0) s_n = 0;
         __syncthreads();                                   // s_end of the round before is in place
         const uint64_t pred = tid ? s_end[tid - 1] : s_pred0;
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
         if (redo) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)tid;
         __syncthreads();
         const uint32_t nl = s_n;
-        if (nl == 0) break;
+        if (nl == 0) { gave_up = false; break; }
         if (tid < nl) {                                    // entry tid of the list: subsequence j again, from where its predecessor ended
             const uint32_t j = s_list[tid];
             const uint64_t tj = t0 + j, hj = min((tj + 1) * kHdSub, S.nbits);
@@ -289,7 +295,69 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
     count[t] = my_cnt;
     // Only a moved END matters to anybody outside the block.  If no end moves in a pass, every thread's start equals its
     // predecessor's end and the chain from the first bit is exact.
-    if (end_prev && my_end != end_at_entry) *changed = 1u;
+    if (end_prev && (my_end != end_at_entry || gave_up)) *changed = 1u;
+}
+
+// ---------------------------------------------------------------- streams that do not fall into step (round 3)
+// A code whose words are nearly all the same length -- uniform noise over a small alphabet: `delta` on the 512 x 512 U image, 33 K
+// symbols of 15 bits -- does not self-synchronise: a decoder that starts on a wrong bit stays wrong, the settle loop above cures one
+// subsequence per round, and the decode is a chain (18-25 ms for 262 K symbols, nine checks).  For such a stream (codes of at most 32
+// bits) every subsequence is decoded from EACH of the 32 bit positions its first symbol can start at (k_hd_phase_maps: where the walk
+// enters the next subsequence and how many symbols it met), the maps are composed along the stream (k_hd_phase_chain: per group of
+// subsequences, then the 512 groups by one thread, then inside the groups with the entries known), and every subsequence's true
+// start and count fall out -- what k_hd_write needs.  32 times the first pass's work, no chain: taken when the blind checks have not
+// settled the stream (CNIIC_HD_PHASES=1: always, for the tests).
+constexpr uint32_t kHpGroups = 512;   // groups of subsequences whose maps k_hd_phase_chain composes (one thread each)
+constexpr uint32_t kHpSubs = 32, kHpThreads = kHpSubs * 32, kHpStageWords = kHpSubs * (kHdSub / 32) + kHdTail + 2;
+__global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTables T, uint64_t nsub, uint8_t *__restrict__ maps /* [nsub][32] */,
+                                                              uint16_t *__restrict__ cnts /* [nsub][32] */) {
+    __shared__ uint32_t lut_s[1u << kHdLut];
+    __shared__ uint32_t stage[kHpStageWords];
+    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHpThreads) lut_s[i] = T.lut1[i];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kHpSubs, base = t0 * kHdSub, w0 = base / 32;
+    for (uint32_t i = threadIdx.x; i < kHpStageWords; i += kHpThreads) stage[i] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
+    __syncthreads();
+    const uint64_t t = t0 + (threadIdx.x >> 5);
+    const uint32_t o = threadIdx.x & 31;
+    if (t >= nsub) return;
+    const uint64_t next = (t + 1) * kHdSub, hi = min(next, S.nbits);
+    uint64_t at = t * kHdSub + o;
+    uint32_t cn = 0;
+    if (at < hi) hd_run<false, true>(T, lut_s, stage, base, S.nbits, at, hi, cn);
+    maps[t * 32 + o] = (uint8_t)(at >= next ? min<uint64_t>(at - next, 31) : 0);   // (a walk that ends with the stream enters nothing)
+    cnts[t * 32 + o] = (uint16_t)cn;
+}
+__global__ __launch_bounds__(kHpGroups) void k_hd_phase_chain(const uint8_t *__restrict__ maps, const uint16_t *__restrict__ cnts, uint64_t nsub, uint64_t nbits, uint32_t bit0,
+                                                         uint64_t *__restrict__ start, uint32_t *__restrict__ count) {
+    __shared__ uint8_t s_row[kHpGroups][36];   // a thread's current map (rows padded: bank spread)
+    __shared__ uint8_t s_g[kHpGroups][32];     // the groups' composed maps
+    __shared__ uint8_t s_entry[kHpGroups + 1];
+    const uint32_t j = threadIdx.x;
+    const uint64_t G = (nsub + kHpGroups - 1) / kHpGroups, lo = min<uint64_t>(j * G, nsub), hi = min<uint64_t>(lo + G, nsub);
+    uint8_t f[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) f[k] = (uint8_t)k;   // identity
+    for (uint64_t t = lo; t < hi; t++) {
+        const uint4 a = reinterpret_cast<const uint4 *>(maps + t * 32)[0], b = reinterpret_cast<const uint4 *>(maps + t * 32)[1];
+        uint32_t *row = reinterpret_cast<uint32_t *>(s_row[j]);
+        row[0] = a.x; row[1] = a.y; row[2] = a.z; row[3] = a.w; row[4] = b.x; row[5] = b.y; row[6] = b.z; row[7] = b.w;
+#pragma unroll
+        for (int k = 0; k < 32; k++) f[k] = s_row[j][f[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 32; k++) s_g[j][k] = f[k];
+    __syncthreads();
+    if (j == 0) {
+        uint32_t e = bit0;   // the payload's first symbol starts at its first bit
+        for (uint32_t g = 0; g < kHpGroups; g++) { s_entry[g] = (uint8_t)e; e = s_g[g][e]; }
+    }
+    __syncthreads();
+    uint32_t e = s_entry[j];
+    for (uint64_t t = lo; t < hi; t++) {
+        start[t] = min(t * kHdSub + e, nbits);
+        count[t] = cnts[t * 32 + e];
+        e = maps[t * 32 + e];
+    }
 }
 
 // every thread decodes its symbols once more and writes them: MODE 0 = packed keys (u32 each), 1 = RGB bytes (3 each).
@@ -454,9 +522,13 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
     const size_t lds = kHdLds;
     const bool wide = lt.max_len > 32;
+    const char *ph_env = getenv("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
+    const bool phases_ok = !wide && !(ph_env && !atoi(ph_env)), phases_force = phases_ok && ph_env && atoi(ph_env);
+    const bool phases_first = phases_ok && (nsub <= kHdPhasesMaxSub || phases_force);   // a short stream: instead of more checks
+    int pass_rounds = phases_first ? kHdRoundsShort : kHdMaxRounds;
     auto pass = [&](const uint64_t *prev, uint64_t *cur) {
-        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>());
-        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>());
+        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds);
+        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), pass_rounds);
     };
     auto write = [&]() -> int {
         CNIIC_TRY(pack_scan(c, count.as<uint32_t>(), (uint32_t)nsub, off.as<uint64_t>(), tot.as<uint64_t>()));
@@ -507,7 +579,22 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         t2.stop();
     }
     CNIIC_TRY(look());
-    if ((uint32_t)pin[1]) {
+    auto phases = [&]() -> int {   // every phase of every subsequence (see k_hd_phase_maps) -> start_d, count
+        DevBuf maps_d, cnts_d;
+        CNIIC_HIP_TRY(c, maps_d.alloc(nsub * 32));
+        CNIIC_HIP_TRY(c, cnts_d.alloc(nsub * 64));
+        hipLaunchKernelGGL(k_hd_phase_maps, dim3((uint32_t)ceil_div(nsub, (uint64_t)kHpSubs)), dim3(kHpThreads), 0, c->stream, S, T, nsub, maps_d.as<uint8_t>(), cnts_d.as<uint16_t>());
+        hipLaunchKernelGGL(k_hd_phase_chain, dim3(1), dim3(kHpGroups), 0, c->stream, (const uint8_t *)maps_d.as<uint8_t>(), (const uint16_t *)cnts_d.as<uint16_t>(), nsub, S.nbits,
+                           (uint32_t)S.bit0, start_d.as<uint64_t>(), count.as<uint32_t>());
+        CNIIC_HIP_TRY(c, hipGetLastError());
+        if (hd_stats) fprintf(stderr, "[hd] not in step: every phase of every subsequence\n");
+        CNIIC_TRY(write());
+        CNIIC_TRY(look());
+        return CNIIC_OK;
+    };
+    if (phases_first && ((uint32_t)pin[1] || phases_force)) {
+        CNIIC_TRY(phases());   // not in step after the blind checks: no more checks one subsequence at a time
+    } else if ((uint32_t)pin[1]) {
         bool settled = false;
         for (int r = kHdBlindChecks; r < kHdMaxPasses; r++) {
             CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
@@ -517,9 +604,9 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
             if (hd_stats) fprintf(stderr, "[hd] check %d (after a look): an end moved: %u\n", r + 1, (uint32_t)pin[1]);
             if (!(uint32_t)pin[1]) { settled = true; break; }
         }
-        if (!settled) { *status = 2; return CNIIC_OK; }
-        CNIIC_TRY(write());
-        CNIIC_TRY(look());
+        if (!settled && !phases_ok) { *status = 2; return CNIIC_OK; }
+        if (!settled) CNIIC_TRY(phases());   // (a long stream that kHdMaxPasses checks have not settled)
+        else { CNIIC_TRY(write()); CNIIC_TRY(look()); }
     }
     if (pin[0] < nsyms) { *status = 1; return CNIIC_OK; }
     return CNIIC_OK;

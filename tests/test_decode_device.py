@@ -152,3 +152,36 @@ def test_decoder_parsed_on_the_gpu_equals_oracle(env, monkeypatch, expr, shape, 
                 assert np.array_equal(b2, e2)
     finally:
         ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
+@pytest.mark.parametrize("phases", ["1", "0", None])
+@pytest.mark.parametrize("expr,kind,shape", [("delta", "U", (512, 512)), ("hufman", "U", (256, 256)), ("delta", "P", (300, 200)),
+                                              ("cluster-colors(16)", "U", (128, 128)), ("hufman", "P", (97, 131))])
+def test_streams_that_do_not_fall_into_step(env, monkeypatch, expr, kind, shape, phases):
+    """A code whose words are nearly all the same length (uniform noise over a small alphabet: `delta` on the 512 x 512 U image) does not
+    self-synchronise: such a stream is decoded from every possible entry phase of every subsequence and the phase maps are composed
+    (k_hd_phase_maps / k_hd_phase_chain).  CNIIC_HD_PHASES=1 forces that route for every stream, 0 forbids it (the checks go on one
+    subsequence at a time), unset: taken when the blind checks have not settled a short stream.  The same pixels every way, at every
+    byte alignment of the stream."""
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    h, w = shape
+    img = (synth.uniform if kind == "U" else synth.photo)(w, h, synth.SEED0 + 5 + h)
+    rc, data, _ = ctx.encode(expr, img, allow=(_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE))
+    assert rc == 0
+    rco, exp = O.decode(expr, data)
+    assert rco == 0
+    if phases is not None:
+        monkeypatch.setenv("CNIIC_HD_PHASES", phases)
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        for shift in (0, 3):
+            buf = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+            buf[shift:shift + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+            out = torch.zeros(h * w * 3 + 16, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            rc, dw, dh = ctx.decode_into(expr, buf[shift:], len(data), out)
+            assert rc == 0 and (dw, dh) == (w, h)
+            assert np.array_equal(out[:h * w * 3].cpu().numpy().reshape(h, w, 3), exp)
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
