@@ -127,6 +127,10 @@ def main():
     ctx = cniic_amd.Context(local_rank, stream=stream.cuda_stream)
     native = "native" if world == 1 and os.environ.get("CNIIC_COLLECTIVES", "native") == "native" else None
 
+    def coll_desc(c):
+        return {"native": "library communicator, in-stream", "mailbox": "one-shot exchange over IPC-mapped mailboxes, in-stream, instead of RCCL",
+                "host": "the library's loop over a host transport"}.get(c, "torch.distributed")
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -200,7 +204,7 @@ def main():
                            "bytes_per_px": round(nbytes / (F * FRAME_W * FRAME_H), 4),
                            "parallelism": "1 GPU" if world == 1 else "frames sharded over %d GPUs (each keeps its own frames' colours), shared palette: RCCL all-reduce of the "
                                           "colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
-                                          % (world, "library communicator, in-stream" if enc.collectives == "native" else "torch.distributed")},
+                                          % (world, coll_desc(enc.collectives))},
                 "roofline": roof, "cpu_baseline": cpu,
             }
         enc.close()
@@ -409,6 +413,27 @@ def main():
                 # the HIP path on the SAME crop (the two bytes/px figures were of different images)
                 rcg, ng, stg = ctx.encode(expr, crop, max_iters=args.max_iters)
                 cpu["hip_same_crop"] = {"bytes_per_px": round(len(ng) / (s * s), 4) if rcg == 0 else None, "iterations": int(stg["iterations"]) if rcg == 0 else None}
+        if world > 1 and os.environ.get("CNIIC_BENCH_MAILBOX", "1") != "0" and enc_collectives != "mailbox":
+            # the same step with the K partial sums exchanged ONE-SHOT (every rank writes its sums into every peer's mailbox over the
+            # direct xGMI links, k_mailbox.hip) instead of RCCL's ring; `value` above stays the RCCL figure.  Waits are bounded inside
+            # the kernel (5 s here), a rank that cannot map its peers' mailboxes makes every rank skip the block.
+            try:
+                os.environ["CNIIC_COLLECTIVE_TIMEOUT_MS"] = "5000"
+                em = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives="mailbox")
+                if em.collectives == "mailbox":
+                    dtm, (nbm, stm) = timed(lambda: em.encode(img, W, H, out), args.warmup, args.steps)
+                    if rank == 0:
+                        extras["mailbox"] = {"what": "the same step, the per-iteration all-reduce of the K partial sums as a one-shot exchange over IPC-mapped mailboxes",
+                                             "value": round(npx_total * args.steps / dtm / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
+                                             "kmeans_iterations": int(stm["iterations"]), "same_stream_as_rccl": bool(nbm == nbytes),
+                                             "speedup_vs_default_collectives": round(dt / dtm, 4)}
+                elif rank == 0:
+                    extras["mailbox"] = {"unavailable": "the mailboxes could not be set up on every rank (IPC mapping or the known-answer exchange failed)"}
+                em.close()
+            except Exception as e:
+                extras["mailbox"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                os.environ.pop("CNIIC_COLLECTIVE_TIMEOUT_MS", None)
         if world > 1 and not args.no_extras:
             try:
                 # configs[3] over these N GPUs (128 frames per GPU, one palette for all N x 128), and -- in the same run -- every rank's
@@ -447,8 +472,7 @@ def main():
                            "bytes_per_px": round(nbytes / (W * H), 4),
                            "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
                                                                        "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
-                                                                       % (world, "library communicator, in-stream" if enc_collectives == "native"
-                                                                          else "torch.distributed")},
+                                                                       % (world, coll_desc(enc_collectives))},
                 "roofline": roofline, "cpu_baseline": cpu,
             }
             line.update(extras)

@@ -28,7 +28,7 @@ SYMBOLS = [
     "cniic_km_result", "cniic_km_time_assign", "cniic_km_destroy", "cniic_hist_rgb24_dense", "cniic_cc_create",
     "cniic_cc_unique", "cniic_cc_label_bytes", "cniic_cc_partials", "cniic_cc_assign", "cniic_cc_update", "cniic_cc_poll", "cniic_cc_poll_lagged",
     "cniic_cc_export_labels", "cniic_cc_import_labels", "cniic_cc_finish", "cniic_cc_finish_frames", "cniic_cc_destroy", "cniic_comm_unique_id",
-    "cniic_comm_create", "cniic_comm_create_host", "cniic_comm_destroy", "cniic_comm_all_reduce", "cniic_comm_set_timeout", "cniic_cc_run", "cniic_occupancy_pack",
+    "cniic_comm_create", "cniic_comm_create_host", "cniic_comm_create_mailbox", "cniic_comm_connect_mailbox", "cniic_comm_destroy", "cniic_comm_all_reduce", "cniic_comm_set_timeout", "cniic_cc_run", "cniic_occupancy_pack",
     "cniic_cc_create_local", "cniic_cc_image_begin", "cniic_cc_image_occupancy", "cniic_cc_image_create", "cniic_remap_rgb", "cniic_hilbert_xy",
     "cniic_hilbert_linearize", "cniic_hilbert_delta", "cniic_hilbert_delta_hist", "cniic_huf_encode_all",
     "cniic_huf_size", "cniic_codec_parse", "cniic_codec_name", "cniic_codec_is_lossless", "cniic_codec_encode",

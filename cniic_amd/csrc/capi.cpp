@@ -601,6 +601,22 @@ int32_t cniic_comm_create_host(cniic_ctx *c, uint32_t rank, uint32_t nranks, cni
     return CNIIC_OK;
 }
 
+int32_t cniic_comm_create_mailbox(cniic_ctx *c, uint32_t rank, uint32_t nranks, uint64_t max_bytes, uint8_t handle[64], cniic_comm **out) {
+    if (!c || !handle || !out) return CNIIC_ERR_BAD_ARG;
+    LOCK(c);
+    Comm *m = nullptr;
+    CNIIC_TRY(comm_create_mailbox(c, rank, nranks, max_bytes, handle, &m));
+    *out = new cniic_comm{m};
+    return CNIIC_OK;
+}
+
+int32_t cniic_comm_connect_mailbox(cniic_comm *cm, const uint8_t *handles) {
+    if (!cm || !cm->m || !handles) return CNIIC_ERR_BAD_ARG;
+    cniic_ctx *c = static_cast<cniic_ctx *>(comm_ctx(cm->m));
+    LOCK(c);
+    return comm_connect_mailbox(cm->m, handles);
+}
+
 void cniic_comm_destroy(cniic_comm *cm) {
     if (!cm) return;
     if (cm->m) {

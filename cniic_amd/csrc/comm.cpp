@@ -59,6 +59,7 @@ struct Comm {
     int32_t (*host_sum)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes) = nullptr;
     void *user = nullptr;
     std::vector<uint8_t> bounce;
+    Mailbox *mb = nullptr;  // the one-shot exchange instead of RCCL (cniic_comm_create_mailbox, k_mailbox.hip)
     bool dead = false;  // aborted after a failure on this rank or a peer: every later collective fails at once
     uint64_t timeout_ms = default_timeout_ms();  // how long a loop waits for a batch that contains collectives (0: for ever)
     static uint64_t default_timeout_ms() {
@@ -99,12 +100,28 @@ int comm_create_host(Ctx *c, uint32_t rank, uint32_t nranks, int32_t (*fn)(void 
     return CNIIC_OK;
 }
 
+int comm_create_mailbox(Ctx *c, uint32_t rank, uint32_t nranks, uint64_t max_bytes, uint8_t *handle64, Comm **out) {
+    Mailbox *mb = nullptr;
+    CNIIC_TRY(mailbox_create(c, rank, nranks, max_bytes, handle64, &mb));
+    Comm *m = new Comm{c, nullptr, rank, nranks};
+    m->mb = mb;
+    *out = m;
+    return CNIIC_OK;
+}
+
+int comm_connect_mailbox(Comm *cm, const uint8_t *handles) {
+    if (!cm->mb) return cm->c->fail(CNIIC_ERR_BAD_ARG, "comm_connect_mailbox: not a mailbox communicator");
+    return mailbox_connect(cm->mb, handles);
+}
+
 void comm_destroy(Comm *cm) {
     if (!cm) return;
+    if (cm->mb) mailbox_destroy(cm->mb);
     if (cm->comm) (void)rccl().CommDestroy(cm->comm);
     delete cm;
 }
 
+// (mailboxes: a word in every peer's mailbox ends their waits; a peer that is simply gone ends them by the kernel's own deadline)
 // A rank that fails inside a loop of collectives must not simply return: its peers sit in (or are about to enter) an
 // all-reduce that will never complete.  RCCL: abort the communicator -- the peers' collectives then end with an error
 // (they poll comm_async_error while they wait, below) instead of hanging.  Host transport: the caller's callback is told
@@ -113,6 +130,7 @@ void comm_abort(Comm *cm) {
     if (!cm || cm->dead) return;
     cm->dead = true;
     if (cm->host_sum) { (void)cm->host_sum(cm->user, nullptr, 0, -1); return; }
+    if (cm->mb) { mailbox_abort(cm->mb); return; }  // a word in every peer's mailbox: their waits end at once
     if (cm->comm && rccl().CommAbort) { (void)rccl().CommAbort(cm->comm); cm->comm = nullptr; }
 }
 
@@ -120,6 +138,10 @@ void comm_abort(Comm *cm) {
 int comm_async_error(Comm *cm) {
     if (!cm) return CNIIC_OK;
     if (cm->dead) return CNIIC_ERR_RCCL;
+    if (cm->mb) {
+        const int st = mailbox_status(cm->mb);
+        if (st) return cm->c->fail(CNIIC_ERR_RCCL, st == 2 ? "mailbox exchange: a peer aborted" : "mailbox exchange: a peer's data did not arrive within the communicator's timeout");
+    }
     if (cm->comm && rccl().CommGetAsyncError) {
         ncclResult_t st = ncclSuccess;
         if (rccl().CommGetAsyncError(cm->comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress)
@@ -140,6 +162,10 @@ int comm_all_reduce(Comm *cm, void *buf_d, uint64_t count, int kind) {
     const ncclDataType_t dt = kind == 0 ? ncclUint8 : kind == 1 ? ncclUint32 : ncclUint64;
     if (kind < 0 || kind > 2) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce: unknown element kind %d", kind);
     if (cm->dead) return c->fail(CNIIC_ERR_RCCL, "all_reduce: the communicator was aborted after a failure");
+    if (cm->mb) {
+        CNIIC_TRY(comm_async_error(cm));
+        return mailbox_all_reduce(cm->mb, buf_d, count, kind, cm->timeout_ms);
+    }
     if (cm->host_sum) {  // through the host: drain the stream, bounce, let the caller's transport sum, put it back
         const int eb = kind == 0 ? 1 : kind == 1 ? 4 : 8;
         cm->bounce.resize((size_t)count * eb);

@@ -504,6 +504,17 @@ void comm_abort(Comm *cm);        // after a failure on this rank: the peers' co
 int comm_async_error(Comm *cm);   // CNIIC_OK while healthy; an error once this rank aborted or the transport reports a peer's failure
 uint64_t comm_timeout_ms(const Comm *cm);           // deadline of a loop's wait for a batch with collectives (0: none)
 void comm_set_timeout_ms(Comm *cm, uint64_t ms);
+int comm_create_mailbox(Ctx *c, uint32_t rank, uint32_t nranks, uint64_t max_bytes, uint8_t *handle64, Comm **out);
+int comm_connect_mailbox(Comm *cm, const uint8_t *handles);
+
+// ---- k_mailbox.hip: the one-shot exchange (every rank writes its buffer into a slot of every peer's mailbox)
+struct Mailbox;
+int mailbox_create(Ctx *c, uint32_t rank, uint32_t nranks, uint64_t cap_bytes, uint8_t *handle64, Mailbox **out);
+int mailbox_connect(Mailbox *m, const uint8_t *handles);  // nranks x 64 bytes, in rank order
+int mailbox_all_reduce(Mailbox *m, void *buf_d, uint64_t count, int kind, uint64_t timeout_ms);
+int mailbox_status(const Mailbox *m);  // 0 healthy, 1 a wait ran out, 2 a peer aborted
+void mailbox_abort(Mailbox *m);
+void mailbox_destroy(Mailbox *m);
 
 int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs

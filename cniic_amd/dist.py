@@ -21,6 +21,9 @@ Collectives, two ways:
     (cniic_comm_*); the whole K-means loop is one C call (cniic_cc_run) that enqueues
     assign -> ncclAllReduce -> update per iteration with no host round trip.  torch.distributed
     only carries the 128-byte RCCL id at set-up.
+  * mailbox (CNIIC_COLLECTIVES=mailbox / collectives="mailbox"): the same C loop, the all-reduce a one-shot exchange
+    over IPC-mapped mailboxes (cniic_comm_create_mailbox, k_mailbox.hip): every rank writes its sums into every peer's
+    mailbox and adds the slots in rank order.  torch.distributed carries the 64-byte IPC handles at set-up.
   * torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests), driven from
     Python per iteration.  Used when RCCL cannot be bound, with CNIIC_COLLECTIVES=torch, and by the
     CPU tests, which plug a CPU checker in as compute backend to exercise this driver without a GPU.
@@ -176,6 +179,50 @@ class HipBackend:
             return None
         return h
 
+    def comm_create_mailbox(self, dist, rank, world, max_bytes=0):
+        """the one-shot exchange (cniic_comm_create_mailbox): every rank's 64-byte IPC handle is all-gathered over
+        torch.distributed, then a known-answer all-reduce; None (on every rank) when any rank could not set it up"""
+        torch = self.torch
+        backend = dist.get_backend() if dist is not None else "gloo"
+        where = self.dev if backend == "nccl" else "cpu"
+
+        def agreed(mine):  # all ranks or none
+            if dist is None or world == 1:
+                return mine
+            f = torch.tensor([mine], dtype=torch.int32, device=where)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return int(f.item())
+
+        hb = (C.c_uint8 * 64)()
+        h = C.c_void_p()
+        rc = self.L.cniic_comm_create_mailbox(self.ctx.h, C.c_uint32(rank), C.c_uint32(world), C.c_uint64(max_bytes), hb, C.byref(h))
+        mine = 1 if rc == _lib.OK else 0
+        if not agreed(mine):
+            if mine:
+                self.L.cniic_comm_destroy(h)
+            return None
+        t = torch.tensor(list(hb), dtype=torch.uint8, device=where)
+        if dist is not None and world > 1:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            allh = torch.cat(parts).cpu()
+        else:
+            allh = t.cpu()
+        raw = (C.c_uint8 * (64 * world))(*allh.tolist())
+        rc = self.L.cniic_comm_connect_mailbox(h, raw)
+        if not agreed(1 if rc == _lib.OK else 0):
+            self.L.cniic_comm_destroy(h)
+            return None
+        probe = torch.full((5 * 256 + 2,), rank + 1, dtype=torch.int64, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        rc = self.L.cniic_comm_all_reduce(h, C.c_void_p(probe.data_ptr()), C.c_uint64(probe.numel()), C.c_int32(8))
+        torch.cuda.synchronize(self.dev)
+        good = 1 if rc == _lib.OK and bool((probe == world * (world + 1) // 2).all()) else 0
+        if not agreed(good):
+            self.L.cniic_comm_destroy(h)
+            return None
+        return h
+
     def comm_create_host(self, dist, rank, world):
         """the same communicator over torch.distributed's CPU path (gloo): the library's C loop runs unchanged, every
         all-reduce goes through host memory.  For hosts without RCCL, and for exercising the C loop with several ranks
@@ -240,6 +287,8 @@ class ShardedClusterColors:
         self.comm = None
         if want == "native" and hasattr(self.be, "comm_create") and (self.world > 1 or collectives == "native"):
             self.comm = self.be.comm_create(dist, self.rank, self.world)
+        elif want == "mailbox" and hasattr(self.be, "comm_create_mailbox"):
+            self.comm = self.be.comm_create_mailbox(dist, self.rank, self.world)   # one-shot exchange over IPC-mapped mailboxes
         elif want == "host" and hasattr(self.be, "comm_create_host") and dist is not None:
             self.comm = self.be.comm_create_host(dist, self.rank, self.world)   # "host": the C loop over the caller's transport
         self.collectives = want if self.comm is not None else "torch"

@@ -284,6 +284,22 @@ int32_t  cniic_comm_all_reduce(cniic_comm *comm, void *buf_dev, uint64_t count, 
 typedef int32_t (*cniic_host_sum_fn)(void *user, void *buf_host, uint64_t count, int32_t elem_bytes);
 int32_t  cniic_comm_create_host(cniic_ctx *ctx, uint32_t rank, uint32_t nranks, cniic_host_sum_fn fn, void *user, cniic_comm **out);
 int32_t  cniic_comm_set_timeout(cniic_comm *comm, uint64_t milliseconds);
+/* The same communicator as a ONE-SHOT exchange over mailboxes (k_mailbox.hip), for buffers where RCCL's ring is all latency
+ * (the K partial sums: 10 KiB an iteration): every rank owns a mailbox in fine-grained HBM that its peers map through HIP
+ * IPC; an all-reduce is one kernel per rank that writes the buffer into a slot of EVERY peer's mailbox over the direct xGMI
+ * links, raises a flag behind it, waits for the flags of its own mailbox and adds the slots in rank order (unsigned integer
+ * sums: bit-identical to RCCL's result).  At most 16 ranks; buffers larger than max_bytes (0: 1 MiB) go in pieces.
+ *   every rank: cniic_comm_create_mailbox -> all-gather the 64-byte handles by any means, in rank order ->
+ *   every rank: cniic_comm_connect_mailbox -> cniic_comm_all_reduce / cniic_cc_run / cniic_comm_set_timeout as above
+ * (one process per GPU; ranks inside one process find each other's mailboxes without IPC, and need streams that do not share a
+ * hardware queue -- a process has four -- since each rank's kernel waits for the kernels of the others).  A wait is bounded INSIDE the
+ * kernel by the communicator's timeout (0 or more than 600 000 ms: 600 000 ms), an abort by a peer ends it at once; both
+ * surface as CNIIC_ERR_RCCL from cniic_cc_run or the next cniic_comm_all_reduce.  RCCL stays the default transport: this one
+ * has only been run between processes that share ONE GPU (tests/test_mailbox.py), not yet across xGMI. */
+#define CNIIC_MAILBOX_HANDLE_BYTES 64
+int32_t  cniic_comm_create_mailbox(cniic_ctx *ctx, uint32_t rank, uint32_t nranks, uint64_t max_bytes,
+                                   uint8_t handle[CNIIC_MAILBOX_HANDLE_BYTES], cniic_comm **out);
+int32_t  cniic_comm_connect_mailbox(cniic_comm *comm, const uint8_t *handles /* nranks x 64 bytes, rank order */);
 int32_t  cniic_cc_run(cniic_cc *cc, cniic_comm *comm /* NULL: one rank */, cniic_kmeans_stats *stats);
 
 /* ------------------------------------------------------------------ cluster-colors remap */

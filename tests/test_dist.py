@@ -170,6 +170,8 @@ def _frames_worker(rank, world, port, K, use_hip, q, F, h, w, env=None):
             torch.cuda.set_stream(torch.cuda.Stream(device=dev))
             ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
             enc = ShardedClusterColors(ctx, K, dist, dev, collectives=(env or {}).get("TEST_COLLECTIVES"))
+            if env and env.get("TEST_COLLECTIVES"):
+                assert enc.collectives == env["TEST_COLLECTIVES"]
             tf = torch.from_numpy(frames).to(dev)
             out = torch.zeros(stride * F, dtype=torch.uint8, device=dev)
         else:
@@ -403,6 +405,23 @@ def test_native_loop_world2_over_a_host_transport(route):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,route", [(2, "dense"), (2, "partition"), (4, "partition")])
+def test_native_loop_over_mailboxes(world, route):
+    """cniic_cc_run with the ONE-SHOT exchange (cniic_comm_create_mailbox): two / four processes that share the test box's GPU map
+    each other's mailboxes through HIP IPC (the handles travel over gloo); every iteration's K partial sums are written into
+    every peer's mailbox and added in rank order, and the 8 MiB of occupancy nibbles go through the same mailboxes in pieces.
+    Result = the oracle's union result, as over RCCL or a host transport."""
+    K = 8 if world == 2 else 16
+    env = {"TEST_COLLECTIVES": "mailbox", "CNIIC_COLLECTIVE_TIMEOUT_MS": "20000",
+           "CNIIC_SP_MIN_PIXELS": "0" if route == "partition" else str(1 << 40)}
+    res = _run(world, K, use_hip=True, env=env)
+    exp, iters = expected_streams([make_img(r) for r in range(world)], K)
+    for r in range(world):
+        assert res[r][0] == exp[r], "rank %d stream differs" % r
+        assert res[r][1] == iters
+
+
+@pytest.mark.gpu
 def test_native_loop_world4_over_a_host_transport():
     """four ranks (occupancy nibbles summed over four images, four-way partial sums) through the library's own loop"""
     K = 16
@@ -535,8 +554,16 @@ def test_two_image_sessions_open_on_one_context(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_frame_batch_hip_world2_over_mailboxes():
+    """two ranks x three frames, the loop's all-reduce the one-shot exchange"""
+    K, F, h, w = 16, 3, 40, 56
+    env = {"TEST_COLLECTIVES": "mailbox", "CNIIC_COLLECTIVE_TIMEOUT_MS": "20000", "CNIIC_SP_MIN_PIXELS": "0"}
+    _check_frames(_run_frames(2, K, True, F, h, w, env=env), 2, K, F, h, w)
+
+
 # ------------------------------------------------------------------ a rank that fails must not strand its peers
-def _failing_worker(rank, world, port, q):
+def _failing_worker(rank, world, port, q, collectives="host"):
     import datetime
     import torch
     import torch.distributed as dist
@@ -551,7 +578,8 @@ def _failing_worker(rank, world, port, q):
     torch.cuda.set_device(0)
     torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    enc = ShardedClusterColors(ctx, 8, dist, dev, collectives="host")
+    enc = ShardedClusterColors(ctx, 8, dist, dev, collectives=collectives)
+    assert enc.collectives == collectives
     img = make_img(rank)
     h, w = img.shape[:2]
     out = torch.zeros(w * h * 16 + 4096, dtype=torch.uint8, device=dev)
@@ -594,6 +622,32 @@ def test_a_failing_rank_aborts_its_communicator_and_its_peer_errors_out():
                 p.terminate()
     assert res[1][0] == _lib.HIP and res[1][1], res          # the injected failure, and the abort notification reached the transport
     assert res[0][0] == _lib.RCCL, res                       # the peer: an error, not a hang
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_ends_its_peers_wait_in_the_mailbox_kernel():
+    """the same with the one-shot exchange: rank 1 fails before its fourth launch and writes the abort word into rank 0's
+    mailbox; rank 0's kernel, waiting for rank 1's slice, leaves at once and rank 0 returns CNIIC_ERR_RCCL"""
+    import torch.multiprocessing as mp
+    from cniic_amd import _lib
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, "mailbox"), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, code, aborted, msg = q.get(timeout=150)
+            res[r] = (code, msg)
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.terminate()
+    assert res[1][0] == _lib.HIP, res
+    assert res[0][0] == _lib.RCCL and "peer aborted" in res[0][1], res
 
 
 @pytest.mark.gpu
@@ -649,6 +703,8 @@ def test_bench_two_ranks_same_workload_as_one_rank_and_self_contained_c4_block()
     assert two["config"]["workload"] == one["config"]["workload"]            # the same per-GPU workload at every N
     assert two["config"]["pixels_per_gpu"] == one["config"]["pixels_per_gpu"] == 1024 * 1024
     assert two["value"] > 0 and two["cpu_baseline"] is None
+    mb = two["mailbox"]     # the same step once more with the one-shot exchange (here: two processes mapping each other's mailboxes on one GPU)
+    assert mb["value"] > 0 and mb["same_stream_as_rccl"] and mb["kmeans_iterations"] == two["config"]["kmeans_iterations"], mb
     c4 = two["c4"]
     assert c4["value"] > 0 and c4["one_gpu_same_run"]["value"] > 0
     assert abs(c4["efficiency_vs_one_gpu"] - c4["value"] / (2 * c4["one_gpu_same_run"]["value"])) < 1e-3
