@@ -13,7 +13,10 @@ KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_H
          {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_HUF_RUNS_MIN": "0"},   # round 3: the tree from runs of equal count whatever the alphabet's size
          {"CNIIC_HUF_GPU_CODES_MIN": "0", "CNIIC_TEST_INLINE_CODE_BITS": "7"}, {"CNIIC_TEST_PACK_IMG_WORDS": "30"},
          {"CNIIC_GPU_DECODE_MIN": "0"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1"},   # round 3: the parallel decoder / the GPU trie parse whatever the size
-         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HILBERT_MOVE": "any"}]
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HILBERT_MOVE": "any"},
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_PHASES": "1"},                              # round 3: every stream through the phase maps
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1", "CNIIC_HD_LUT2_BITS": "21"},  # the second table built from the leaves' side
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT2_BITS": "13"}]
 
 
 def image():

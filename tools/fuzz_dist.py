@@ -1,4 +1,4 @@
-"""Multi-rank fuzz on one GPU: the library's K-means loop over the host-transport communicator (2-3 ranks), random images and
+"""Multi-rank fuzz on one GPU: the library's K-means loop over the host-transport communicator or the one-shot mailbox exchange (2-3 ranks), random images and
 K, against the oracle's clustering of the union.  usage: fuzz_dist.py [cases] [seed]   (tools only; needs tests/ on the path)"""
 import json
 import os
@@ -19,7 +19,7 @@ def main():
         world = int(rng.choice([2, 3]))
         K = int(rng.choice([2, 5, 16, 40]))
         h, w = int(rng.integers(8, 90)), int(rng.integers(8, 90))
-        env = {"TEST_COLLECTIVES": "host", "CNIIC_SP_MIN_PIXELS": str(int(rng.choice([0, 1 << 40]))),
+        env = {"TEST_COLLECTIVES": str(rng.choice(["host", "mailbox"])), "CNIIC_COLLECTIVE_TIMEOUT_MS": "20000", "CNIIC_SP_MIN_PIXELS": str(int(rng.choice([0, 1 << 40]))),
                "FUZZ_SEED0": str(int(rng.integers(0, 1000))), "FUZZ_H": str(h), "FUZZ_W": str(w)}
         os.environ.update({k: v for k, v in env.items() if k.startswith("FUZZ_")})   # make_img here = make_img in the workers
         res = T._run(world, K, use_hip=True, env=env)
