@@ -1,12 +1,12 @@
 """Multi-rank fuzz on one GPU: the library's K-means loop over the host-transport communicator or the one-shot mailbox exchange (2-3 ranks), random images and
-K, against the oracle's clustering of the union.  usage: fuzz_dist.py [cases] [seed]   (tools only; needs tests/ on the path)"""
+K, against the oracle's clustering of the union.  usage: python tests/fuzz_dist.py [cases] [seed]   (test infrastructure: the oracle is the checker)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this directory)
 
 
 def main():

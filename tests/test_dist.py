@@ -35,7 +35,7 @@ def make_img(rank, h=40, w=56):
     from cniic_amd import synth
     if os.environ.get("TEST_RESEED_IMAGES") == "1":
         return reseed_img(rank)
-    if "FUZZ_SEED0" in os.environ:  # tools/fuzz_dist.py: other sizes and seeds, the same in the spawned workers
+    if "FUZZ_SEED0" in os.environ:  # tests/fuzz_dist.py: other sizes and seeds, the same in the spawned workers
         return synth.photo(int(os.environ["FUZZ_W"]), int(os.environ["FUZZ_H"]), 12345 + int(os.environ["FUZZ_SEED0"]) + rank)
     return synth.photo(w, h, synth.SEED0 + 40 + rank)
 

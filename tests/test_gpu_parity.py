@@ -436,6 +436,13 @@ def test_fuzz_lossless_codecs(ctx):
     assert fuzz_codecs.run(ctx, float(os.environ.get("CNIIC_FUZZ_SECONDS", "6"))) > 0
 
 
+def test_fuzz_lossy_codecs(ctx):
+    """a few seconds of tests/fuzz_kmeans.py: random images x K x route knobs through cluster-colors / voronoi -- return code, bytes,
+    iteration count and decode against the oracle (`python tests/fuzz_kmeans.py 300` ran 3.4 K cases)"""
+    import fuzz_kmeans
+    assert fuzz_kmeans.run(ctx, float(os.environ.get("CNIIC_FUZZ_SECONDS", "6"))) > 0
+
+
 @pytest.mark.parametrize("case", ["flat", "stripes", "levels2", "long_runs", "wide", "tall"])
 def test_hilbert_rle_runs_equal_oracle(ctx, case):
     """run boundaries, the 255 cap across chunk borders (4096 positions per block) and ragged sizes"""
