@@ -439,6 +439,7 @@ def test_fuzz_lossless_codecs(ctx):
 def test_fuzz_lossy_codecs(ctx):
     """a few seconds of tests/fuzz_kmeans.py: random images x K x route knobs through cluster-colors / voronoi -- return code, bytes,
     iteration count and decode against the oracle (`python tests/fuzz_kmeans.py 300` ran 3.4 K cases)"""
+    import os
     import fuzz_kmeans
     assert fuzz_kmeans.run(ctx, float(os.environ.get("CNIIC_FUZZ_SECONDS", "6"))) > 0
 
