@@ -207,12 +207,20 @@ __device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s,
 // on until the list is empty.  What remains between launches is the first thread of a block against the block before it.
 constexpr int kHdMaxRounds = 320;   // (a cure moves at least one thread forward for good: 256 rounds settle any block)
 constexpr int kHdRoundsShort = 24;
+// of a block's out-of-step list still there after three rounds: the stream does not self-synchronise well enough for the settle loop.
+// By measurement (tools/all_probe.py, photograph and uniform noise, `hufman` and `delta`, 512^2 .. 4096^2): a round is a chain of ~25
+// dependent look-ups (12 us when every code goes to the second table) whatever the stream's size, the phase maps are 32 decodes of
+// EVERYTHING -- short streams give up early, long ones late, streams of more than 2^19 subsequences (32 MiB of payload) never.
+__host__ inline uint32_t hd_hopeless_pct(uint64_t nsub) { return nsub <= (1ull << 16) ? 35u : nsub <= (1ull << 19) ? 60u : 0u; }
 constexpr uint64_t kHdPhasesMaxSub = 1ull << 16;   // streams of up to this many subsequences (4 MiB) go to k_hd_phase_maps when the blind checks have not settled them
 template <bool WIDE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
                                                         uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ changed, int max_rounds) {
+                                                        uint32_t *__restrict__ changed, int max_rounds, uint32_t hopeless_min, uint32_t hopeless_pct) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
+    // (hopeless_min != 0: pass 0 counts in changed[5] the blocks whose threads do not fall into step -- see the settle loop -- and once
+    // that many have said so, the checks and the write behind it return at once: the host takes k_hd_phase_maps after its one look)
+    if (hopeless_min && end_prev && changed[5] >= hopeless_min) return;
     __shared__ unsigned long long s_end[kHdThreads], s_nstart[kHdThreads], s_nend[kHdThreads];
     __shared__ uint32_t s_ncnt[kHdThreads];
     __shared__ uint16_t s_list[kHdThreads];
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
     // an ordinary stream needs a handful, belongs to a stream that does not fall into step at all; it stops curing one subsequence per
     // round and says so, and the host takes k_hd_phase_maps.  Such a block used to spend its 256 rounds, 2 ms, in each of three passes.)
     bool gave_up = true;
+    uint32_t nl0 = 0;
     for (int round = 0; round < max_rounds; round++) {
         if (tid == 0) s_n = 0;
         __syncthreads();                                   // s_end of the round before is in place
@@ -276,6 +285,17 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
         __syncthreads();
         const uint32_t nl = s_n;
         if (nl == 0) { gave_up = false; break; }
+        // Does this stream fall into step at all?  Every round re-decodes the listed subsequences from where their predecessors ended; on
+        // an ordinary stream that cures four in five of them, on a near-fixed-length code next to none, and the loop becomes a chain of
+        // one cure per round.  Curing a fraction p per round costs list / p decodes and ln(list) / p rounds per pass, the phase maps 32
+        // decodes and no chain: a block whose list has kept hopeless_pct per cent of its length over three rounds stops here and says so.
+        if (hopeless_min && !end_prev) {
+            if (round == 0) nl0 = nl;
+            else if (round == 3 && nl0 >= 64 && nl * 100 > nl0 * hopeless_pct) {
+                if (tid == 0) atomicAdd(&changed[5], 1u);
+                break;
+            }
+        }
         if (tid < nl) {                                    // entry tid of the list: subsequence j again, from where its predecessor ended
             const uint32_t j = s_list[tid];
             const uint64_t tj = t0 + j, hj = min((tj + 1) * kHdSub, S.nbits);
@@ -365,8 +385,10 @@ __global__ __launch_bounds__(kHpGroups) void k_hd_phase_chain(const uint8_t *__r
 // L2 request per lane, 16.7 M of them at 4096^2.
 template <bool WIDE, int MODE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ start,
-                                                         const uint64_t *__restrict__ off, uint64_t nsyms, void *__restrict__ out) {
+                                                         const uint64_t *__restrict__ off, uint64_t nsyms, void *__restrict__ out,
+                                                         const uint32_t *__restrict__ hopeless /* null, or the count and its bound: see k_hd_pass */, uint32_t hopeless_min) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
+    if (hopeless && *hopeless >= hopeless_min) return;
     uint32_t *lut_s = hd_lds;
     uint32_t *stage = hd_lds + (1u << kHdLut);
     const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
@@ -524,27 +546,35 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     const bool wide = lt.max_len > 32;
     const char *ph_env = getenv("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
     const bool phases_ok = !wide && !(ph_env && !atoi(ph_env)), phases_force = phases_ok && ph_env && atoi(ph_env);
-    const bool phases_first = phases_ok && (nsub <= kHdPhasesMaxSub || phases_force);   // a short stream: instead of more checks
+    const uint64_t phases_max_sub = getenv("CNIIC_HD_PHASES_MAX_SUB") ? strtoull(getenv("CNIIC_HD_PHASES_MAX_SUB"), nullptr, 10) : kHdPhasesMaxSub;   // (for measurements)
+    const bool phases_first = phases_ok && (nsub <= phases_max_sub || phases_force);   // a short stream: instead of more checks
     int pass_rounds = phases_first ? kHdRoundsShort : kHdMaxRounds;
+    // a stream that does not fall into step is found out by pass 0 itself (k_hd_pass: blocks whose lists do not shrink count themselves in
+    // changed[5]); from a quarter of the blocks on, the checks and the write behind pass 0 return at once and the one look sends the host
+    // to the phase maps -- instead of three passes that cure one subsequence a round first (1024^2 photograph, `hufman`: 3.2 -> 1.6 ms)
+    const uint32_t hopeless_pct = getenv("CNIIC_HD_HOPELESS_PCT") ? (uint32_t)atoi(getenv("CNIIC_HD_HOPELESS_PCT")) : hd_hopeless_pct(nsub);   // (0: no such verdict)
+    const uint32_t hopeless_min = phases_ok && !phases_force && hopeless_pct ? std::max(1u, grid / 4) : 0u;
     auto pass = [&](const uint64_t *prev, uint64_t *cur) {
-        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds);
-        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), pass_rounds);
+        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds, 0u, 0u);
+        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), pass_rounds, hopeless_min, hopeless_pct);
     };
-    auto write = [&]() -> int {
+    auto write = [&](bool guarded) -> int {   // guarded: nothing to write if pass 0 has given the stream up
         CNIIC_TRY(pack_scan(c, count.as<uint32_t>(), (uint32_t)nsub, off.as<uint64_t>(), tot.as<uint64_t>()));
         const uint64_t *st = start_d.as<uint64_t>(), *of = off.as<uint64_t>();
+        const uint32_t *hp = guarded && hopeless_min ? changed.as<uint32_t>() + 5 : nullptr;
         if (wide) {
-            if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
-            else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
+            if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u);
+            else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u);
         } else {
-            if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
-            else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d);
+            if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min);
+            else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min);
         }
         CNIIC_HIP_TRY(c, hipGetLastError());
         return CNIIC_OK;
     };
-    auto look = [&]() -> int {   // total and flag to the host
+    auto look = [&]() -> int {   // total and flags to the host
         CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin), tot.p, 8, hipMemcpyDeviceToHost, c->stream));
+        CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin) + 2, changed.as<uint32_t>() + 5, 4, hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin) + 1, changed.p, 4, hipMemcpyDeviceToHost, c->stream));
         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
         return CNIIC_OK;
@@ -555,7 +585,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     // next check repairs; a check that finds its whole block in step stages nothing and costs next to nothing.)  Should the last
     // blind check still have moved an end, checks go on one look at a time and the symbols are written again.
     uint64_t *cur = end_a.as<uint64_t>(), *nxt = end_b.as<uint64_t>();
-    pin[1] = 0;
+    pin[1] = 0; pin[2] = 0;
     {
         ScopedKernelTimer t0(c, "hd_pass0");   // (stage timers: CNIIC_OPT_STAGE_TIMERS; they synchronise)
         pass(nullptr, cur);
@@ -575,7 +605,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         }
         t1.stop();
         ScopedKernelTimer t2(c, "hd_write");
-        CNIIC_TRY(write());
+        CNIIC_TRY(write(true));
         t2.stop();
     }
     CNIIC_TRY(look());
@@ -588,11 +618,13 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
                            (uint32_t)S.bit0, start_d.as<uint64_t>(), count.as<uint32_t>());
         CNIIC_HIP_TRY(c, hipGetLastError());
         if (hd_stats) fprintf(stderr, "[hd] not in step: every phase of every subsequence\n");
-        CNIIC_TRY(write());
+        CNIIC_TRY(write(false));
         CNIIC_TRY(look());
         return CNIIC_OK;
     };
-    if (phases_first && ((uint32_t)pin[1] || phases_force)) {
+    const bool hopeless = hopeless_min && (uint32_t)pin[2] >= hopeless_min;
+    if (hd_stats) fprintf(stderr, "[hd] blocks of pass 0 that did not fall into step: %u of %u%s\n", (uint32_t)pin[2], grid, hopeless ? " -- given up" : "");
+    if (hopeless || (phases_first && ((uint32_t)pin[1] || phases_force))) {
         CNIIC_TRY(phases());   // not in step after the blind checks: no more checks one subsequence at a time
     } else if ((uint32_t)pin[1]) {
         bool settled = false;
@@ -606,7 +638,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         }
         if (!settled && !phases_ok) { *status = 2; return CNIIC_OK; }
         if (!settled) CNIIC_TRY(phases());   // (a long stream that kHdMaxPasses checks have not settled)
-        else { CNIIC_TRY(write()); CNIIC_TRY(look()); }
+        else { CNIIC_TRY(write(false)); CNIIC_TRY(look()); }
     }
     if (pin[0] < nsyms) { *status = 1; return CNIIC_OK; }
     return CNIIC_OK;

@@ -16,7 +16,8 @@ KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_H
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HILBERT_MOVE": "any"},
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_PHASES": "1"},                              # round 3: every stream through the phase maps
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1", "CNIIC_HD_LUT2_BITS": "21"},  # the second table built from the leaves' side
-         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT2_BITS": "13"}]
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT2_BITS": "13"},
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "1"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "0"}]   # pass 0's verdict: eager / never
 
 
 def image():

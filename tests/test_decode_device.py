@@ -154,15 +154,16 @@ def test_decoder_parsed_on_the_gpu_equals_oracle(env, monkeypatch, expr, shape, 
         ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
 
 
-@pytest.mark.parametrize("phases", ["1", "0", None])
+@pytest.mark.parametrize("phases", ["1", "0", None, "verdict-off", "verdict-eager"])
 @pytest.mark.parametrize("expr,kind,shape", [("delta", "U", (512, 512)), ("hufman", "U", (256, 256)), ("delta", "P", (300, 200)),
-                                              ("cluster-colors(16)", "U", (128, 128)), ("hufman", "P", (97, 131))])
+                                              ("cluster-colors(16)", "U", (128, 128)), ("hufman", "P", (97, 131)), ("hufman", "P", (640, 512))])
 def test_streams_that_do_not_fall_into_step(env, monkeypatch, expr, kind, shape, phases):
     """A code whose words are nearly all the same length (uniform noise over a small alphabet: `delta` on the 512 x 512 U image) does not
     self-synchronise: such a stream is decoded from every possible entry phase of every subsequence and the phase maps are composed
     (k_hd_phase_maps / k_hd_phase_chain).  CNIIC_HD_PHASES=1 forces that route for every stream, 0 forbids it (the checks go on one
-    subsequence at a time), unset: taken when the blind checks have not settled a short stream.  The same pixels every way, at every
-    byte alignment of the stream."""
+    subsequence at a time), unset: taken when the blind checks have not settled a short stream -- or at once when pass 0 itself finds
+    that its blocks' out-of-step lists do not shrink (the verdict; CNIIC_HD_HOPELESS_PCT=0 switches it off, 1 makes every block
+    with a list of 64 give the stream up).  The same pixels every way, at every byte alignment of the stream."""
     ctx, torch, dev = env
     from cniic_amd import _lib, synth
     h, w = shape
@@ -171,7 +172,9 @@ def test_streams_that_do_not_fall_into_step(env, monkeypatch, expr, kind, shape,
     assert rc == 0
     rco, exp = O.decode(expr, data)
     assert rco == 0
-    if phases is not None:
+    if phases in ("verdict-off", "verdict-eager"):
+        monkeypatch.setenv("CNIIC_HD_HOPELESS_PCT", "0" if phases == "verdict-off" else "1")
+    elif phases is not None:
         monkeypatch.setenv("CNIIC_HD_PHASES", phases)
     ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
     try:
