@@ -1026,7 +1026,7 @@ int huff_tree_serialize_dev(Ctx *c, const uint32_t *keys_d, const uint64_t *off_
 struct TreeDesc { uint32_t k0, kind, a, b; };   // kind 0: leaf run from sorted position a; 1: branch run from branch a; 2: one pair (refs a, b)
 constexpr uint32_t kRefBranch = 0x80000000u;    // a node reference: a sorted leaf position, or kRefBranch | branch number
 constexpr uint32_t kMaxLeafRuns = 1u << 16;     // more runs of equal count than this: the plain merge on the host
-constexpr uint32_t kRunsMinLeaves = 1u << 18;   // fewer leaves than this: the plain merge on the host
+constexpr uint32_t kRunsMinLeaves = 1u << 16;   // (by the sweep in NOTES.md C: from 384^2 `hufman` on the runs win; below, and when the counts do not come in runs, the host's merge)
 
 __global__ __launch_bounds__(256) void k_leaf_run_count(const uint64_t *__restrict__ sorted, uint32_t n, uint32_t *__restrict__ nruns) {
     uint32_t mine = 0;
@@ -1158,8 +1158,10 @@ static bool merge_runs(const uint2 *runs, uint32_t R, uint32_t n, std::vector<Tr
 int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts_d, uint32_t n, int sym_kind, uint8_t *len_d, uint64_t *code_d,
                         uint64_t *off_d, uint64_t *nbits_h, bool *built) {
     *built = false;
-    // (below ~3 10^5 leaves the host's merge is the faster one: this path has three waits for the stream and a sort by code in it,
-    // ~0.4 ms whatever n is -- `delta` at 16384^2, 54 K leaves: 2.06 ms against 1.68; CNIIC_HUF_RUNS_MIN moves the line, tests set 0)
+    // (this path has three waits for the stream and a sort by code in it, ~0.4 ms whatever n is, and its host part is linear in the
+    // RUNS: `delta` at 16384^2, 54 K leaves of as many different counts: 2.06 ms against 1.68 through the host's merge.  So: from 2^16
+    // leaves on, and only when the leaves outnumber the runs four to one -- an image whose colours are nearly all distinct (`hufman`
+    // 512^2: 2.5 10^5 leaves, a dozen runs: 0.73 -> 0.40 ms).  CNIIC_HUF_RUNS_MIN moves the line, tests set 0 and take any runs.)
     const char *rm = getenv("CNIIC_HUF_RUNS_MIN");
     if (n < 2 || n < (rm ? (uint32_t)atoi(rm) : kRunsMinLeaves) || getenv("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
     DevBuf small, runs_d, desc_d, tree_d, par, keys_a, keys_b, z_d, zex_d, tot_d;
@@ -1174,7 +1176,7 @@ int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts
     CNIIC_HIP_TRY(c, hipMemcpyAsync(const_cast<uint64_t *>(pin), nruns_d, 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t R = (uint32_t)pin[0];
-    if (R == 0 || R > kMaxLeafRuns) return CNIIC_OK;
+    if (R == 0 || R > kMaxLeafRuns || (!rm && R > n / 4)) return CNIIC_OK;
     CNIIC_HIP_TRY(c, runs_d.alloc((uint64_t)R * 8));
     hipLaunchKernelGGL(k_leaf_run_list, dim3(g), dim3(256), 0, c->stream, sorted_d, n, runs_d.as<uint2>(), cursor_d);
     // (pinned_huf is the caller's: used as it is when large enough, never grown here -- the caller holds pointers into it)
