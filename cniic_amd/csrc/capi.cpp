@@ -83,6 +83,7 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     c->dense.release();
     c->scan_xy.release();
+    c->scan_leaves.reset();   // (device tables of the scan of large rectangles)
     c->pool.trim();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -146,6 +146,7 @@ struct Ctx {
     void  *pinned_huf = nullptr;  // pinned host memory of a `delta` encode: distinct symbols, counts, codes, the serialised decoder
     uint64_t pinned_huf_bytes = 0;
     hipEvent_t huf_ev = nullptr;   // behind the D2H copies of the compacted histogram (huf_encode_all_dev)
+    std::shared_ptr<void> scan_leaves;  // the built-in scan of large rectangles: per image size, the recursion's leaves and class tables (k_hilbert.hip)
     DevBuf scan_xy;         // cniic_ctx_set_scan: an injected scan of scan_w x scan_h images, (x, y) per position (uint2[w h])
     uint32_t scan_w = 0, scan_h = 0;
     std::vector<void *> batch_workers;  // cniic_codec_encode_batch: worker contexts (cniic_ctx *), created on first use

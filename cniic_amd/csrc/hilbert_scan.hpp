@@ -7,30 +7,25 @@
 namespace cniic {
 
 // ---------------------------------------------------------------- generic rectangles
-__device__ __forceinline__ int32_t sgn32(int32_t v) { return (v > 0) - (v < 0); }
-__device__ __forceinline__ int32_t floordiv2(int32_t v) { return v >> 1; }  // arithmetic shift = floor
-
-// position d of the scan of a w x h rectangle (d < w*h < 2^32, sides < 2^31)
-__device__ __forceinline__ void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t d0, uint32_t &xo, uint32_t &yo) {
-    int32_t x = 0, y = 0, ax, ay, bx, by;
-    int64_t d = (int64_t)d0;
-    if (w0 >= h0) { ax = (int32_t)w0; ay = 0; bx = 0; by = (int32_t)h0; }
-    else { ax = 0; ay = (int32_t)h0; bx = (int32_t)w0; by = 0; }
+// the walk inside the rectangle spanned by a = (ax, ay) and b = (bx, by) from its origin: position d -> the offset added to (x, y)
+__host__ __device__ inline int32_t gl_abs(int32_t v) { return v < 0 ? -v : v; }
+__host__ __device__ inline int32_t gl_sgn(int32_t v) { return (v > 0) - (v < 0); }
+__host__ __device__ inline void gilbert_walk(int32_t ax, int32_t ay, int32_t bx, int32_t by, int64_t d, int32_t &x, int32_t &y) {
     for (;;) {
-        const int32_t w = abs(ax + ay), h = abs(bx + by);
-        const int32_t dax = sgn32(ax), day = sgn32(ay), dbx = sgn32(bx), dby = sgn32(by);
+        const int32_t w = gl_abs(ax + ay), h = gl_abs(bx + by);
+        const int32_t dax = gl_sgn(ax), day = gl_sgn(ay), dbx = gl_sgn(bx), dby = gl_sgn(by);
         if (h == 1) { x += dax * (int32_t)d; y += day * (int32_t)d; break; }
         if (w == 1) { x += dbx * (int32_t)d; y += dby * (int32_t)d; break; }
-        int32_t ax2 = floordiv2(ax), ay2 = floordiv2(ay), bx2 = floordiv2(bx), by2 = floordiv2(by);
-        const int32_t w2 = abs(ax2 + ay2), h2 = abs(bx2 + by2);
+        int32_t ax2 = ax >> 1, ay2 = ay >> 1, bx2 = bx >> 1, by2 = by >> 1;   // (arithmetic shift = floor)
+        const int32_t w2 = gl_abs(ax2 + ay2), h2 = gl_abs(bx2 + by2);
         if (2 * (int64_t)w > 3 * (int64_t)h) {  // long rectangle: two halves
             if ((w2 & 1) && w > 2) { ax2 += dax; ay2 += day; }
-            const int64_t n1 = (int64_t)abs(ax2 + ay2) * h;
+            const int64_t n1 = (int64_t)gl_abs(ax2 + ay2) * h;
             if (d < n1) { ax = ax2; ay = ay2; }
             else { d -= n1; x += ax2; y += ay2; ax -= ax2; ay -= ay2; }
         } else {  // up, across, down
             if ((h2 & 1) && h > 2) { bx2 += dbx; by2 += dby; }
-            const int32_t hh = abs(bx2 + by2);
+            const int32_t hh = gl_abs(bx2 + by2);
             const int64_t n1 = (int64_t)hh * w2;
             const int64_t n2 = (int64_t)w * (h - hh);
             if (d < n1) {
@@ -46,9 +41,33 @@ __device__ __forceinline__ void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t 
             }
         }
     }
+}
+
+// position d of the scan of a w x h rectangle (d < w*h < 2^32, sides < 2^31)
+__host__ __device__ inline void gilbert_d2xy(uint32_t w0, uint32_t h0, uint64_t d0, uint32_t &xo, uint32_t &yo) {
+    int32_t x = 0, y = 0;
+    if (w0 >= h0) gilbert_walk((int32_t)w0, 0, 0, (int32_t)h0, (int64_t)d0, x, y);
+    else gilbert_walk(0, (int32_t)h0, (int32_t)w0, 0, (int64_t)d0, x, y);
     xo = (uint32_t)x;
     yo = (uint32_t)y;
 }
+
+// ---------------------------------------------------------------- large rectangles: the walk's recursion cut into leaves (round 3)
+// Thirteen levels of that recursion per position -- 64-bit products, branches, ~1500 instructions -- made every kernel that follows
+// the scan on a rectangle that is no 2^n square ALU-bound at 37 ps a pixel (k_delta_gather_any at 4000 x 3000: 0.44 ms; the tile
+// kernel of a 2^n square: 1.5 ps a pixel).  The recursion's tree depends on (w, h) alone: its upper levels are walked ONCE per image
+// size on the host down to sub-rectangles ("leaves") of at most a few thousand positions -- a leaf = its first position, its origin
+// and the pair of vectors that span it -- and the walk inside a leaf depends on those vectors alone, of which an image has a few
+// dozen different ones: one table of (dx, dy) per such class, filled by a kernel.  Position d -> idx[d >> shift] names the leaf of
+// the span's first position, a step or two forward finds d's, the class table gives the offset: five loads that neighbours share.
+constexpr uint32_t kScanLeavesBit = 0x80000000u;   // in a kernel's `order` argument: `lut` points to a ScanLeavesDev
+struct ScanLeavesDev {
+    const uint32_t *idx;   // [(n >> shift) + 1]: the leaf that holds position j << shift
+    const uint32_t *d0;    // [nleaf + 1]: first position of every leaf, then n
+    const int4 *rec;       // [nleaf]: x, y of the leaf's origin, z = first entry of its class in lut
+    const uint32_t *lut;   // per class: (int16 dx) | (int16 dy) << 16 for every position of a leaf of that class
+    uint32_t shift, nleaf;
+};
 
 // ---------------------------------------------------------------- 2^n squares: state machine (tables built in k_hilbert.hip)
 struct HilbertLut {
@@ -76,8 +95,18 @@ struct Scan {
     const uint16_t *l4;
     const uint8_t *l1;
     const uint2 *custom;
+    ScanLeavesDev lf;      // lf.d0 != null: the leaves of this image size
     __device__ __forceinline__ void xy(uint64_t d, uint32_t &x, uint32_t &y) const {
         if (order) pow2_d2xy(l4, l1, order, (uint32_t)d, x, y);
+        else if (lf.d0) {
+            const uint32_t dd = (uint32_t)d;
+            uint32_t k = lf.idx[dd >> lf.shift];
+            while (lf.d0[k + 1] <= dd) k++;
+            const int4 r = lf.rec[k];
+            const uint32_t e = lf.lut[(uint32_t)r.z + (dd - lf.d0[k])];
+            x = (uint32_t)(r.x + (int32_t)(int16_t)(e & 0xffffu));
+            y = (uint32_t)(r.y + (int32_t)(int16_t)(e >> 16));
+        }
         else if (custom) { const uint2 v = custom[d]; x = v.x; y = v.y; }
         else gilbert_d2xy(w, h, d, x, y);
     }
@@ -86,12 +115,13 @@ struct Scan {
 // `lut`: the state-machine tables when order > 0; with order == 0 it is either null (the generalised curve is computed) or the
 // injected table of positions (scan_select below hands the kernels one or the other)
 __device__ __forceinline__ Scan load_scan(uint32_t w, uint32_t h, uint32_t order, const HilbertLut *lut, uint16_t *s_l4, uint8_t *s_l1) {
-    if (order) {
+    if (order && !(order & kScanLeavesBit)) {
         for (uint32_t i = threadIdx.x; i < 1024; i += blockDim.x) s_l4[i] = lut->l4[i];
         if (threadIdx.x < 16) s_l1[threadIdx.x] = lut->l1[threadIdx.x];
         __syncthreads();
     }
-    return Scan{w, h, order, s_l4, s_l1, order ? nullptr : reinterpret_cast<const uint2 *>(lut)};
+    if (order & kScanLeavesBit) return Scan{w, h, 0u, s_l4, s_l1, nullptr, *reinterpret_cast<const ScanLeavesDev *>(lut)};
+    return Scan{w, h, order, s_l4, s_l1, order ? nullptr : reinterpret_cast<const uint2 *>(lut), ScanLeavesDev{}};
 }
 
 // pixel idx as r | g << 8 | b << 16 (bits 24..31 unspecified) with one load; the buffer's last pixel by bytes
@@ -110,7 +140,9 @@ int hilbert_lut(Ctx *c, const HilbertLut **lut_d);
 uint32_t pow2_order(uint32_t w, uint32_t h);
 // what the scan kernels of a w x h image are launched with: (order, tables) of the built-in scan, or (0, the injected positions)
 // when the context holds an order for exactly these dimensions (cniic_ctx_set_scan); the tile kernels want sel.order >= 6
-struct ScanSel { uint32_t order; const HilbertLut *arg; };
+// korder: what a per-position kernel is handed as `order` -- sel.order, or kScanLeavesBit with arg = the image size's leaves (large
+// rectangles that are no 2^n square and have no injected scan)
+struct ScanSel { uint32_t order; const HilbertLut *arg; uint32_t korder; };
 int scan_select(Ctx *c, uint32_t w, uint32_t h, ScanSel *sel);
 
 }  // namespace cniic

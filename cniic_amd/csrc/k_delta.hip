@@ -594,7 +594,7 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
                            pages_d, coldkeys_d, chunk_cold_d, overflow_d);
     } else {
         const uint32_t grid = (uint32_t)std::min<uint64_t>(ceil_div(npad / kChunk16, (uint64_t)4), 256 * 8);
-        hipLaunchKernelGGL(k_delta_gather_any, dim3(grid), dim3(256), 0, c->stream, rgb_d, w, h, order, lut, hot16_d, table_d, pages_d, coldkeys_d,
+        hipLaunchKernelGGL(k_delta_gather_any, dim3(grid), dim3(256), 0, c->stream, rgb_d, w, h, sel.korder, lut, hot16_d, table_d, pages_d, coldkeys_d,
                            chunk_cold_d, overflow_d);
     }
     CNIIC_HIP_TRY(c, hipGetLastError());

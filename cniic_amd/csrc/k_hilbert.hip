@@ -16,7 +16,11 @@
 // LDS-private bins for the hot cube of deltas in [-16,15]^3 (u32[32768] = 128 KiB per 1024-thread
 // block), flushed once per block with global atomics; symbols outside the cube go straight to the
 // dense 2^27-bin table.  Without this the kernel runs at the global-atomic rate (~27 G/s).
+#include <array>
+#include <map>
+#include <memory>
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -478,12 +482,183 @@ static bool move_by_tiles(uint32_t order, const void *a, const void *b) {
     return order >= 6 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !(e && e[0] == 'a');
 }
 
+// ---------------------------------------------------------------- the leaves of an image size (hilbert_scan.hpp, ScanLeavesDev)
+namespace {
+struct LeafClass { int32_t ax, ay, bx, by; uint32_t base, area; };
+__global__ void k_scan_leaf_lut(const LeafClass *__restrict__ cls, uint32_t ncls, uint32_t total, uint32_t *__restrict__ lut) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    uint32_t lo = 0, hi = ncls - 1;   // the class whose entries hold e
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (cls[mid].base <= e) lo = mid; else hi = mid - 1; }
+    const LeafClass c = cls[lo];
+    int32_t x = 0, y = 0;
+    gilbert_walk(c.ax, c.ay, c.bx, c.by, (int64_t)(e - c.base), x, y);
+    lut[e] = ((uint32_t)x & 0xffffu) | ((uint32_t)y << 16);
+}
+// the tables against the recursion itself: every leaf's first and last position and every 997th position of the scan
+__global__ void k_scan_leaf_check(ScanLeavesDev L, uint32_t w, uint32_t h, uint64_t n, uint32_t *__restrict__ bad) {
+    const Scan sc{w, h, 0u, nullptr, nullptr, nullptr, L};
+    const uint64_t nsamp = n / 997 + 1, total = nsamp + 2ull * L.nleaf;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        uint64_t d;
+        if (t < nsamp) d = t * 997;
+        else { const uint64_t k = (t - nsamp) >> 1; d = ((t - nsamp) & 1) ? (uint64_t)L.d0[k + 1] - 1 : L.d0[k]; }
+        if (d >= n) continue;
+        uint32_t x, y, ex, ey;
+        sc.xy(d, x, y);
+        gilbert_d2xy(w, h, d, ex, ey);
+        if (x != ex || y != ey) *bad = 1u;
+    }
+}
+struct ScanLeavesEntry {
+    uint32_t w = 0, h = 0;
+    uint64_t stamp = 0;
+    DevBuf idx, d0, rec, lut, hdr;
+};
+struct ScanLeavesCache {
+    std::vector<std::unique_ptr<ScanLeavesEntry>> e;
+    uint64_t clock = 0;
+};
+constexpr size_t kScanLeavesKept = 4;          // image sizes whose leaves a context keeps
+constexpr uint64_t kScanLeavesMinPx = 1ull << 20;   // smaller images: the recursion per position (a kernel of some microseconds either way)
+}  // namespace
+
+void scan_leaves_drop(Ctx *c) { c->scan_leaves.reset(); }
+
+// the leaves of a w x h image, built on first use of the size (host: the upper levels of the recursion; a kernel: the class tables;
+// another: the self-check) and kept by the context
+static int scan_leaves_get(Ctx *c, uint32_t w, uint32_t h, const ScanLeavesDev **hdr_d) {
+    if (!c->scan_leaves) c->scan_leaves = std::make_shared<ScanLeavesCache>();
+    ScanLeavesCache *cache = static_cast<ScanLeavesCache *>(c->scan_leaves.get());
+    for (auto &en : cache->e)
+        if (en->w == w && en->h == h) { en->stamp = ++cache->clock; *hdr_d = en->hdr.as<ScanLeavesDev>(); return CNIIC_OK; }
+    const uint64_t n = (uint64_t)w * h;
+    uint64_t max_area = 4096;
+    while (max_area < n / 8192) max_area <<= 1;   // <= ~3 x 10^4 leaves whatever the image
+    if (const char *e = getenv("CNIIC_SCAN_LEAF_AREA")) max_area = std::max<uint64_t>(2, strtoull(e, nullptr, 10));   // (tests: deep trees on small images)
+    max_area = std::min<uint64_t>(max_area, 1u << 14);   // (a leaf's offsets are int16)
+    uint32_t shift = 0;
+    while ((1ull << (shift + 1)) <= max_area) shift++;
+    struct Node { int32_t x, y, ax, ay, bx, by; };
+    std::vector<Node> stack;
+    std::vector<uint32_t> d0;
+    std::vector<int4> rec;
+    std::vector<LeafClass> cls;
+    std::map<std::array<int32_t, 4>, uint32_t> cls_of;
+    uint64_t at = 0, total = 0;
+    auto leaf = [&](int32_t x, int32_t y, int32_t ax, int32_t ay, int32_t bx, int32_t by, uint32_t area) {
+        const std::array<int32_t, 4> key{ax, ay, bx, by};
+        auto it = cls_of.find(key);
+        uint32_t ci;
+        if (it == cls_of.end()) {
+            ci = (uint32_t)cls.size();
+            cls_of.emplace(key, ci);
+            cls.push_back(LeafClass{ax, ay, bx, by, (uint32_t)total, area});
+            total += area;
+        } else ci = it->second;
+        d0.push_back((uint32_t)at);
+        rec.push_back(make_int4(x, y, (int32_t)cls[ci].base, 0));
+        at += area;
+    };
+    if (w >= h) stack.push_back(Node{0, 0, (int32_t)w, 0, 0, (int32_t)h});
+    else stack.push_back(Node{0, 0, 0, (int32_t)h, (int32_t)w, 0});
+    while (!stack.empty()) {   // gilbert_walk's own case distinctions, every branch taken
+        const Node q = stack.back();
+        stack.pop_back();
+        const int32_t W = gl_abs(q.ax + q.ay), H = gl_abs(q.bx + q.by);
+        const int32_t dax = gl_sgn(q.ax), day = gl_sgn(q.ay), dbx = gl_sgn(q.bx), dby = gl_sgn(q.by);
+        if (H == 1 || W == 1) {   // a line: along a (H == 1 is asked first there, too), else along b; in pieces of at most max_area
+            const int32_t len = H == 1 ? W : H, sx = H == 1 ? dax : dbx, sy = H == 1 ? day : dby;
+            for (int32_t o = 0; o < len; o += (int32_t)max_area) {
+                const int32_t l = (int32_t)std::min<int64_t>((int64_t)max_area, len - o);
+                if (H == 1) leaf(q.x + sx * o, q.y + sy * o, dax * l, day * l, q.bx, q.by, (uint32_t)l);
+                else leaf(q.x + sx * o, q.y + sy * o, q.ax, q.ay, dbx * l, dby * l, (uint32_t)l);
+            }
+            continue;
+        }
+        if ((uint64_t)W * (uint64_t)H <= max_area) { leaf(q.x, q.y, q.ax, q.ay, q.bx, q.by, (uint32_t)(W * H)); continue; }
+        int32_t ax2 = q.ax >> 1, ay2 = q.ay >> 1, bx2 = q.bx >> 1, by2 = q.by >> 1;
+        const int32_t w2 = gl_abs(ax2 + ay2), h2 = gl_abs(bx2 + by2);
+        if (2 * (int64_t)W > 3 * (int64_t)H) {
+            if ((w2 & 1) && W > 2) { ax2 += dax; ay2 += day; }
+            stack.push_back(Node{q.x + ax2, q.y + ay2, q.ax - ax2, q.ay - ay2, q.bx, q.by});
+            stack.push_back(Node{q.x, q.y, ax2, ay2, q.bx, q.by});
+        } else {
+            if ((h2 & 1) && H > 2) { bx2 += dbx; by2 += dby; }
+            stack.push_back(Node{q.x + (q.ax - dax) + (bx2 - dbx), q.y + (q.ay - day) + (by2 - dby), -bx2, -by2, -(q.ax - ax2), -(q.ay - ay2)});
+            stack.push_back(Node{q.x + bx2, q.y + by2, q.ax, q.ay, q.bx - bx2, q.by - by2});
+            stack.push_back(Node{q.x, q.y, bx2, by2, ax2, ay2});
+        }
+    }
+    if (at != n) return c->fail(CNIIC_ERR_HIP, "hilbert: the leaves of a %ux%u image cover %llu positions", w, h, (unsigned long long)at);
+    const uint32_t nleaf = (uint32_t)d0.size();
+    d0.push_back((uint32_t)n);   // (n < 2^32: check_dims)
+    std::vector<uint32_t> idx((n >> shift) + 1);
+    for (uint64_t j = 0, k = 0; j < idx.size(); j++) {
+        while (k + 1 < nleaf && d0[k + 1] <= (j << shift)) k++;
+        idx[j] = (uint32_t)k;
+    }
+    host_trace().mark("hilbert: leaves of the image size (host)");
+    auto en = std::make_unique<ScanLeavesEntry>();
+    en->w = w; en->h = h; en->stamp = ++cache->clock;
+    DevBuf cls_d, bad_d;
+    {
+        DevPool *saved = current_pool();
+        current_pool() = nullptr;   // live as long as the context keeps the entry, not recycled
+        hipError_t e = en->idx.alloc(idx.size() * 4);
+        if (e == hipSuccess) e = en->d0.alloc(d0.size() * 4);
+        if (e == hipSuccess) e = en->rec.alloc((uint64_t)nleaf * sizeof(int4));
+        if (e == hipSuccess) e = en->lut.alloc(std::max<uint64_t>(total, 1) * 4);
+        if (e == hipSuccess) e = en->hdr.alloc(sizeof(ScanLeavesDev));
+        current_pool() = saved;
+        if (e != hipSuccess) return c->fail(CNIIC_ERR_NOMEM, "hilbert: no memory for the leaves of a %ux%u image", w, h);
+    }
+    CNIIC_HIP_TRY(c, cls_d.alloc(cls.size() * sizeof(LeafClass)));
+    CNIIC_HIP_TRY(c, bad_d.alloc(4));
+    CNIIC_HIP_TRY(c, hipMemsetAsync(bad_d.p, 0, 4, c->stream));
+    const ScanLeavesDev L{en->idx.as<uint32_t>(), en->d0.as<uint32_t>(), en->rec.as<int4>(), en->lut.as<uint32_t>(), shift, nleaf};
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(en->idx.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(en->d0.p, d0.data(), d0.size() * 4, hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(en->rec.p, rec.data(), (uint64_t)nleaf * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(cls_d.p, cls.data(), cls.size() * sizeof(LeafClass), hipMemcpyHostToDevice, c->stream));
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(en->hdr.p, &L, sizeof L, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scan_leaf_lut, dim3((uint32_t)ceil_div(total, (uint64_t)256)), dim3(256), 0, c->stream, (const LeafClass *)cls_d.as<LeafClass>(), (uint32_t)cls.size(),
+                       (uint32_t)total, en->lut.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_leaf_check, dim3(256), dim3(256), 0, c->stream, L, w, h, n, bad_d.as<uint32_t>());
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    uint32_t bad = 0;
+    CNIIC_HIP_TRY(c, hipMemcpyAsync(&bad, bad_d.p, 4, hipMemcpyDeviceToHost, c->stream));
+    CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));   // (the host vectors above are pageable: they must outlive the copies)
+    if (bad) return c->fail(CNIIC_ERR_HIP, "hilbert: the leaves of a %ux%u image failed their self-check", w, h);
+    host_trace().mark("hilbert: class tables + self-check");
+    if (cache->e.size() >= kScanLeavesKept) {   // the size used longest ago makes room
+        size_t old = 0;
+        for (size_t i = 1; i < cache->e.size(); i++) if (cache->e[i]->stamp < cache->e[old]->stamp) old = i;
+        CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        cache->e.erase(cache->e.begin() + (long)old);
+    }
+    *hdr_d = en->hdr.as<ScanLeavesDev>();
+    cache->e.push_back(std::move(en));
+    return CNIIC_OK;
+}
+
 int scan_select(Ctx *c, uint32_t w, uint32_t h, ScanSel *sel) {
-    if (c->scan_xy.p && c->scan_w == w && c->scan_h == h) { *sel = ScanSel{0u, reinterpret_cast<const HilbertLut *>(c->scan_xy.p)}; return CNIIC_OK; }
+    if (c->scan_xy.p && c->scan_w == w && c->scan_h == h) { *sel = ScanSel{0u, reinterpret_cast<const HilbertLut *>(c->scan_xy.p), 0u}; return CNIIC_OK; }
     const HilbertLut *lut = nullptr;
     CNIIC_TRY(hilbert_lut(c, &lut));
     const uint32_t order = pow2_order(w, h);
-    *sel = ScanSel{order, order ? lut : nullptr};
+    if (!order) {
+        const char *e = getenv("CNIIC_SCAN_LEAVES_MIN");   // pixels from which an image size gets its leaves (tests: 0; never: a huge number)
+        const uint64_t min_px = e ? strtoull(e, nullptr, 10) : kScanLeavesMinPx;
+        if ((uint64_t)w * h >= std::max<uint64_t>(min_px, 2)) {
+            const ScanLeavesDev *hdr = nullptr;
+            CNIIC_TRY(scan_leaves_get(c, w, h, &hdr));
+            *sel = ScanSel{0u, reinterpret_cast<const HilbertLut *>(hdr), kScanLeavesBit};
+            return CNIIC_OK;
+        }
+    }
+    *sel = ScanSel{order, order ? lut : nullptr, order};
     return CNIIC_OK;
 }
 
@@ -533,7 +708,7 @@ int hilbert_xy(Ctx *c, uint32_t w, uint32_t h, uint32_t *xy_d) {
     if (!n) return CNIIC_OK;
     ScanSel sel;
     CNIIC_TRY(scan_select(c, w, h, &sel));
-    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, sel.order, sel.arg, xy_d);
+    hipLaunchKernelGGL(k_hilbert_xy, dim3(hgrid(n)), dim3(256), 0, c->stream, w, h, sel.korder, sel.arg, xy_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -548,7 +723,7 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
         hipLaunchKernelGGL(k_hilbert_move_p2<false>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, rgb_d, sel.order, sel.arg,
                            out_d);
     else
-        hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, sel.order, sel.arg, out_d);
+        hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, sel.korder, sel.arg, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -563,7 +738,7 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
         hipLaunchKernelGGL(k_hilbert_move_p2<true>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, lin_d, sel.order, sel.arg,
                            rgb_out_d);
     else
-        hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, sel.order, sel.arg, rgb_out_d);
+        hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, sel.korder, sel.arg, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -620,11 +795,11 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
         else
             hipLaunchKernelGGL(k_hilbert_delta_p2<false>, dim3(g2), dim3(kDeltaThreads), 0, c->stream, rgb_d, order, lut, syms_d, table_d);
     } else if (table_d)
-        hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, order, lut,
+        hipLaunchKernelGGL(k_hilbert_delta<true>, dim3(grid), dim3(kDeltaThreads), kHotBins * 4, c->stream, rgb_d, w, h, sel.korder, lut,
                            syms_d, table_d);
     else
         hipLaunchKernelGGL(k_hilbert_delta<false>, dim3(std::min<uint32_t>(grid * 4, 1024)), dim3(kDeltaThreads), 0, c->stream, rgb_d, w, h,
-                           order, lut, syms_d, table_d);
+                           sel.korder, lut, syms_d, table_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
     timer.stop(1);
     return CNIIC_OK;

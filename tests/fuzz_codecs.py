@@ -17,7 +17,9 @@ KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_H
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_PHASES": "1"},                              # round 3: every stream through the phase maps
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1", "CNIIC_HD_LUT2_BITS": "21"},  # the second table built from the leaves' side
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT2_BITS": "13"},
-         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "1"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "0"}]   # pass 0's verdict: eager / never
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "1"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "0"},   # pass 0's verdict: eager / never
+         {"CNIIC_SCAN_LEAVES_MIN": "0"}, {"CNIIC_SCAN_LEAVES_MIN": "0", "CNIIC_SCAN_LEAF_AREA": "7"},   # the scan of rectangles from leaves + class tables
+         {"CNIIC_SCAN_LEAVES_MIN": "0", "CNIIC_SCAN_LEAF_AREA": "64", "CNIIC_GPU_DECODE_MIN": "0"}]
 
 
 def image():

@@ -251,6 +251,36 @@ def test_hilbert_linearize_and_delta(ctx, shape):
     assert np.array_equal(keys, ek) and np.array_equal(counts, ec) and np.array_equal(syms2, esyms)
 
 
+@pytest.mark.parametrize("area", [2, 3, 16, 100, 4096])
+@pytest.mark.parametrize("w,h", [(1, 9), (9, 1), (1, 5000), (5000, 1), (2, 700), (700, 3), (5, 3), (13, 8), (100, 37), (97, 131), (300, 200), (1000, 7), (255, 257), (640, 480),
+                                 (1023, 517), (96, 64), (64, 96)])
+def test_scan_leaves_equal_the_recursion(ctx, monkeypatch, w, h, area):
+    """the scan of rectangles that are no 2^n square, cut into leaves (ScanLeavesDev: the recursion's upper levels walked once per
+    image size, a table of offsets per class of leaf): every position as the oracle's iterator gives it, for leaves from two
+    positions (a tree as deep as the recursion itself) to 4096 (the product's), lines and thin strips included; then the codecs
+    that follow the scan, both ways"""
+    monkeypatch.setenv("CNIIC_SCAN_LEAVES_MIN", "0")
+    monkeypatch.setenv("CNIIC_SCAN_LEAF_AREA", str(area))
+    assert np.array_equal(ctx.hilbert_xy(w, h), O.hilbert_iter(w, h))
+    if area in (3, 4096):
+        img = synth_img(h, w, seed=w + h)
+        assert np.array_equal(ctx.hilbert_linearize(img), O.hilbert_linearize(img))
+        for expr in ("delta", "hilbert(rle)"):
+            rc, data, _ = ctx.encode(expr, img)
+            assert rc == 0 and data == O.encode(expr, img)[1], expr
+            rc, back = ctx.decode(expr, data)
+            assert rc == 0 and np.array_equal(back, img), expr
+
+
+def test_scan_leaves_of_several_sizes_are_kept_and_replaced(ctx, monkeypatch):
+    """a context keeps the leaves of four image sizes; a fifth replaces the one used longest ago"""
+    monkeypatch.setenv("CNIIC_SCAN_LEAVES_MIN", "0")
+    sizes = [(33, 20), (75, 130), (100, 37), (64, 48), (31, 10), (33, 20), (200, 90), (75, 130)]
+    for rep in range(2):
+        for w, h in sizes:
+            assert np.array_equal(ctx.hilbert_xy(w, h), O.hilbert_iter(w, h))
+
+
 @pytest.mark.parametrize("move", ["", "any"])
 @pytest.mark.parametrize("size", [64, 128, 512])
 def test_hilbert_move_by_tiles_and_by_positions(ctx, monkeypatch, size, move):
