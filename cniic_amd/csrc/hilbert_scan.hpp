@@ -90,6 +90,8 @@ __device__ __forceinline__ void pow2_d2xy(const uint16_t *l4, const uint8_t *l1,
 
 // scan position -> pixel; order > 0 selects the table-driven path (w == h == 1 << order)
 // ... or an order the caller injected (cniic_ctx_set_scan): position d -> custom[d] = (x, y)
+// a thread that walks consecutive positions keeps the leaf it is in (leaves mode; the other modes have nothing to keep)
+struct ScanCursor { uint32_t first = 1, end = 0, base = 0; int32_t ox = 0, oy = 0; };
 struct Scan {
     uint32_t w, h, order;
     const uint16_t *l4;
@@ -109,6 +111,19 @@ struct Scan {
         }
         else if (custom) { const uint2 v = custom[d]; x = v.x; y = v.y; }
         else gilbert_d2xy(w, h, d, x, y);
+    }
+    __device__ __forceinline__ void xy_seq(ScanCursor &cu, uint64_t d, uint32_t &x, uint32_t &y) const {
+        if (order || !lf.d0) { xy(d, x, y); return; }
+        const uint32_t dd = (uint32_t)d;
+        if (dd < cu.first || dd >= cu.end) {
+            uint32_t k = lf.idx[dd >> lf.shift];
+            while (lf.d0[k + 1] <= dd) k++;
+            const int4 r = lf.rec[k];
+            cu.first = lf.d0[k]; cu.end = lf.d0[k + 1]; cu.base = (uint32_t)r.z; cu.ox = r.x; cu.oy = r.y;
+        }
+        const uint32_t e = lf.lut[cu.base + (dd - cu.first)];
+        x = (uint32_t)(cu.ox + (int32_t)(int16_t)(e & 0xffffu));
+        y = (uint32_t)(cu.oy + (int32_t)(int16_t)(e >> 16));
     }
 };
 

@@ -200,12 +200,13 @@ __global__ __launch_bounds__(256) void k_delta_gather_any(const uint8_t *__restr
     for (uint32_t ch = blockIdx.x * 4 + (threadIdx.x >> 6); ch < nchunks; ch += nw) {
         const uint64_t d0 = (uint64_t)ch * kChunk16 + lane * 8;
         uint32_t px[8];
+        ScanCursor cu;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             px[i] = 0;
             if (d0 + i < n) {
                 uint32_t x, y;
-                sc.xy(d0 + i, x, y);
+                sc.xy_seq(cu, d0 + i, x, y);
                 px[i] = px_le24(rgb, (uint64_t)y * w + x, n);
             }
         }

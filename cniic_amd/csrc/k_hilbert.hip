@@ -123,6 +123,62 @@ __global__ __launch_bounds__(256) void k_hilbert_move(const uint8_t *__restrict_
     }
 }
 
+// The same along the leaves of a large rectangle (ScanLeavesDev), four consecutive positions per thread: the scan side moves as 12
+// contiguous bytes (one load or store instead of twelve byte accesses a wave instruction each), the four table entries are
+// neighbours, and the leaf is looked up once unless the four straddle its end.  Scan-side buffer 4-byte aligned.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_hilbert_move_leaves(const uint8_t *__restrict__ src, uint32_t w, uint32_t h, const ScanLeavesDev *__restrict__ hdr,
+                                                             uint8_t *__restrict__ dst) {
+    const ScanLeavesDev L = *hdr;
+    const uint64_t n = (uint64_t)w * h, nquad = n >> 2;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        const uint32_t d = (uint32_t)(q << 2);
+        uint32_t k = L.idx[d >> L.shift];
+        while (L.d0[k + 1] <= d) k++;
+        int4 r = L.rec[k];
+        uint32_t first = L.d0[k], end = L.d0[k + 1];
+        uint32_t v[4];
+        if (SCATTER) {
+            const uint32_t *s3 = reinterpret_cast<const uint32_t *>(src + 3ull * d);
+            const uint32_t a = s3[0], b = s3[1], c3 = s3[2];
+            v[0] = a; v[1] = (a >> 24) | (b << 8); v[2] = (b >> 16) | (c3 << 16); v[3] = c3 >> 8;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t dj = d + j;
+            if (dj >= end) {   // the next leaf (leaves are never empty)
+                k++;
+                r = L.rec[k]; first = end; end = L.d0[k + 1];
+            }
+            const uint32_t e = L.lut[(uint32_t)r.z + (dj - first)];
+            const uint32_t x = (uint32_t)(r.x + (int32_t)(int16_t)(e & 0xffffu)), y = (uint32_t)(r.y + (int32_t)(int16_t)(e >> 16));
+            const uint64_t p = (uint64_t)y * w + x;
+            if (SCATTER) {
+                uint8_t *o = dst + 3 * p;
+                o[0] = (uint8_t)v[j]; o[1] = (uint8_t)(v[j] >> 8); o[2] = (uint8_t)(v[j] >> 16);
+            } else {
+                v[j] = px_le24(src, p, n) & 0xffffffu;
+            }
+        }
+        if (!SCATTER) {
+            uint32_t *o3 = reinterpret_cast<uint32_t *>(dst + 3ull * d);
+            o3[0] = v[0] | (v[1] << 24); o3[1] = (v[1] >> 8) | (v[2] << 16); o3[2] = (v[2] >> 16) | (v[3] << 8);
+        }
+    }
+    // the last n mod 4 positions, one by one
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const Scan sc{w, h, 0u, nullptr, nullptr, nullptr, L};
+        const uint64_t d = (nquad << 2) + threadIdx.x;
+        uint32_t x, y;
+        sc.xy(d, x, y);
+        const uint64_t p = (uint64_t)y * w + x;
+        const uint32_t vv = px_le24(src, SCATTER ? d : p, n);
+        uint8_t *o = dst + 3 * (SCATTER ? p : d);
+        o[0] = (uint8_t)vv; o[1] = (uint8_t)(vv >> 8); o[2] = (uint8_t)(vv >> 16);
+    }
+}
+
 // The same on 2^n squares of side >= 64 with 16-byte aligned buffers, by 64 x 64 tiles = 4096 consecutive scan positions
 // (k_delta_gather_p2's scheme): the image side of a tile is read or written as rows of 48-byte pieces, the scan side as
 // 48-byte pieces of 16 positions, and the permutation happens in LDS -- one word per pixel, stored 8 x 8 block by block
@@ -294,12 +350,13 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
         const uint64_t d0 = run * kDeltaRun;
         // the run's pixels: one (unaligned) dword each -- three byte loads per pixel were 15 load instructions per thread
         uint32_t px[kDeltaRun];
+        ScanCursor cu;
 #pragma unroll
         for (int i = 0; i < kDeltaRun; i++) {
             px[i] = 0;
             if (d0 + i < n) {
                 uint32_t x, y;
-                sc.xy(d0 + i, x, y);
+                sc.xy_seq(cu, d0 + i, x, y);
                 px[i] = px_le24(rgb, (uint64_t)y * w + x, n);
             }
         }
@@ -722,6 +779,8 @@ int hilbert_linearize(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     if (move_by_tiles(sel.order, rgb_d, out_d))
         hipLaunchKernelGGL(k_hilbert_move_p2<false>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, rgb_d, sel.order, sel.arg,
                            out_d);
+    else if ((sel.korder & kScanLeavesBit) && (reinterpret_cast<uintptr_t>(out_d) & 3) == 0)
+        hipLaunchKernelGGL(k_hilbert_move_leaves<false>, dim3(hgrid(n >> 2)), dim3(256), 0, c->stream, rgb_d, w, h, reinterpret_cast<const ScanLeavesDev *>(sel.arg), out_d);
     else
         hipLaunchKernelGGL(k_hilbert_move<false>, dim3(hgrid(n)), dim3(256), 0, c->stream, rgb_d, w, h, sel.korder, sel.arg, out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
@@ -737,6 +796,8 @@ int hilbert_scatter(Ctx *c, const uint8_t *lin_d, uint32_t w, uint32_t h, uint8_
     if (move_by_tiles(sel.order, lin_d, rgb_out_d))
         hipLaunchKernelGGL(k_hilbert_move_p2<true>, dim3((uint32_t)std::min<uint64_t>(n >> 12, 256 * 8)), dim3(256), 0, c->stream, lin_d, sel.order, sel.arg,
                            rgb_out_d);
+    else if ((sel.korder & kScanLeavesBit) && (reinterpret_cast<uintptr_t>(lin_d) & 3) == 0)
+        hipLaunchKernelGGL(k_hilbert_move_leaves<true>, dim3(hgrid(n >> 2)), dim3(256), 0, c->stream, lin_d, w, h, reinterpret_cast<const ScanLeavesDev *>(sel.arg), rgb_out_d);
     else
         hipLaunchKernelGGL(k_hilbert_move<true>, dim3(hgrid(n)), dim3(256), 0, c->stream, lin_d, w, h, sel.korder, sel.arg, rgb_out_d);
     CNIIC_HIP_TRY(c, hipGetLastError());
