@@ -22,6 +22,7 @@
 // binary search over a handful of neighbouring leaves.  The block's stretch of the stream is staged in LDS, byte-swapped
 // once, so a symbol costs two or three LDS reads and a shift.  Same symbols as the walk, bit for bit (tests).
 #include "common.hpp"
+#include "hilbert_scan.hpp"
 #include "device_utils.hpp"
 #include "huff_host.hpp"
 
@@ -725,8 +726,12 @@ __global__ __launch_bounds__(1024) void k_ud_scan(int32_t *__restrict__ chunk_su
         for (int ch = 0; ch < 3; ch++) { const int32_t v = chunk_sum[3 * (size_t)i + ch]; chunk_sum[3 * (size_t)i + ch] = run[ch]; run[ch] += v; }
 }
 
+// LEAVES: the colours go straight to their pixels along the leaves of a large rectangle (lin = the image, w its width) instead of
+// into a linearised image that a scatter pass then reads again (6 of 17 bytes per pixel and a launch, as on 2^n squares)
+template <bool LEAVES>
 __global__ __launch_bounds__(kUdThreads) void k_ud_apply(const uint32_t *__restrict__ keys, uint64_t n, const int32_t *__restrict__ chunk_off,
-                                                         uint8_t *__restrict__ lin, uint32_t *__restrict__ bad) {
+                                                         uint8_t *__restrict__ lin, uint32_t *__restrict__ bad, uint32_t w = 0,
+                                                         const ScanLeavesDev *__restrict__ hdr = nullptr) {
     __shared__ int32_t wsum[3][kUdThreads / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * kUdChunk + (uint64_t)threadIdx.x * kUdPer;
@@ -752,14 +757,23 @@ __global__ __launch_bounds__(kUdThreads) void k_ud_apply(const uint32_t *__restr
         run[ch] += chunk_off[3 * (size_t)blockIdx.x + ch];
     }
     bool oob = false;
+    Scan sc{};
+    ScanCursor cu;
+    if (LEAVES) sc.lf = *hdr;
 #pragma unroll
     for (int j = 0; j < kUdPer; j++) {
         if (base + j < n) {
+            uint64_t at = base + j;
+            if (LEAVES) {
+                uint32_t x, y;
+                sc.xy_seq(cu, base + j, x, y);
+                at = (uint64_t)y * w + x;
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 run[ch] += d[j][ch];
                 oob |= run[ch] < 0 || run[ch] > 255;
-                lin[3 * (base + j) + ch] = (uint8_t)run[ch];
+                lin[3 * at + ch] = (uint8_t)run[ch];
             }
         }
     }
@@ -793,11 +807,19 @@ int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_
     bool fused = false;
     CNIIC_TRY(hilbert_undiff_scatter(c, keys_d, sums.as<int32_t>(), w, h, rgb_out_d, bad.as<uint32_t>(), &fused));
     if (!fused) {
-        CNIIC_HIP_TRY(c, lin.alloc(n * 3));
-        hipLaunchKernelGGL(k_ud_apply, dim3((uint32_t)ceil_div(n, kUdChunk)), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(),
-                           lin.as<uint8_t>(), bad.as<uint32_t>());
-        CNIIC_HIP_TRY(c, hipGetLastError());
-        CNIIC_TRY(hilbert_scatter(c, lin.as<uint8_t>(), w, h, rgb_out_d));
+        ScanSel sel;
+        CNIIC_TRY(scan_select(c, w, h, &sel));
+        if (sel.korder & kScanLeavesBit) {   // a large rectangle: undiff and scatter in one pass along its leaves
+            hipLaunchKernelGGL(k_ud_apply<true>, dim3((uint32_t)ceil_div(n, kUdChunk)), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(),
+                               rgb_out_d, bad.as<uint32_t>(), w, reinterpret_cast<const ScanLeavesDev *>(sel.arg));
+            CNIIC_HIP_TRY(c, hipGetLastError());
+        } else {
+            CNIIC_HIP_TRY(c, lin.alloc(n * 3));
+            hipLaunchKernelGGL(k_ud_apply<false>, dim3((uint32_t)ceil_div(n, kUdChunk)), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(),
+                               lin.as<uint8_t>(), bad.as<uint32_t>());
+            CNIIC_HIP_TRY(c, hipGetLastError());
+            CNIIC_TRY(hilbert_scatter(c, lin.as<uint8_t>(), w, h, rgb_out_d));
+        }
     }
     CNIIC_HIP_TRY(c, hipMemcpyAsync(bad_h, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
     CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -817,7 +839,7 @@ int delta_undiff_dev(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *lin_d,
     CNIIC_HIP_TRY(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
     hipLaunchKernelGGL(k_ud_sums, dim3(nchunks), dim3(kUdThreads), 0, c->stream, keys_d, n, sums.as<int32_t>());
     hipLaunchKernelGGL(k_ud_scan, dim3(1), dim3(1024), 0, c->stream, sums.as<int32_t>(), nchunks);
-    hipLaunchKernelGGL(k_ud_apply, dim3(nchunks), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(), lin_d,
+    hipLaunchKernelGGL(k_ud_apply<false>, dim3(nchunks), dim3(kUdThreads), 0, c->stream, keys_d, n, (const int32_t *)sums.as<int32_t>(), lin_d,
                        bad.as<uint32_t>());
     CNIIC_HIP_TRY(c, hipGetLastError());
     CNIIC_HIP_TRY(c, hipMemcpyAsync(bad_h, bad.p, 4, hipMemcpyDeviceToHost, c->stream));
