@@ -150,6 +150,12 @@ __device__ __forceinline__ uint32_t px_le24(const uint8_t *__restrict__ rgb, uin
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 
+// the three bytes of a pixel at an address of any alignment: a 16-bit store and a byte instead of three bytes
+__device__ __forceinline__ void store_px3(uint8_t *o, uint32_t v) {
+    if (reinterpret_cast<uintptr_t>(o) & 1) { o[0] = (uint8_t)v; *reinterpret_cast<uint16_t *>(o + 1) = (uint16_t)(v >> 8); }
+    else { *reinterpret_cast<uint16_t *>(o) = (uint16_t)v; o[2] = (uint8_t)(v >> 16); }
+}
+
 // the context's copy of the tables (built and self-checked once per process); order of a 2^n square (n >= 1), else 0
 int hilbert_lut(Ctx *c, const HilbertLut **lut_d);
 uint32_t pow2_order(uint32_t w, uint32_t h);

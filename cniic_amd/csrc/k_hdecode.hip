@@ -773,8 +773,9 @@ __global__ __launch_bounds__(kUdThreads) void k_ud_apply(const uint32_t *__restr
             for (int ch = 0; ch < 3; ch++) {
                 run[ch] += d[j][ch];
                 oob |= run[ch] < 0 || run[ch] > 255;
-                lin[3 * at + ch] = (uint8_t)run[ch];
+                if (!LEAVES) lin[3 * at + ch] = (uint8_t)run[ch];
             }
+            if (LEAVES) store_px3(lin + 3 * at, (uint32_t)(run[0] & 255) | ((uint32_t)(run[1] & 255) << 8) | ((uint32_t)(run[2] & 255) << 16));
         }
     }
     if (oob) *bad = 1u;

@@ -155,8 +155,7 @@ __global__ __launch_bounds__(256) void k_hilbert_move_leaves(const uint8_t *__re
             const uint32_t x = (uint32_t)(r.x + (int32_t)(int16_t)(e & 0xffffu)), y = (uint32_t)(r.y + (int32_t)(int16_t)(e >> 16));
             const uint64_t p = (uint64_t)y * w + x;
             if (SCATTER) {
-                uint8_t *o = dst + 3 * p;
-                o[0] = (uint8_t)v[j]; o[1] = (uint8_t)(v[j] >> 8); o[2] = (uint8_t)(v[j] >> 16);
+                store_px3(dst + 3 * p, v[j]);
             } else {
                 v[j] = px_le24(src, p, n) & 0xffffffu;
             }
