@@ -15,7 +15,7 @@ from cniic_amd import _lib, synth
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-which = sys.argv[1:] or ["voronoi", "delta", "hufman", "delta16k", "rle", "rle16k"]
+which = sys.argv[1:] or ["voronoi", "delta", "hufman", "delta16k", "rle", "rle16k", "rect"]
 
 
 def image(size, seed):
@@ -61,4 +61,17 @@ for name, size in (("delta", 4096), ("hufman", 4096), ("delta16k", 16384), ("rle
             extra[k + "_ms"] = round(ms / n, 3)
     print(json.dumps({"row": "%s encode %dx%d" % (expr, size, size), "ms": round(dt * 1e3, 2), "Mpx_per_s": round(size * size / dt / 1e6, 1),
                       "bytes_per_px": round(ln / (size * size), 4), **extra}))
+# rectangles that are no 2^n square (the reference's data set and frames): the scan by leaves + class tables
+if "rect" in which:
+    for w, h in ((1920, 1080), (4000, 3000), (8000, 6000)):
+        img = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 5, w, h, out=img)
+        out = torch.empty(w * h * 13 + (1 << 22), dtype=torch.uint8, device=dev)
+        back = torch.empty(w * h * 3, dtype=torch.uint8, device=dev)
+        for expr in ("delta", "hilbert(rle)"):
+            dt, (rc, ln, st) = timed(lambda: ctx.encode(expr, img, w=w, h=h, out=out), reps=3)
+            dd, _ = timed(lambda: ctx.decode_into(expr, out, ln, back), reps=3)
+            print(json.dumps({"row": "%s %dx%d" % (expr, w, h), "encode_ms": round(dt * 1e3, 3), "decode_ms": round(dd * 1e3, 3),
+                              "encode_Mpx_per_s": round(w * h / dt / 1e6, 1), "decode_Mpx_per_s": round(w * h / dd / 1e6, 1), "bytes_per_px": round(ln / (w * h), 4)}))
+        del img, out, back
 ctx.close()
