@@ -1038,6 +1038,7 @@ static int stream_head(Ctx *c, const uint8_t *bytes, bool bytes_dev, uint64_t nb
     return CNIIC_OK;
 }
 
+constexpr uint64_t kTrieSecondLook = 512ull << 10;   // bytes of a `delta` stream the host parses before the GPU is asked (~7 10^4 leaves)
 int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbytes, uint8_t *rgb_out, uint64_t cap,
                  uint32_t *w, uint32_t *h) {
     const bool bytes_dev = is_device_ptr(bytes);
@@ -1074,6 +1075,22 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
             return CNIIC_OK;
         };
         const bool force_gpu_parse = getenv("CNIIC_TEST_TRIE_GPU") != nullptr;   // tests: every decoder through k_trieparse.hip
+        // A `delta` decoder of a photograph has 4-6 10^4 leaves (0.3-0.5 MB): more than the head that was looked at, far fewer than the
+        // GPU parse needs to pay for its launches and waits (0.49 ms at 4 10^4 leaves; this core parses them in 0.15) -- a second, longer
+        // look before the stream goes to k_trieparse.hip.  (`hufman` decoders that outgrow the first look are ten times that size.)
+        if (!parsed && !force_gpu_parse && head.n < nbytes) {
+            const char *e2 = getenv("CNIIC_TRIE_HOST_SECOND");
+            // (whatever the stream's length: the decoder's share of it grows as the image shrinks -- 57 % at 512^2 -- and a photograph's
+            // alphabet stays under 6 10^4 differences at any size.  Uniform noise, whose decoder is most of the stream, pays for the look in
+            // vain -- 0.33 ms -- and goes to the GPU as before.)
+            const uint64_t second = e2 ? strtoull(e2, nullptr, 10) : delta ? std::min<uint64_t>(kTrieSecondLook, nbytes) : 0;
+            if (second > head.n) {
+                CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, second, &head));
+                tpos = pos;
+                parsed = huff_parse_leaves(sym_kind, head.p, head.n, tpos, lt);
+                host_trace().mark("decode: second look at the decoder (host)");
+            }
+        }
         if (force_gpu_parse || (!parsed && head.n < nbytes)) {
             // The decoder is longer than the head of the stream that was looked at (4 MiB at most): an alphabet of hundreds of
             // thousands of symbols -- `hufman` on a photograph.  Parsed on the GPU (k_trieparse.hip), from the stream in HBM.

@@ -83,6 +83,35 @@ def test_decoder_longer_than_the_first_head_fetch(env):
     assert rc == 0 and np.array_equal(out.cpu().numpy().reshape(200, 300, 3), img)
 
 
+@pytest.mark.parametrize("second", [None, "1", "100000000"])
+@pytest.mark.parametrize("shape,kind", [((200, 300), "photo"), ((256, 256), "uniform"), ((700, 500), "photo")])
+def test_delta_decoder_longer_than_the_first_look(env, monkeypatch, shape, kind, second):
+    """a `delta` decoder that outgrows the head of the stream the host looks at first: a second, longer look (512 KiB) parses it on
+    the host; one that outgrows that too -- or CNIIC_TRIE_HOST_SECOND=1: no second look -- is parsed on the GPU.  Same pixels."""
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    h, w = shape
+    img = getattr(synth, kind)(w, h, synth.SEED0 + 3 + h)
+    rc, data, _ = ctx.encode("delta", img)
+    assert rc == 0 and len(data) > 8192 * 2
+    if second is not None:
+        monkeypatch.setenv("CNIIC_TRIE_HOST_SECOND", second)
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        out = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+        full = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        torch.cuda.synchronize()
+        rc, dw, dh = ctx.decode_into("delta", full, len(data), out)
+        assert rc == 0 and (dw, dh) == (w, h) and np.array_equal(out.cpu().numpy().reshape(h, w, 3), img)
+        rc, back = ctx.decode("delta", data)     # the stream in host memory
+        assert rc == 0 and np.array_equal(back, img)
+        for cut in (9, len(data) // 3, len(data) // 2):
+            rc, _, _ = ctx.decode_into("delta", full, len(data) - cut, out, allow=(_lib.DECODE,))
+            assert (rc == 0) == (O.decode("delta", data[:len(data) - cut])[0] == 0), cut
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
 def test_context_options_replace_the_environment(env, monkeypatch):
     ctx, torch, dev = env
     from cniic_amd import _lib, synth
