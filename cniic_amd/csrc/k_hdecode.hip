@@ -329,18 +329,21 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
 // start and count fall out -- what k_hd_write needs.  32 times the first pass's work, no chain: taken when the blind checks have not
 // settled the stream (CNIIC_HD_PHASES=1: always, for the tests).
 constexpr uint32_t kHpGroups = 512;   // groups of subsequences whose maps k_hd_phase_chain composes (one thread each)
-constexpr uint32_t kHpSubs = 32, kHpThreads = kHpSubs * 32, kHpStageWords = kHpSubs * (kHdSub / 32) + kHdTail + 2;
+// (a subsequence is entered at most max_len - 1 bits past its start -- the overshoot of the symbol that straddles its boundary -- so
+// only `phases` = max(16, longest code) of the 32 are walked: a block's 1024 threads take 1024 / phases subsequences)
+constexpr uint32_t kHpSubsMax = 64, kHpThreads = 1024, kHpStageWords = kHpSubsMax * (kHdSub / 32) + kHdTail + 2;
 __global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTables T, uint64_t nsub, uint8_t *__restrict__ maps /* [nsub][32] */,
-                                                              uint16_t *__restrict__ cnts /* [nsub][32] */) {
+                                                              uint16_t *__restrict__ cnts /* [nsub][32] */, uint32_t phases, uint32_t subs_per_block) {
     __shared__ uint32_t lut_s[1u << kHdLut];
     __shared__ uint32_t stage[kHpStageWords];
     for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHpThreads) lut_s[i] = T.lut1[i];
-    const uint64_t t0 = (uint64_t)blockIdx.x * kHpSubs, base = t0 * kHdSub, w0 = base / 32;
-    for (uint32_t i = threadIdx.x; i < kHpStageWords; i += kHpThreads) stage[i] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
+    const uint64_t t0 = (uint64_t)blockIdx.x * subs_per_block, base = t0 * kHdSub, w0 = base / 32;
+    const uint32_t nstage = subs_per_block * (kHdSub / 32) + kHdTail + 2;
+    for (uint32_t i = threadIdx.x; i < nstage; i += kHpThreads) stage[i] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
     __syncthreads();
-    const uint64_t t = t0 + (threadIdx.x >> 5);
-    const uint32_t o = threadIdx.x & 31;
-    if (t >= nsub) return;
+    const uint32_t sub = threadIdx.x / phases, o = threadIdx.x - sub * phases;
+    const uint64_t t = t0 + sub;
+    if (sub >= subs_per_block || t >= nsub) return;
     const uint64_t next = (t + 1) * kHdSub, hi = min(next, S.nbits);
     uint64_t at = t * kHdSub + o;
     uint32_t cn = 0;
@@ -614,7 +617,11 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         DevBuf maps_d, cnts_d;
         CNIIC_HIP_TRY(c, maps_d.alloc(nsub * 32));
         CNIIC_HIP_TRY(c, cnts_d.alloc(nsub * 64));
-        hipLaunchKernelGGL(k_hd_phase_maps, dim3((uint32_t)ceil_div(nsub, (uint64_t)kHpSubs)), dim3(kHpThreads), 0, c->stream, S, T, nsub, maps_d.as<uint8_t>(), cnts_d.as<uint16_t>());
+        const uint32_t nph = std::min(32u, std::max(16u, lt.max_len)), spb = kHpThreads / nph;   // (the other entries of a map are never asked for)
+        CNIIC_HIP_TRY(c, hipMemsetAsync(maps_d.p, 0, nsub * 32, c->stream));
+        hipLaunchKernelGGL(k_hd_phase_maps, dim3((uint32_t)ceil_div(nsub, (uint64_t)spb)), dim3(kHpThreads), 0, c->stream, S, T, nsub, maps_d.as<uint8_t>(), cnts_d.as<uint16_t>(), nph, spb);
+        if (S.bit0 >= nph)   // the first subsequence alone is entered where the payload begins, which may be any bit of its first word
+            hipLaunchKernelGGL(k_hd_phase_maps, dim3(1), dim3(kHpThreads), 0, c->stream, S, T, (uint64_t)1, maps_d.as<uint8_t>(), cnts_d.as<uint16_t>(), 32u, 32u);
         hipLaunchKernelGGL(k_hd_phase_chain, dim3(1), dim3(kHpGroups), 0, c->stream, (const uint8_t *)maps_d.as<uint8_t>(), (const uint16_t *)cnts_d.as<uint16_t>(), nsub, S.nbits,
                            (uint32_t)S.bit0, start_d.as<uint64_t>(), count.as<uint32_t>());
         CNIIC_HIP_TRY(c, hipGetLastError());
