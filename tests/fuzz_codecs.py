@@ -52,8 +52,11 @@ except Exception:
 
 def run(ctx, budget):
     """`budget` seconds of random cases on ctx; returns how many were checked (an assertion stops at the first difference)"""
-    t0, cases = time.time(), 0
+    t0, cases, said = time.time(), 0, time.time()
     while time.time() - t0 < budget:
+        if time.time() - said > 60:   # (a long run says that it is alive)
+            said = time.time()
+            sys.stderr.write("fuzz: %d cases after %.0f s\n" % (cases, said - t0)); sys.stderr.flush()
         img = image()
         knob = KNOBS[int(rng.integers(0, len(KNOBS)))]
         saved = {k: os.environ.get(k) for k in knob}

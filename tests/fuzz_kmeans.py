@@ -33,8 +33,11 @@ def image():
 def run(ctx, budget):
     """`budget` seconds of random cases; returns how many were checked (an assertion stops at the first difference)"""
     from cniic_amd import _lib
-    t0, cases = time.time(), 0
+    t0, cases, said = time.time(), 0, time.time()
     while time.time() - t0 < budget:
+        if time.time() - said > 60:   # (a long run says that it is alive)
+            said = time.time()
+            sys.stderr.write("fuzz: %d cases after %.0f s\n" % (cases, said - t0)); sys.stderr.flush()
         img = image()
         vor = rng.random() < 0.4
         K = int(rng.choice([1, 2, 3, 7, 16, 40, 64] if vor else [1, 2, 3, 7, 16, 64, 255, 256, 257, 600]))
