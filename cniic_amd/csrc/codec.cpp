@@ -1081,9 +1081,12 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         if (!parsed && !force_gpu_parse && head.n < nbytes) {
             const char *e2 = getenv("CNIIC_TRIE_HOST_SECOND");
             // (whatever the stream's length: the decoder's share of it grows as the image shrinks -- 57 % at 512^2 -- and a photograph's
-            // alphabet stays under 6 10^4 differences at any size.  Uniform noise, whose decoder is most of the stream, pays for the look in
-            // vain -- 0.33 ms -- and goes to the GPU as before.)
-            const uint64_t second = e2 ? strtoull(e2, nullptr, 10) : delta ? std::min<uint64_t>(kTrieSecondLook, nbytes) : 0;
+            // alphabet stays under 6 10^4 differences at any size.  Uniform noise, whose decoder is most of the stream, paid for the look in
+            // vain -- 0.33 ms; see `worth`.)
+            // A stream of more than 6 bytes a pixel is mostly decoder (the payload has at most 27 bits a symbol): more leaves than the look
+            // could hold, unless the whole stream fits into it.
+            const bool worth = nbytes <= kTrieSecondLook || nbytes <= 6 * n;
+            const uint64_t second = e2 ? strtoull(e2, nullptr, 10) : delta && worth ? std::min<uint64_t>(kTrieSecondLook, nbytes) : 0;
             if (second > head.n) {
                 CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, second, &head));
                 tpos = pos;
