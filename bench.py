@@ -182,6 +182,133 @@ def main():
                                         "over this GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K))
         return dt, int(sum(lens)), st, U, roof
 
+    def golden(case):
+        """the oracle's digest of this workload (tests/golden/fullsize_digests.json, made by tests/golden/make_fullsize_digests.py), or None"""
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")) as f:
+                return json.load(f)["cases"].get(case)
+        except Exception:
+            return None
+
+    def digest_check(case, stream, nbytes, w, h, iterations=None):
+        """-> {"oracle_digest": ..., "matches": bool} when rank 0's workload is one the oracle was run on at full size"""
+        g = golden(case)
+        if not g or rank != 0 or (g.get("w"), g.get("h")) != (w, h):
+            return None
+        import hashlib
+        got = hashlib.sha256(stream[:nbytes].cpu().numpy().tobytes()).hexdigest()
+        ok = got == g.get("sha256") and int(nbytes) == g.get("length") and (iterations is None or g.get("iterations") in (None, int(iterations)))
+        return {"case": case, "stream_sha256": got, "matches_oracle": bool(ok)}
+
+    def run_c3(size, warmup, steps):
+        """configs[2]: voronoi(2048), 5-D position + colour K-means on one size^2 image per GPU (replicas), to convergence.
+        roofline = k_xy_assign per iteration, SURVEY 8(d): 7 B/px/iteration (3 B pixel + u16 label read and written)."""
+        W = H = size
+        Kv = 2048
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 3 + rank, W, H, out=img)
+        out = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            rc, ln, st = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, allow=(_lib.FEW_ACTIVE,))
+            return ln, st
+        dt, (nbytes, st) = timed(step, warmup, steps)
+        if rank != 0:
+            return None
+        rc, ln, stp = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE, allow=(_lib.FEW_ACTIVE,))
+        ms, n = ctx.kernel_time("kmeans_xyrgb_iter")
+        roofline = None
+        if n:
+            it_ms = ms / n
+            algo = 7.0 * W * H
+            traffic3 = None   # PMC passes over a whole run (tools/make_profiles.sh): mean HBM bytes per k_xy_assign launch, 2 * FETCH_SIZE + WRITE_SIZE
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    t3 = json.load(f).get("c3")
+                if t3 and t3.get("size") == W and t3.get("K") == Kv:
+                    traffic3 = t3.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            roofline = {"kernel": "k_xy_assign (+ k_xy_update)", "bound": "hbm", "achieved": round(algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic3, "launch_ms": round(it_ms, 5),
+                        "launches": int(n), "algorithmic_bytes_per_launch": algo,
+                        "note": "HIP events around the whole K-means loop of one more encode / its %d iterations (assign + update launches); "
+                                "algorithmic bytes = 7 B/px/iteration (SURVEY 8(d)); tiles nothing changed for are skipped, so late iterations read less" % int(n)}
+        cpu = None
+        if args.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            s = min(768, W)
+            crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+            t0 = time.perf_counter()
+            rc, data, ost = O.encode("voronoi(%d)" % Kv, crop, mode=O.MODE_R)
+            cdt = time.perf_counter() - t0
+            cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                   "sample": "%dx%d crop of the same image, voronoi(%d), oracle mode R, %d iterations, %.1f s (rc %d)" % (s, s, Kv, ost.get("iterations", 0), cdt, rc)}
+        return {"metric": "Mpixels/sec encode (voronoi K=%d)" % Kv, "value": round(W * H * world * steps / dt / 1e6, 3), "unit": "Mpixels/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "i32/u64", "data": "synthetic",
+                "config": {"workload": "configs[2]: voronoi(%d) encode (5-D position + colour K-means to convergence) of one %dx%d photo-like synthetic RGB "
+                                       "image per GPU (seed 0x636E696963+3+rank); image and stream HBM-resident" % (Kv, W, H), "pixels_per_gpu": W * H,
+                           "kmeans_iterations": int(st["iterations"]),
+                           "centroids_tested_per_px_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / (W * H), 2) if "pair_evals" in st else None,
+                           "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
+                "roofline": roofline, "cpu_baseline": cpu, "parity": digest_check("v%d" % W, out, nbytes, W, H, st["iterations"])}
+
+    def run_c5(size, warmup, steps):
+        """configs[4]: `delta` (Hilbert gather + neighbour differences + symbol histogram + Huffman) on one size^2 image per GPU
+        (independent images: replicas, no collective).  roofline = the gather kernel, SURVEY 8(d): 3 B/px read."""
+        W = H = size
+        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 5 + rank, W, H, out=img)
+        out = torch.empty(W * H * 3 + (1 << 24), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            rc, ln, st = ctx.encode("delta", img, w=W, h=H, out=out)
+            return ln, st
+        dt, (nbytes, st) = timed(step, warmup, steps)
+        if rank != 0:
+            return None
+        parity = digest_check("c5", out, nbytes, W, H)
+        ctx.encode("delta", img, w=W, h=H, out=out, flags=_lib.KM_PROFILE)  # one more call with the stage timers (HIP events on the ctx stream)
+        stages = {}
+        for k in ("delta_gather", "delta_hist", "huff_pack"):
+            ms, n = ctx.kernel_time(k)
+            if n:
+                stages[k + "_ms"] = round(ms / n, 4)
+        g_ms = stages.get("delta_gather_ms")
+        roofline = None
+        if g_ms:
+            algo = 3.0 * W * H
+            roofline = {"kernel": "k_delta_gather_p2", "bound": "hbm", "achieved": round(algo / (g_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": g_ms, "launches": 1,
+                        "algorithmic_bytes_per_launch": algo,
+                        "with_symbol_stream": {"bytes_per_launch": 5.0 * W * H, "GBps": round(5.0 * W * H / (g_ms * 1e-3) / 1e9, 2),
+                                               "frac": round(5.0 * W * H / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                        "note": "HIP events around the gather launch of one more encode (stage timers); algorithmic bytes = 3 B/px read (SURVEY 8(d), "
+                                "Hilbert gather + delta); the kernel also writes the 2 B/px symbol stream the later passes read: with_symbol_stream"}
+        cpu = None
+        if args.cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            s = min(2048, W)
+            crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
+            t0 = time.perf_counter()
+            rc, data, _ = O.encode("delta", crop)
+            cdt = time.perf_counter() - t0
+            cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                   "sample": "%dx%d crop of the same image, the CPU restatement of Delta::encode, %.1f s" % (s, s, cdt), "bytes_per_px": round(len(data) / (s * s), 4)}
+        return {"metric": "Mpixels/sec encode (delta)", "value": round(W * H * world * steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
+                "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+                "config": {"workload": "configs[4]: delta encode (Hilbert gather + differences + histogram + Huffman) of one %dx%d photo-like synthetic RGB "
+                                       "image per GPU (seed 0x636E696963+5+rank); image and stream HBM-resident" % (W, H), "pixels_per_gpu": W * H,
+                           "bytes_per_px": round(nbytes / (W * H), 4),
+                           "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
+                "roofline": roofline, "cpu_baseline": cpu, "stages": stages, "parity": parity}
+
     line = None
     if args.decode:
         line = bench_decode(args, ctx, torch, np, dev, rank, world, timed, config)
@@ -199,7 +326,7 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
                 "config": {"workload": "configs[3]: cluster-colors(%d) over a batch of %d 1920x1080 photo-like synthetic frames (%d per GPU, frame f: seed "
-                                       "0x636E696963+4+f), one palette for the whole batch, one Hufman stream per frame, to convergence" % (K, F * world, F),
+                                       "0x636E696963+4+f), one palette for the whole batch, one Hufman stream per frame, to convergence; frames and streams HBM-resident" % (K, F * world, F),
                            "frames_per_gpu": F, "pixels_per_gpu": F * FRAME_W * FRAME_H, "unique_colours_rank0": U, "kmeans_iterations": int(st["iterations"]),
                            "bytes_per_px": round(nbytes / (F * FRAME_W * FRAME_H), 4),
                            "parallelism": "1 GPU" if world == 1 else "frames sharded over %d GPUs (each keeps its own frames' colours), shared palette: RCCL all-reduce of the "
@@ -209,108 +336,9 @@ def main():
             }
         enc.close()
     elif config == "c3":
-        # configs[2]: voronoi(2048), 5-D position + colour K-means on one 4096^2 image per GPU (replicas), to convergence.
-        # roofline = k_xy_assign per iteration, SURVEY 8(d): 7 B/px/iteration (3 B pixel + u16 label read and written).
-        W = H = args.size
-        Kv = 2048
-        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 3 + rank, W, H, out=img)
-        out = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-
-        def step():
-            rc, ln, st = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, allow=(_lib.FEW_ACTIVE,))
-            return ln, st
-        dt, (nbytes, st) = timed(step, args.warmup, args.steps)
-        if rank == 0:
-            rc, ln, stp = ctx.encode("voronoi(%d)" % Kv, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE, allow=(_lib.FEW_ACTIVE,))
-            ms, n = ctx.kernel_time("kmeans_xyrgb_iter")
-            roofline = None
-            if n:
-                it_ms = ms / n
-                algo = 7.0 * W * H
-                traffic3 = None   # PMC passes over a whole run (tools/make_profiles.sh): mean HBM bytes per k_xy_assign launch, 2 * FETCH_SIZE + WRITE_SIZE
-                try:
-                    with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                        t3 = json.load(f).get("c3")
-                    if t3 and t3.get("size") == W and t3.get("K") == Kv:
-                        traffic3 = t3.get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
-                roofline = {"kernel": "k_xy_assign (+ k_xy_update)", "bound": "hbm", "achieved": round(algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                            "unit": "GB/s", "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic3, "launch_ms": round(it_ms, 5),
-                            "launches": int(n), "algorithmic_bytes_per_launch": algo,
-                            "note": "HIP events around the whole K-means loop of one more encode / its %d iterations (assign + update launches); "
-                                    "algorithmic bytes = 7 B/px/iteration (SURVEY 8(d)); tiles nothing changed for are skipped, so late iterations read less" % int(n)}
-            cpu = None
-            if args.cpu_sample > 0:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib as O
-                s = min(768, W)
-                crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
-                t0 = time.perf_counter()
-                rc, data, ost = O.encode("voronoi(%d)" % Kv, crop, mode=O.MODE_R)
-                cdt = time.perf_counter() - t0
-                cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                       "sample": "%dx%d crop of the same image, voronoi(%d), oracle mode R, %d iterations, %.1f s (rc %d)" % (s, s, Kv, ost.get("iterations", 0), cdt, rc)}
-            line = {"metric": "Mpixels/sec encode (voronoi K=%d)" % Kv, "value": round(W * H * world * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
-                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": "i32/u64", "data": "synthetic",
-                    "config": {"workload": "configs[2]: voronoi(%d) encode (5-D position + colour K-means to convergence) of one %dx%d photo-like synthetic RGB "
-                                           "image per GPU (seed 0x636E696963+3+rank)" % (Kv, W, H), "pixels_per_gpu": W * H,
-                               "kmeans_iterations": int(st["iterations"]),
-                               "centroids_tested_per_px_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / (W * H), 2) if "pair_evals" in st else None,
-                               "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
-                    "roofline": roofline, "cpu_baseline": cpu}
+        line = run_c3(args.size, args.warmup, args.steps)
     elif config == "c5":
-        # configs[4]: `delta` (Hilbert gather + neighbour differences + symbol histogram + Huffman) on one 16384^2 image per GPU
-        # (independent images: replicas, no collective).  roofline = the gather kernel, SURVEY 8(d): 3 B/px read.
-        W = H = args.c5_size
-        img = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-        ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 5 + rank, W, H, out=img)
-        out = torch.empty(W * H * 3 + (1 << 24), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-
-        def step():
-            rc, ln, st = ctx.encode("delta", img, w=W, h=H, out=out)
-            return ln, st
-        dt, (nbytes, st) = timed(step, args.warmup, args.steps)
-        if rank == 0:
-            ctx.encode("delta", img, w=W, h=H, out=out, flags=_lib.KM_PROFILE)  # one more call with the stage timers (HIP events on the ctx stream)
-            stages = {}
-            for k in ("delta_gather", "delta_hist", "huff_pack"):
-                ms, n = ctx.kernel_time(k)
-                if n:
-                    stages[k + "_ms"] = round(ms / n, 4)
-            g_ms = stages.get("delta_gather_ms")
-            roofline = None
-            if g_ms:
-                algo = 3.0 * W * H
-                roofline = {"kernel": "k_delta_gather_p2", "bound": "hbm", "achieved": round(algo / (g_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": round(algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": g_ms, "launches": 1,
-                            "algorithmic_bytes_per_launch": algo,
-                            "with_symbol_stream": {"bytes_per_launch": 5.0 * W * H, "GBps": round(5.0 * W * H / (g_ms * 1e-3) / 1e9, 2),
-                                                   "frac": round(5.0 * W * H / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
-                            "note": "HIP events around the gather launch of one more encode (stage timers); algorithmic bytes = 3 B/px read (SURVEY 8(d), "
-                                    "Hilbert gather + delta); the kernel also writes the 2 B/px symbol stream the later passes read: with_symbol_stream"}
-            cpu = None
-            if args.cpu_sample > 0:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                import oracle_lib as O
-                s = min(2048, W)
-                crop = np.ascontiguousarray(img[:s, :s].cpu().numpy())
-                t0 = time.perf_counter()
-                rc, data, _ = O.encode("delta", crop)
-                cdt = time.perf_counter() - t0
-                cpu = {"value": round(s * s / cdt / 1e6, 4), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-                       "sample": "%dx%d crop of the same image, the CPU restatement of Delta::encode, %.1f s" % (s, s, cdt), "bytes_per_px": round(len(data) / (s * s), 4)}
-            line = {"metric": "Mpixels/sec encode (delta)", "value": round(W * H * world * args.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world,
-                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                    "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
-                    "config": {"workload": "configs[4]: delta encode (Hilbert gather + differences + histogram + Huffman) of one %dx%d photo-like synthetic RGB "
-                                           "image per GPU (seed 0x636E696963+5+rank)" % (W, H), "pixels_per_gpu": W * H, "bytes_per_px": round(nbytes / (W * H), 4),
-                               "parallelism": "1 GPU" if world == 1 else "%d independent images, one per GPU (replicas, no collective)" % world},
-                    "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
+        line = run_c5(args.c5_size, args.warmup, args.steps)
     else:
         W = H = args.size
         seed = synth.SEED0 + 2 + rank  # config 2 of SURVEY 8(d); one image per rank
@@ -330,6 +358,8 @@ def main():
                 return ln, st
         dt, (nbytes, st) = timed(step, args.warmup, args.steps)
         npx_total = W * H * world
+        # the timed stream against the oracle's digest at this size (one image, its own palette: the un-sharded step only)
+        parity = digest_check("c2", out, nbytes, W, H, st["iterations"]) if not sharded and K == 256 and not args.max_iters else None
         roofline, cpu, extras, U = None, None, {}, 0
         enc_collectives = enc.collectives if enc is not None else None
         if enc is not None:
@@ -369,7 +399,7 @@ def main():
                     e4 = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
                     d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=True)
                     e4.close()
-                    extras["c4_one_gpu"] = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams" % (F, F),
+                    extras["c4_one_gpu"] = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams; frames and streams HBM-resident" % (F, F),
                                             "value": round(F * FRAME_W * FRAME_H * 2 / d4 / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3),
                                             "kmeans_iterations": int(st4["iterations"]), "unique_colours": U4, "bytes_per_px": round(nb4 / (F * FRAME_W * FRAME_H), 4),
                                             "roofline": roof4}
@@ -395,6 +425,16 @@ def main():
                     ctx.set_opt(_lib.OPT_BATCH_STREAMS, None)
                     extras["batch_own_palettes"] = best
                     del frames, outb
+                    # configs[2] and configs[4] as blocks of the same line (every BASELINE config driver-timed); the
+                    # same functions that make the --config c3 / c5 lines
+                    for name, fn, size in (("c3", run_c3, 4096), ("c5", run_c5, 16384)):
+                        try:
+                            blk = fn(size, 1, 3)
+                            extras[name] = {k: blk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline", "parity") if k in blk}
+                            if "stages" in blk:
+                                extras[name]["stages"] = blk["stages"]
+                        except Exception as e:
+                            extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 except Exception as e:   # (the headline above is measured: a failing extra is reported, not fatal)
                     extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
             # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
@@ -413,7 +453,9 @@ def main():
                 # the HIP path on the SAME crop (the two bytes/px figures were of different images)
                 rcg, ng, stg = ctx.encode(expr, crop, max_iters=args.max_iters)
                 cpu["hip_same_crop"] = {"bytes_per_px": round(len(ng) / (s * s), 4) if rcg == 0 else None, "iterations": int(stg["iterations"]) if rcg == 0 else None}
-        if world > 1 and os.environ.get("CNIIC_BENCH_MAILBOX", "1") != "0" and enc_collectives != "mailbox":
+        if world > 1 and os.environ.get("CNIIC_BENCH_MAILBOX", "0") == "1" and enc_collectives != "mailbox":
+            # OPT-IN (CNIIC_BENCH_MAILBOX=1): the exchange has only ever run between processes that share one GPU, and a fault
+            # in a never-exercised cross-GPU path must not cost the driver its N > 1 line.
             # the same step with the K partial sums exchanged ONE-SHOT (every rank writes its sums into every peer's mailbox over the
             # direct xGMI links, k_mailbox.hip) instead of RCCL's ring; `value` above stays the RCCL figure.  Waits are bounded inside
             # the kernel (5 s here), a rank that cannot map its peers' mailboxes makes every rank skip the block.
@@ -466,7 +508,7 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
                 "config": {"workload": "configs[1]: cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
-                                       "(seed 0x636E696963+2+rank), to convergence" % (K, W, H),
+                                       "(seed 0x636E696963+2+rank), to convergence; image and stream HBM-resident" % (K, W, H),
                            "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
                            "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2) if "pair_evals" in st else None,
                            "bytes_per_px": round(nbytes / (W * H), 4),
@@ -475,6 +517,8 @@ def main():
                                                                        % (world, coll_desc(enc_collectives))},
                 "roofline": roofline, "cpu_baseline": cpu,
             }
+            if parity is not None:
+                line["parity"] = parity
             line.update(extras)
         if enc is not None:
             enc.close()

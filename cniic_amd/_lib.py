@@ -20,7 +20,7 @@ OPT_SP_MIN_PIXELS, OPT_HUF_GPU_CODES_MIN, OPT_GPU_DECODE_MIN, OPT_DELTA_ROUTE, O
 
 # every symbol include/cniic_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cniic_ctx_create", "cniic_ctx_destroy", "cniic_last_error", "cniic_version", "cniic_sync", "cniic_dev_alloc",
+    "cniic_ctx_create", "cniic_ctx_destroy", "cniic_last_error", "cniic_version", "cniic_is_testing_build", "cniic_sync", "cniic_dev_alloc",
     "cniic_dev_free", "cniic_memcpy", "cniic_ctx_set_opt", "cniic_ctx_unset_opt", "cniic_ctx_get_opt", "cniic_ctx_set_scan", "cniic_last_kernel_time", "cniic_hist_rgb24", "cniic_hist_syms",
     "cniic_kmeans_rgbw", "cniic_kmeans_xyrgb", "cniic_kmeans_step_rgbw", "cniic_kmeans_step_xyrgb",
     "cniic_km_create_rgbw", "cniic_km_partial_words", "cniic_km_partials", "cniic_km_begin",
@@ -57,7 +57,10 @@ COLORPOS = np.dtype([("x", "<u4"), ("y", "<u4"), ("rgb", "u1", (3,)), ("pad", "u
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcniic_hip.so")
+    """libcniic_hip.so -- or, with CNIIC_USE_TESTING_LIB=1 (tests/conftest.py, tools/), libcniic_hip_testing.so: the same code built with
+    -DCNIIC_TESTING, the only build in which the CNIIC_TEST_* / CNIIC_DBG_* / route-forcing environment knobs exist"""
+    name = "libcniic_hip_testing.so" if os.environ.get("CNIIC_USE_TESTING_LIB") == "1" else "libcniic_hip.so"
+    return os.path.join(_HERE, name)
 
 
 _lib = None

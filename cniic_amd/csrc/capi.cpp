@@ -56,6 +56,13 @@ static int from_caller(Ctx *c, void *dst_host, const void *src, uint64_t bytes) 
 extern "C" {
 
 int32_t cniic_version(void) { return 100; }
+int32_t cniic_is_testing_build(void) {
+#ifdef CNIIC_TESTING
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int32_t cniic_ctx_create(int32_t device, void *stream, cniic_ctx **out) {
     if (!out) return CNIIC_ERR_BAD_ARG;

@@ -1074,12 +1074,12 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
             if (!img_d.p && (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3))) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
             return CNIIC_OK;
         };
-        const bool force_gpu_parse = getenv("CNIIC_TEST_TRIE_GPU") != nullptr;   // tests: every decoder through k_trieparse.hip
+        const bool force_gpu_parse = test_env("CNIIC_TEST_TRIE_GPU") != nullptr;   // tests: every decoder through k_trieparse.hip
         // A `delta` decoder of a photograph has 4-6 10^4 leaves (0.3-0.5 MB): more than the head that was looked at, far fewer than the
         // GPU parse needs to pay for its launches and waits (0.49 ms at 4 10^4 leaves; this core parses them in 0.15) -- a second, longer
         // look before the stream goes to k_trieparse.hip.  (`hufman` decoders that outgrow the first look are ten times that size.)
         if (!parsed && !force_gpu_parse && head.n < nbytes) {
-            const char *e2 = getenv("CNIIC_TRIE_HOST_SECOND");
+            const char *e2 = test_env("CNIIC_TRIE_HOST_SECOND");
             // (whatever the stream's length: the decoder's share of it grows as the image shrinks -- 57 % at 512^2 -- and a photograph's
             // alphabet stays under 6 10^4 differences at any size.  Uniform noise, whose decoder is most of the stream, paid for the look in
             // vain -- 0.33 ms; see `worth`.)

@@ -110,6 +110,17 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Knobs of the test-suite, the probes under tools/ and measuring builds (CNIIC_TEST_*, CNIIC_DBG_*, route forcing, tuning constants) are
+// read from the environment ONLY by the testing build (-DCNIIC_TESTING: libcniic_hip_testing.so, which tests/conftest.py and tools/ ask
+// for with CNIIC_USE_TESTING_LIB=1).  In the release library test_env() is a constant nullptr: no getenv, and the names are not even in
+// the binary (tests/test_abi.py checks `strings`).  What a host may set on a release build are the context options of the ABI, whose
+// documented environment fallbacks (Ctx::opt below) stay.
+#ifdef CNIIC_TESTING
+inline const char *test_env(const char *name) { return getenv(name); }
+#else
+inline const char *test_env(const char *) { return nullptr; }
+#endif
+
 struct Ctx {
     int         device = 0;
     hipStream_t stream = nullptr;
@@ -389,7 +400,7 @@ struct LaggedPoll {
 struct HostTrace {
     bool on;
     std::vector<std::pair<const char *, double>> marks;
-    HostTrace() : on(getenv("CNIIC_TRACE_HOST") != nullptr) {}
+    HostTrace() : on(test_env("CNIIC_TRACE_HOST") != nullptr) {}
     static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void mark(const char *what) { if (on) marks.emplace_back(what, now()); }
     void dump() {

@@ -588,7 +588,7 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
     const uint64_t npad = delta_stream_len(n);
     ScopedKernelTimer timer(c, "delta_gather");  // (bench.py --config c5 takes the gather's roofline from this one)
     const uint32_t order = sel.order;
-    const char *force = getenv("CNIIC_DELTA_GATHER");  // "any": the per-position kernel on 2^n squares too (tests)
+    const char *force = test_env("CNIIC_DELTA_GATHER");  // "any": the per-position kernel on 2^n squares too (tests)
     if (order >= 6 && (reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && !(force && force[0] == 'a')) {
         const uint32_t ntiles = (uint32_t)(n >> 12);
         hipLaunchKernelGGL(k_delta_gather_p2, dim3(std::min<uint32_t>(ntiles, 256 * 8)), dim3(256), 0, c->stream, rgb_d, order, lut, hot16_d, table_d,
@@ -637,7 +637,7 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
     });
     // codes of up to 26 bits sit in the word itself; longer ones (nearly never) send the pack to the per-rank tables -- tests
     // lower the limit (CNIIC_TEST_INLINE_CODE_BITS) so that ordinary images take that way
-    const char *im = getenv("CNIIC_TEST_INLINE_CODE_BITS");
+    const char *im = test_env("CNIIC_TEST_INLINE_CODE_BITS");
     const uint32_t inline_max = im ? std::min<uint32_t>((uint32_t)atoi(im), 26u) : 26u;
     hipLaunchKernelGGL(k_delta_fill_codes, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
                        dense_d, keep->hot.as<uint32_t>(), keep->hotlen.as<uint8_t>(), inline_max);

@@ -500,7 +500,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     // symbol) decodes in 12.3 / 10.0 / 8.8 / 11.0 / 17.9 ms with 14 / 16 / 18 / 20 / 24 bits; for a decoder of a million leaves and more
     // 2^24 entries = 128 MiB -- there even 20 bits leave half a dozen leaves per entry, i.e. a few more dependent reads for EVERY symbol:
     // `hufman` 4096^2 (6.8 M leaves) 7.0 / 5.3 / 4.6 / 4.6 ms with 20 / 22 / 24 / 26.  CNIIC_HD_LUT2_BITS: the cap, for measurements.
-    const uint32_t cap2 = getenv("CNIIC_HD_LUT2_BITS") ? (uint32_t)atoi(getenv("CNIIC_HD_LUT2_BITS")) : (n >= (1u << 20) ? 24u : 18u);
+    const uint32_t cap2 = test_env("CNIIC_HD_LUT2_BITS") ? (uint32_t)atoi(test_env("CNIIC_HD_LUT2_BITS")) : (n >= (1u << 20) ? 24u : 18u);
     const uint32_t bits2 = max_len > (uint32_t)kHdLut ? std::min<uint32_t>(max_len, std::max(cap2, (uint32_t)kHdLut + 1)) : 0u;
     DevBuf lut1_d, lut2_d;
     CNIIC_HIP_TRY(c, lut1_d.alloc((4ull << kHdLut)));
@@ -510,7 +510,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     DevBuf lo_d, big_d;
     if (bits2) {
         CNIIC_HIP_TRY(c, lut2_d.alloc(8ull << bits2));
-        if (bits2 > 20 && !getenv("CNIIC_HD_LUT2_SEARCH")) {   // a large table: from the leaves' side (see k_hd_lut_owner)
+        if (bits2 > 20 && !test_env("CNIIC_HD_LUT2_SEARCH")) {   // a large table: from the leaves' side (see k_hd_lut_owner)
             const uint32_t big_cap = (1u << bits2) / kHdOwnMax + 1;   // (leaves that own more than kHdOwnMax prefixes: at most this many)
             CNIIC_HIP_TRY(c, lo_d.alloc(4ull << bits2));
             CNIIC_HIP_TRY(c, big_d.alloc(((uint64_t)big_cap + 1) * 4));
@@ -541,22 +541,22 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     CNIIC_HIP_TRY(c, tot.alloc(8));
     CNIIC_HIP_TRY(c, changed.alloc(32));   // [0] an end moved in this check; [2] statistics wanted, [3] threads out of step, [4] blocks that staged
     CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 32, c->stream));
-    const bool hd_stats = getenv("CNIIC_HD_STATS") != nullptr;
+    const bool hd_stats = test_env("CNIIC_HD_STATS") != nullptr;
     if (hd_stats) { const uint32_t one = 1; CNIIC_HIP_TRY(c, hipMemcpyAsync(changed.as<uint32_t>() + 2, &one, 4, hipMemcpyHostToDevice, c->stream)); }
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4096;   // (slots of this function's own) [0] total symbols, [1] did the last pass move an end?
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
     const size_t lds = kHdLds;
     const bool wide = lt.max_len > 32;
-    const char *ph_env = getenv("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
+    const char *ph_env = test_env("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
     const bool phases_ok = !wide && !(ph_env && !atoi(ph_env)), phases_force = phases_ok && ph_env && atoi(ph_env);
-    const uint64_t phases_max_sub = getenv("CNIIC_HD_PHASES_MAX_SUB") ? strtoull(getenv("CNIIC_HD_PHASES_MAX_SUB"), nullptr, 10) : kHdPhasesMaxSub;   // (for measurements)
+    const uint64_t phases_max_sub = test_env("CNIIC_HD_PHASES_MAX_SUB") ? strtoull(test_env("CNIIC_HD_PHASES_MAX_SUB"), nullptr, 10) : kHdPhasesMaxSub;   // (for measurements)
     const bool phases_first = phases_ok && (nsub <= phases_max_sub || phases_force);   // a short stream: instead of more checks
     int pass_rounds = phases_first ? kHdRoundsShort : kHdMaxRounds;
     // a stream that does not fall into step is found out by pass 0 itself (k_hd_pass: blocks whose lists do not shrink count themselves in
     // changed[5]); from a quarter of the blocks on, the checks and the write behind pass 0 return at once and the one look sends the host
     // to the phase maps -- instead of three passes that cure one subsequence a round first (1024^2 photograph, `hufman`: 3.2 -> 1.6 ms)
-    const uint32_t hopeless_pct = getenv("CNIIC_HD_HOPELESS_PCT") ? (uint32_t)atoi(getenv("CNIIC_HD_HOPELESS_PCT")) : hd_hopeless_pct(nsub);   // (0: no such verdict)
+    const uint32_t hopeless_pct = test_env("CNIIC_HD_HOPELESS_PCT") ? (uint32_t)atoi(test_env("CNIIC_HD_HOPELESS_PCT")) : hd_hopeless_pct(nsub);   // (0: no such verdict)
     const uint32_t hopeless_min = phases_ok && !phases_force && hopeless_pct ? std::max(1u, grid / 4) : 0u;
     auto pass = [&](const uint64_t *prev, uint64_t *cur) {
         if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds, 0u, 0u);

@@ -534,7 +534,7 @@ int hilbert_lut(Ctx *c, const HilbertLut **lut_d) {
 
 // 2^n squares from 64 x 64 with 16-byte aligned buffers go by tiles (CNIIC_HILBERT_MOVE=any: the per-position kernel; tests)
 static bool move_by_tiles(uint32_t order, const void *a, const void *b) {
-    const char *e = getenv("CNIIC_HILBERT_MOVE");
+    const char *e = test_env("CNIIC_HILBERT_MOVE");
     return order >= 6 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !(e && e[0] == 'a');
 }
 
@@ -592,7 +592,7 @@ static int scan_leaves_get(Ctx *c, uint32_t w, uint32_t h, const ScanLeavesDev *
     const uint64_t n = (uint64_t)w * h;
     uint64_t max_area = 4096;
     while (max_area < n / 8192) max_area <<= 1;   // <= ~3 x 10^4 leaves whatever the image
-    if (const char *e = getenv("CNIIC_SCAN_LEAF_AREA")) max_area = std::max<uint64_t>(2, strtoull(e, nullptr, 10));   // (tests: deep trees on small images)
+    if (const char *e = test_env("CNIIC_SCAN_LEAF_AREA")) max_area = std::max<uint64_t>(2, strtoull(e, nullptr, 10));   // (tests: deep trees on small images)
     max_area = std::min<uint64_t>(max_area, 1u << 14);   // (a leaf's offsets are int16)
     uint32_t shift = 0;
     while ((1ull << (shift + 1)) <= max_area) shift++;
@@ -705,7 +705,7 @@ int scan_select(Ctx *c, uint32_t w, uint32_t h, ScanSel *sel) {
     CNIIC_TRY(hilbert_lut(c, &lut));
     const uint32_t order = pow2_order(w, h);
     if (!order) {
-        const char *e = getenv("CNIIC_SCAN_LEAVES_MIN");   // pixels from which an image size gets its leaves (tests: 0; never: a huge number)
+        const char *e = test_env("CNIIC_SCAN_LEAVES_MIN");   // pixels from which an image size gets its leaves (tests: 0; never: a huge number)
         const uint64_t min_px = e ? strtoull(e, nullptr, 10) : kScanLeavesMinPx;
         if ((uint64_t)w * h >= std::max<uint64_t>(min_px, 2)) {
             const ScanLeavesDev *hdr = nullptr;
@@ -841,7 +841,7 @@ int hilbert_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t
     // Measured at 16384^2: without the histogram the lane-per-position kernel takes 0.75 ms against 0.89 ms; with it 1.30 against
     // 1.14 ms (one block per CU for the 128 KiB of bins either way), so the fused encode keeps the 4-positions-per-thread kernel.
     // CNIIC_HILBERT_LANE_SCAN=1 / 0 forces one or the other (tests run both).
-    const char *ls = getenv("CNIIC_HILBERT_LANE_SCAN");
+    const char *ls = test_env("CNIIC_HILBERT_LANE_SCAN");
     const bool lane_scan = ls ? atoi(ls) != 0 : table_d == nullptr;
     if (order >= 3 && lane_scan) {  // 2^n squares from 8 x 8: one position per lane, the shared levels walked once per group of 64
         static std::once_flag attr2;

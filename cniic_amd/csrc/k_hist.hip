@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_hist_syms(const uint32_t *__restrict__ 
 
 int hist_rgb_dense(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *table_d) {
     if (npx == 0) return CNIIC_OK;
-    static const bool partition = !(getenv("CNIIC_HIST_PARTITION") && atoi(getenv("CNIIC_HIST_PARTITION")) == 0);
+    static const bool partition = !(test_env("CNIIC_HIST_PARTITION") && atoi(test_env("CNIIC_HIST_PARTITION")) == 0);
     if ((reinterpret_cast<uintptr_t>(rgb_d) & 15) == 0 && partition && npx >= (1u << 20) && npx < (1ull << 32)) {
         const uint64_t groups = npx / 16, gpb = ceil_div(groups, kPartBlocks);
         DevBuf counts, total, start, item, payload;

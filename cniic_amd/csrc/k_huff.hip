@@ -142,7 +142,7 @@ int pack_scan(Ctx *c, const uint32_t *chunk_bits_d, uint32_t nchunks, uint64_t *
 
 // tests: CNIIC_TEST_PACK_IMG_WORDS caps the packs' LDS bit image so that chunks take the direct-to-memory route
 uint32_t pack_img_cap() {
-    const char *e = getenv("CNIIC_TEST_PACK_IMG_WORDS");
+    const char *e = test_env("CNIIC_TEST_PACK_IMG_WORDS");
     return e ? (uint32_t)atoi(e) : 0xffffffffu;
 }
 
@@ -1162,8 +1162,8 @@ int huff_tree_from_runs(Ctx *c, const uint64_t *sorted_d, const uint64_t *counts
     // RUNS: `delta` at 16384^2, 54 K leaves of as many different counts: 2.06 ms against 1.68 through the host's merge.  So: from 2^16
     // leaves on, and only when the leaves outnumber the runs four to one -- an image whose colours are nearly all distinct (`hufman`
     // 512^2: 2.5 10^5 leaves, a dozen runs: 0.73 -> 0.40 ms).  CNIIC_HUF_RUNS_MIN moves the line, tests set 0 and take any runs.)
-    const char *rm = getenv("CNIIC_HUF_RUNS_MIN");
-    if (n < 2 || n < (rm ? (uint32_t)atoi(rm) : kRunsMinLeaves) || getenv("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
+    const char *rm = test_env("CNIIC_HUF_RUNS_MIN");
+    if (n < 2 || n < (rm ? (uint32_t)atoi(rm) : kRunsMinLeaves) || test_env("CNIIC_HUF_HOST_MERGE")) return CNIIC_OK;
     DevBuf small, runs_d, desc_d, tree_d, par, keys_a, keys_b, z_d, zex_d, tot_d;
     CNIIC_HIP_TRY(c, small.alloc(64));
     CNIIC_HIP_TRY(c, hipMemsetAsync(small.p, 0, 64, c->stream));

@@ -2101,14 +2101,14 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->cells = !(opts && (opts->flags & CNIIC_KM_BRUTE_FORCE));
     s->profile = opts && (opts->flags & CNIIC_KM_PROFILE);
     s->no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
-    if (const char *al = getenv("CNIIC_KM_AGG_LAUNCHES")) s->agg_launches = (uint32_t)atoi(al);
-    if (const char *bb = getenv("CNIIC_KM_BIG_BLOCKS_FROM")) s->big_blocks_from = (uint32_t)atoi(bb);
-    if (const char *ms = getenv("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
+    if (const char *al = test_env("CNIIC_KM_AGG_LAUNCHES")) s->agg_launches = (uint32_t)atoi(al);
+    if (const char *bb = test_env("CNIIC_KM_BIG_BLOCKS_FROM")) s->big_blocks_from = (uint32_t)atoi(bb);
+    if (const char *ms = test_env("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     // (every knob of the loop is read here, once: getenv() per launch raced with tools that set variables between contexts)
-    if (const char *tl = getenv("CNIIC_DBG_TIMELINE")) s->dbg_timeline = (uint32_t)atoi(tl) + 1u;
-    if (const char *ds = getenv("CNIIC_SUP_STOP")) s->dbg_sup_bits |= ((uint32_t)atoi(ds) & 255u) << 8;
-    if (const char *ds = getenv("CNIIC_DBG_LAUNCH")) s->dbg_sup_bits |= (uint32_t)atoi(ds) << 16;
-    if (const char *fa = getenv("CNIIC_TEST_FAIL_AT_LAUNCH")) s->fail_at = atol(fa);
+    if (const char *tl = test_env("CNIIC_DBG_TIMELINE")) s->dbg_timeline = (uint32_t)atoi(tl) + 1u;
+    if (const char *ds = test_env("CNIIC_SUP_STOP")) s->dbg_sup_bits |= ((uint32_t)atoi(ds) & 255u) << 8;
+    if (const char *ds = test_env("CNIIC_DBG_LAUNCH")) s->dbg_sup_bits |= (uint32_t)atoi(ds) << 16;
+    if (const char *fa = test_env("CNIIC_TEST_FAIL_AT_LAUNCH")) s->fail_at = atol(fa);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
     const uint64_t n = hi - lo;
@@ -2121,7 +2121,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     s->res_bytes = s->res_wsum + (uint64_t)K * 8;
     // one zeroed arena (one fill instead of seven): result block | own partials | running sums | the fused loop's
     // buffers | moved list; the centroid kernel below writes the non-zero parts
-    s->fused = s->cells && !s->wide && !(getenv("CNIIC_KM_UNFUSED") && atoi(getenv("CNIIC_KM_UNFUSED")));
+    s->fused = s->cells && !s->wide && !(test_env("CNIIC_KM_UNFUSED") && atoi(test_env("CNIIC_KM_UNFUSED")));
     {
         auto up = [](uint64_t x) { return (x + 255) & ~255ull; };
         const uint64_t o_part = up(s->res_bytes), o_run = o_part + up(partials_dev ? 0 : W * 8), o_fp = o_run + up(s->cells ? W * 8 : 0);
@@ -2177,10 +2177,10 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
-        s->no_block_build = !(getenv("CNIIC_KM_BLOCK_BUILD") && atoi(getenv("CNIIC_KM_BLOCK_BUILD")));
+        s->no_block_build = !(test_env("CNIIC_KM_BLOCK_BUILD") && atoi(test_env("CNIIC_KM_BLOCK_BUILD")));
         // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
         // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
-        s->sup = !s->wide && nshards == 1 && getenv("CNIIC_KM_SUP") && atoi(getenv("CNIIC_KM_SUP"));
+        s->sup = !s->wide && nshards == 1 && test_env("CNIIC_KM_SUP") && atoi(test_env("CNIIC_KM_SUP"));
         if (s->sup) {
             KM_ALLOC(s->sup_rec, (uint64_t)kNumCells * kSupRecWords * 4);
             KM_ALLOC(s->sup_agg, (uint64_t)kNumCells * 4 * 8);
@@ -2190,8 +2190,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
         KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8 * 2);
         uint32_t fixed_cost = kCellFixedCost, sweep_cost = kCellSweepCost;
-        if (const char *ev = getenv("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knobs
-        if (const char *ev = getenv("CNIIC_CELL_SWEEP_COST")) sweep_cost = (uint32_t)atoi(ev);
+        if (const char *ev = test_env("CNIIC_CELL_COST")) fixed_cost = (uint32_t)atoi(ev);  // tuning knobs
+        if (const char *ev = test_env("CNIIC_CELL_SWEEP_COST")) sweep_cost = (uint32_t)atoi(ev);
         if (points_follow) {
             // the caller's partition (k_points.hip) writes ckeys / cweight / labels itself, from cell_start
             hipLaunchKernelGGL(k_cell_totals, dim3(kCellGroups), dim3(64), 0, c->stream, cell_count_d, cell_tot.as<uint2>());
@@ -2420,9 +2420,10 @@ int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done) {
 // The state as of the PREVIOUS call (have = false on the first one): the copy enqueued by this call is waited for
 // by the next, so a caller that polls after every batch of iterations never makes the GPU wait for the host.
 int km_rgbw_poll_lagged(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done, uint32_t *have) {
-    if (!s->lagged) {
-        s->lagged = std::make_unique<LaggedPoll>(s->c, s->dstate.p);
-        CNIIC_TRY(s->lagged->prepare());
+    if (!s->lagged) {   // kept only once prepare() has succeeded: a poll refused by the owner guard must not leave a half-made object
+        auto lp = std::make_unique<LaggedPoll>(s->c, s->dstate.p);   // behind that the next call would use without owning the context's slots
+        CNIIC_TRY(lp->prepare());
+        s->lagged = std::move(lp);
     }
     KmDevState h{};
     bool got = false;
@@ -2473,15 +2474,15 @@ int km_rgbw_run(KmRgbwState *s, Comm *cm) {
 
 static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     Ctx *c = s->c;
-    int batch = getenv("CNIIC_KM_BATCH") ? atoi(getenv("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
+    int batch = test_env("CNIIC_KM_BATCH") ? atoi(test_env("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
                                    // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
-    const bool batch_fixed = getenv("CNIIC_KM_BATCH") != nullptr || cm != nullptr;
+    const bool batch_fixed = test_env("CNIIC_KM_BATCH") != nullptr || cm != nullptr;
     KmDevState h;
     LaunchTimer lt;
     LaggedPoll poll(c, s->dstate.p);
     CNIIC_TRY(poll.prepare());
     poll.watch = cm;
-    const long fail_at = s->fail_at;  // fault injection (tests): this rank fails before enqueuing launch n
+    [[maybe_unused]] const long fail_at = s->fail_at;  // fault injection (testing build only): this rank fails before enqueuing launch n
     KmDevState *st_host = nullptr;
     // The mapped slot shows the host a state AT LEAST as new as the batch it asks about -- how much newer depends on timing.
     // Alone that only ends the loop a little earlier; with collectives every rank must leave after the SAME batch (a rank
@@ -2499,7 +2500,9 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
                 // assign j with update j - 1 in its prologue; the sums are triple-buffered, running sums and the
                 // centroids to compare with ping-pong (see FusedUpdate)
                 const uint32_t j = launch_no++;
+#ifdef CNIIC_TESTING
                 if (fail_at >= 0 && (long)j == fail_at) return c->fail(CNIIC_ERR_HIP, "injected failure before launch %u (CNIIC_TEST_FAIL_AT_LAUNCH)", j);
+#endif
                 auto *P = s->fused_partials.as<unsigned long long>();
                 auto *Rn = s->fused_running.as<unsigned long long>();
                 auto *Cn = s->fused_cent.as<uint32_t>();
@@ -2579,7 +2582,7 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         double cms[5] = {0, 0, 0, 0, 0};
         uint64_t cn[5] = {0, 0, 0, 0, 0};
         FILE *f = nullptr;
-        if (const char *path = getenv("CNIIC_KM_LAUNCH_TRACE")) f = fopen(path, "w");  // one line per launch: number, duration, class, what the iteration before it moved
+        if (const char *path = test_env("CNIIC_KM_LAUNCH_TRACE")) f = fopen(path, "w");  // one line per launch: number, duration, class, what the iteration before it moved
         if (f) fprintf(f, "launch,us,class,centroids_moved_before,points_moved\n");
         for (size_t i = 0; i < lt.used / 2; i++) {
             float ms = 0.f;
@@ -2603,7 +2606,7 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         CNIIC_HIP_TRY(c, hipDeviceSynchronize());
         CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_rgbw_phase), sizeof ph));
         CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_phase), zero, sizeof zero));
-        if (s->sup && getenv("CNIIC_DBG_LAUNCH")) {
+        if (s->sup && test_env("CNIIC_DBG_LAUNCH")) {
             static unsigned long long B[512][4];
             CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(B, HIP_SYMBOL(g_rgbw_blk), sizeof B));
             unsigned long long t0 = ~0ull, t1 = 0;
@@ -2622,7 +2625,7 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         }
         if (s->sup) fprintf(stderr, "assign_sup (wave clocks): prologue %llu S build %llu classify %llu first loads %llu sweeps %llu tail wait %llu flush %llu\n",
                             ph[0], ph[2], ph[3], ph[1], ph[4], ph[11], ph[5]);
-        if (const char *tf = getenv("CNIIC_DBG_TIMELINE_FILE")) {
+        if (const char *tf = test_env("CNIIC_DBG_TIMELINE_FILE")) {
             static unsigned long long T[8192][12];
             CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(T, HIP_SYMBOL(g_wave_tl), sizeof T));
             if (FILE *f = fopen(tf, "w")) {

@@ -925,8 +925,8 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.sup_piv.p, 0xff, (uint64_t)nsuper * 4, c->stream));
     CNIIC_HIP_TRY(c, hipMemsetAsync(s.sup_mask.p, 0xff, (uint64_t)nsuper * MW * 8, c->stream));
     s.no_skip = opts && (opts->flags & CNIIC_KM_NO_SKIP);
-    s.fused = s.use_tab && !s.brute && !(getenv("CNIIC_XY_UNFUSED") && atoi(getenv("CNIIC_XY_UNFUSED")));
-    if (const char *e = getenv("CNIIC_XY_DYN")) s.dyn = (uint32_t)atoi(e);
+    s.fused = s.use_tab && !s.brute && !(test_env("CNIIC_XY_UNFUSED") && atoi(test_env("CNIIC_XY_UNFUSED")));
+    if (const char *e = test_env("CNIIC_XY_DYN")) s.dyn = (uint32_t)atoi(e);
     if (s.fused) {
         const uint64_t Wb = (6 * (uint64_t)K + 4 + 2 * kXHeavyWords) * 8;   // (+ the launch's super-tile counter, a word of padding, the two bitmaps of its busy super-tiles)
         CNIIC_HIP_TRY(c, s.f_partials.alloc(3 * Wb));

@@ -9,6 +9,8 @@
 //
 //   mailbox of rank r (fine-grained HBM of r's GPU, mapped by every peer through HIP IPC):
 //       header   u32 abort                                  (a failing rank sets it on every peer: their waits end)
+//                u32 poisoned                               (set by the OWNER's kernel on its first timeout / abort: every later
+//                                                            exchange of this rank returns at once, buffer untouched -- ADVICE r03)
 //       flags    u32 [2 parities][N sources][slices]        (= the sequence number of the all-reduce the slice belongs to)
 //       slots    u8  [2 parities][N sources][cap bytes]
 //   one all-reduce = ONE kernel per rank, one block per 4 KiB slice: load the slice, store it to the N mailboxes, fence,
@@ -62,6 +64,13 @@ template <typename T, bool BYTES>
 __global__ __launch_bounds__(kMbThreads) void k_mb_all_reduce(MbArgs a, T *buf, uint64_t count) {
     constexpr uint32_t E = kMbSlice / sizeof(T), PER = E / kMbThreads;
     const uint32_t tid = threadIdx.x, sl = blockIdx.x;
+    __shared__ uint32_t s_bad;
+    // a mailbox that has seen a timeout or an abort is dead for good: the exchanges already enqueued behind the failed one (the loop
+    // keeps two iterations in flight, several slices each) must not each spin a full timeout for the same dead peer, nor add stale
+    // slots into the caller's sums
+    if (tid == 0) s_bad = __hip_atomic_load(reinterpret_cast<const uint32_t *>(a.peer[a.rank]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (s_bad) return;
     const uint64_t nwords = BYTES ? (count + 3) / 4 : count;
     const uint64_t base = (uint64_t)sl * E;
     T v[PER];
@@ -102,9 +111,14 @@ __global__ __launch_bounds__(kMbThreads) void k_mb_all_reduce(MbArgs a, T *buf, 
             }
             __builtin_amdgcn_s_sleep(4);
         }
-        if (why) __hip_atomic_store(a.status, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (why) {
+            __hip_atomic_store(a.status, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(a.peer[a.rank]) + 1, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // poisoned, sticky
+            s_bad = why;
+        }
     }
     __syncthreads();
+    if (s_bad) return;   // a slice some source never delivered: the sums stay what they were, the status word tells the host
     __threadfence_system();
     const uint8_t *src = a.peer[a.rank] + a.slots_off + (uint64_t)a.parity * a.nranks * a.cap + (uint64_t)sl * kMbSlice;
 #pragma unroll
@@ -219,9 +233,14 @@ int mailbox_connect(Mailbox *m, const uint8_t *handles) {
     return CNIIC_OK;
 }
 
+// 0 while healthy; 1: a wait for a peer's slice ran out; 2: a peer aborted
+int mailbox_status(const Mailbox *m) { return m && m->status ? (int)*reinterpret_cast<volatile uint32_t *>(m->status) : 0; }
+
 int mailbox_all_reduce(Mailbox *m, void *buf_d, uint64_t count, int kind, uint64_t timeout_ms) {
     Ctx *c = m->c;
     if (!m->connected) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce: the mailboxes are not connected yet (cniic_comm_connect_mailbox)");
+    if (const int st = mailbox_status(m))   // sticky: once a wait ran out or a peer aborted nothing more is enqueued
+        return c->fail(CNIIC_ERR_RCCL, "all_reduce over mailboxes: the exchange is dead (%s)", st == 1 ? "a wait for a peer ran out" : "a peer aborted");
     const uint32_t eb = kind == 0 ? 1 : kind == 1 ? 4 : 8;
     if ((uintptr_t)buf_d % (kind == 2 ? 8 : 4)) return c->fail(CNIIC_ERR_BAD_ARG, "all_reduce over mailboxes: the buffer must be %d-byte aligned", kind == 2 ? 8 : 4);
     const uint64_t per = m->cap / eb;  // elements per launch
@@ -240,9 +259,6 @@ int mailbox_all_reduce(Mailbox *m, void *buf_d, uint64_t count, int kind, uint64
     return CNIIC_OK;
 }
 
-// 0 while healthy; 1: a wait for a peer's slice ran out; 2: a peer aborted
-int mailbox_status(const Mailbox *m) { return m && m->status ? (int)*reinterpret_cast<volatile uint32_t *>(m->status) : 0; }
-
 void mailbox_abort(Mailbox *m) {
     if (!m || !m->connected) return;
     if (!m->side && hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) { m->side = nullptr; return; }
@@ -252,6 +268,11 @@ void mailbox_abort(Mailbox *m) {
 
 void mailbox_destroy(Mailbox *m) {
     if (!m) return;
+    // nothing of this rank may still be running on the mailbox when it is unmapped and freed: the exchanges on the context's stream
+    // (a poisoned mailbox makes them return at once) and the abort note on the side stream.  Peers are not waited for -- a peer that
+    // still stores into this mailbox holds its own mapping of the allocation, which outlives this free.
+    if (m->c && m->c->stream) (void)hipStreamSynchronize(m->c->stream);
+    if (m->side) (void)hipStreamSynchronize(m->side);
     { std::lock_guard<std::mutex> g(g_reg_mu); g_reg.erase(m->key); }
     for (uint32_t p = 0; p < m->nranks; p++)
         if (m->opened[p]) (void)hipIpcCloseMemHandle(m->peer[p]);

@@ -322,8 +322,13 @@ __global__ __launch_bounds__(kRdThreads) void k_rle_dec_expand(const uint32_t *_
     for (uint32_t j = 0; j < kRdPer; j++) {
         const uint32_t p = p0 + j;
         uint32_t col = 0;
-        if (c0 + p < total) {   // (colours past the stream stay zero: ImageBuffer::new)
-            while (s_rel[k + 1] <= p) k++;
+        // Only colours INSIDE the image are looked up (colours past the stream stay zero: ImageBuffer::new).  Records that start at or
+        // after colour n are never read by the decoder and may therefore have count 0 (k_rle_dec_verdict accepts them, as the reference
+        // does): a thread that straddles n must not walk over them -- thousands of zero-count records at start == n would keep
+        // s_rel[k + 1] <= p for every staged entry.  Inside the image every record has count >= 1, so at most p + 1 staged
+        // entries start at or before p; the bound on k is the belt to those braces.
+        if (c0 + p < total && c0 + p < n) {
+            while (k + 1 < kRdStretch + 2 && s_rel[k + 1] <= p) k++;
             col = s_col[k];
         }
         px[j] = col;

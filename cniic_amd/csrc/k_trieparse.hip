@@ -330,7 +330,9 @@ int huff_parse_leaves_dev(Ctx *c, int sym_kind, const uint8_t *stream_d, uint64_
     const int R = 1 + huff_symbol_size(sym_kind);
     if (R != 12 && R != 7) return c->fail(CNIIC_ERR_BAD_ARG, "trie parse: unknown symbol kind");
     const uint64_t span = nbytes - pos0;
-    if (span / kTpChunk >= 0x7fffffffull) return c->fail(CNIIC_ERR_BAD_ARG, "trie parse: stream too long");
+    // node, leaf and dP totals are 32-bit scans; a node is at least one byte, so below 4 GiB of span they cannot wrap.  Anything longer
+    // (no histogram makes such a decoder; a crafted stream of branch tags could) goes to the host's walk, which caps its leaves
+    if (span >= 0xfff00000ull) { *status = 2; return CNIIC_OK; }
     const uint32_t nchunks = (uint32_t)ceil_div(span, kTpChunk);
     DevBuf maps, info, entry, nodebase, leafbase, pbase, tot_d, picked;
     CNIIC_HIP_TRY(c, maps.alloc((uint64_t)nchunks * 8));

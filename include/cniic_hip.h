@@ -17,6 +17,17 @@
  *     encode/decode from rayon workers, src/bench.rs:24-28).  No process-global mutable state.
  *   - Functions return after their results are complete (stream synchronised) unless the name
  *     ends in _async.
+ *   - STREAM ORDER OF DEVICE BUFFERS.  A context enqueues on ITS stream only (the one given to
+ *     cniic_ctx_create, or its own).  A DEVICE buffer handed to any call must be complete with
+ *     respect to that stream when the call is made: either the caller produced it on the same
+ *     stream, or the caller has synchronised the producing stream (hipStreamSynchronize /
+ *     hipDeviceSynchronize / an event the context's stream waits on) first.  The library does
+ *     NOT wait for other streams: an image or byte stream still being filled by another stream
+ *     is read half-written (round 3: a `delta` decode answered "colour out of range" once in
+ *     40 000 fuzz cases because the test filled the stream's buffer on torch's stream and
+ *     decoded on a private one; tests/test_stream_order.py replays that input).  Likewise a
+ *     device OUTPUT buffer is complete when the call returns, for every stream.  Host buffers
+ *     need nothing: they are staged by copies on the context's stream.
  *   - Images are RGB8, row-major, interleaved (image::DynamicImage::to_rgb, row-major pixels()).
  *   - The library fails (CNIIC_ERR_HIP) when no gfx950 device is usable; there is no CPU fallback.
  */
@@ -49,6 +60,9 @@ int32_t     cniic_ctx_create(int32_t device, void *stream, cniic_ctx **out);
 void        cniic_ctx_destroy(cniic_ctx *ctx);
 const char *cniic_last_error(const cniic_ctx *ctx);
 int32_t     cniic_version(void);
+/* 1 for libcniic_hip_testing.so (built with -DCNIIC_TESTING: the test-suite's CNIIC_TEST_* / CNIIC_DBG_* / route-forcing environment
+ * knobs are compiled in), 0 for the release library libcniic_hip.so, which reads only the option fallbacks documented below. */
+int32_t     cniic_is_testing_build(void);
 int32_t     cniic_sync(cniic_ctx *ctx);
 /* optional helpers so callers without a HIP binding can keep images resident in HBM */
 int32_t     cniic_dev_alloc(cniic_ctx *ctx, uint64_t bytes, void **dptr);

@@ -150,6 +150,15 @@ int orc_kmeans(int kind, int mode, const int32_t *pts, const uint32_t *weight, u
 int orc_kmeans_step(int kind, const int32_t *pts, const uint32_t *weight, uint64_t n, uint32_t K,
                     const int32_t *centroids, uint32_t *labels,
                     uint64_t *sums, uint64_t *wsum, uint64_t *members, uint64_t *changed);
+/* The same step, threaded over contiguous point ranges and vectorised over the centroids (kmeans_fast.c);
+ * falls back to orc_kmeans_step outside its limits.  orc_set_lloyd_threads(t > 1) makes orc_kmeans (mode L, and
+ * with it the codecs) use it: only tests/golden/make_fullsize_digests.py and tests/test_oracle_fast.py do. */
+int orc_kmeans_step_fast(int kind, const int32_t *pts, const uint32_t *weight, uint64_t n, uint32_t K,
+                         const int32_t *centroids, uint32_t *labels,
+                         uint64_t *sums, uint64_t *wsum, uint64_t *members, uint64_t *changed, int threads);
+int  orc_kmeans_fast_ok(int kind, const int32_t *pts, uint64_t n, uint32_t K, const int32_t *centroids);
+void orc_set_lloyd_threads(int t);
+int  orc_get_lloyd_threads(void);
 /* Point::mean per cluster (clusterc.rs:83-113, 216-247) + empty-cluster reseed (deviation D2). */
 int orc_kmeans_finalize(int kind, const int32_t *pts, uint64_t n, uint32_t K, uint64_t seed,
                         uint64_t iter, const uint64_t *sums, const uint64_t *wsum,

@@ -290,7 +290,12 @@ int orc_kmeans(int kind, int mode, const int32_t *pts, const uint32_t *weight, u
     if (mode == ORC_KM_MODE_L) {
         uint64_t changed = 1;
         while (changed) { /* kmeans.rs:26-32 */
-            rc = orc_kmeans_step(kind, pts, weight, n, K, centroids, labels, sums, wsum, members, &changed);
+            /* orc_set_lloyd_threads(t > 1): the same step, threaded and vectorised (kmeans_fast.c) */
+            if (orc_get_lloyd_threads() > 1)
+                rc = orc_kmeans_step_fast(kind, pts, weight, n, K, centroids, labels, sums, wsum, members, &changed,
+                                          orc_get_lloyd_threads());
+            else
+                rc = orc_kmeans_step(kind, pts, weight, n, K, centroids, labels, sums, wsum, members, &changed);
             if (rc) break;
             st.dist_evals += n * (uint64_t)K;
             uint64_t res = 0;

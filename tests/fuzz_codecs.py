@@ -3,6 +3,7 @@
 # `hilbert(rle)` on the GPU against the oracle (tests/oracle_lib.py), bytes and round trip; with the knobs that move the
 # routes (16-bit / 32-bit delta stream, tile / per-position gather and linearise, host / GPU Huffman codes).
 import os, sys, time
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np

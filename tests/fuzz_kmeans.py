@@ -4,6 +4,7 @@
 # dynamic dealing of super-tiles): same return code, same bytes, same iteration count; the stream decodes to what the oracle
 # decodes it to.  Test infrastructure: the oracle is the checker.  FUZZ_SEED picks the sequence.
 import os, sys, time
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np

@@ -26,6 +26,29 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SYMBOLS) == decl
 
 
+def test_release_library_has_no_test_hooks():
+    """CNIIC_TEST_* / CNIIC_DBG_* and the other route-forcing knobs are compiled into the testing build only.
+    The release library exports the same symbols, says it is the release build, and none of those names is in its binary."""
+    import ctypes as C
+    rel = os.path.join(ROOT, "cniic_amd", "libcniic_hip.so")
+    tst = os.path.join(ROOT, "cniic_amd", "libcniic_hip_testing.so")
+    assert os.path.exists(rel) and os.path.exists(tst), "build both with make -C cniic_amd/csrc"
+    R, T = C.CDLL(rel), C.CDLL(tst)
+    assert R.cniic_is_testing_build() == 0 and T.cniic_is_testing_build() == 1
+    missing = [s for s in declared_symbols() if not hasattr(R, s)]
+    assert not missing, missing
+    blob_r, blob_t = open(rel, "rb").read(), open(tst, "rb").read()
+    hooks = [b"CNIIC_TEST_", b"CNIIC_DBG_", b"CNIIC_KM_SUP", b"CNIIC_KM_BATCH", b"CNIIC_HD_PHASES", b"CNIIC_TRACE_HOST", b"CNIIC_XY_UNFUSED"]
+    for h in hooks:
+        assert h not in blob_r, "release library still carries %s" % h.decode()
+        assert h in blob_t, "testing library lost %s" % h.decode()
+    # what the release build does read: the documented fallbacks of the context options
+    for name in (b"CNIIC_SP_MIN_PIXELS", b"CNIIC_KERNEL_TIMERS", b"CNIIC_COLLECTIVE_TIMEOUT_MS"):
+        assert name in blob_r
+    from cniic_amd import _lib
+    assert _lib.lib().cniic_is_testing_build() == 1     # the suite itself runs on the testing build (conftest.py)
+
+
 def test_no_oracle_in_product():
     """the product path must not route through oracle/ (tests-only infrastructure)"""
     pkg = os.path.join(ROOT, "cniic_amd")

@@ -217,3 +217,35 @@ def test_streams_that_do_not_fall_into_step(env, monkeypatch, expr, kind, shape,
             assert np.array_equal(out[:h * w * 3].cpu().numpy().reshape(h, w, 3), exp)
     finally:
         ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
+@pytest.mark.parametrize("shape", [(5, 5), (7, 9), (64, 65)])
+@pytest.mark.parametrize("zeros", [1, 4098, 9000])
+def test_rle_zero_count_records_behind_the_image_are_never_walked(env, shape, zeros):
+    """a hilbert(rle) stream whose records fill the image, followed by thousands of ZERO-count records (they start
+    at colour n, are never read by the decoder -- hilbertc.rs:304-337 zipped with the scan -- and so are legal) and one long run.  The
+    thread that straddles n (w*h is no multiple of 16) used to walk over them without bound.  Same pixels as the oracle, no hang."""
+    ctx, torch, dev = env
+    from cniic_amd import synth
+    h, w = shape
+    img = synth.uniform(w, h, synth.SEED0 + 13 + zeros)          # noise: every run has length 1
+    rc, data, _ = ctx.encode("hilbert(rle)", img)
+    assert rc == 0
+    rec0 = bytes([0, 3, 0, 0, 0, 0, 0, 0, 0, 9, 9, 9])           # count 0, colour (9, 9, 9): well-formed bytes, count the decoder would refuse IF it read it
+    last = bytes([255, 3, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3])
+    hostile = data + rec0 * zeros + last
+    rco, exp = O.decode("hilbert(rle)", hostile)
+    assert rco == 0 and np.array_equal(exp, img)
+    rc, back = ctx.decode("hilbert(rle)", hostile)
+    assert rc == 0 and np.array_equal(back, img)
+    full = torch.frombuffer(bytearray(hostile), dtype=torch.uint8).to(dev)
+    out = torch.zeros(h * w * 3, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    rc, _, _ = ctx.decode_into("hilbert(rle)", full, len(hostile), out)
+    assert rc == 0 and np.array_equal(out.cpu().numpy().reshape(h, w, 3), img)
+    # and a zero count INSIDE the image is still the reference's assert
+    bad = bytearray(hostile)
+    bad[8 + 12 * (h * w // 2)] = 0
+    assert O.decode("hilbert(rle)", bytes(bad))[0] != 0
+    rc, _ = ctx.decode("hilbert(rle)", bytes(bad), allow=(-6,))
+    assert rc != 0

@@ -2,6 +2,7 @@
 """Every codec, encode and decode, device-resident, at a few sizes and both synthetic generators: one line each (ms).  Finds what nobody
 timed -- `hilbert(rle)` decode was 1.2 s at 16384^2 until this existed.  Tools only."""
 import os, sys, time, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

@@ -3,6 +3,7 @@
 voronoi K-means per iteration, delta encode, Hufman encode, hilbert map.  Prints one line per row."""
 import json
 import os
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 import sys
 import time
 

@@ -1,5 +1,6 @@
 """One cluster-colors encode of the headline image (for rocprofv3 passes; tools only)."""
 import sys, os, time, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

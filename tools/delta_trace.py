@@ -1,4 +1,5 @@
 import sys, os
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/cniic_amd") else os.getcwd())
 import torch, cniic_amd
 from cniic_amd import _lib, synth

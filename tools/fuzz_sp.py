@@ -1,6 +1,7 @@
 """Differential fuzz: cluster-colors through the pixel partition vs through the dense table, random images / sizes / K.
 usage: fuzz_sp.py [cases] [seed]   (tools only)"""
 import os, sys, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, cniic_amd
 from cniic_amd import _lib

@@ -2,6 +2,7 @@
 brute-force repaint route (coordinates forced large via a no-op: the oracle is the checker in tests; here GPU vs GPU).
 usage: fuzz_vor.py [cases] [seed]   (tools only)"""
 import os, sys, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, cniic_amd
 from cniic_amd import _lib

@@ -2,6 +2,7 @@
 """The trait as the reference calls it -- host image in, host bytes out, and back (bench.rs:33-35, 45-46) -- for every codec at two sizes,
 beside the HBM-resident call: what the PCIe legs and the host-side staging add.  Tools only."""
 import os, sys, time, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, cniic_amd
 from cniic_amd import _lib, synth

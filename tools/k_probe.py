@@ -2,6 +2,7 @@
 """The reference's K lists (README: cluster-colors 16 .. 256, voronoi 64 .. 2048) on one 4096^2 and one 1920x1080 photo-like image: encode ms,
 iterations, ms per iteration.  Looks for a K that is slower than its neighbours.  Tools only."""
 import os, sys, time, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

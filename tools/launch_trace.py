@@ -7,6 +7,7 @@ come from this.
     python tools/launch_trace.py out.csv [size] [K]
 """
 import os
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

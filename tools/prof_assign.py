@@ -3,6 +3,7 @@
 usage: prof_assign.py [size] [K] [reps] [flags]"""
 import ctypes as C
 import os
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

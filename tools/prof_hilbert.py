@@ -1,4 +1,5 @@
 import os, sys, ctypes as C
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

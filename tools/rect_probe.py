@@ -2,6 +2,7 @@
 """Every codec both ways on RECTANGLES that are no power of two (the reference's data set, DIV2K, is ~2040 x 1356; frames are 1920 x 1080):
 the generalised Hilbert scan, the per-position gather, ragged tiles.  One line each (ms, Mpixels/s).  Tools only."""
 import os, sys, time, json
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

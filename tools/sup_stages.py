@@ -2,6 +2,7 @@
 """Timing experiment (a -DCNIIC_RGBW_PHASES build): the super-cell assign kernel cut short after a stage (CNIIC_SUP_STOP = 1 prologue,
 2 S build, 3 classification, 4 everything but the sweeps), per-launch durations of launches 2..11."""
 import os, sys
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cniic_amd

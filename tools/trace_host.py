@@ -1,5 +1,6 @@
 """Host-side stage marks of one call (CNIIC_TRACE_HOST=1): where the host waits.  usage: CNIIC_TRACE_HOST=1 python3 tools/trace_host.py [codec] [w] [h] [decode]"""
 import os, sys
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, cniic_amd
 from cniic_amd import _lib, synth

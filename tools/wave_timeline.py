@@ -6,6 +6,7 @@ end of its cell loop, after the block barrier and at its end.  Prints where the 
     python tools/wave_timeline.py <launch> [<launch> ...]
 """
 import os
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")   # the probes' knobs exist in the testing build of the library only
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
