@@ -90,6 +90,9 @@ struct KmRgbwState {
     uint32_t big_blocks_from = 10;  // launches from this one on run in blocks of kCellWavesBig waves (CNIIC_KM_BIG_BLOCKS_FROM; a huge value: never)
     uint32_t agg_launches = 3;  // launches 1 .. agg_launches book their movers round by round (CNIIC_KM_AGG_LAUNCHES)
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
+    DevBuf pk;                   // packed points of the fused loop (K <= 256, one shard): see kPk* below
+    bool packed = false;
+    uint32_t abl_launch = 0, abl_bits = 0;       // measuring builds (-DCNIIC_RGBW_ABL): CNIIC_DBG_ABL="launch:bits" leaves parts of ONE launch out (its duration is what is read; the run is wrong afterwards)
     uint32_t dbg_timeline = 0, dbg_sup_bits = 0;  // measuring knobs (CNIIC_DBG_TIMELINE, CNIIC_SUP_STOP, CNIIC_DBG_LAUNCH), read ONCE when the state is made
     long fail_at = -1;           // fault injection for the multi-rank tests (CNIIC_TEST_FAIL_AT_LAUNCH), read once as well
     uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
@@ -614,6 +617,55 @@ __device__ __forceinline__ void block_candidates(const uint2 *tab, uint32_t K, u
     }
 }
 
+// ---- packed points (round 4).  One-launch ablations (profiles/r04_assign_ablation.txt) showed where a full-schedule launch's 35 us go:
+// 11 us fixed, 7-10 us candidate builds and 14-17 us sweeps -- of which 13 us remain when a sweep does NOTHING with its points: the
+// sweeps wait for their 9 B a point (4 B key, 1 B label, 4 B weight: 61 MB a launch at ~4.5 TB/s), not for their arithmetic.  A point of
+// a cell-major list needs far less: its colour INSIDE its 8^3 cell is 9 bits (the cell is known), its label 8 bits (K <= 256), and its
+// weight -- a pixel count, 2.4 on average for a photograph -- fits 8 bits with an escape.  So the fused loop keeps ONE u32 per point:
+//     bits 0..8   colour inside the cell: r3 << 6 | g3 << 3 | b3          bits 16..23  weight, 255 = look it up in cweight[]
+//     bits 24..31 label                                                   bits 9..15   zero
+// written for every point by the launch of iteration 0 (which reads the classic arrays once), read as one load per point by every
+// later launch (4 B instead of 9 B, one load instruction instead of three, four registers in flight per sweep instead of twelve), the
+// label byte rewritten in place when a point moves, and unpacked into the u8 label array once after the loop (k_rgbw_unpack_labels).
+__device__ __forceinline__ uint32_t pk_make(uint32_t key, uint32_t w, uint32_t label) {
+    return (((key >> 16) & 7u) << 6) | (((key >> 8) & 7u) << 3) | (key & 7u) | (min(w, 255u) << 16) | (label << 24);
+}
+__device__ __forceinline__ uint32_t pk_key(uint32_t pw, uint32_t cell_base) {   // cell_base = the cell's low corner r0 << 16 | g0 << 8 | b0
+    return cell_base | ((pw & 0x1c0u) << 10) | ((pw & 0x38u) << 5) | (pw & 7u);
+}
+__device__ __forceinline__ uint32_t cell_base_key(uint32_t c) {
+    const CellBox b = cell_box(c);
+    return ((uint32_t)b.r0 << 16) | ((uint32_t)b.g0 << 8) | (uint32_t)b.b0;
+}
+// a sweep's packed words -> colour keys, labels, weights (a weight of 255 and more is fetched: rare in a photograph, every point of a flat image)
+__device__ __forceinline__ void pk_unpack(const uint32_t (&pw)[kSweep], uint32_t base, uint32_t e, int lane, uint32_t cell_base, const uint32_t *__restrict__ cweight,
+                                          uint32_t (&key)[kSweep], uint32_t (&cur)[kSweep], uint32_t (&wt)[kSweep]) {
+    bool heavy = false;
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        key[u] = pk_key(pw[u], cell_base);
+        cur[u] = pw[u] >> 24;
+        wt[u] = (pw[u] >> 16) & 255u;
+        heavy = heavy || wt[u] == 255u;
+    }
+    if (__ballot(heavy)) {
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) {
+            const uint32_t q = base + u * 64 + lane;
+            if (wt[u] == 255u && q < e) wt[u] = cweight[q];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_rgbw_unpack_labels(const uint32_t *__restrict__ pk, uint8_t *__restrict__ labels, uint64_t U) {
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= U && (reinterpret_cast<uintptr_t>(labels) & 3) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(pk + i);
+        *reinterpret_cast<uint32_t *>(labels + i) = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
+    } else {
+        for (uint64_t j = i; j < U && j < i + 4; j++) labels[j] = (uint8_t)(pk[j] >> 24);
+    }
+}
+
 // one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip.
 // AGG (the full schedule, where centroids still travel): when a centroid shifts, whole cells change hands -- every lane of the
 // sweep moves from the same old cluster to the same new one, and ten LDS atomics per point on the same ten words run one lane
@@ -623,11 +675,15 @@ __device__ __forceinline__ void block_candidates(const uint2 *tab, uint32_t K, u
 // (Not in the skip schedule: few points move per sweep there.  The kernel must not spill a single register for this: a
 // scratch segment costs every full-schedule launch 20 us)
 constexpr uint32_t kAggMin = 16;  // points that must share the first mover's (old, new) pair for a round to be worth it
-template <typename LabelT, int IDBITS, bool ALLWRITE = false, bool AGG = false>  // ALLWRITE: the labels in memory are stale (a cell kept as "uniform"): write every one
+// LAZYW (round 4): the weight of a point is needed only when it MOVES (delta sums) -- 4 of the 10 bytes a colour costs per launch and a
+// third of the loads in flight were fetched for nothing.  With LAZYW the callers do not load wt at all and a mover gathers its own.
+// LSTRIDE: 1 = a label array; 4 = the label byte of the packed points (labels = byte 3 of word 0)
+template <typename LabelT, int IDBITS, bool ALLWRITE = false, bool AGG = false, bool LAZYW = false, int LSTRIDE = 1>  // ALLWRITE: the labels in memory are stale (a cell kept as "uniform"): write every one
 __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
-                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
+                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved,
+                                             const uint32_t *__restrict__ cweight = nullptr) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     if (!first && !ALLWRITE && ncand == 1) {
         // More than half of the cells lie inside one cluster's region: ONE candidate, and every point already carries its label.
@@ -660,7 +716,7 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
                 const uint2 cc = tab[cur[u]];
                 const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
                 rem[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
-                if (rem[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
+                if (rem[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[(size_t)q * LSTRIDE] = (LabelT)nl[u]; moved++; }
             }
             anym = anym || rem[u];
         }
@@ -731,10 +787,10 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
             const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
             const uint32_t ol = cur[u], pp = p[u];
             const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
-            if (mv || ALLWRITE) labels[q] = (LabelT)nl;
+            if (mv || ALLWRITE) labels[(size_t)q * LSTRIDE] = (LabelT)nl;
             if (mv) moved++;
             if (mv || first) {
-                const uint64_t w = wt[u];  // loaded with the key: a gather here would stall every sweep that moves a point
+                const uint64_t w = LAZYW ? cweight[q] : wt[u];  // (not LAZYW: loaded with the key)
                 const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
                 atomicAdd(&acc[3 * nl + 0], rw);
                 atomicAdd(&acc[3 * nl + 1], gw);
@@ -755,10 +811,11 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
 
 // one sweep with the candidates given as a bitmask of cluster ids (K <= 256) instead of a list: the set bits are walked on the
 // scalar unit, each candidate read from the block's table (no candidate list, no compaction)
-template <typename LabelT, int IDBITS>
+template <typename LabelT, int IDBITS, bool LAZYW = false, int LSTRIDE = 1>
 __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                                   uint32_t base, uint32_t e, int lane, const unsigned long long (&nm)[4],
-                                                  const uint2 *tab, uint32_t K, LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
+                                                  const uint2 *tab, uint32_t K, LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved,
+                                                  const uint32_t *__restrict__ cweight = nullptr) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     uint32_t best[kSweep];
 #pragma unroll
@@ -783,9 +840,9 @@ __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], c
             const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
             if (mv) {
                 const uint32_t ol = cur[u], pp = p[u], nl = IDMASK - (best[u] & IDMASK);
-                labels[q] = (LabelT)nl;
+                labels[(size_t)q * LSTRIDE] = (LabelT)nl;
                 moved++;
-                const uint64_t w = wt[u];
+                const uint64_t w = LAZYW ? cweight[q] : wt[u];
                 const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
                 atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * nl + 2], bw);
                 atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[4 * K + nl], 1ull);
@@ -798,11 +855,12 @@ __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], c
 
 // the same sweep at iteration 0, where every point adds to the sums of its cluster (kept apart from
 // sweep_points: sharing the code cost the later iterations 30 % through the register allocation)
+// pkout: the packed points (above) are written here for every point of the sweep, new label included, INSTEAD of the label array
 template <typename LabelT, int IDBITS, bool ROUNDS = false>
 __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K,
-                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
+                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved, uint32_t *__restrict__ pkout = nullptr) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     uint32_t best[kSweep];
 #pragma unroll
@@ -823,7 +881,8 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
             const uint2 cc = tab[cur[u]];
             const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
             mvd[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
-            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
+            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); if (!pkout) labels[q] = (LabelT)nl[u]; moved++; }
+            if (pkout) pkout[q] = pk_make(p[u], wt[u], nl[u]);
         }
     }
     bool rem[kSweep];
@@ -979,16 +1038,32 @@ __device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIM
 // round by round, sweep_points_first), 2 = one of the next three (the same body as 0 plus the rounds for movers that share an
 // (old, new) pair, sweep_points<AGG>: whole cells change hands while the centroids still travel; the rounds' code costs the
 // launches that do not need it 4-5 us each, so only these get it), 0 = a later one.
-template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_assign_cells(
+// Round 4, measured on the headline encode (profiles/r04_lazyw_bench.json): weights gathered by the movers themselves take 27 MB out of
+// every 67.5 MB full-schedule launch and six registers out of the body (77 -> 71 VGPRs) -- and the launches get SLOWER: full schedule
+// 36.3 -> 38.3 us, skip 17.2 -> 18.4 us (a sweep with a mover now waits for a dependent gather in front of its LDS atomics; at 64
+// VGPRs, which a fourth block per CU needs, the body still spills 20 bytes a lane).  Off; -DCNIIC_LAZYW=1 builds it.
+#ifndef CNIIC_LAZYW
+#define CNIIC_LAZYW 0
+#endif
+#ifndef CNIIC_LAZYW_MINW
+#define CNIIC_LAZYW_MINW 6
+#endif
+template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1, bool PKT = false>   // PKT: the launch reads the packed points (pk_make; FIRSTK 0 and 2 only)
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW) ? CNIIC_LAZYW_MINW : 6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
-    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz) {
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz, uint32_t *__restrict__ pk) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
+    // the launches of the fused loop after the first read the packed points (pk_make); the first one writes them
+    constexpr bool PK = PKT && (FIRSTK == 0 || FIRSTK == 2) && IDBITS == 8;
+    constexpr int LS = PK ? 4 : 1;
+    LabelT *const lab_st = PK ? reinterpret_cast<LabelT *>(reinterpret_cast<uint8_t *>(pk) + 3) : labels;   // where a mover's new label goes
     __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ uint32_t s_nS[WAVES];        // full schedule: lengths of the block's shared super-cell lists
+    constexpr uint32_t kDescCap = 256;      // packed points: the descriptors of the first kDescCap cells of the block's range, staged once
+    __shared__ uint32_t s_dstart[PK ? kDescCap + 1 : 1], s_dcell[PK ? kDescCap : 1];
     __shared__ uint32_t s_piv[kBlkCells];   // ... the block-wide candidate build: per cell of the range (distance to the cube's centre << 8 | position in S) of its pivot,
     __shared__ unsigned long long s_cm[kBlkCells][2];  // ... and the members of S its pivot does not dominate
     __shared__ unsigned long long s_mm[4];  // K <= 256: bit k <=> centroid k moved in the last update
@@ -998,6 +1073,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr bool LAZYW = FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW;   // the settled launches of the fused loop: weights only for the points that move
     const uint32_t MW = (K + 63) >> 6;  // mask words per cell
     const uint32_t scap = (K + 1) / 2;  // super-cell list capacity (it rarely holds more than a quarter of the table)
     uint2 *S = tab + K + (size_t)wid * (scap + K);
@@ -1137,6 +1213,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             if (lane == 0) s_nS[wid] = n;
         }
         if (threadIdx.x == 0) s_cell = mb0;
+        if constexpr (PK) {   // the range's cell descriptors into LDS: a draw then costs no round trip to memory, and a wave can fetch two cells ahead
+            const uint32_t ncb = min(mb1 - mb0, kDescCap);
+            for (uint32_t i = threadIdx.x; i < ncb; i += THREADS) { s_dstart[i] = ne_start[mb0 + i]; s_dcell[i] = ne_cell[mb0 + i]; }
+            if (threadIdx.x == 0 && ncb) s_dstart[ncb] = ne_start[mb0 + ncb];
+        }
         // The candidates of ALL the block's cells at once (round 3; K <= 256): lane = cell, the members of the cell's list S dealt to
         // the waves.  The wave-per-cell build below costs ~300 wave-instructions a cell whatever |S| is (two wave reductions for the
         // pivot, a ballot per 64 members) and was 47 % of what a full-schedule launch issued; here a block's ~27 cells cost 8 waves x
@@ -1154,6 +1235,113 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         };
         RG_PHASE(10);
+        if constexpr (PK) {
+            // ---- packed points, fetched TWO CELLS AHEAD.  The ablations of round 4 (profiles/r04_assign_ablation.txt) put 13 us of a
+            // 35 us launch into sweeps that do nothing but wait for their points: a wave asked for a cell's points one sweep before it
+            // needed them -- less time than the request takes to come back -- seven times per launch.  With 4 B a point a cell's (at most
+            // two) sweeps are eight registers, so a wave now holds the cell it works on, the next and the one after: a request has two
+            // cells' builds and sweeps to come back in.  The descriptors come from LDS, so drawing ahead costs no round trip either.
+            auto desc = [&](uint32_t mi, uint32_t &fs, uint32_t &fe, uint32_t &fc) {
+                fs = fe = fc = 0u;
+                if (mi < mb1) {
+                    const uint32_t i = mi - mb0;
+                    if (i < kDescCap) { fs = s_dstart[i]; fe = s_dstart[i + 1]; fc = s_dcell[i]; }
+                    else { fs = ne_start[mi]; fe = ne_start[mi + 1]; fc = ne_cell[mi]; }
+                    // (wave-uniform: on the scalar side, where three cells' descriptors cost no vector register)
+                    fs = (uint32_t)__builtin_amdgcn_readfirstlane((int)fs); fe = (uint32_t)__builtin_amdgcn_readfirstlane((int)fe); fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)fc);
+                }
+            };
+            // One buffer descriptor per cell (base = its first point, size = its points: four scalar instructions) and the range check
+            // of the buffer unit does what a compare, a predicate and a 64-bit address per load did on the vector unit: the launch is
+            // bound by VALU issue (every million wave-instructions cost it 1.6 us; an early-exit sweep was ~100 of them, most of that the
+            // twelve predicated loads' addresses), and a point beyond the cell's end reads as 0 exactly as before.
+            const uint32_t voff = (uint32_t)lane * 4u;
+            auto loadpts = [&](uint32_t fs, uint32_t fe, uint32_t (&a)[kSweep], uint32_t (&b)[kSweep]) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + fs, 0, (int)((fe - fs) * 4u), 0x00020000);
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) {
+                    a[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + u * 256u), 0, 0);
+                    b[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 64 * kSweep * 4u + u * 256u), 0, 0);
+                }
+            };
+            constexpr bool AHEAD2 = FIRSTK == 0;   // (the instance with the rounds for movers, launches 1-3, has no registers for a third cell: one cell ahead there)
+            uint32_t m = draw(), mn = draw();
+            uint32_t s = 0, e = 0, c = 0, s1 = 0, e1 = 0, c1 = 0;
+            uint32_t pa[kSweep], pb[kSweep], qa[kSweep], qb[kSweep];
+            desc(m, s, e, c); loadpts(s, e, pa, pb);
+            desc(mn, s1, e1, c1); loadpts(s1, e1, qa, qb);
+            uint32_t sup = 0xffffffffu, nSup = 0;
+            while (m < mb1) {
+                const uint32_t mnn = draw();
+                uint32_t s2, e2, c2, ra[kSweep], rb[kSweep];
+                desc(mnn, s2, e2, c2);
+                if constexpr (AHEAD2) loadpts(s2, e2, ra, rb);
+                RG_PHASE(1);
+                const uint2 *Sl = S;
+                if (nsl) {
+                    const uint32_t slot = (c >> kSuperShift) - sup_first;
+                    Sl = tab + K + (size_t)slot * (scap + K);
+                    nSup = s_nS[slot];
+                } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
+                RG_PHASE(2);
+                uint32_t ncand;
+                const uint32_t ib = m - mb0;
+                const uint32_t pvw = ib < nbc ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_piv[ib]) : 0xffffffffu;
+                if (pvw != 0xffffffffu) {
+                    const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cm[ib][0]);
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]), c1w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[1]);
+                    const uint32_t c2w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]), c3w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
+                    ncand = expand_candidates<IDBITS>(Sl, pvw & 255u, ((unsigned long long)c1w << 32) | c0, ((unsigned long long)c3w << 32) | c2w, c, lane, cand, wmask, cs.rec, m, MW);
+                }
+                else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
+                                          : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+                RG_PHASE(3);
+                RG_COUNT(9, 1);
+                RG_TL1(2);
+                RG_TLC(7, 1);
+                RG_TLC(6, (e - s + 64 * kSweep - 1) / (64 * kSweep));
+                RG_TLC(8, ncand);
+                RG_TLC(9, e - s);
+                const uint32_t cbk = cell_base_key(c);
+                if constexpr (!AHEAD2) {   // (one cell ahead: this cell's second sweep is asked for now and arrives during its first)
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + s, 0, (int)((e - s) * 4u), 0x00020000);
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) pb[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 64 * kSweep * 4u + u * 256u), 0, 0);
+                }
+                {
+                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
+                    pk_unpack(pa, s, e, lane, cbk, cweight, kx, cx, wx);
+                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, s, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
+                }
+                if (s + 64 * kSweep < e) {
+                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
+                    pk_unpack(pb, s + 64 * kSweep, e, lane, cbk, cweight, kx, cx, wx);
+                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, s + 64 * kSweep, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
+                }
+                for (uint32_t base = s + 2 * 64 * kSweep; base < e; base += 64 * kSweep) {   // (a cell of more than 512 points: several ranks' copies of a colour)
+                    uint32_t pw[kSweep], kx[kSweep], cx[kSweep], wx[kSweep];
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) { const uint32_t q = base + u * 64 + lane; pw[u] = q < e ? pk[q] : 0u; }
+                    pk_unpack(pw, base, e, lane, cbk, cweight, kx, cx, wx);
+                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
+                }
+                evals += (unsigned long long)(e - s) * (ncand + 1);
+                RG_PHASE(4);
+                __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
+                m = mn; s = s1; e = e1; c = c1;
+                mn = mnn; s1 = s2; e1 = e2; c1 = c2;
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) pa[u] = qa[u];
+                if constexpr (AHEAD2) {
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) { pb[u] = qb[u]; qa[u] = ra[u]; qb[u] = rb[u]; }
+                } else {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + s1, 0, (int)((e1 - s1) * 4u), 0x00020000);
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) qa[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + u * 256u), 0, 0);
+                }
+            }
+        } else {
         uint32_t m = draw();
         uint32_t s = 0, e = 0, c = 0;
         uint32_t p[kSweep], cur[kSweep], wt[kSweep];
@@ -1162,9 +1350,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
             for (int u = 0; u < kSweep; u++) {
                 const uint32_t q = s + u * 64 + lane;
+                if constexpr (PK) { p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
+                else {
                 p[u] = q < e ? ckeys[q] : 0u;
                 cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-                wt[u] = q < e ? cweight[q] : 0u;
+                wt[u] = (!LAZYW && q < e) ? cweight[q] : 0u;
+                }
             }
         }
         uint32_t sup = 0xffffffffu, nSup = 0;
@@ -1182,6 +1373,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
             RG_PHASE(2);
             uint32_t ncand;
+#ifdef CNIIC_RGBW_ABL
+            const uint32_t abl_ = (cs.opts >> 8) & 255u;   // 1: no sweeps, 2: no candidate build, 4: no flush, 8: no point loads either
+            if (abl_ & 2u) { if (lane == 0) cand[0] = Sl[0]; __builtin_amdgcn_wave_barrier(); ncand = 1; }
+            else {
+#endif
             const uint32_t ib = m - mb0;
             const uint32_t pvw = ib < nbc ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_piv[ib]) : 0xffffffffu;
             if (pvw != 0xffffffffu) {
@@ -1192,6 +1388,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             }
             else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
                                       : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+#ifdef CNIIC_RGBW_ABL
+            }
+            if (abl_ & 1u) { m = mn; s = s_next; e = e_next; c = c_next; continue; }
+#endif
             RG_PHASE(3);
             RG_COUNT(9, 1);
             RG_TL1(2);
@@ -1207,12 +1407,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) {
                     const uint32_t qn = nts + u * 64 + lane;
+                    if constexpr (PK) { pn[u] = qn < nte ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
+                    else {
                     pn[u] = qn < nte ? ckeys[qn] : 0u;
                     curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
-                    wtn[u] = qn < nte ? cweight[qn] : 0u;
+                    wtn[u] = (!LAZYW && qn < nte) ? cweight[qn] : 0u;
+                    }
                 }
-                if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved);
-                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
+                if constexpr (PK) {
+                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
+                    pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
+                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
+                }
+                else if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved, FIRSTK == 1 ? pk : nullptr);   // (pk: null unless the loop runs on packed points)
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved, cweight);
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
@@ -1220,6 +1428,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
             RG_PHASE(4);
             __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
             m = mn; s = s_next; e = e_next; c = c_next;
+        }
         }
     } else {
         // ================================================================= SKIP schedule
@@ -1307,9 +1516,12 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) {
                         const uint32_t q = s + u * 64 + lane;
+                        if constexpr (PK) { p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
+                        else {
                         p[u] = q < e ? ckeys[q] : 0u;
                         cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-                        wt[u] = q < e ? cweight[q] : 0u;
+                        wt[u] = (!LAZYW && q < e) ? cweight[q] : 0u;
+                        }
                     }
                     // A mask is COMPLETE if it holds every centroid of the table that the cell's pivot does not dominate (the full
                     // schedule builds from the super-cell's list instead: what that list left out was beaten by ANOTHER centroid,
@@ -1369,11 +1581,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
                         for (int u = 0; u < kSweep; u++) {
                             const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
+                            if constexpr (PK) { pn[u] = qn < e ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
+                            else {
                             pn[u] = qn < e ? ckeys[qn] : 0u;
                             curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
-                            wtn[u] = qn < e ? cweight[qn] : 0u;
+                            wtn[u] = (!LAZYW && qn < e) ? cweight[qn] : 0u;
+                            }
                         }
-                        sweep_points_mask<LabelT, IDBITS>(p, cur, wt, base, e, lane, nm, tab, K, labels, acc, moved);
+                        if constexpr (PK) {
+                            uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
+                            pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
+                            sweep_points_mask<LabelT, IDBITS, false, LS>(kx, cx, wx, base, e, lane, nm, tab, K, lab_st, acc, moved);
+                        }
+                        else sweep_points_mask<LabelT, IDBITS, LAZYW>(p, cur, wt, base, e, lane, nm, tab, K, labels, acc, moved, cweight);
 #pragma unroll
                         for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                     }
@@ -1467,6 +1687,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8
     RG_TL(4);
     uint32_t i_first = threadIdx.x;
     asm volatile("" : "+v"(i_first));  // (or the flush's addresses are computed before the cell loops and held in two registers across them)
+#ifdef CNIIC_RGBW_ABL
+    if (!((cs.opts >> 8) & 4u))
+#endif
     for (uint32_t i = i_first; i < 5 * K; i += THREADS)
         if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
@@ -2106,6 +2329,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (const char *ms = test_env("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     // (every knob of the loop is read here, once: getenv() per launch raced with tools that set variables between contexts)
     if (const char *tl = test_env("CNIIC_DBG_TIMELINE")) s->dbg_timeline = (uint32_t)atoi(tl) + 1u;
+    if (const char *ab = test_env("CNIIC_DBG_ABL")) { s->abl_launch = (uint32_t)atoi(ab) + 1u; if (const char *q = strchr(ab, ':')) s->abl_bits = (uint32_t)atoi(q + 1) & 255u; }
     if (const char *ds = test_env("CNIIC_SUP_STOP")) s->dbg_sup_bits |= ((uint32_t)atoi(ds) & 255u) << 8;
     if (const char *ds = test_env("CNIIC_DBG_LAUNCH")) s->dbg_sup_bits |= (uint32_t)atoi(ds) << 16;
     if (const char *fa = test_env("CNIIC_TEST_FAIL_AT_LAUNCH")) s->fail_at = atol(fa);
@@ -2166,6 +2390,8 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         }
         if (s->wide) s->nblocks = (s->nblocks + 7) & ~7u;  // (wide: a wave each; launch_assign groups them by up to eight)
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
+        s->packed = !s->wide && nshards == 1 && test_env("CNIIC_KM_PACKED") && atoi(test_env("CNIIC_KM_PACKED"));   // (opt-in; decided for good below)
+        if (s->packed) KM_ALLOC(s->pk, std::max<uint64_t>(U, 1) * 4);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
         if (!points_follow) KM_ALLOC(s->crank, U * 4);
@@ -2181,6 +2407,11 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
         // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
         s->sup = !s->wide && nshards == 1 && test_env("CNIIC_KM_SUP") && atoi(test_env("CNIIC_KM_SUP"));
+        // Packed points are exact (the parity suite runs them) and read 27 MB a launch instead of 61 MB -- and are 2-4 % SLOWER on the
+        // headline encode (full schedule 38.1 against 36.3 us, skip 17.9 against 17.2, the first launch 81 against 76: it writes them):
+        // the launch is bound by VALU issue, not by bytes or their latency (profiles/r04_assign_ablation.txt, NOTES.md D).  Opt-in:
+        // CNIIC_KM_PACKED=1 in the testing build.
+        if (s->sup || !(test_env("CNIIC_KM_PACKED") && atoi(test_env("CNIIC_KM_PACKED")))) s->packed = false;
         if (s->sup) {
             KM_ALLOC(s->sup_rec, (uint64_t)kNumCells * kSupRecWords * 4);
             KM_ALLOC(s->sup_agg, (uint64_t)kNumCells * 4 * 8);
@@ -2310,7 +2541,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : s->max_skip, s->dbg_timeline,
-                     s->no_block_build ? 1u : 0u};
+                     (s->no_block_build ? 1u : 0u) | ((fz.on && s->abl_launch == fz.launch_no + 1) ? s->abl_bits << 8 : 0u)};
         if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
             // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
             // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.
@@ -2325,7 +2556,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             hipLaunchKernelGGL(kern, dim3(s->nblocks / wv), dim3(64 * wv), lds, c->stream,
                                (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
-                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
+                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz, (uint32_t *)nullptr);
         } else if (s->sup) {
             SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
             ss.no_skip |= s->dbg_sup_bits;
@@ -2345,19 +2576,21 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             // The same wave ranges in blocks of 12 waves, two per CU, once the run has settled (from launch big_blocks_from):
             // measured on the headline encode, the first ten launches are 5-13 us faster in blocks of 8 (three per CU), every later
             // one 1-3 us faster in blocks of 12.  (The ranges are per wave, so regrouping them needs nothing but a multiple of 12.)
+            const bool pkd = fz.on && s->packed;   // the fused loop on packed points (pk_make: opt-in, see there)
             const bool big = kCellWaves == 8 && fz.on && fz.launch_no >= s->big_blocks_from && (s->nblocks * (uint32_t)kCellWaves) % kCellWavesBig == 0;
             const uint32_t wpb = big ? kCellWavesBig : (uint32_t)kCellWaves, nblk = s->nblocks * (uint32_t)kCellWaves / wpb;
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
-            auto kern = big ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>
+            auto kern = big ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>)
                         : !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
                         : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>
-                        : fz.launch_no <= s->agg_launches ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
+                        : fz.launch_no <= s->agg_launches ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2>)
+                        : (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>);
             hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(64 * wpb), (uint32_t)lds,
                                   c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                   (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                   (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
                                   (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
-                                  part, st, cs, fz);
+                                  part, st, cs, fz, pkd ? s->pk.as<uint32_t>() : (uint32_t *)nullptr);
         }
         return;
     }
@@ -2554,6 +2787,11 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         // The tail of a run (a few thousand points still moving) is launches of ~11 us that do little: four in flight keep the GPU fed
         // as well as eight, and up to eight fewer launches past convergence (4 us each) are paid at the end.
         if (have && !batch_fixed && h.iter > 8) batch = h.moved_last < 20000 ? 4 : 8;
+    }
+    if (s->fused && s->packed) {   // the labels lived in the packed points while the loop ran: back into the label array everybody else reads
+        hipLaunchKernelGGL(k_rgbw_unpack_labels, dim3((uint32_t)ceil_div(std::max<uint64_t>(s->U, 1), (uint64_t)1024)), dim3(256), 0, c->stream,
+                           (const uint32_t *)s->pk.as<uint32_t>(), s->labels.as<uint8_t>(), s->U);
+        CNIIC_HIP_TRY(c, hipGetLastError());
     }
     // (the state the loop ended on is final -- launches past convergence change nothing: callers that only want the statistics
     // need not wait for those launches, km_rgbw_run_stats)

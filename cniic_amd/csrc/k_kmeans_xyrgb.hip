@@ -201,10 +201,12 @@ struct TileState {              // per tile, carried between iterations
     uint32_t dyn;               // the loop with the folded-in update: while at least this many centroids move (0: never), super-tiles beyond a block's first are
                                 // drawn from a counter (word 6 K + 2 of the launch's sums)
     uint32_t sup_cap;           // ... at most this many per block: its u32 accumulators hold what that many super-tiles can add (xy_create: per_block_max)
+    uint32_t tl_launch;         // measuring builds (-DCNIIC_XY_PHASES): 1 + the launch whose blocks write their timeline (CNIIC_XY_TL_LAUNCH)
 };
 
 // -DCNIIC_XY_PHASES: wave-clock totals per phase of k_xy_assign (a measuring build, never the shipped one)
 #ifdef CNIIC_XY_PHASES
+__device__ unsigned long long g_xy_tl[256][8];   // one launch (CNIIC_XY_TL_LAUNCH): per block the 100 MHz clock at entry, set-up loads out, prologue done, loop done, flush done; [5] super-tiles taken, [6] dirty ones
 __device__ unsigned long long g_xy_phase[12];
 #define XY_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
 #define XY_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
@@ -290,6 +292,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
     }
 #ifdef CNIIC_XY_PHASES
+    const bool tl_on_ = fz.on && ts.tl_launch == fz.launch_no + 1 && blockIdx.x < 256 && threadIdx.x == 0;
+    unsigned long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tl_on_) tl_[0] = wall_clock64();
     long long t_ph = clock64();
     unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     __shared__ unsigned long long s_ph[12];
@@ -356,6 +361,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             }
         }
         if (done) return;   // a launch past convergence
+#ifdef CNIIC_XY_PHASES
+        if (tl_on_) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl_[1] = wall_clock64(); }
+#endif
         __syncthreads();    // (the accumulators and counters above are in place)
 #pragma unroll
         for (int i = 0; i < kXMaxR; i++) {
@@ -418,6 +426,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     }
     const bool skip_mode = !first && !brute && nS <= ts.max_moved;
     XY_PHASE(0);
+#ifdef CNIIC_XY_PHASES
+    if (tl_on_) tl_[2] = wall_clock64();
+#endif
 
     const uint64_t npix = (uint64_t)w * h;
     uint32_t par = 0, sit = 0;
@@ -759,6 +770,9 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         }
         XY_PHASE(5);
     }
+#ifdef CNIIC_XY_PHASES
+    if (tl_on_) { tl_[3] = wall_clock64(); tl_[5] = sit; }
+#endif
     __syncthreads();
     XY_PHASE(2);
     // the host sizes the grid so that one block's pixels * max coordinate stays below 2^31: one flush at the end
@@ -780,6 +794,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
     }
     XY_PHASE(6);
 #ifdef CNIIC_XY_PHASES
+    if (tl_on_) { tl_[4] = wall_clock64(); for (int i = 0; i < 8; i++) g_xy_tl[blockIdx.x][i] = tl_[i]; }
     if (lane == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&s_ph[i], ph_[i]);
     __syncthreads();
@@ -983,7 +998,8 @@ static int xy_assign(KmXyState &s, bool fused = false) {
                        part, s.dstate.as<KmDevState>(), s.wcap, s.use_tab ? 1 : 0, s.brute ? 1 : 0,
                        TileState{s.tile_box.as<uint2>(), s.super_box.as<uint2>(), s.tile_piv.as<int4>(), s.tile_mask.as<unsigned long long>(),
                                  s.moved_list.as<uint32_t>(), s.no_skip ? 0u : kXMaxMovedSkip, s.sup_piv.as<uint32_t>(),
-                                 s.sup_mask.as<unsigned long long>(), s.dyn, s.sup_cap}, fz);
+                                 s.sup_mask.as<unsigned long long>(), s.dyn, s.sup_cap,
+                                 test_env("CNIIC_XY_TL_LAUNCH") ? (uint32_t)atoi(test_env("CNIIC_XY_TL_LAUNCH")) + 1u : 0u}, fz);
     CNIIC_HIP_TRY(c, hipGetLastError());
     return CNIIC_OK;
 }
@@ -1028,6 +1044,19 @@ int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t 
         unsigned long long ph[12], zero[12] = {0};
         CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_xy_phase), sizeof ph));
         CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_xy_phase), zero, sizeof zero));
+        if (test_env("CNIIC_XY_TL_LAUNCH")) {
+            static unsigned long long tl[256][8];
+            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_xy_tl), sizeof tl));
+            unsigned long long t0 = ~0ull;
+            for (uint32_t b = 0; b < s.nblocks && b < 256; b++) if (tl[b][0]) t0 = std::min(t0, tl[b][0]);
+            const char *names[5] = {"entry", "set-up loads back", "prologue done", "super-tile loop done", "flush done"};
+            for (int q = 0; q < 5; q++) {
+                std::vector<double> v;
+                for (uint32_t b = 0; b < s.nblocks && b < 256; b++) if (tl[b][q]) v.push_back((double)(tl[b][q] - t0) / 100.0);
+                std::sort(v.begin(), v.end());
+                if (!v.empty()) fprintf(stderr, "xy timeline launch %s: %-22s min %7.2f p50 %7.2f p90 %7.2f max %7.2f us (%zu blocks)\n", test_env("CNIIC_XY_TL_LAUNCH"), names[q], v.front(), v[v.size() / 2], v[v.size() * 9 / 10], v.back(), v.size());
+            }
+        }
         fprintf(stderr, "xy phases (wave clocks): prologue %llu skiptest %llu barrier %llu S %llu tile %llu eval %llu epilogue %llu | dirty tiles %llu iters %llu | eval: loadwait %llu candloop %llu\n",
                 ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], (unsigned long long)hst.iter, ph[8], ph[9]);
     }

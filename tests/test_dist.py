@@ -685,7 +685,8 @@ def test_bench_two_ranks_same_workload_as_one_rank_and_self_contained_c4_block()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, CNIIC_BENCH_BACKEND="gloo", CNIIC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CNIIC_USE_TESTING_LIB="0")   # bench.py runs on the release library
+    env = dict(os.environ, CNIIC_BENCH_BACKEND="gloo", CNIIC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CNIIC_USE_TESTING_LIB="0",   # bench.py runs on the release library
+               CNIIC_BENCH_MAILBOX="1")                                    # ... and the opt-in mailbox block is asked for
     common = ["--steps", "1", "--warmup", "1", "--size", "1024", "--frames-per-gpu", "2", "--cpu-sample", "0"]
     p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,

@@ -48,9 +48,13 @@ def photo(ctx, torch, dev, seed, w, h):
     return img
 
 
-def test_configs1_cluster_colors_256_at_4096(env):
-    """configs[1]: the stream bench.py times, byte for byte the oracle's (61 iterations of exact Lloyd over 6.8 M colours)"""
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_configs1_cluster_colors_256_at_4096(env, monkeypatch, packed):
+    """configs[1]: the stream bench.py times, byte for byte the oracle's (61 iterations of exact Lloyd over 6.8 M colours);
+    `packed` = 1: the same through the opt-in loop on packed points (CNIIC_KM_PACKED, k_kmeans_rgbw.hip: heavy colours take the
+    weight escape here -- the image has colours of more than 254 pixels)"""
     ctx, torch, dev = env
+    monkeypatch.setenv("CNIIC_KM_PACKED", packed)
     g = golden("c2")
     img = photo(ctx, torch, dev, SEED + g["seed_offset"], g["w"], g["h"])
     assert hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest() == g["image_sha256"], "GPU generator != numpy generator"

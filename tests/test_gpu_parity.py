@@ -97,11 +97,15 @@ def test_kmeans_step_rgbw_ties_stay(ctx):
         assert got["labels"].tolist() == [0, 1, lab] and got["changed"] == 0
 
 
+@pytest.mark.parametrize("packed", ["0", "1"])
 @pytest.mark.parametrize("block_build", ["0", "1"])
 @pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (300, (128, 160)), (200, (300, 260))])
-def test_kmeans_rgbw_run(ctx, monkeypatch, K, shape, block_build):
-    """`block_build`: the candidates of all of a block's cells built at once, one lane per cell (opt-in, CNIIC_KM_BLOCK_BUILD)"""
+def test_kmeans_rgbw_run(ctx, monkeypatch, K, shape, block_build, packed):
+    """`block_build`: the candidates of all of a block's cells built at once, one lane per cell (opt-in, CNIIC_KM_BLOCK_BUILD);
+    `packed`: the loop on packed points -- one u32 per colour (colour inside its cell, weight with an escape, label), fetched two
+    cells ahead through buffer loads (opt-in, CNIIC_KM_PACKED: exact, a third of the traffic, and no faster -- NOTES.md D)"""
     monkeypatch.setenv("CNIIC_KM_BLOCK_BUILD", block_build)
+    monkeypatch.setenv("CNIIC_KM_PACKED", packed)
     img = synth_img(*shape, seed=7 + K)
     keys, counts = O.count_freqs(keys_of(img))
     w = counts.astype(np.uint32)
