@@ -623,9 +623,10 @@ uint64_t delta_stream_len(uint64_t n);                           // u16 entries 
 int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint16_t *hot16_d, uint32_t *table_d, uint8_t *pages_d,
                       uint32_t *coldkeys_d, uint8_t *chunk_cold_d, uint32_t *overflow_d);
 struct DeltaPackScratch { DevBuf cb, co, edge, hot, hotlen; };
-int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
-                 const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint8_t *out_d, uint64_t bit_base, uint64_t *total_d,
-                 DeltaPackScratch *keep);
+int delta_pack16_count(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
+                       const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint64_t *total_d, DeltaPackScratch *keep);
+int delta_pack16_write(Ctx *c, const uint16_t *hot16_d, uint64_t n, const uint32_t *coldkeys_d, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
+                       uint64_t bit_base, DeltaPackScratch *keep);
 
 // ---- k_huff.hip ----
 // the leaves count << 32 | rank sorted by (count, rank): stable radix sort (see k_huff.hip); the result is in *out_d = buf_a or buf_b

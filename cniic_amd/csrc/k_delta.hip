@@ -32,6 +32,9 @@ namespace cniic {
 
 constexpr uint32_t kHot = 32 * 32 * 32;
 constexpr uint32_t kCold16 = 0x8000u, kPad16 = 0x8040u;  // kCold16 + r, r < 64
+#ifndef CNIIC_COUNT_WAVES
+#define CNIIC_COUNT_WAVES 8
+#endif
 constexpr int kChunk16 = 512;  // symbols per wave and step of the count and the pack: one 16-byte read per lane
 
 // DiffStream::next (hilbertc.rs:458-476) on two r | g << 8 | b << 16 pixels: the packed SignedColor key and the cube index
@@ -320,16 +323,18 @@ __global__ void k_delta_fill_codes(const uint32_t *__restrict__ keys, const uint
 
 // ---------------------------------------------------------------- pass 3: bits per chunk
 constexpr int kCountBatch = 4;  // chunks whose reads a wave has in flight together
-__global__ __launch_bounds__(256) void k_delta_count16(const uint16_t *__restrict__ hot16, uint32_t nchunks, const uint8_t *__restrict__ hotlen,
+constexpr int kCountWaves = CNIIC_COUNT_WAVES;   // waves per block: four blocks per CU (32 KiB of lengths each), so 8 -> 32 waves per CU.  The kernel is a chain of four dependent
+                                                 // round trips per batch (symbols -> cold keys -> their words -> escaped lengths): round 4, twice the waves = twice the chains in flight
+__global__ __launch_bounds__(kCountWaves * 64) void k_delta_count16(const uint16_t *__restrict__ hot16, uint32_t nchunks, const uint8_t *__restrict__ hotlen,
                                                        uint32_t *__restrict__ coldcodes /* in: keys */, const uint8_t *__restrict__ chunk_cold,
                                                        const uint32_t *__restrict__ dense, const uint8_t *__restrict__ len,
                                                        uint32_t *__restrict__ chunk_bits) {
     __shared__ __align__(16) uint8_t s_len[kHot];
-    for (uint32_t i = threadIdx.x; i < kHot / 16; i += 256) reinterpret_cast<uint4 *>(s_len)[i] = reinterpret_cast<const uint4 *>(hotlen)[i];
+    for (uint32_t i = threadIdx.x; i < kHot / 16; i += kCountWaves * 64) reinterpret_cast<uint4 *>(s_len)[i] = reinterpret_cast<const uint4 *>(hotlen)[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t nw = gridDim.x * 4;
-    for (uint32_t ch0 = blockIdx.x * 4 + (threadIdx.x >> 6); ch0 < nchunks; ch0 += nw * kCountBatch) {
+    const uint32_t nw = gridDim.x * kCountWaves;
+    for (uint32_t ch0 = blockIdx.x * kCountWaves + (threadIdx.x >> 6); ch0 < nchunks; ch0 += nw * kCountBatch) {
         uint4 q[kCountBatch];
         uint32_t ncold[kCountBatch];
 #pragma unroll
@@ -617,10 +622,11 @@ int delta_gather_hist(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint
 // the bytes before bit_base in its first word come out as zero -- the header goes there afterwards).  At least one code has
 // a length above zero.  keys_d / len_d / code_d: the U distinct symbols and their codes; dense_d: the table (overwritten at
 // the U keys).  Nothing waits: *total_d (device) = the bits written, once the stream has run; scratch lives in `keep`.
-int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
-                 const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint8_t *out_d, uint64_t bit_base, uint64_t *total_d,
-                 DeltaPackScratch *keep) {
-    if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
+// The pack in two halves: the first (codes into the tables, bits per chunk, their offsets) needs the codes but neither the output nor the
+// payload's size, so the encoder enqueues it BEFORE it waits for that size -- the wait (a round trip to the host: 25-40 us of idle GPU at
+// 16384^2) then passes while k_delta_count16 runs.
+int delta_pack16_count(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys_d, const uint8_t *chunk_cold_d, uint32_t *dense_d,
+                       const uint32_t *keys_d, const uint8_t *len_d, const uint64_t *code_d, uint64_t U, uint64_t *total_d, DeltaPackScratch *keep) {
     const uint64_t nchunks64 = delta_stream_len(n) / kChunk16;
     if (nchunks64 > 0x7fffffffull || U >= (1ull << 26)) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: too many symbols");
     const uint32_t nchunks = (uint32_t)nchunks64;
@@ -641,9 +647,18 @@ int delta_pack16(Ctx *c, const uint16_t *hot16_d, uint64_t n, uint32_t *coldkeys
     const uint32_t inline_max = im ? std::min<uint32_t>((uint32_t)atoi(im), 26u) : 26u;
     hipLaunchKernelGGL(k_delta_fill_codes, dim3((uint32_t)std::min<uint64_t>(ceil_div(U, 256), 2048)), dim3(256), 0, c->stream, keys_d, len_d, code_d, U,
                        dense_d, keep->hot.as<uint32_t>(), keep->hotlen.as<uint8_t>(), inline_max);
-    hipLaunchKernelGGL(k_delta_count16, dim3(std::min<uint32_t>(ceil_div(nchunks, 4u), 256 * 4)), dim3(256), 0, c->stream, hot16_d, nchunks,
+    hipLaunchKernelGGL(k_delta_count16, dim3(std::min<uint32_t>(ceil_div(nchunks, (uint32_t)kCountWaves), 256 * 4)), dim3(kCountWaves * 64), 0, c->stream, hot16_d, nchunks,
                        (const uint8_t *)keep->hotlen.as<uint8_t>(), coldkeys_d, chunk_cold_d, (const uint32_t *)dense_d, len_d, keep->cb.as<uint32_t>());
     CNIIC_TRY(pack_scan(c, keep->cb.as<uint32_t>(), nchunks, keep->co.as<uint64_t>(), total_d));
+    CNIIC_HIP_TRY(c, hipGetLastError());
+    return CNIIC_OK;
+}
+
+int delta_pack16_write(Ctx *c, const uint16_t *hot16_d, uint64_t n, const uint32_t *coldkeys_d, const uint8_t *len_d, const uint64_t *code_d, uint8_t *out_d,
+                       uint64_t bit_base, DeltaPackScratch *keep) {
+    if (reinterpret_cast<uintptr_t>(out_d) & 3) return c->fail(CNIIC_ERR_BAD_ARG, "huff_pack: output must be 4-byte aligned");
+    const uint32_t nchunks = (uint32_t)(delta_stream_len(n) / kChunk16);
+    constexpr uint32_t kWriteLds = (kHot + kWriteWaves * (kWriteCold + kWriteImg)) * 4;
     hipLaunchKernelGGL(k_delta_write16, dim3(std::min<uint32_t>(ceil_div(nchunks, (uint32_t)kWriteWaves), 256)), dim3(kWriteWaves * 64), kWriteLds,
                        c->stream, hot16_d, nchunks, (const uint32_t *)keep->hot.as<uint32_t>(), len_d, code_d,
                        (const uint64_t *)keep->co.as<uint64_t>(), reinterpret_cast<uint32_t *>(out_d), bit_base, pack_img_cap(),
