@@ -78,6 +78,38 @@ def test_harness_program_config1_hufman_512(tmp_path):
     assert abs(float(ratio) - len(data) / (512 * 512 * 24) * 100.0) < 1e-9 and float(err) == 0.0
 
 
+def test_harness_program_config0_reads_png_files(tmp_path):
+    """configs[0] as BASELINE.json states it: `Hufman` on one 512 x 512 RGB **PNG** through the harness (bench.rs:30 `image::open`).
+    The harness's own PNG reader (zlib inflate + the five scanline filters) against PIL-written files: 8-bit RGB (with and without
+    the optimiser, so that several filter types occur), RGBA (alpha dropped like `to_rgb8`), palette and grey -- the CSV's size is the
+    oracle's for the decoded pixels and the lossless round trip holds (error 0)."""
+    from PIL import Image
+    from cniic_amd import synth
+    exe = os.path.join(ROOT, "tools", "cniic_bench")
+    rgb = synth.photo(512, 512, synth.SEED0 + 1)
+    small = synth.photo(97, 61, synth.SEED0 + 2)
+    files = {}
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c0.png"); files["c0.png"] = rgb
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c0_opt.png", optimize=True, compress_level=9); files["c0_opt.png"] = rgb
+    rgba = np.dstack([small, np.full(small.shape[:2], 77, np.uint8)])
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "rgba.png"); files["rgba.png"] = small
+    pal = Image.fromarray(small, "RGB").quantize(64)
+    pal.save(tmp_path / "pal.png"); files["pal.png"] = np.asarray(pal.convert("RGB"))
+    grey = small[..., 1].copy()
+    Image.fromarray(grey, "L").save(tmp_path / "grey.png"); files["grey.png"] = np.dstack([grey] * 3)
+    r = subprocess.run([exe, "--codec=hufman"] + sorted(files), cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = {l.split(",")[0]: l.split(",")[1:] for l in open(tmp_path / "output" / "Hufman.csv").read().strip().split("\n")[1:]}
+    assert set(rows) == set(files)
+    for name, img in files.items():
+        rc, data, _ = O.encode("hufman", np.ascontiguousarray(img))
+        assert rc == 0 and int(rows[name][0]) == len(data), name
+        assert float(rows[name][2]) == 0.0
+    (tmp_path / "bad.png").write_bytes(open(tmp_path / "c0.png", "rb").read()[:2000])      # a cut file: refused, not crashed on
+    r = subprocess.run([exe, "--codec=hufman", "bad.png"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot read image" in r.stderr
+
+
 def test_harness_program_two_images_on_worker_threads(tmp_path):
     """two images, two worker threads with a context each, a lossy codec: two CSV rows, sizes as the oracle's"""
     from cniic_amd import synth

@@ -5,17 +5,20 @@
 // written to output/<codec.name()>.csv (bench.rs:85-91) and echoed to stdout with four more columns:
 //   mpix_per_s, iters (K-means iterations), hbm_gbps (algorithmic bytes of the encode, SURVEY 8(d), over its wall time),
 //   roofline_frac (that over the 8 TB/s of HBM3E).  A lossless codec whose
-// decode differs is an error (bench.rs:50-59).  Images are binary PPM (P6) files or synthetic specs
-// "synth:P:4096x4096:2" / "synth:U:512x512:1" (kind, size, seed offset).
+// decode differs is an error (bench.rs:50-59).  Images are PNG files (bench.rs:30 `image::open`; configs[0] is "one 512x512 RGB PNG":
+// 8-bit grey / grey+alpha / RGB / RGBA / palette, non-interlaced, inflated with zlib, alpha dropped like DynamicImage::to_rgb8),
+// binary PPM (P6) files or synthetic specs "synth:P:4096x4096:2" / "synth:U:512x512:1" (kind, size, seed offset).
 // The raw size is computed in 64 bits (the reference's u32 h*w*24 wraps above 13377^2 pixels).
 // Images run one per worker thread, each with its own cniic_ctx (the reference uses rayon, bench.rs:24-28).
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -47,6 +50,65 @@ static bool read_ppm(const std::string &path, Image &im) {
     im.rgb.resize((size_t)w * h * 3);
     f.read(reinterpret_cast<char *>(im.rgb.data()), (std::streamsize)im.rgb.size());
     return (bool)f;
+}
+
+// A PNG of the kinds a photograph comes in (bench.rs:30: `image::open(path)`, then every codec takes `to_rgb8()`): bit depth 8, colour type
+// 0 / 2 / 3 / 4 / 6, no interlace.  Chunks: IHDR, PLTE, IDAT (concatenated, one zlib stream), IEND; CRCs are not checked.
+static bool read_png(const std::string &path, Image &im) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (b.size() < 33 || memcmp(b.data(), sig, 8) != 0) return false;
+    auto be32 = [&](size_t at) { return ((uint32_t)b[at] << 24) | ((uint32_t)b[at + 1] << 16) | ((uint32_t)b[at + 2] << 8) | b[at + 3]; };
+    uint32_t w = 0, h = 0, ctype = 0;
+    std::vector<uint8_t> idat, plte;
+    for (size_t at = 8; at + 12 <= b.size();) {
+        const uint32_t len = be32(at);
+        if (at + 12 + (size_t)len > b.size()) return false;
+        const char *ty = reinterpret_cast<const char *>(&b[at + 4]);
+        const uint8_t *d = &b[at + 8];
+        if (!memcmp(ty, "IHDR", 4)) {
+            if (len != 13) return false;
+            w = be32(at + 8); h = be32(at + 12); ctype = d[9];
+            if (d[8] != 8 || d[10] != 0 || d[11] != 0 || d[12] != 0) return false;   // bit depth 8, deflate, adaptive filters, no interlace
+        } else if (!memcmp(ty, "PLTE", 4)) plte.assign(d, d + len);
+        else if (!memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+        else if (!memcmp(ty, "IEND", 4)) break;
+        at += 12 + (size_t)len;
+    }
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || !w || !h || (ctype == 3 && plte.size() < 3)) return false;
+    const size_t stride = (size_t)w * ch;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw.size()) return false;
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    im.w = w; im.h = h;
+    im.rgb.resize((size_t)w * h * 3);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t *row = &raw[(stride + 1) * y];
+        const uint8_t ft = row[0];
+        for (size_t i = 0; i < stride; i++) {   // the five scanline filters of the PNG specification, per byte, on a stride of `ch` bytes
+            const int a = i >= (size_t)ch ? cur[i - ch] : 0, up = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = up;
+            else if (ft == 3) pred = (a + up) >> 1;
+            else if (ft == 4) { const int pq = a + up - c, pa = abs(pq - a), pb = abs(pq - up), pc = abs(pq - c); pred = (pa <= pb && pa <= pc) ? a : pb <= pc ? up : c; }
+            else if (ft != 0) return false;
+            cur[i] = (uint8_t)(row[1 + i] + pred);
+        }
+        uint8_t *o = &im.rgb[(size_t)y * w * 3];
+        for (uint32_t x = 0; x < w; x++) {
+            const uint8_t *px = &cur[(size_t)x * ch];
+            if (ctype == 2 || ctype == 6) { o[3 * x] = px[0]; o[3 * x + 1] = px[1]; o[3 * x + 2] = px[2]; }
+            else if (ctype == 3) { const size_t e = (size_t)px[0] * 3; if (e + 3 > plte.size()) return false; o[3 * x] = plte[e]; o[3 * x + 1] = plte[e + 1]; o[3 * x + 2] = plte[e + 2]; }
+            else { o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = px[0]; }
+        }
+        prev.swap(cur);
+    }
+    return true;
 }
 
 static bool parse_synth(const std::string &s, Image &im) {  // synth:P:4096x4096:2
@@ -89,7 +151,7 @@ int main(int argc, char **argv) {
                 Image im;
                 void *dimg = nullptr;
                 auto fail = [&](const char *what) { std::lock_guard<std::mutex> lk(mu); fprintf(stderr, "%s: %s (%s)\n", p.c_str(), what, cniic_last_error(ctx)); failures++; };
-                if (!parse_synth(p, im) && !read_ppm(p, im)) { fail("cannot read image (binary PPM or synth:<P|U>:<w>x<h>[:seed])"); continue; }
+                if (!parse_synth(p, im) && !read_png(p, im) && !read_ppm(p, im)) { fail("cannot read image (PNG, binary PPM or synth:<P|U>:<w>x<h>[:seed])"); continue; }
                 const uint64_t npx = (uint64_t)im.w * im.h;
                 if (cniic_dev_alloc(ctx, npx * 3, &dimg) != CNIIC_OK) { fail("device allocation"); continue; }
                 if (im.synth) cniic_synth_image(ctx, im.kind, im.seed, im.w, im.h, (uint8_t *)dimg);

@@ -2,7 +2,7 @@
 # Everything under profiles/ for one round, on one MI355X:  tools/make_profiles.sh r02   (writes gpurun_out/prof_<tag>/, copy what is wanted)
 set -e
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
