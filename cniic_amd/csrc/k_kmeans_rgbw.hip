@@ -532,6 +532,9 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
+#ifdef CNIIC_RGBW_ABL
+    if (!cell_rec) return ncand;   // (ablation: no record stores)
+#endif
     // (the lane's index made afresh and pinned: or "cell_rec + 8 lane + 8" is computed once per launch and two registers hold it
     // across the cell loop -- or are spilled, and a scratch reload per cell sits in front of the loads in flight)
     uint32_t i_first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -787,7 +790,11 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
             const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
             const uint32_t ol = cur[u], pp = p[u];
             const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
+#ifdef CNIIC_RGBW_ABL
+            if ((mv || ALLWRITE) && !(reinterpret_cast<uintptr_t>(labels) >> 62)) labels[(size_t)q * LSTRIDE] = (LabelT)nl;
+#else
             if (mv || ALLWRITE) labels[(size_t)q * LSTRIDE] = (LabelT)nl;
+#endif
             if (mv) moved++;
             if (mv || first) {
                 const uint64_t w = LAZYW ? cweight[q] : wt[u];  // (not LAZYW: loaded with the key)
@@ -1374,7 +1381,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
             RG_PHASE(2);
             uint32_t ncand;
 #ifdef CNIIC_RGBW_ABL
-            const uint32_t abl_ = (cs.opts >> 8) & 255u;   // 1: no sweeps, 2: no candidate build, 4: no flush, 8: no point loads either
+            const uint32_t abl_ = (cs.opts >> 8) & 255u;   // 1: no sweeps, 2: no candidate build, 4: no flush, 16: no record stores, 32: no label stores
+            if (abl_ & 16u) cs.rec = nullptr;
+            LabelT *lab_sw = (abl_ & 32u) ? reinterpret_cast<LabelT *>(reinterpret_cast<uintptr_t>(labels) | (1ull << 62)) : labels;   // (bit 62: the sweep stores no label)
             if (abl_ & 2u) { if (lane == 0) cand[0] = Sl[0]; __builtin_amdgcn_wave_barrier(); ncand = 1; }
             else {
 #endif
@@ -1420,7 +1429,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
                 }
                 else if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved, FIRSTK == 1 ? pk : nullptr);   // (pk: null unless the loop runs on packed points)
+#ifdef CNIIC_RGBW_ABL
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, lab_sw, acc, moved, cweight);
+#else
                 else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved, cweight);
+#endif
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
