@@ -28,11 +28,15 @@ constexpr int kSleep = SLEEP;  // x 64 clocks between polls
 // an acquire on every poll invalidates the cache every time and the barrier takes 75 us)
 constexpr unsigned int kMaxSpins = 1u << 18;  // every wait gives up after ~10 ms: a grid that is not resident ends wrong, not never
 
+// Round 4: every counter and every generation word on a 128-byte line of its own.  The first version kept all of them in
+// ONE line -- every arrival and every poll of every level hit the same line, and its "xcd" figure (21 us) said more about that line than
+// about barriers (MI355X_MICROARCH.md, barrier-xcd: 4.1 / 5.9 / 9.7 us at 256 / 512 / 1024 workgroups).
+struct alignas(128) Line { unsigned int v; unsigned int pad[31]; };
 struct Bar {
-    unsigned int count, gen;          // flat
-    unsigned int xcount[8], xgen[8];  // per XCD
-    unsigned int xblocks[8];          // blocks resident on each XCD (counted in the first round)
-    unsigned int top, topgen;
+    Line count, gen;          // flat
+    Line xcount[8], xgen[8];  // per XCD
+    Line xblocks[8];          // blocks resident on each XCD (counted in the first round)
+    Line top, topgen;
 };
 
 __device__ __forceinline__ unsigned int xcc_id() {
@@ -45,12 +49,12 @@ __device__ __forceinline__ void barrier_flat(Bar *b, unsigned int nblocks) {
     __syncthreads();
     if (threadIdx.x == 0) {
         FENCE;
-        const unsigned int g = __hip_atomic_load(&b->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(&b->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
-            __hip_atomic_store(&b->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&b->gen, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int g = __hip_atomic_load(&b->gen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&b->count.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblocks - 1) {
+            __hip_atomic_store(&b->count.v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b->gen.v, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            for (unsigned int spins = 0; __hip_atomic_load(&b->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
+            for (unsigned int spins = 0; __hip_atomic_load(&b->gen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
         }
         FENCE;
     }
@@ -61,19 +65,19 @@ __device__ __forceinline__ void barrier_xcd(Bar *b, unsigned int x, unsigned int
     __syncthreads();
     if (threadIdx.x == 0) {
         FENCE;
-        const unsigned int g = __hip_atomic_load(&b->xgen[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(&b->xcount[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nx_blocks - 1) {
-            __hip_atomic_store(&b->xcount[x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int tg = __hip_atomic_load(&b->topgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(&b->top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nxcd - 1) {
-                __hip_atomic_store(&b->top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&b->topgen, tg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int g = __hip_atomic_load(&b->xgen[x].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&b->xcount[x].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nx_blocks - 1) {
+            __hip_atomic_store(&b->xcount[x].v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int tg = __hip_atomic_load(&b->topgen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&b->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nxcd - 1) {
+                __hip_atomic_store(&b->top.v, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&b->topgen.v, tg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                for (unsigned int spins = 0; __hip_atomic_load(&b->topgen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tg && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
+                for (unsigned int spins = 0; __hip_atomic_load(&b->topgen.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tg && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
             }
-            __hip_atomic_store(&b->xgen[x], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b->xgen[x].v, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            for (unsigned int spins = 0; __hip_atomic_load(&b->xgen[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
+            for (unsigned int spins = 0; __hip_atomic_load(&b->xgen[x].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g && spins < kMaxSpins; spins++) __builtin_amdgcn_s_sleep(kSleep);
         }
         FENCE;
     }
@@ -85,12 +89,12 @@ __global__ __launch_bounds__(512) void k_loop(Bar *b, int mode, int rounds, int 
     const unsigned int x = xcc_id();
     __shared__ unsigned int s_nx, s_nxcd;
     if (mode == 1) {  // census: how many blocks does my XCD hold, how many XCDs are in use?
-        if (threadIdx.x == 0) atomicAdd(&b->xblocks[x], 1u);
+        if (threadIdx.x == 0) atomicAdd(&b->xblocks[x].v, 1u);
         barrier_flat(b, gridDim.x);
         if (threadIdx.x == 0) {
             unsigned int n = 0;
-            for (int i = 0; i < 8; i++) n += __hip_atomic_load(&b->xblocks[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            s_nx = __hip_atomic_load(&b->xblocks[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 8; i++) n += __hip_atomic_load(&b->xblocks[i].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            s_nx = __hip_atomic_load(&b->xblocks[x].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_nxcd = n;
         }
         __syncthreads();
