@@ -382,6 +382,41 @@ def main():
             roofline = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one encode (%d iterations); exact cell-pruned assign over %d "
                                             "distinct colours, K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form); traffic = PMC 2*FETCH_SIZE+WRITE_SIZE "
                                             "of a full-schedule launch (profiles/traffic.json)" % (stp["iterations"], U, K), traffic)
+        def headline():
+            ln = {
+                "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
+                "config": {"workload": "configs[1]: cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
+                                       "(seed 0x636E696963+2+rank), to convergence; image and stream HBM-resident" % (K, W, H),
+                           "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
+                           "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2) if "pair_evals" in st else None,
+                           "bytes_per_px": round(nbytes / (W * H), 4),
+                           "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
+                                                                       "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
+                                                                       % (world, coll_desc(enc_collectives))},
+                "roofline": roofline, "cpu_baseline": cpu,
+            }
+            if parity is not None:
+                ln["parity"] = parity
+            return ln
+
+        # The headline is measured.  Everything below is optional blocks -- at N > 1 code that has never run on more than one device
+        # (ADVICE r03): a watchdog guarantees the line.  If the blocks are not done in time, rank 0 writes the headline with what was
+        # finished and every rank leaves (rank 0 first: its peers may be stuck in a collective with it).
+        import threading
+        limit_s = float(os.environ.get("CNIIC_BENCH_EXTRAS_LIMIT_S", "300"))
+
+        def fire():
+            if rank == 0:
+                ln = headline()
+                ln.update(extras)
+                ln["extras_error"] = "watchdog: the optional blocks did not finish within %.0f s; the line carries what had" % limit_s
+                os.write(json_fd, (json.dumps(ln) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(limit_s + (0.0 if rank == 0 else 10.0), fire)
+        watchdog.daemon = True
+        watchdog.start()
         if rank == 0 and world == 1 and not sharded:
             if not args.no_extras:
                 try:
@@ -502,23 +537,9 @@ def main():
                                     "efficiency_vs_one_gpu": round(vN / (world * v1), 4)}
             except Exception as e:   # the headline line above is already measured: an extra that fails must not take it down
                 extras["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
         if rank == 0:
-            line = {
-                "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64", "data": "synthetic",
-                "config": {"workload": "configs[1]: cluster-colors(%d) encode of one %dx%d photo-like synthetic RGB image per GPU "
-                                       "(seed 0x636E696963+2+rank), to convergence; image and stream HBM-resident" % (K, W, H),
-                           "pixels_per_gpu": W * H, "unique_colours": U, "kmeans_iterations": int(st["iterations"]),
-                           "centroids_tested_per_colour_per_iteration": round(st["pair_evals"] / max(1, st["iterations"]) / max(1, U), 2) if "pair_evals" in st else None,
-                           "bytes_per_px": round(nbytes / (W * H), 4),
-                           "parallelism": "1 GPU" if not sharded else "pixels sharded over %d GPUs (each keeps its own image's colours), shared palette: RCCL "
-                                                                       "all-reduce of the colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
-                                                                       % (world, coll_desc(enc_collectives))},
-                "roofline": roofline, "cpu_baseline": cpu,
-            }
-            if parity is not None:
-                line["parity"] = parity
+            line = headline()
             line.update(extras)
         if enc is not None:
             enc.close()

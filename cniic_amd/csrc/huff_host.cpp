@@ -74,11 +74,43 @@ static void build_tree_u64(const uint64_t *counts, uint64_t n, uint32_t *left, u
 }
 
 // the merge alone: leaf[] = count << 32 | leaf id, sorted by (count, id)
+// Round 4: the same picks in the same order, taken in STRETCHES.  While the two rarest subtrees are both leaves -- the leaf queue's next two
+// are no heavier than the branch queue's head, which does not change while branches are only appended -- leaves pair off in a loop that
+// compares two counts with a register; while they are both branches (strictly lighter than the next leaf: at equal weight a leaf goes
+// first) branches pair off likewise; only the mixed pairs take the general step.  The general loop spent its time on the mispredicted
+// "which queue" branch of every pick (0.19 ms for the 54 K leaves of a `delta` encode at 16384^2, the GPU idle meanwhile).
 static void merge_sorted_u32(const uint64_t *leaf, uint64_t n, uint32_t *left, uint32_t *right, uint32_t *nl, HuffScratch &sc) {
     std::vector<uint64_t> &bfreq = sc.bfreq;
     bfreq.resize(n > 1 ? n - 1 : 0);
     uint64_t li = 0, bi = 0, made = 0;
+    constexpr uint64_t kInf = ~0ull;
     while (made + 1 < n) {
+        {   // a stretch of leaf pairs
+            uint64_t bw = bi < made ? bfreq[bi] : kInf;
+            while (li + 1 < n && (leaf[li + 1] >> 32) <= bw) {   // (sorted: leaf[li] <= leaf[li + 1])
+                const uint64_t a = leaf[li], b = leaf[li + 1];
+                left[made] = (uint32_t)a;
+                right[made] = (uint32_t)b;
+                if (nl) nl[made] = 2;
+                bfreq[made] = (a >> 32) + (b >> 32);
+                made++;
+                li += 2;
+                if (bw == kInf) bw = bfreq[bi];   // (the queue was empty: the branch just made is its head)
+            }
+            if (made + 1 >= n) break;
+        }
+        {   // a stretch of branch pairs
+            const uint64_t lw = li < n ? leaf[li] >> 32 : kInf;
+            while (bi + 1 < made && bfreq[bi + 1] < lw) {   // (non-decreasing: bfreq[bi] <= bfreq[bi + 1]; strict: a leaf of equal weight goes first)
+                left[made] = (uint32_t)(n + bi);
+                right[made] = (uint32_t)(n + bi + 1);
+                if (nl) nl[made] = nl[bi] + nl[bi + 1];
+                bfreq[made] = bfreq[bi] + bfreq[bi + 1];
+                made++;
+                bi += 2;
+            }
+            if (made + 1 >= n) break;
+        }
         uint32_t node[2], leaves = 0;
         uint64_t f[2];
         for (int k = 0; k < 2; k++) {
