@@ -167,6 +167,14 @@ def main():
         out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         dt, (lens, st) = timed(lambda: enc.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride), warmup, steps, reduce_max)
+        # the timed streams against the oracle's (configs[3]'s one-GPU share: one palette over these frames, every frame's own stream)
+        g4 = golden("c4")
+        run_c4.parity = None
+        if g4 and rank == 0 and world == 1 and enc.dist is None and (g4.get("frames"), g4.get("w"), g4.get("h")) == (F, FRAME_W, FRAME_H) and K == 256 and not args.max_iters:
+            import hashlib
+            hs = [hashlib.sha256(out[f * stride:f * stride + lens[f]].cpu().numpy().tobytes()).hexdigest() for f in range(F)]
+            allh = hashlib.sha256("".join(hs).encode()).hexdigest()
+            run_c4.parity = {"case": "c4", "all_frames_sha256": allh, "matches_oracle": bool(allh == g4.get("all_frames_sha256") and int(st["iterations"]) == g4.get("iterations"))}
         roof, U = None, 0
         if profile:
             keys, counts = ctx.hist_rgb24(frames, npx=F * FRAME_W * FRAME_H)
@@ -332,7 +340,7 @@ def main():
                            "parallelism": "1 GPU" if world == 1 else "frames sharded over %d GPUs (each keeps its own frames' colours), shared palette: RCCL all-reduce of the "
                                           "colour occupancy (8 MiB, once) and of the K partial sums per iteration (%s)"
                                           % (world, coll_desc(enc.collectives))},
-                "roofline": roof, "cpu_baseline": cpu,
+                "roofline": roof, "cpu_baseline": cpu, "parity": run_c4.parity,
             }
         enc.close()
     elif config == "c3":
@@ -437,7 +445,7 @@ def main():
                     extras["c4_one_gpu"] = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams; frames and streams HBM-resident" % (F, F),
                                             "value": round(F * FRAME_W * FRAME_H * 2 / d4 / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3),
                                             "kmeans_iterations": int(st4["iterations"]), "unique_colours": U4, "bytes_per_px": round(nb4 / (F * FRAME_W * FRAME_H), 4),
-                                            "roofline": roof4}
+                                            "roofline": roof4, "parity": run_c4.parity}
                     if args.cpu_sample > 0:
                         extras["c4_one_gpu"]["cpu_baseline"] = cpu_all_cores(np, make_frames, expr)
                     # the reference's OWN batch semantics (bench.rs:24-35): the same frames, one palette EACH -- F independent encodes in
