@@ -79,6 +79,7 @@ static bool read_png(const std::string &path, Image &im) {
     }
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch || !w || !h || (ctype == 3 && plte.size() < 3)) return false;
+    if (w > 65535u || h > 65535u || (uint64_t)w * h > (1ull << 30)) return false;   // (a header that asks for more than any image here has)
     const size_t stride = (size_t)w * ch;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf got = (uLongf)raw.size();
