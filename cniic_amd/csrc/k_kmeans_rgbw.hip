@@ -1040,6 +1040,85 @@ __device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIM
 #define RG_TLC(i, v) do {} while (0)
 #endif
 
+// ---- the exchange folded into the launches (MbFold, common.hpp): device side
+// block 0, all threads: wait for every source's flags of exchange f.seq_prev, add the N slots in rank order into `sums`, tell the other
+// blocks.  false: a wait ran out or a peer aborted (status word, poison and the ready word are set: every block leaves).
+template <int THREADS>
+__device__ __forceinline__ bool mbf_collect(const MbFold &f, unsigned long long *sums, uint32_t *s_flag) {
+    const uint32_t tid = threadIdx.x, par = f.seq_prev & 1u;
+    const uint32_t nsl = (f.words * 8u + 4095u) / 4096u;
+    uint32_t *own = reinterpret_cast<uint32_t *>(f.peer[f.rank]);
+    if (tid == 0) *s_flag = __hip_atomic_load(own + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // poisoned before?
+    __syncthreads();
+    if (tid < f.nranks * nsl && !*s_flag) {
+        const uint32_t src = tid / nsl, sl = tid % nsl;
+        const uint32_t *fl = reinterpret_cast<const uint32_t *>(f.peer[f.rank] + f.flags_off) + ((uint64_t)par * f.nranks + src) * f.nslices_cap + sl;
+        const unsigned long long t0 = wall_clock64();
+        uint32_t spins = 0, why = 0;
+        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != f.seq_prev) {
+            if ((++spins & 31u) == 0) {
+                if (__hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { why = 2; break; }
+                if (wall_clock64() - t0 > f.wait_ticks) { why = 1; break; }
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (why) {
+            __hip_atomic_store(f.status, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(own + 1, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *s_flag = why;
+        }
+    }
+    __syncthreads();
+    const bool ok = *s_flag == 0;
+    if (ok) {
+        __threadfence_system();
+        const uint8_t *src = f.peer[f.rank] + f.slots_off + (uint64_t)par * f.nranks * f.cap;
+        for (uint32_t i = tid; i < f.words; i += THREADS) {
+            unsigned long long acc = 0;
+            for (uint32_t r = 0; r < f.nranks; r++)   // rank order: the same additions on every rank
+                acc += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + (uint64_t)r * f.cap) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(sums + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written through: the other blocks read it past their own L2)
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(f.ready, ok ? f.seq_prev : 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return ok;
+}
+// every other block, thread 0 polls: true once block 0 has put the sums of exchange f.seq_prev in place
+__device__ __forceinline__ bool mbf_wait_ready(const MbFold &f, uint32_t *s_flag) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        uint32_t v, spins = 0;
+        while ((v = __hip_atomic_load(f.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != f.seq_prev && v != 0xffffffffu) {
+            if ((++spins & 63u) == 0 && wall_clock64() - t0 > 2 * f.wait_ticks) { v = 0xffffffffu; break; }   // (block 0 never came: it has its own, shorter deadline)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_flag = v == f.seq_prev ? 0u : 1u;
+    }
+    __syncthreads();
+    return *s_flag == 0;
+}
+// the LAST block of a launch to have flushed its sums (all threads): the launch's sums into every peer's mailbox, then the flags
+template <int THREADS>
+__device__ __forceinline__ void mbf_publish(const MbFold &f, const unsigned long long *sums) {
+    const uint32_t tid = threadIdx.x, par = f.seq_pub & 1u;
+    const uint32_t nsl = (f.words * 8u + 4095u) / 4096u;
+    const uint64_t slot = f.slots_off + ((uint64_t)par * f.nranks + f.rank) * f.cap;
+    for (uint32_t i = tid; i < f.words; i += THREADS) {
+        const unsigned long long v = __hip_atomic_load(sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the blocks added with device-scope atomics)
+        for (uint32_t p = 0; p < f.nranks; p++)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.peer[p] + slot) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < f.nranks * nsl) {
+        const uint32_t p = tid / nsl, sl = tid % nsl;
+        uint32_t *fl = reinterpret_cast<uint32_t *>(f.peer[p] + f.flags_off) + ((uint64_t)par * f.nranks + f.rank) * f.nslices_cap + sl;
+        __hip_atomic_store(fl, f.seq_pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // FIRSTK: -1 = everything found out on the device (the loops without the folded-in update).  The loop with the folded-in update
 // knows which launch it enqueues: 1 = the launch of iteration 0 (alone that body has registers to spare for booking its points
 // round by round, sweep_points_first), 2 = one of the next three (the same body as 0 plus the rounds for movers that share an
@@ -1055,12 +1134,12 @@ __device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIM
 #ifndef CNIIC_LAZYW_MINW
 #define CNIIC_LAZYW_MINW 6
 #endif
-template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1, bool PKT = false>   // PKT: the launch reads the packed points (pk_make; FIRSTK 0 and 2 only)
+template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1, bool PKT = false, bool MBX = false>   // PKT: the launch reads the packed points (pk_make; FIRSTK 0 and 2 only); MBX: the exchange with the other ranks is folded into the launch (MbFold)
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW) ? CNIIC_LAZYW_MINW : 6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
-    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz, uint32_t *__restrict__ pk) {
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz, uint32_t *__restrict__ pk, MbFold mf) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
     // the launches of the fused loop after the first read the packed points (pk_make); the first one writes them
     constexpr bool PK = PKT && (FIRSTK == 0 || FIRSTK == 2) && IDBITS == 8;
@@ -1077,6 +1156,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
     constexpr int THREADS = WAVES * 64;
+    if constexpr (MBX) {
+        // the sums this launch's update reads are the other ranks' too: block 0 completes the exchange the previous launch's tail
+        // published (every rank's last block did) and adds the N slots into the buffer, the other blocks wait for its word
+        __shared__ uint32_t s_mbf;
+        if (mf.on && mf.seq_prev && !done) {
+            const bool ok = blockIdx.x == 0 ? mbf_collect<THREADS>(mf, const_cast<unsigned long long *>(fz.partials_prev), &s_mbf) : mbf_wait_ready(mf, &s_mbf);
+            if (!ok) {   // (the status word tells the host; a dead exchange ends the run -- but the launch still leaves its state record, or the
+                         // host would report a missing record instead of the exchange's failure)
+                if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
+                return;
+            }
+        }
+    }
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1708,6 +1800,21 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
     if (threadIdx.x == 0) {
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
         if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
+    }
+    if constexpr (MBX) {
+        if (mf.on) {   // the last block to get here sends the launch's sums to every rank (its own mailbox included)
+            __shared__ uint32_t s_last;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this block's atomics have been acknowledged; no cache to write back for them)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned int *tk = mf.ticket + (mf.seq_pub & 1u);
+                const bool last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+                if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (used again two launches on)
+                s_last = last ? 1u : 0u;
+            }
+            __syncthreads();
+            if (s_last) mbf_publish<THREADS>(mf, partials);
+        }
     }
     RG_PHASE(5);
     RG_TL(5);
@@ -2545,10 +2652,12 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
 // own begin and end as a profiler sees them, not an event pair around it (which adds ~4 us of dispatch per launch)
 // fused: the update of the previous iteration runs in this launch's prologue and the sums go to part_fused
 static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FusedUpdate *fused = nullptr,
-                          unsigned long long *part_fused = nullptr) {
+                          unsigned long long *part_fused = nullptr, const MbFold *fold = nullptr) {
     Ctx *c = s->c;
     FusedUpdate fz{};
     if (fused) fz = *fused;
+    MbFold mf{};
+    if (fold) mf = *fold;
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
@@ -2569,7 +2678,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             hipLaunchKernelGGL(kern, dim3(s->nblocks / wv), dim3(64 * wv), lds, c->stream,
                                (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
-                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz, (uint32_t *)nullptr);
+                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz, (uint32_t *)nullptr, mf);
         } else if (s->sup) {
             SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
             ss.no_skip |= s->dbg_sup_bits;
@@ -2593,17 +2702,18 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             const bool big = kCellWaves == 8 && fz.on && fz.launch_no >= s->big_blocks_from && (s->nblocks * (uint32_t)kCellWaves) % kCellWavesBig == 0;
             const uint32_t wpb = big ? kCellWavesBig : (uint32_t)kCellWaves, nblk = s->nblocks * (uint32_t)kCellWaves / wpb;
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
-            auto kern = big ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>)
+            const bool mbx = mf.on != 0;   // the exchange folded into the launches (km_rgbw_run_loop: fused, classic arrays, a mailbox communicator)
+            auto kern = big ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>)
                         : !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
-                        : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>
-                        : fz.launch_no <= s->agg_launches ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2>)
-                        : (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>);
+                        : fz.launch_no == 0 ? (mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>)
+                        : fz.launch_no <= s->agg_launches ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2>)
+                        : (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>);
             hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(64 * wpb), (uint32_t)lds,
                                   c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                   (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                   (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
                                   (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
-                                  part, st, cs, fz, pkd ? s->pk.as<uint32_t>() : (uint32_t *)nullptr);
+                                  part, st, cs, fz, pkd ? s->pk.as<uint32_t>() : (uint32_t *)nullptr, mf);
         }
         return;
     }
@@ -2740,6 +2850,13 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     ScopedKernelTimer timer(c, "kmeans_rgbw_iter", s->profile);  // (its stop() synchronises: profiling runs only)
     const uint64_t W = 5 * (uint64_t)s->K + 2;
     uint32_t launch_no = 0;
+    // A mailbox communicator's exchange can be FOLDED into the launches themselves (no kernel of its own between two of them; VERDICT r03
+    // item 6) when the loop is the fused one on the classic arrays with narrow labels.  OPT-IN (CNIIC_MB_FOLD=1, testing build): with the
+    // fold every block of a launch waits for block 0, which waits for the peers' previous launch -- fine with one process per GPU, which
+    // is what it is for, and a deadlock until the timeout when the ranks SHARE a GPU at full occupancy (the only set-up this build has ever
+    // run on: a rank's spinning grid leaves its peer's blocks no CU to finish on).  Tested on grids that fit side by side (tests/test_dist.py).
+    const bool fold = cm && comm_mailbox(cm) && s->fused && s->cells && !s->wide && !s->sup && !s->packed && s->nshards == 1 &&
+                      test_env("CNIIC_MB_FOLD") && atoi(test_env("CNIIC_MB_FOLD"));
     for (;;) {
         for (int b = 0; b < batch; b++) {
             if (s->fused) {
@@ -2769,9 +2886,14 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
                 fz.st_host = st_host;
                 fz.st_ring = st_ring;
                 unsigned long long *cur = P + (j % 3) * W;
-                if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur); }
-                else launch_assign(s, nullptr, nullptr, &fz, cur);
-                if (cm) CNIIC_TRY(comm_all_reduce(cm, cur, W, 2));  // the sums of all shards, before launch j + 1 reads them
+                MbFold mf{};
+                if (fold) {   // the exchange rides on the launches: this one's prologue completes the last, its tail publishes the next
+                    CNIIC_TRY(comm_async_error(cm));
+                    CNIIC_TRY(mailbox_fold_next(comm_mailbox(cm), comm_timeout_ms(cm), j == 0, (uint32_t)W, &mf));
+                }
+                if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur, fold ? &mf : nullptr); }
+                else launch_assign(s, nullptr, nullptr, &fz, cur, fold ? &mf : nullptr);
+                if (cm && !fold) CNIIC_TRY(comm_all_reduce(cm, cur, W, 2));  // the sums of all shards, before launch j + 1 reads them
                 continue;
             }
             if (s->profile && s->cells && !s->wide) {
