@@ -126,6 +126,18 @@ __global__ void k_xy_super_boxes(const uint2 *__restrict__ box, uint32_t tiles_x
     sbox[s] = make_uint2(lo[0] | (hi[0] << 8) | (lo[1] << 16) | (hi[1] << 24), lo[2] | (hi[2] << 8));
 }
 
+// floor(sum / m) for a centroid's coordinate: sum < 2^42 (a coordinate below 2^14 times at most 2^28 members), m < 2^32, quotient < 2^14.
+// A SINGLE-precision estimate is within one of it (relative error 3 * 2^-24 on a value below 2^14) and is put right with one 32 x 32 -> 64
+// product; two steps either way are allowed for.  (Until round 4: a double quotient and 64 x 64 products, five per changed centroid and
+// 2048 centroids per block and launch -- the folded-in update's 2.5 us.)
+__device__ __forceinline__ uint32_t xy_div_floor(unsigned long long sum, uint32_t m, float rm) {
+    uint32_t e = (uint32_t)((float)sum * rm);
+    unsigned long long em = (unsigned long long)e * m;
+    if (em > sum) { e--; em -= m; if (em > sum) e--; }
+    else if (em + m <= sum) { e++; em += m; if (em + m <= sum) e++; }
+    return e;
+}
+
 struct Box5 { int32_t lo[5], hi[5]; };  // x, y, r, g, b extents
 
 __device__ __forceinline__ void box_colours(Box5 &b, uint2 pb) {
@@ -186,7 +198,8 @@ constexpr uint32_t kXGroupLaunches = 3;  // launches 1 .. this book a row's move
 constexpr uint32_t kXGroupMin = 8;
 constexpr uint32_t kXHeavyWords = 64;   // super-tiles whose order of issue follows the launch before: 64 x 64 (a 8192 x 8192 image); more: index order
 
-// partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) ;
+// partials layout (u64 words): [5k+d] sums of x,y,r,g,b ; [5K+k] member count (also wsum) -- the step ABI and the loop with a separate
+// update kernel; the loop with the folded-in update keeps [d K + k] (d = 0..4 the sums, 5 the members) so that a wave reads consecutive words;
 // [6K] moved ; [6K+1] pair evaluations.  At iteration 0 the partials are the full sums of the new
 // assignment; afterwards they are SIGNED deltas of the pixels that moved, added to running sums.
 struct TileState {              // per tile, carried between iterations
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             if ((uint32_t)i < R && k < K) {
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const size_t at = q < 5 ? 5 * (size_t)k + q : 5 * (size_t)K + k;
+                    const size_t at = (size_t)q * K + k;   // (the fused loop's buffers are [6][K]: a wave's loads of one sum are consecutive words -- [K][5] | [K] cost 40 cache lines an instruction)
                     const unsigned long long dd = fz.partials_prev[at];
                     anyd[i] |= dd != 0;
                     r[i][q] = fz.running_prev[at] + dd;
@@ -379,16 +392,12 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                     atomicAdd(&s_reseed, 1u);
                 } else {
                     atomicAdd(&s_active, 1u);
-                    if (any) {  // floor(sum / m) with sum < 2^42 and m < 2^28: a double quotient is within one of it
+                    if (any) {  // floor(sum / m): see xy_div_floor
                         uint32_t q5[5];
-                        const double md = (double)m;
+                        const uint32_t m32 = (uint32_t)m;
+                        const float rm = 1.0f / (float)m32;
 #pragma unroll
-                        for (int q = 0; q < 5; q++) {
-                            unsigned long long e = (unsigned long long)((double)r[i][q] / md);
-                            if (e * m > r[i][q]) e--;
-                            else if ((e + 1) * m <= r[i][q]) e++;
-                            q5[q] = (uint32_t)e;
-                        }
+                        for (int q = 0; q < 5; q++) q5[q] = xy_div_floor(r[i][q], m32, rm);
                         nc = make_cent((int32_t)q5[0], (int32_t)q5[1], ((q5[2] & 255) << 16) | ((q5[3] & 255) << 8) | (q5[4] & 255));
                     }
                 }
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
                 }
                 if (blockIdx.x == 0) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) fz.running_new[q < 5 ? 5 * (size_t)k + q : 5 * (size_t)K + k] = r[i][q];
+                    for (int q = 0; q < 6; q++) fz.running_new[(size_t)q * K + k] = r[i][q];
                     fz.cent_new[k] = nc;
                     fz.cent_g[k] = nc;
                     fz.members_out[k] = m;
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         const uint32_t v = acc[i];
         if (v) {
             const uint32_t k = i / 6, d = i % 6;
-            atomicAdd(&partials[d < 5 ? 5 * (size_t)k + d : 5 * (size_t)K + k], (unsigned long long)(long long)(int32_t)v);
+            atomicAdd(&partials[fz.on ? (size_t)d * K + k : (d < 5 ? 5 * (size_t)k + d : 5 * (size_t)K + k)], (unsigned long long)(long long)(int32_t)v);   // (fused loop: [6][K])
         }
     }
     moved = block_reduce_sum<kXThreads>(moved);
@@ -853,14 +862,10 @@ __global__ __launch_bounds__(1024) void k_xy_update(unsigned long long *__restri
             if (any) {
                 // floor(sum / m) with sum < 2^42 and m < 2^28: a double quotient is within one of it
                 uint32_t q[5];
-                const double md = (double)m;
+                const uint32_t m32 = (uint32_t)m;
+                const float rm = 1.0f / (float)m32;
 #pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    unsigned long long e = (unsigned long long)((double)r[i] / md);
-                    if (e * m > r[i]) e--;
-                    else if ((e + 1) * m <= r[i]) e++;
-                    q[i] = (uint32_t)e;
-                }
+                for (int i = 0; i < 5; i++) q[i] = xy_div_floor(r[i], m32, rm);
                 const int4 nc = make_cent((int32_t)q[0], (int32_t)q[1], ((q[2] & 255) << 16) | ((q[3] & 255) << 8) | (q[4] & 255));
                 if (oc.x != nc.x || oc.y != nc.y || oc.z != nc.z) moved_list[1 + atomicAdd(&s_nmoved, 1u)] = k;
                 cent[k] = nc;
