@@ -36,13 +36,17 @@
 namespace cniic {
 
 constexpr int kTW = 64, kTH = 16;          // tile: 64 x 16 pixels = one wave, 16 pixels (a column) per lane
-constexpr int kSTX = 4, kSTY = 4;          // super-tile: 4 x 4 tiles = one block
+#ifndef CNIIC_XY_STY
+#define CNIIC_XY_STY 4                     // (measuring builds: 2 = super-tiles of 4 x 2 tiles, 8-wave blocks, two per CU while K <= 1024 -- NOTES D)
+#endif
+constexpr int kSTX = 4, kSTY = CNIIC_XY_STY;  // super-tile: 4 x 4 tiles = one block
 constexpr int kXWaves = kSTX * kSTY;
 constexpr int kXThreads = 64 * kXWaves;    // 1024
 constexpr int kXRows = 4;                  // rows of a tile evaluated together (4 groups per tile)
-constexpr uint32_t kXMaxK = 4096;
+constexpr int kXUS = kXWaves / 4;          // dirty tiles in work at a time: wave v takes row group v & 3 of dirty tiles number v >> 2, (v >> 2) + kXUS, ...
+constexpr uint32_t kXMaxK = kSTY == 4 ? 4096 : 2048;
 constexpr int kXMaxR = kXMaxK / kXThreads; // centroids per thread in the super-tile pass (4)
-constexpr uint32_t kSCap = 1024;           // super-tile list capacity; beyond it the super-tile is brute-forced
+constexpr uint32_t kSCap = kSTY == 4 ? 1024 : 512;  // super-tile list capacity; beyond it the super-tile is brute-forced
 constexpr uint32_t kXMaxMovedSkip = 512;   // skip schedule when at most this many centroids moved
 constexpr uint64_t kSuperPx = (uint64_t)kSTX * kTW * kSTY * kTH;
 
@@ -113,10 +117,10 @@ __global__ void k_xy_super_boxes(const uint2 *__restrict__ box, uint32_t tiles_x
                                  uint2 *__restrict__ sbox) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsuper) return;
-    const uint32_t stx = (s % super_x) * 4, sty = (s / super_x) * 4;
+    const uint32_t stx = (s % super_x) * kSTX, sty = (s / super_x) * kSTY;
     uint32_t lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
-    for (uint32_t t = 0; t < 16; t++) {
-        const uint32_t ux = stx + (t & 3), uy = sty + (t >> 2);
+    for (uint32_t t = 0; t < (uint32_t)kXWaves; t++) {
+        const uint32_t ux = stx + (t % kSTX), uy = sty + (t / kSTX);
         if (ux >= tiles_x || uy >= tiles_y) continue;
         const uint2 b = box[uy * tiles_x + ux];
         lo[0] = min(lo[0], b.x & 255); hi[0] = max(hi[0], (b.x >> 8) & 255);
@@ -255,7 +259,7 @@ struct XyFused {
 // GROUP: the instance for the launches right after the first (the loop with the folded-in update knows which launch it enqueues):
 // the same body plus the label-by-label booking of a row's movers -- whose mere presence costs the other 180 launches 6 us each.
 template <bool GROUP>
-__global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
+__global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_xy_assign(const uint8_t *__restrict__ rgb, uint32_t w, uint32_t h,
                                                          uint32_t tiles_x, uint32_t tiles_y, uint32_t super_x, uint32_t nsuper,
                                                          uint32_t K, const int4 *__restrict__ cent,
                                                          uint16_t *__restrict__ labels,
@@ -546,12 +550,12 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         XY_PHASE(1);
         __syncthreads();  // (also frees S and the strips of the previous super-tile)
         XY_PHASE(2);
-        const uint32_t dm16 = (uint32_t)__ballot(s_dirty[par][lane & (kXWaves - 1)] != 0u) & 0xffffu;  // wave-uniform
+        const uint32_t dm16 = (uint32_t)__ballot(s_dirty[par][lane & (kXWaves - 1)] != 0u) & ((1u << kXWaves) - 1u);  // wave-uniform
         const uint32_t nd = (uint32_t)__popc(dm16);
         if (nd == 0) continue;
         if (heavy_cur && threadIdx.x == 0) {   // busy: among the first to be handed out next time, the busiest before the others
             atomicOr(&heavy_cur[sup >> 6], 1ull << (sup & 63));
-            if (nd >= 8) atomicOr(&heavy_cur[kXHeavyWords + (sup >> 6)], 1ull << (sup & 63));
+            if (nd >= (uint32_t)kXWaves / 2) atomicOr(&heavy_cur[kXHeavyWords + (sup >> 6)], 1ull << (sup & 63));
         }
         const uint32_t g4 = (wv & 3) * kXRows;  // this wave's rows within a tile
         uint32_t px[2][kXRows], cur[2][kXRows];
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
         // ---- assign, one unit at a time; the next unit's pixels and labels are in flight meanwhile
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint32_t ui = (wv >> 2) + 4 * r;
+            const uint32_t ui = (wv >> 2) + kXUS * r;
             if (ui >= nd) break;  // wave-uniform
             const uint32_t (&p)[kXRows] = px[r & 1];
             const uint32_t (&c)[kXRows] = cur[r & 1];
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(kXThreads) void k_xy_assign(const uint8_t *__restri
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             XY_PHASE(8);
 #endif
-            if (ui + 4 < nd) load_unit(nth_set_bit(dm16, ui + 4), px[(r + 1) & 1], cur[(r + 1) & 1]);
+            if (ui + kXUS < nd) load_unit(nth_set_bit(dm16, ui + kXUS), px[(r + 1) & 1], cur[(r + 1) & 1]);
             const uint32_t ux0 = (stx + (slot & (kSTX - 1))) * kTW, uy0 = (sty + slot / kSTX) * kTH + g4;
             if (uy0 >= h) continue;  // wave-uniform: the tile ends above this row group
             const uint32_t nrows = min((uint32_t)kXRows, h - uy0), ucols = min((uint32_t)kTW, w - ux0);
@@ -918,12 +922,12 @@ static int xy_create(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint3
     // flushed once, so (pixels one block sees) * max coordinate must stay below 2^31; a larger image gets
     // more blocks than CUs and the surplus queues behind the resident ones.
     const uint64_t per_block_max = std::max<uint64_t>(((1ull << 31) - 1) / ((uint64_t)std::max(w, h) * kSuperPx), 1);
-    s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256), ceil_div(nsuper, per_block_max));
+    s.nblocks = (uint32_t)std::max<uint64_t>(std::min<uint32_t>(nsuper, 256 * 16 / kXWaves), ceil_div(nsuper, per_block_max));
     s.sup_cap = (uint32_t)std::min<uint64_t>(per_block_max, 0x7fffffffull);
     const uint32_t MW = (K + 63) / 64;
     // LDS budget (153 KiB dynamic): accumulators, S, the moved list, the masks, then the centroid table if it fits next
     // to at least 64 candidates per wave, and the per-wave strips take what is left (up to 256 entries each)
-    const size_t lds_max = 153 * 1024;  // (160 KiB less the kernel's static arrays: 6.2 KiB with the super-tile filter's lists and the order of issue)
+    const size_t lds_max = (kSTY == 4 ? 153 : 73) * 1024;  // (160 KiB less the kernel's static arrays: 6.2 KiB with the super-tile filter's lists and the order of issue)
     size_t fixed = (size_t)xy_acc_words(K) * 4 + (size_t)kSCap * 18 + (size_t)kXMaxMovedSkip * 16 + (size_t)kXWaves * MW * 8;
     s.use_tab = fixed + (size_t)K * 16 + (size_t)kXWaves * 64 * 18 <= lds_max;
     if (s.use_tab) fixed += (size_t)K * 16;
