@@ -35,6 +35,12 @@ constexpr uint32_t kCold16 = 0x8000u, kPad16 = 0x8040u;  // kCold16 + r, r < 64
 #ifndef CNIIC_COUNT_WAVES
 #define CNIIC_COUNT_WAVES 8
 #endif
+#ifndef CNIIC_HIST_FLY
+#define CNIIC_HIST_FLY 4
+#endif
+#ifndef CNIIC_COUNT_BATCH
+#define CNIIC_COUNT_BATCH 4
+#endif
 constexpr int kChunk16 = 512;  // symbols per wave and step of the count and the pack: one 16-byte read per lane
 
 // DiffStream::next (hilbertc.rs:458-476) on two r | g << 8 | b << 16 pixels: the packed SignedColor key and the cube index
@@ -275,12 +281,13 @@ __global__ __launch_bounds__(1024) void k_delta_hist16(const uint16_t *__restric
         }
     };
     uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {  // four reads in flight per thread (one block per CU: 64 KiB in flight)
-        const uint4 a = v[i], b = v[i + stride], c2 = v[i + 2 * stride], d = v[i + 3 * stride];
-        count8(a);
-        count8(b);
-        count8(c2);
-        count8(d);
+    constexpr int kFly = CNIIC_HIST_FLY;   // reads in flight per thread (one block per CU: kFly x 16 KiB in flight)
+    for (; i + (kFly - 1) * stride < nvec; i += kFly * stride) {
+        uint4 q[kFly];
+#pragma unroll
+        for (int f = 0; f < kFly; f++) q[f] = v[i + f * stride];
+#pragma unroll
+        for (int f = 0; f < kFly; f++) count8(q[f]);
     }
     for (; i < nvec; i += stride) count8(v[i]);
     __syncthreads();
@@ -322,7 +329,7 @@ __global__ void k_delta_fill_codes(const uint32_t *__restrict__ keys, const uint
 }
 
 // ---------------------------------------------------------------- pass 3: bits per chunk
-constexpr int kCountBatch = 4;  // chunks whose reads a wave has in flight together
+constexpr int kCountBatch = CNIIC_COUNT_BATCH;  // chunks whose reads a wave has in flight together
 constexpr int kCountWaves = CNIIC_COUNT_WAVES;   // waves per block: four blocks per CU (32 KiB of lengths each), so 8 -> 32 waves per CU.  The kernel is a chain of four dependent
                                                  // round trips per batch (symbols -> cold keys -> their words -> escaped lengths): round 4, twice the waves = twice the chains in flight
 __global__ __launch_bounds__(kCountWaves * 64) void k_delta_count16(const uint16_t *__restrict__ hot16, uint32_t nchunks, const uint8_t *__restrict__ hotlen,
