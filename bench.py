@@ -282,7 +282,7 @@ def main():
         parity = digest_check("c5", out, nbytes, W, H)
         ctx.encode("delta", img, w=W, h=H, out=out, flags=_lib.KM_PROFILE)  # one more call with the stage timers (HIP events on the ctx stream)
         stages = {}
-        for k in ("delta_gather", "delta_hist", "huff_pack"):
+        for k in ("delta_gather", "delta_hist", "delta_tree", "huff_pack", "delta_finish"):   # in call order; together the whole call (delta_tree: compaction, sort, the host's merge with the GPU idle, codes)
             ms, n = ctx.kernel_time(k)
             if n:
                 stages[k + "_ms"] = round(ms / n, 4)

@@ -844,6 +844,9 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[2], small.p, 8, hipMemcpyDeviceToHost, c->stream));
     host_trace().mark("delta: gather + hist enqueued");
+    // (stage timers, bench.py --config c5: everything between the histogram and the pack -- compaction, the leaves' sort, the host's merge with
+    // the GPU idle, the codes -- as ONE stage, so that the stages account for the whole call)
+    ScopedKernelTimer timer_tree(c, "delta_tree");
     CompactPlan plan;
     CNIIC_TRY(hist_compact_count(c, table, 27, &plan, nullptr, pages));  // (waits for the stream)
     host_trace().mark("delta: ... + count of the distinct (wait)");
@@ -944,6 +947,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     StreamOut so(c, out, cap, len);
     CNIIC_TRY(so.begin_sized(header_bytes, (nbits + 7) / 8, /*zero=*/false));  // (the pack stores every word of the payload)
     if (!counted) CNIIC_HIP_TRY(c, hipMemsetAsync(small.as<uint64_t>() + 2, 0, 8, c->stream));
+    timer_tree.stop(1);
     if (nbits) {  // (a single symbol: the zero-length code and no payload, huf.rs:140-142)
         ScopedKernelTimer timer(c, "huff_pack");   // (with the count already enqueued this times the second half alone; bench.py's stage figure says so)
         if (!counted)
@@ -953,6 +957,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
                                      &scratch));
         timer.stop(1);
     }
+    ScopedKernelTimer timer_fin(c, "delta_finish");   // (the table's sweep, the header, the decoder, the last wait)
     CNIIC_HIP_TRY(c, hipMemcpyAsync(&c->pinned_u[3], small.as<uint64_t>() + 2, 8, hipMemcpyDeviceToHost, c->stream));
     CNIIC_TRY(delta_table_clean(c));
     host_trace().mark("delta: pack enqueued");
@@ -970,6 +975,7 @@ static int encode_delta(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, ui
     }
     host_trace().mark("delta: header");
     const int rc_fin = so.finish();  // (waits for the stream)
+    timer_fin.stop(1);
     host_trace().mark("delta: pack + finish");
     host_trace().dump();
     if (rc_fin != CNIIC_OK) return rc_fin;
