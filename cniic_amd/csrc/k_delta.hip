@@ -41,6 +41,9 @@ constexpr uint32_t kCold16 = 0x8000u, kPad16 = 0x8040u;  // kCold16 + r, r < 64
 #ifndef CNIIC_COUNT_BATCH
 #define CNIIC_COUNT_BATCH 4
 #endif
+#ifndef CNIIC_HIST_PIPE
+#define CNIIC_HIST_PIPE 0
+#endif
 constexpr int kChunk16 = 512;  // symbols per wave and step of the count and the pack: one 16-byte read per lane
 
 // DiffStream::next (hilbertc.rs:458-476) on two r | g << 8 | b << 16 pixels: the packed SignedColor key and the cube index
@@ -282,6 +285,26 @@ __global__ __launch_bounds__(1024) void k_delta_hist16(const uint16_t *__restric
     };
     uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
     constexpr int kFly = CNIIC_HIST_FLY;   // reads in flight per thread (one block per CU: kFly x 16 KiB in flight)
+#if CNIIC_HIST_PIPE
+    // (measuring builds) the next kFly reads are asked for before the current ones are counted
+    if (i + (kFly - 1) * stride < nvec) {
+        uint4 q[kFly];
+#pragma unroll
+        for (int f = 0; f < kFly; f++) q[f] = v[i + f * stride];
+        i += kFly * stride;
+        for (; i + (kFly - 1) * stride < nvec; i += kFly * stride) {
+            uint4 qn[kFly];
+#pragma unroll
+            for (int f = 0; f < kFly; f++) qn[f] = v[i + f * stride];
+#pragma unroll
+            for (int f = 0; f < kFly; f++) count8(q[f]);
+#pragma unroll
+            for (int f = 0; f < kFly; f++) q[f] = qn[f];
+        }
+#pragma unroll
+        for (int f = 0; f < kFly; f++) count8(q[f]);
+    }
+#else
     for (; i + (kFly - 1) * stride < nvec; i += kFly * stride) {
         uint4 q[kFly];
 #pragma unroll
@@ -289,8 +312,12 @@ __global__ __launch_bounds__(1024) void k_delta_hist16(const uint16_t *__restric
 #pragma unroll
         for (int f = 0; f < kFly; f++) count8(q[f]);
     }
+#endif
     for (; i < nvec; i += stride) count8(v[i]);
     __syncthreads();
+#ifdef CNIIC_HIST_NOFLUSH   // (measuring builds: what the block's 32768 additions to the table cost; the result is wrong)
+    if (blockIdx.x) return;
+#endif
     for (uint32_t b = threadIdx.x; b < kHot; b += 1024) {
         const uint32_t cnt = s_bins[b];
         if (cnt) {
