@@ -68,8 +68,8 @@ def roofline_from_timers(ctx, U, K, note, traffic=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)    # (the driver's own choice; a step is 2 ms.  With 5 / 1 the first run on a fresh box read 2.28 ms:
+    ap.add_argument("--warmup", type=int, default=5)    #  the timed region began while the card was still coming up -- same kernels, same launch times)
     ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5"], default="auto",
                     help="auto = c2 at every N (same per-GPU workload, so the 1/2/4/8 curve is one workload); c4: the frame batch; c3: voronoi(2048) 4096^2; c5: `delta` 16384^2")
     ap.add_argument("--c5-size", type=int, default=16384, help="c5: image side (default: configs[4], 16384)")
