@@ -669,6 +669,49 @@ __global__ __launch_bounds__(256) void k_rgbw_unpack_labels(const uint32_t *__re
     }
 }
 
+// The 64 x kSweep points from `from` on (those below `end`; the others read as 0) as BUFFER loads: the range check is the hardware's, and
+// one load is one vector instruction with an immediate offset -- as flat loads every one of the twelve cost an add, a compare, a select
+// and a 64-bit address (about 60 of a sweep's 120 vector instructions; round 4).  from / end are wave-uniform.
+#ifndef CNIIC_RGBW_BUFLOADS
+#define CNIIC_RGBW_BUFLOADS 1
+#endif
+template <typename LabelT, bool NOWT = false>
+__device__ __forceinline__ void load_points(const uint32_t *__restrict__ ckeys, const LabelT *__restrict__ labels, const uint32_t *__restrict__ cweight,
+                                            uint32_t from, uint32_t end, int lane, uint32_t (&p)[kSweep], uint32_t (&cur)[kSweep], uint32_t (&wt)[kSweep]) {
+#if CNIIC_RGBW_BUFLOADS
+    // (the descriptors keep the ARRAY's base -- scalar registers the kernel holds anyway -- and end at `end`; the lane's offset carries `from`:
+    // a descriptor per range start cost nine more live scalar registers and spilled)
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)from), e = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
+    const uint32_t lim = e > f ? e : 0u;   // (an empty range: no record at all)
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(ckeys), 0, (int)(lim * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<LabelT *>(labels), 0, (int)(lim * (uint32_t)sizeof(LabelT)), 0x00020000);
+    const uint32_t q0 = f + (uint32_t)lane;
+    const uint32_t v4 = q0 * 4u, vl = q0 * (uint32_t)sizeof(LabelT);
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        p[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)(v4 + u * 256u), 0, 0);
+        if constexpr (sizeof(LabelT) == 1) cur[u] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rl, (int)(vl + u * 64u), 0, 0);
+        else cur[u] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rl, (int)(vl + u * 128u), 0, 0);
+    }
+    if constexpr (!NOWT) {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cweight), 0, (int)(lim * 4u), 0x00020000);
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) wt[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(v4 + u * 256u), 0, 0);
+    } else {
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) wt[u] = 0u;
+    }
+#else
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        const uint32_t q = from + u * 64 + lane;
+        p[u] = q < end ? ckeys[q] : 0u;
+        cur[u] = q < end ? (uint32_t)labels[q] : 0u;
+        wt[u] = (!NOWT && q < end) ? cweight[q] : 0u;
+    }
+#endif
+}
+
 // one sweep: the 64 x kSweep points starting at `base` (those < e) against the candidate strip.
 // AGG (the full schedule, where centroids still travel): when a centroid shifts, whole cells change hands -- every lane of the
 // sweep moves from the same old cluster to the same new one, and ten LDS atomics per point on the same ten words run one lane
@@ -1446,16 +1489,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
         uint32_t p[kSweep], cur[kSweep], wt[kSweep];
         if (m < mb1) {
             s = ne_start[m]; e = ne_start[m + 1]; c = ne_cell[m];
+            if constexpr (PK) {
 #pragma unroll
-            for (int u = 0; u < kSweep; u++) {
-                const uint32_t q = s + u * 64 + lane;
-                if constexpr (PK) { p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
-                else {
-                p[u] = q < e ? ckeys[q] : 0u;
-                cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-                wt[u] = (!LAZYW && q < e) ? cweight[q] : 0u;
-                }
-            }
+                for (int u = 0; u < kSweep; u++) { const uint32_t q = s + u * 64 + lane; p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
+            } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
         }
         uint32_t sup = 0xffffffffu, nSup = 0;
         while (m < mb1) {
@@ -1505,16 +1542,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 const uint32_t nts = more ? base + 64 * kSweep : s_next;
                 const uint32_t nte = more ? e : e_next;
                 uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
+                if constexpr (PK) {
 #pragma unroll
-                for (int u = 0; u < kSweep; u++) {
-                    const uint32_t qn = nts + u * 64 + lane;
-                    if constexpr (PK) { pn[u] = qn < nte ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
-                    else {
-                    pn[u] = qn < nte ? ckeys[qn] : 0u;
-                    curn[u] = qn < nte ? (uint32_t)labels[qn] : 0u;
-                    wtn[u] = (!LAZYW && qn < nte) ? cweight[qn] : 0u;
-                    }
-                }
+                    for (int u = 0; u < kSweep; u++) { const uint32_t qn = nts + u * 64 + lane; pn[u] = qn < nte ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
+                } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, nts, nte, lane, pn, curn, wtn);
                 if constexpr (PK) {
                     uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
                     pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
@@ -1618,16 +1649,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     const uint32_t c = cw & 0xffffu, pid = (cw >> 16) & 0x7fffu;
                     const uint32_t s = ne_start[m], e = ne_start[m + 1];
                     uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+                    if constexpr (PK) {
 #pragma unroll
-                    for (int u = 0; u < kSweep; u++) {
-                        const uint32_t q = s + u * 64 + lane;
-                        if constexpr (PK) { p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
-                        else {
-                        p[u] = q < e ? ckeys[q] : 0u;
-                        cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-                        wt[u] = (!LAZYW && q < e) ? cweight[q] : 0u;
-                        }
-                    }
+                        for (int u = 0; u < kSweep; u++) { const uint32_t q = s + u * 64 + lane; p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
+                    } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
                     // A mask is COMPLETE if it holds every centroid of the table that the cell's pivot does not dominate (the full
                     // schedule builds from the super-cell's list instead: what that list left out was beaten by ANOTHER centroid,
                     // which may have moved since).  While the pivot of a complete mask stands where it stood, every centroid that
@@ -1683,16 +1708,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
 #endif
                     for (uint32_t base = s; base < e; base += 64 * kSweep) {
                         uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
+                        if constexpr (PK) {
 #pragma unroll
-                        for (int u = 0; u < kSweep; u++) {
-                            const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
-                            if constexpr (PK) { pn[u] = qn < e ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
-                            else {
-                            pn[u] = qn < e ? ckeys[qn] : 0u;
-                            curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
-                            wtn[u] = (!LAZYW && qn < e) ? cweight[qn] : 0u;
-                            }
-                        }
+                            for (int u = 0; u < kSweep; u++) { const uint32_t qn = base + 64 * kSweep + u * 64 + lane; pn[u] = qn < e ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
+                        } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
                         if constexpr (PK) {
                             uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
                             pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
@@ -1740,13 +1759,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
 #endif
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) {
-                    const uint32_t q = s + u * 64 + lane;
-                    p[u] = q < e ? ckeys[q] : 0u;
-                    cur[u] = q < e ? (uint32_t)labels[q] : 0u;
-                    wt[u] = q < e ? cweight[q] : 0u;
-                }
+                load_points<LabelT>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
                 // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
                 const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
 #ifdef CNIIC_RGBW_PHASES
@@ -1758,13 +1771,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
 #endif
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) {
-                        const uint32_t qn = base + 64 * kSweep + u * 64 + lane;
-                        pn[u] = qn < e ? ckeys[qn] : 0u;
-                        curn[u] = qn < e ? (uint32_t)labels[qn] : 0u;
-                        wtn[u] = qn < e ? cweight[qn] : 0u;
-                    }
+                    load_points<LabelT>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
                     sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
