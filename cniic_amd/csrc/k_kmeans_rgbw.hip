@@ -463,14 +463,15 @@ struct Dominance {
 __device__ __forceinline__ uint32_t wave_all_min(uint32_t v) { return wave_reduce_min(v); }  // (DPP: the result is in every lane)
 
 // position in `list` (n entries, ascending cluster id) of the centroid nearest the cube centre; lowest position on ties
+// (ONE reduction over distance << 12 | position: a distance is below 3 * 255^2 < 2^18 and a list holds at most 4096 entries; until round 4 two
+// reductions, first the distance, then the position among the lanes that had it -- a sixth of a candidate build's vector instructions)
 __device__ __forceinline__ uint32_t nearest_to_centre(const uint2 *list, uint32_t n, const CellBox &bx, int32_t ext, int lane) {
-    uint32_t bd = 0xffffffffu, be = 0xffffffffu;
+    uint32_t bd = 0xfffffu, be = 4095u;
     for (uint32_t e = lane; e < n; e += 64) {
         const uint32_t d = centre_dist(list[e].x, bx, ext);
         if (d < bd) { bd = d; be = e; }
     }
-    const uint32_t dmin = wave_all_min(bd);
-    return wave_all_min(bd == dmin ? be : 0xffffffffu);
+    return wave_all_min((bd << 12) | be) & 4095u;
 }
 
 // S = the centroids of `tab` (ascending id) that can be nearest somewhere in super-cell `sup`; returns |S| >= 1
