@@ -429,34 +429,35 @@ constexpr uint32_t kMaxMovedSkip = 64;  // skip schedule when at most this many 
                                         // headline encode: 128 -> 1.92 ms of assign launches, 96 -> 1.90, 64 -> 1.88, 40 -> 1.88: above ~60 moved
                                         // centroids a third of the cells are dirty and dealing them round-robin costs more than the full schedule's ranges)
 
-// squared distance from colour key ck to the centre of the cube with low corner bx and side ext + 1
+// Both tests of the pruning on PACKED colour bytes (round 4; until then three field extractions, three products and their sums each: 10 and 21
+// vector instructions, a third of a candidate build).  r | g | b in bytes 2, 1, 0 of a key, byte 3 zero; a cube is aligned, so lo + ext <= 255.
+__device__ __forceinline__ uint32_t pack_rgb(int32_t r, int32_t g, int32_t b) { return ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b; }
+
+// squared distance from colour key ck to the centre of the cube with low corner bx and side ext + 1:
+// |v - c|^2 = v.v - 2 v.c + c.c, three byte dot products (two of them per candidate)
 __device__ __forceinline__ uint32_t centre_dist(uint32_t ck, const CellBox &bx, int32_t ext) {
     const int32_t h = (ext + 1) >> 1;
-    const int32_t dr = (int32_t)((ck >> 16) & 255) - bx.r0 - h, dg = (int32_t)((ck >> 8) & 255) - bx.g0 - h,
-                  db = (int32_t)(ck & 255) - bx.b0 - h;
-    return (uint32_t)(__mul24(dr, dr) + __mul24(dg, dg) + __mul24(db, db));
+    const uint32_t c = pack_rgb(bx.r0 + h, bx.g0 + h, bx.b0 + h);
+    return dot4u8(ck, ck, dot4u8(c, c, 0)) - 2u * dot4u8(ck, c, 0);
 }
 
-// a pivot centroid against one cube: a[2 i] = c*_i - 2 lo_i, a[2 i + 1] = c*_i - 2 hi_i
+// a pivot centroid p against one cube [lo, lo + ext]^3.  max over the cube of d(x, p) - d(x, v) -- v can be nearest (or tie) somewhere in the
+// cube only if it is >= 0 -- is, per channel with d = p - v, max(d (v + p - 2 lo), d (v + p - 2 hi)) = d (v + p - 2 lo) + 2 ext max(0, -d);
+// summed: (p.p - 2 p.lo - ext sum(p)) - v.v + v.lo + v.hi + ext sad(p, v)      [sum max(0, -d) = (sad(p, v) - sum(p) + sum(v)) / 2]
+// -- a constant of the pivot, three byte dot products, one sum of absolute differences and one multiply-add per candidate.
 struct Dominance {
-    int32_t p[3], a[6];
-    __device__ __forceinline__ void set(const CellBox &bx, int32_t ext, uint32_t pivot) {
-        p[0] = (pivot >> 16) & 255; p[1] = (pivot >> 8) & 255; p[2] = pivot & 255;
-        const int32_t lo[3] = {bx.r0, bx.g0, bx.b0};
-#pragma unroll
-        for (int i = 0; i < 3; i++) { a[2 * i] = p[i] - 2 * lo[i]; a[2 * i + 1] = p[i] - 2 * (lo[i] + ext); }
+    uint32_t ppk, lopk, hipk;
+    int32_t cp, ext;
+    __device__ __forceinline__ void set(const CellBox &bx, int32_t e, uint32_t pivot) {
+        ppk = pivot & 0xffffffu;
+        ext = e;
+        lopk = pack_rgb(bx.r0, bx.g0, bx.b0);
+        hipk = pack_rgb(bx.r0 + e, bx.g0 + e, bx.b0 + e);
+        cp = (int32_t)dot4u8(ppk, ppk, 0) - 2 * (int32_t)dot4u8(ppk, lopk, 0) - e * (int32_t)dot4u8(ppk, 0x010101u, 0);
     }
-    // max over the cube of d(p, pivot) - d(p, c): c can be nearest (or tie) somewhere in the cube only if >= 0.
-    // Per channel max(d (v + a0), d (v + a1)) with a0 > a1 (lo < hi) = d (v + (d >= 0 ? a0 : a1)): one product, not two.
     __device__ __forceinline__ int32_t worst(uint32_t ck) const {
-        const int32_t v[3] = {(int32_t)((ck >> 16) & 255), (int32_t)((ck >> 8) & 255), (int32_t)(ck & 255)};
-        int32_t f = 0;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            const int32_t d = p[i] - v[i];
-            f += __mul24(d, v[i] + (d >= 0 ? a[2 * i] : a[2 * i + 1]));
-        }
-        return f;
+        const uint32_t v = ck;   // (a colour key: byte 3 is zero)
+        return cp - (int32_t)dot4u8(v, v, 0) + (int32_t)dot4u8(v, hipk, dot4u8(v, lopk, 0)) + __mul24(ext, (int32_t)__builtin_amdgcn_sad_u8(ppk, v, 0u));
     }
 };
 
