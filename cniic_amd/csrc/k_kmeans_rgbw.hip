@@ -826,13 +826,25 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
         }
         return;
     }
+    // every slot's current centroid first (lanes past the cell's end hold point 0 of cluster 0: harmless), the four products before anything
+    // that depends on one, ONE branch for the sweeps in which nothing moves -- as four "if (q < e)" bodies each slot saved and restored the
+    // exec mask and waited three cycles behind its product
+    bool mvs[kSweep], any = ALLWRITE || first;
+#pragma unroll
+    for (int u0 = 0; u0 < kSweep; u0 += 2) {   // (two slots at a time: four held six more registers than the body has)
+        const uint2 ca = tab[cur[u0]], cb = tab[cur[u0 + 1]];
+        const uint32_t da = dot4u8(p[u0], ca.x, 0), db = dot4u8(p[u0 + 1], cb.x, 0);
+        const uint32_t ka = (da << (IDBITS + 1)) + ca.y, kb = (db << (IDBITS + 1)) + cb.y;
+        mvs[u0] = base + u0 * 64 + lane < e && (best[u0] >> IDBITS) > (ka >> IDBITS);  // strictly closer (kmeans.rs:375)
+        mvs[u0 + 1] = base + (u0 + 1) * 64 + lane < e && (best[u0 + 1] >> IDBITS) > (kb >> IDBITS);
+        any = any || mvs[u0] || mvs[u0 + 1];
+    }
+    if (!__ballot(any)) return;
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
         const uint32_t q = base + u * 64 + lane;
         if (q < e) {
-            const uint2 cc = tab[cur[u]];
-            const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
-            const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
+            const bool mv = mvs[u];
             const uint32_t ol = cur[u], pp = p[u];
             const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
 #ifdef CNIIC_RGBW_ABL
