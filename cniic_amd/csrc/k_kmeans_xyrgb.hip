@@ -36,6 +36,9 @@
 namespace cniic {
 
 constexpr int kTW = 64, kTH = 16;          // tile: 64 x 16 pixels = one wave, 16 pixels (a column) per lane
+#ifndef CNIIC_XY_BUFLOADS
+#define CNIIC_XY_BUFLOADS 1
+#endif
 #ifndef CNIIC_XY_STY
 #define CNIIC_XY_STY 4                     // (measuring builds: 2 = super-tiles of 4 x 2 tiles, 8-wave blocks, two per CU while K <= 1024 -- NOTES D)
 #endif
@@ -444,6 +447,10 @@ __global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
 #endif
 
     const uint64_t npix = (uint64_t)w * h;
+#if CNIIC_XY_BUFLOADS
+    const __amdgpu_buffer_rsrc_t rs_rgb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(rgb), 0, (int)(3u * (uint32_t)npix), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lab = __builtin_amdgcn_make_buffer_rsrc(labels, 0, (int)(2u * (uint32_t)npix), 0x00020000);
+#endif
     uint32_t par = 0, sit = 0;
     // Which super-tiles a block takes.  Statically: every gridDim-th.  The loop with the folded-in update, while centroids still move
     // (dyn): whatever the launch's counter hands out next -- the dirty tiles lie in patches of the image, and a block that met four
@@ -562,6 +569,20 @@ __global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
         // pixel (lane, row j) of the unit: x = first column of the tile + lane, y = first row of the tile + g4 + j
         auto load_unit = [&](uint32_t slot, uint32_t (&p)[kXRows], uint32_t (&c)[kXRows]) {
             const uint32_t ux = (stx + (slot & (kSTX - 1))) * kTW + lane, uy0 = (sty + slot / kSTX) * kTH + g4;
+#if CNIIC_XY_BUFLOADS
+            // (round 4) buffer loads: a pixel outside the image gets an offset outside the buffer and reads as 0 -- no exec mask per row -- and
+            // a pixel's 32-bit index is its offset (N <= 2^28).  The image's last pixel, whose dword would end a byte behind the buffer, reads
+            // the dword a byte earlier and shifts.
+            const uint32_t i0 = uy0 * w + ux;
+#pragma unroll
+            for (int j = 0; j < kXRows; j++) {
+                const uint32_t idx = i0 + (uint32_t)j * w;
+                const bool in = ux < w && uy0 + j < h, last = idx == (uint32_t)npix - 1u;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs_rgb, (int)(in ? 3u * idx - (last ? 1u : 0u) : 0xffffffffu), 0, 0);
+                p[j] = key_from_le24(last ? v >> 8 : v);
+                c[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs_lab, (int)(in ? 2u * idx : 0xffffffffu), 0, 0);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < kXRows; j++) {
                 p[j] = 0; c[j] = 0;
@@ -571,6 +592,7 @@ __global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
                     c[j] = labels[idx];
                 }
             }
+#endif
         };
         // the first unit's pixels and labels are requested now and arrive while the block builds S
         if ((wv >> 2) < nd) load_unit(nth_set_bit(dm16, wv >> 2), px[0], cur[0]);
