@@ -510,9 +510,10 @@ __global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
         // matters to is done without reading a tile record.
         const uint32_t it3 = sit % 3;
         uint32_t nrel = nS;
+        const uint32_t prev_piv = (first || brute) ? 0xffffffffu : ts.spiv[sup];   // the pivot of the super-tile's last list build
         if (skip_mode) {
             if (threadIdx.x == 0) s_nrel[(sit + 1) % 3] = 0;   // (the counter of the NEXT super-tile; its last readers are two barriers back)
-            const uint32_t pid = ts.spiv[sup];
+            const uint32_t pid = prev_piv;
             if (threadIdx.x < nS) {
                 const int4 m = M_c[threadIdx.x];
                 bool rel = true;
@@ -605,17 +606,30 @@ __global__ __launch_bounds__(kXThreads) __attribute__((amdgpu_waves_per_eu(4, 4)
             sb.lo[0] = (int32_t)(stx * kTW); sb.hi[0] = (int32_t)min(w, (stx + kSTX) * kTW) - 1;
             sb.lo[1] = (int32_t)(sty * kTH); sb.hi[1] = (int32_t)min(h, (sty + kSTY) * kTH) - 1;
             box_colours(sb, ts.sbox[sup]);
-            unsigned long long key = ~0ull;
+            // The pivot: the centroid nearest the box centre -- searched for every eighth launch; in between the pivot of the last build
+            // serves (ANY centroid gives a correct list; one that was nearest a few launches ago is still near: centroids creep), which
+            // saves the search, its reduction and a block barrier per super-tile (round 4).
+            uint32_t pk = prev_piv;
+            bool reuse = prev_piv < K && fz.on && (fz.launch_no & 7u) != 0u;   // (block-uniform)
+            if (reuse) {   // ... unless it has left the box's neighbourhood (a reseeded centroid lands anywhere, and a far pivot dominates nothing)
+                uint32_t r2 = 0;
 #pragma unroll
-            for (int i = 0; i < kXMaxR; i++) {
-                const uint32_t k = threadIdx.x * R + i;
-                if ((uint32_t)i < R && k < K) key = min(key, ((unsigned long long)centre_dist(sb, mine[i]) << 12) | k);
+                for (int i = 0; i < 5; i++) { const int32_t hd = (sb.hi[i] - sb.lo[i] + 1) >> 1; r2 += (uint32_t)(hd * hd); }
+                reuse = centre_dist(sb, tab[prev_piv]) <= 2u * r2;
             }
-            key = wave_reduce_min64(key);
-            if (lane == 0) atomicMin(&s_key, key);
-            __syncthreads();
-            const uint32_t pk = (uint32_t)(s_key & 4095ull);
-            if (threadIdx.x == 0) ts.spiv[sup] = pk;
+            if (!reuse) {
+                unsigned long long key = ~0ull;
+#pragma unroll
+                for (int i = 0; i < kXMaxR; i++) {
+                    const uint32_t k = threadIdx.x * R + i;
+                    if ((uint32_t)i < R && k < K) key = min(key, ((unsigned long long)centre_dist(sb, mine[i]) << 12) | k);
+                }
+                key = wave_reduce_min64(key);
+                if (lane == 0) atomicMin(&s_key, key);
+                __syncthreads();
+                pk = (uint32_t)(s_key & 4095ull);
+                if (threadIdx.x == 0) ts.spiv[sup] = pk;
+            }
             Dominance dm;
             dm.set(sb, use_tab ? tab[pk] : cent[pk]);
             bool keep[kXMaxR];
