@@ -738,9 +738,9 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
         // Nothing can move then (the lone candidate beats every other centroid for every colour of the cube): the sweep is over
         // after four compares and a ballot instead of ~90 instructions of scores and label checks.
         const uint32_t only = IDMASK - (cand[0].y & IDMASK);
-        bool same = true;
+        bool same = true;   // (bitwise: the short-circuit form compiled to four nested exec-masked branches)
 #pragma unroll
-        for (int u = 0; u < kSweep; u++) same = same && (base + u * 64 + lane >= e || cur[u] == only);
+        for (int u = 0; u < kSweep; u++) same = same & ((base + u * 64 + lane >= e) | (cur[u] == only));
         if (__ballot(!same) == 0ull) return;
     }
     uint32_t best[kSweep];
@@ -835,9 +835,9 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
         const uint2 ca = tab[cur[u0]], cb = tab[cur[u0 + 1]];
         const uint32_t da = dot4u8(p[u0], ca.x, 0), db = dot4u8(p[u0 + 1], cb.x, 0);
         const uint32_t ka = (da << (IDBITS + 1)) + ca.y, kb = (db << (IDBITS + 1)) + cb.y;
-        mvs[u0] = base + u0 * 64 + lane < e && (best[u0] >> IDBITS) > (ka >> IDBITS);  // strictly closer (kmeans.rs:375)
-        mvs[u0 + 1] = base + (u0 + 1) * 64 + lane < e && (best[u0 + 1] >> IDBITS) > (kb >> IDBITS);
-        any = any || mvs[u0] || mvs[u0 + 1];
+        mvs[u0] = (base + u0 * 64 + lane < e) & ((best[u0] >> IDBITS) > (ka >> IDBITS));  // strictly closer (kmeans.rs:375)
+        mvs[u0 + 1] = (base + (u0 + 1) * 64 + lane < e) & ((best[u0 + 1] >> IDBITS) > (kb >> IDBITS));
+        any = any | mvs[u0] | mvs[u0 + 1];
     }
     if (!__ballot(any)) return;
 #pragma unroll
