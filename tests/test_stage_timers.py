@@ -41,4 +41,5 @@ def test_delta_stages_account_for_the_call():
             ms[k] = t / cnt
         total = sum(ms.values())
         # consecutive stages on one stream, each closed by a wait: their sum is the call less the host's few microseconds between them
-        assert 0.6 * wall_ms <= total <= 1.05 * wall_ms, (ms, wall_ms)
+        # (the lower bound is loose on purpose: at this size the call is a quarter of a millisecond and the host's share between stages shows)
+        assert 0.4 * wall_ms <= total <= 1.05 * wall_ms, (ms, wall_ms)
