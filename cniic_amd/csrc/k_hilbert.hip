@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
                 if (HIST) {
                     const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
                     if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
-                    else atomicAdd(&table[key[i]], 1u);
+                    else atomic_count(table, key[i]);
                 }
             }
         }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta_p2(const uint8_
             if (HIST) {
                 const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
                 if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
-                else atomicAdd(&table[key], 1u);
+                else atomic_count(table, key);
             }
             if (syms) syms[(uint64_t)g * 64 + lane] = key;
         }

@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void k_hist_rgb(const uint8_t *__restrict__ rg
         uint32_t key[16];
         load16px_keys(v + 3 * g, key);
 #pragma unroll
-        for (int i = 0; i < 16; i++) atomicAdd(&table[key[i]], 1u);
+        for (int i = 0; i < 16; i++) atomic_count(table, key[i]);
     }
     // tail (< 16 px) by the first threads of block 0
     if (blockIdx.x == 0) {
         uint64_t i = ngroups * 16 + threadIdx.x;
-        if (i < npx) atomicAdd(&table[rgb_key(rgb + 3 * i)], 1u);
+        if (i < npx) atomic_count(table, rgb_key(rgb + 3 * i));
     }
 }
 
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(256) void k_hist_rgb_bytes(const uint8_t *__restric
                                                         uint32_t *__restrict__ table) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += stride)
-        atomicAdd(&table[rgb_key(rgb + 3 * i)], 1u);
+        atomic_count(table, rgb_key(rgb + 3 * i));
 }
 
 __global__ __launch_bounds__(256) void k_hist_syms(const uint32_t *__restrict__ syms, uint64_t n,
                                                    uint32_t *__restrict__ table, uint32_t mask) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        atomicAdd(&table[syms[i] & mask], 1u);
+        atomic_count(table, syms[i] & mask);
 }
 
 int hist_rgb_dense(Ctx *c, const uint8_t *rgb_d, uint64_t npx, uint32_t *table_d) {
