@@ -142,12 +142,12 @@ template <int THREADS> __device__ __forceinline__ uint32_t block_reduce_sum(uint
 
 // table[key] += 1 for every calling lane, with the lanes of the wave that hold the same key as the first (then the second) lane still to do
 // adding TOGETHER: atomics on one address are served tens of nanoseconds apart, so a flat image (one colour, one difference) or a two-colour
-// pattern made 16.8 M of them 0.1 s (round 4: `delta` on a 4096^2 checkerboard took 110 ms instead of 0.4).  Two rounds cover one or two
-// dominant keys at ~16 instructions; whoever is left adds alone.  Safe under divergence: the ballots see the calling lanes only.
+// pattern made 16.8 M of them 0.1 s (round 4: `delta` on a 4096^2 checkerboard took 110 ms instead of 0.4).  Eight rounds cover up to eight
+// dominant keys at ~8 instructions each; whoever is left adds alone.  Safe under divergence: the ballots see the calling lanes only.
 __device__ __forceinline__ void atomic_count(uint32_t *table, uint32_t key) {
     bool todo = true;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
+#pragma unroll 1
+    for (int r = 0; r < 8; r++) {   // (a call with one or two lanes -- the ordinary case of a rare symbol -- leaves after as many rounds)
         const unsigned long long act = __ballot(todo);
         if (!act) return;
         const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(act));

@@ -212,7 +212,10 @@ constexpr int kHdRoundsShort = 24;
 // By measurement (tools/all_probe.py, photograph and uniform noise, `hufman` and `delta`, 512^2 .. 4096^2): a round is a chain of ~25
 // dependent look-ups (12 us when every code goes to the second table) whatever the stream's size, the phase maps are 32 decodes of
 // EVERYTHING -- short streams give up early, long ones late, streams of more than 2^19 subsequences (32 MiB of payload) never.
-__host__ inline uint32_t hd_hopeless_pct(uint64_t nsub) { return nsub <= (1ull << 16) ? 35u : nsub <= (1ull << 19) ? 60u : 0u; }
+// (round 4) ... never, that is, unless the stream does not fall into step AT ALL: codes of one length (every colour once, a ramp of equally frequent
+// colours) cure exactly one subsequence a round, 48 passes of 320 rounds later the phase maps ran anyway -- 425 ms for a 4096^2 image of 2^24
+// different colours, 51 ms for a ramp.  A list that has kept 97 per cent of its length over three rounds is such a stream at any size.
+__host__ inline uint32_t hd_hopeless_pct(uint64_t nsub) { return nsub <= (1ull << 16) ? 35u : nsub <= (1ull << 19) ? 60u : 97u; }
 constexpr uint64_t kHdPhasesMaxSub = 1ull << 16;   // streams of up to this many subsequences (4 MiB) go to k_hd_phase_maps when the blind checks have not settled them
 template <bool WIDE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
@@ -292,7 +295,9 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
         // decodes and no chain: a block whose list has kept hopeless_pct per cent of its length over three rounds stops here and says so.
         if (hopeless_min && !end_prev) {
             if (round == 0) nl0 = nl;
-            else if (round == 3 && nl0 >= 64 && nl * 100 > nl0 * hopeless_pct) {
+            else if ((round == 3 && nl0 >= 64 && nl * 100 > nl0 * hopeless_pct) ||
+                     (round == kHdRoundsShort && nl0 >= 64 && nl * 2 > nl0)) {   // (round 4: ... or half of it over 24 rounds: codes of nearly one length
+                                                                                 // cure a few entries a round, and the block would chain through all 256)
                 if (tid == 0) atomicAdd(&changed[5], 1u);
                 break;
             }

@@ -20,12 +20,27 @@ def ramp():
 def noise(): return torch.randint(0, 256, (size, size, 3), dtype=torch.uint8, device=dev, generator=g)
 def half():
     img = photo(); img[size // 2:] = 200; return img
+def distinct():   # every pixel a colour of its own (as far as 2^24 colours go)
+    i = torch.arange(size * size, device=dev, dtype=torch.int64)
+    v = (i * 2654435761) % (1 << 24)
+    return torch.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], dim=1).to(torch.uint8).reshape(size, size, 3).contiguous()
+def stripes():
+    img = torch.zeros((size, size, 3), dtype=torch.uint8, device=dev); img[:, ::2] = 255; return img
+def noise6():    # noise in the low six bits: few hundred thousand colours of nearly equal counts
+    return torch.randint(0, 64, (size, size, 3), dtype=torch.uint8, device=dev, generator=g) * 3
+def blocks():    # 64 x 64 blocks of few colours
+    x = torch.arange(size, device=dev) // 64; y = torch.arange(size, device=dev) // 64
+    v = ((x[None, :] * 7 + y[:, None] * 13) % 5 * 50).to(torch.uint8)
+    return torch.stack([v, v // 2, 255 - v], dim=2).contiguous()
 out = torch.empty(size * size * 16 + (1 << 24), dtype=torch.uint8, device=dev)
 back = torch.empty(size * size * 3, dtype=torch.uint8, device=dev)
-for name, mk in (("photo", photo), ("flat", flat), ("two colours", two), ("ramp", ramp), ("noise", noise), ("half flat", half)):
+which = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+for name, mk in (("photo", photo), ("flat", flat), ("two colours", two), ("ramp", ramp), ("noise", noise), ("half flat", half), ("distinct", distinct),
+                 ("stripes", stripes), ("blocks", blocks), ("noise6", noise6)):
+    if which and name not in which: continue
     img = mk(); torch.cuda.synchronize()
     row = {}
-    for expr in ("cluster-colors(256)", "delta", "hufman", "hilbert(rle)"):
+    for expr in ("cluster-colors(256)", "voronoi(256)", "delta", "hufman", "hilbert(rle)"):
         allow = (_lib.TOO_FEW_POINTS, _lib.FEW_ACTIVE)
         rc, n, st = ctx.encode(expr, img, w=size, h=size, out=out, allow=allow); torch.cuda.synchronize()
         if rc not in (0, _lib.FEW_ACTIVE):
@@ -37,6 +52,6 @@ for name, mk in (("photo", photo), ("flat", flat), ("two colours", two), ("ramp"
         t = time.perf_counter()
         for _ in range(3): rcd, dw, dh = ctx.decode_into(expr, out, n, back)
         torch.cuda.synchronize(); dec = (time.perf_counter() - t) / 3 * 1e3
-        ok = rcd == 0 and (expr.startswith("cluster") or bool(torch.equal(back[:size * size * 3], img.reshape(-1))))
-        row[expr] = "enc %.2f ms  dec %.2f ms  %.3f B/px%s%s" % (enc, dec, n / (size * size), "" if ok else "  ROUND TRIP WRONG", "  it %d" % st["iterations"] if expr.startswith("cluster") else "")
+        ok = rcd == 0 and (expr.startswith("cluster") or expr.startswith("voronoi") or bool(torch.equal(back[:size * size * 3], img.reshape(-1))))
+        row[expr] = "enc %.2f ms  dec %.2f ms  %.3f B/px%s%s" % (enc, dec, n / (size * size), "" if ok else "  ROUND TRIP WRONG", "  it %d" % st["iterations"] if (expr.startswith("cluster") or expr.startswith("voronoi")) else "")
     print(name); [print("   %-20s %s" % (k, v)) for k, v in row.items()]
