@@ -1,0 +1,64 @@
+"""Images that are not photographs, at 4096^2 (tools/adversarial_probe.py found both in round 4):
+  * a checkerboard of two colours: every neighbour difference lies outside the [-16, 15]^3 cube, so every symbol of `delta` took a per-lane atomic
+    on one of two table entries -- 110 ms instead of 0.4 (atomic_count, device_utils.hpp: 2.4 ms);
+  * 2^24 different colours / a ramp of equally frequent colours: Huffman codes of one length, a stream that never falls into step -- the decoder
+    ran 48 passes before it took the phase maps: 425 ms / 51 ms (now given up after pass 0: 19 / 16 ms).
+Round trips (the codecs are lossless; the oracle would take minutes at this size) and a generous bound on the time that the pathologies exceed
+several times over while the repaired paths stay an order of magnitude below it."""
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZE = 4096
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    import cniic_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+    ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = torch.empty(SIZE * SIZE * 16 + (1 << 24), dtype=torch.uint8, device=dev)
+    back = torch.empty(SIZE * SIZE * 3, dtype=torch.uint8, device=dev)
+    yield ctx, torch, dev, out, back
+    ctx.close()
+
+
+def images(torch, dev):
+    n = SIZE
+    two = torch.zeros((n, n, 3), dtype=torch.uint8, device=dev)
+    two[::2, 1::2] = 255
+    two[1::2, ::2] = 255
+    i = torch.arange(n * n, device=dev, dtype=torch.int64)
+    v = (i * 2654435761) % (1 << 24)
+    distinct = torch.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], dim=1).to(torch.uint8).reshape(n, n, 3).contiguous()
+    x = torch.arange(n, device=dev)
+    ramp = torch.stack([(x[None, :] % 256).expand(n, n), (x[:, None] % 256).expand(n, n), ((x[None, :] + x[:, None]) // 32 % 256)], dim=2).to(torch.uint8).contiguous()
+    return {"two colours": two, "distinct": distinct, "ramp": ramp}
+
+
+def timed(torch, f):
+    f()   # (first call: pools, tables)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = f()
+    torch.cuda.synchronize()
+    return r, (time.perf_counter() - t) * 1e3
+
+
+@pytest.mark.parametrize("name,expr,enc_ms,dec_ms", [("two colours", "delta", 40.0, 40.0), ("distinct", "hufman", 60.0, 150.0),
+                                                      ("ramp", "hufman", 40.0, 40.0 * 2), ("distinct", "delta", 100.0, 40.0)])
+def test_round_trip_and_no_pathology(env, name, expr, enc_ms, dec_ms):
+    ctx, torch, dev, out, back = env
+    img = images(torch, dev)[name]
+    (rc, n, _), t_enc = timed(torch, lambda: ctx.encode(expr, img, w=SIZE, h=SIZE, out=out))
+    assert rc == 0
+    (rcd, w, h), t_dec = timed(torch, lambda: ctx.decode_into(expr, out, n, back))
+    assert rcd == 0 and (w, h) == (SIZE, SIZE)
+    assert torch.equal(back, img.reshape(-1))
+    assert t_enc < enc_ms, "encode took %.1f ms" % t_enc
+    assert t_dec < dec_ms, "decode took %.1f ms" % t_dec
