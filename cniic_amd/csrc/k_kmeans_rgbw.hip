@@ -54,6 +54,11 @@ constexpr uint32_t kMaxBlocks = 512;
 #define CNIIC_CELL_WAVES 8
 #endif
 constexpr int kCellWaves = CNIIC_CELL_WAVES;                  // waves per block (narrow labels); they share the block's cell range
+// LDS strips of a wave: the super-cell list (scap) and the cell's candidates (ccap).  K <= 256: half the table and the whole table -- nothing
+// can overflow.  Larger K (u16 labels): both capped (round 4; whole-table strips left a block TWO waves at K = 2048, 0.27 ms an iteration against
+// 0.07 at K = 1024): a longer list falls back to the table, a longer strip too (the table IS a candidate list: ascending ids, the same records).
+__host__ __device__ constexpr uint32_t km_scap(uint32_t K) { return K <= 256 ? (K + 1) / 2 : (K + 1) / 2 < 512u ? (K + 1) / 2 : 512u; }
+__host__ __device__ constexpr uint32_t km_ccap(uint32_t K) { return K <= 256 ? K : 256u; }
 constexpr uint32_t kCellWavesBig = 12;                        // ... and in the settled part of a run (launch_assign)
 constexpr uint32_t kCellBlocks = 256 * (kCellWaves == 4 ? 6 : kCellWaves == 6 ? 4 : kCellWaves == 8 ? 3 : 2);  // every block resident at once (LDS, K <= 256)
 constexpr int kSweep = 4;                  // points per lane per sweep (cells kernel)
@@ -505,10 +510,12 @@ __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, ui
 // candidates of cell c = the members of `list` that can be nearest somewhere in the cell's cube, into the
 // wave's strip (ascending id).  The pivot's colour and the candidate bitmask (bit k <=> centroid k) are
 // stored for the skip test.
+// (ccap: the strip's capacity; more candidates than that are counted -- and recorded in the mask -- but not written: the caller sweeps
+// against the whole table then, see km_ccap)
 template <int IDBITS>
 __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t n, uint32_t c, int lane, unsigned long long lt_mask,
                                                      uint2 *cand, unsigned long long *wmask, uint32_t *cell_rec, uint32_t m,
-                                                     uint32_t MW) {
+                                                     uint32_t MW, uint32_t ccap = 0xffffffffu) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     constexpr int32_t ext = (1 << kCellShift) - 1;
     const CellBox bx = cell_box(c);
@@ -526,7 +533,8 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
         if (e < n) { cc = list[e]; keep = dm.worst(cc.x) >= 0; }
         const unsigned long long bm = __ballot(keep);
         if (keep) {
-            cand[ncand + lanes_below(bm)] = cc;
+            const uint32_t pos = ncand + lanes_below(bm);
+            if (IDBITS == 8 || pos < ccap) cand[pos] = cc;
             const uint32_t k = IDMASK - (cc.y & IDMASK);
             atomicOr(&wmask[k >> 6], 1ull << (k & 63));
         }
@@ -598,7 +606,7 @@ __device__ __forceinline__ void block_candidates(const uint2 *tab, uint32_t K, u
             const uint32_t slot = (ci >> kSuperShift) - sup_first;
             uint32_t ni = act ? s_nS[slot] : 0u;
             if (ni > scap) ni = 0u;  // (a list that did not fit: the cell keeps the wave-per-cell build from the whole table)
-            const uint2 *Sl = tab + K + (size_t)slot * (scap + K);
+            const uint2 *Sl = tab + K + (size_t)slot * (scap + K);   // (K <= 256 here: the strip holds the whole table)
             const CellBox bx = cell_box(ci);
             if (phase == 0) {
                 uint32_t best = 0xffffffffu;
@@ -1231,10 +1239,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr bool LAZYW = FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW;   // the settled launches of the fused loop: weights only for the points that move
     const uint32_t MW = (K + 63) >> 6;  // mask words per cell
-    const uint32_t scap = (K + 1) / 2;  // super-cell list capacity (it rarely holds more than a quarter of the table)
-    uint2 *S = tab + K + (size_t)wid * (scap + K);
+    const uint32_t scap = km_scap(K);  // super-cell list capacity (it rarely holds more than a quarter of the table)
+    const uint32_t ccap = km_ccap(K);  // ... and the candidate strip's
+    uint2 *S = tab + K + (size_t)wid * (scap + ccap);
     uint2 *cand = S + scap;
-    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(tab + K + (size_t)WAVES * (scap + K)) + (size_t)wid * MW;
+    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(tab + K + (size_t)WAVES * (scap + ccap)) + (size_t)wid * MW;
     const uint32_t gw0 = shard * gridDim.x * WAVES;          // first wave index of this shard
     // Iteration 0 accumulates the FULL sums of the new assignment (the running sums start at zero:
     // the initial chunk assignment, kmeans.rs:61-78, only matters through the labels); later
@@ -1436,7 +1445,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 const uint2 *Sl = S;
                 if (nsl) {
                     const uint32_t slot = (c >> kSuperShift) - sup_first;
-                    Sl = tab + K + (size_t)slot * (scap + K);
+                    Sl = tab + K + (size_t)slot * (scap + ccap);
                     nSup = s_nS[slot];
                 } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
                 RG_PHASE(2);
@@ -1518,7 +1527,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
             const uint2 *Sl = S;
             if (nsl) {
                 const uint32_t slot = (c >> kSuperShift) - sup_first;
-                Sl = tab + K + (size_t)slot * (scap + K);
+                Sl = tab + K + (size_t)slot * (scap + ccap);
                 nSup = s_nS[slot];
             } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
             RG_PHASE(2);
@@ -1538,8 +1547,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]), c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
                 ncand = expand_candidates<IDBITS>(Sl, pvw & 255u, ((unsigned long long)c1 << 32) | c0, ((unsigned long long)c3 << 32) | c2, c, lane, cand, wmask, cs.rec, m, MW);
             }
-            else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
-                                      : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+            else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap)
+                                      : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap);
+            const uint2 *cl = cand;   // (u16 labels: a strip that overflowed -- the table is the candidate list then)
+            if (IDBITS != 8 && ncand > ccap) { cl = tab; ncand = K; }
 #ifdef CNIIC_RGBW_ABL
             }
             if (abl_ & 1u) { m = mn; s = s_next; e = e_next; c = c_next; continue; }
@@ -1565,11 +1576,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
                     sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
                 }
-                else if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cand, ncand, tab, K, labels, acc, moved, FIRSTK == 1 ? pk : nullptr);   // (pk: null unless the loop runs on packed points)
+                else if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cl, ncand, tab, K, labels, acc, moved, FIRSTK == 1 ? pk : nullptr);   // (pk: null unless the loop runs on packed points)
 #ifdef CNIIC_RGBW_ABL
-                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, lab_sw, acc, moved, cweight);
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, lab_sw, acc, moved, cweight);
 #else
-                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved, cweight);
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, labels, acc, moved, cweight);
 #endif
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
@@ -1775,7 +1786,9 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
                 load_points<LabelT>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
                 // few cells survive and they are dealt round-robin: straight from the table, no super-cell list
-                const uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
+                uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap);
+                const uint2 *cl = cand;
+                if (IDBITS != 8 && ncand > ccap) { cl = tab; ncand = K; }
 #ifdef CNIIC_RGBW_PHASES
                 if (tl_on_) {
                     unsigned long long n_ = wall_clock64(); tl_[8] += n_ - tq_; tq_ = n_;
@@ -1786,7 +1799,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
                     load_points<LabelT>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
-                    sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cand, ncand, tab, K, false, labels, acc, moved);
+                    sweep_points<LabelT, IDBITS>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                 }
@@ -2689,7 +2702,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
             // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.
             auto lds_for = [&](uint32_t wv) {
-                return (size_t)s->K * (5 * 8 + 8) + (size_t)wv * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wv * ((s->K + 63) / 64) * 8;
+                return (size_t)s->K * (5 * 8 + 8) + (size_t)wv * (km_scap(s->K) + km_ccap(s->K)) * 8 + (size_t)wv * ((s->K + 63) / 64) * 8;
             };
             uint32_t wv = 8;
             while (wv > 1 && (lds_for(wv) > 150 * 1024 || s->nblocks % wv)) wv >>= 1;
@@ -2722,7 +2735,7 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             const bool pkd = fz.on && s->packed;   // the fused loop on packed points (pk_make: opt-in, see there)
             const bool big = kCellWaves == 8 && fz.on && fz.launch_no >= s->big_blocks_from && (s->nblocks * (uint32_t)kCellWaves) % kCellWavesBig == 0;
             const uint32_t wpb = big ? kCellWavesBig : (uint32_t)kCellWaves, nblk = s->nblocks * (uint32_t)kCellWaves / wpb;
-            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * ((s->K + 1) / 2 + s->K) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
+            const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * (km_scap(s->K) + km_ccap(s->K)) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
             const bool mbx = mf.on != 0;   // the exchange folded into the launches (km_rgbw_run_loop: fused, classic arrays, a mailbox communicator)
             auto kern = big ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>)
                         : !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
