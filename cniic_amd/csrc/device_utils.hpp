@@ -161,6 +161,20 @@ __device__ __forceinline__ void atomic_count(uint32_t *table, uint32_t key) {
     if (todo) atomicAdd(&table[key], 1u);
 }
 
+// ... and, where a block has 512 bytes of LDS to spare, a 64-slot cache in front of it: a slot belongs to the first key that hashes to it for the
+// block's life and counts it there; the block adds its slots to the table once (cold_flush, behind a barrier).  An image whose differences are ALL
+// rare symbols of a few kinds (stripes, a dither pattern, 2^24 colours in scan order) then costs two LDS atomics a symbol instead of one global
+// atomic per key and WAVE on two or three addresses (8192^2 stripes: 14 ms of `delta` encode).  Slots start at 0xffffffff (no 27-bit key).
+__device__ __forceinline__ void cold_count(uint32_t *table, uint32_t *ck, uint32_t *cc, uint32_t key) {
+    const uint32_t h = (key * 2654435761u) >> 26;
+    const uint32_t old = atomicCAS(&ck[h], 0xffffffffu, key);
+    if (old == 0xffffffffu || old == key) atomicAdd(&cc[h], 1u);
+    else atomic_count(table, key);
+}
+__device__ __forceinline__ void cold_flush(uint32_t *table, const uint32_t *ck, const uint32_t *cc) {
+    if (threadIdx.x < 64 && ck[threadIdx.x] != 0xffffffffu && cc[threadIdx.x]) atomicAdd(&table[ck[threadIdx.x]], cc[threadIdx.x]);
+}
+
 // block-wide exclusive scan in thread order; wsum = LDS scratch of THREADS/64 words
 template <int THREADS> __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum) {
     uint32_t inc = wave_inclusive_scan(v);

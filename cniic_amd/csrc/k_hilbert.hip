@@ -338,8 +338,11 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
     extern __shared__ uint32_t s_bins[];  // HIST: u32[kHotBins]
     __shared__ uint16_t s_l4[1024];
     __shared__ uint8_t s_l1[16];
-    if (HIST)
+    __shared__ uint32_t s_ck[64], s_cc[64];   // the block's cache of keys outside the cube (cold_count)
+    if (HIST) {
         for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) s_bins[i] = 0;
+        if (threadIdx.x < 64) { s_ck[threadIdx.x] = 0xffffffffu; s_cc[threadIdx.x] = 0; }
+    }
     const Scan sc = load_scan(w, h, order, lut, s_l4, s_l1);
     if (HIST && !order) __syncthreads();
     const uint64_t n = (uint64_t)w * h;
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
                 if (HIST) {
                     const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
                     if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
-                    else atomic_count(table, key[i]);
+                    else cold_count(table, s_ck, s_cc, key[i]);
                 }
             }
         }
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta(const uint8_t *
     }
     if (HIST) {
         __syncthreads();
+        cold_flush(table, s_ck, s_cc);
         for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) {
             const uint32_t cnt = s_bins[i];
             if (cnt) {
@@ -417,8 +421,11 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta_p2(const uint8_
     __shared__ uint16_t s_l4[1024];
     __shared__ uint8_t s_l1[16];
     __shared__ uint8_t s_l3[4 * 64];  // three levels from state s for the 6 low bits q: x:3 | y:3 << 3
-    if (HIST)
+    __shared__ uint32_t s_ck[64], s_cc[64];   // the block's cache of keys outside the cube (cold_count)
+    if (HIST) {
         for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) s_bins[i] = 0;
+        if (threadIdx.x < 64) { s_ck[threadIdx.x] = 0xffffffffu; s_cc[threadIdx.x] = 0; }
+    }
     const uint32_t w = 1u << order;
     const Scan sc = load_scan(w, w, order, lut, s_l4, s_l1);
     if (threadIdx.x < 256) {
@@ -477,13 +484,14 @@ __global__ __launch_bounds__(kDeltaThreads) void k_hilbert_delta_p2(const uint8_
             if (HIST) {
                 const uint32_t hr = (uint32_t)(dr + 16), hg = (uint32_t)(dg + 16), hb = (uint32_t)(db + 16);
                 if ((hr | hg | hb) < 32u) atomicAdd(&s_bins[(hr << 10) | (hg << 5) | hb], 1u);
-                else atomic_count(table, key);
+                else cold_count(table, s_ck, s_cc, key);
             }
             if (syms) syms[(uint64_t)g * 64 + lane] = key;
         }
     }
     if (HIST) {
         __syncthreads();
+        cold_flush(table, s_ck, s_cc);
         for (uint32_t i = threadIdx.x; i < kHotBins; i += kDeltaThreads) {
             const uint32_t cnt = s_bins[i];
             if (cnt) {
