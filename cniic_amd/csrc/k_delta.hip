@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void k_delta_gather_p2(const uint8_t *__restri
                     const uint32_t dd = s_cold[wave * kColdPerChunk + lane];
                     const uint32_t key = ((((dd >> 20) & 1023u) - (kField - 255)) << 18) | ((((dd >> 10) & 1023u) - (kField - 255)) << 9) |
                                          ((dd & 1023u) - (kField - 255));
-                    atomic_count(table, key);
+                    // (a photograph's chunk holds five such symbols of five kinds: one atomic each.  A chunk with sixteen or more is not a
+                    // photograph's -- a pattern of few colours, whose keys repeat: those add together, atomic_count.  crank is wave-uniform.)
+                    if (crank >= 16) atomic_count(table, key);
+                    else atomicAdd(&table[key], 1u);
                     pages[key >> kPageShift] = 1;
                     coldkeys[(uint64_t)ch * kColdPerChunk + lane] = key;
                 }
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void k_delta_gather_any(const uint8_t *__restr
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 if (hot[i] == kCold16) {
-                    atomic_count(table, key[i]);
+                    if (total >= 16) atomic_count(table, key[i]);   // (as in the tile gather: total is the chunk's count, wave-uniform)
+                    else atomicAdd(&table[key[i]], 1u);
                     pages[key[i] >> kPageShift] = 1;
                     if (r < kColdPerChunk) coldkeys[(uint64_t)ch * kColdPerChunk + r] = key[i];
                     hot[i] = kCold16 + min(r, kColdPerChunk - 1);
