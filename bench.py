@@ -46,6 +46,21 @@ def roofline_from_timers(ctx, U, K, note, traffic=None):
     Algorithmic bytes per launch = 10 B per distinct colour (dedup form: 4 B key + 4 B weight + 1 B label read
     + 1 B written).  `frac` is over the WORKING launches (one per iteration, and the one that finishes the last iteration);
     launches past convergence, which exit on the device-side flag, are listed apart."""
+    ms_p, n_p = ctx.kernel_time("kmeans_rgbw_persist")
+    if n_p:
+        # the loop as ONE launch (k_kmeans_persist.hip): a launch processes U colours in every one of its iterations, so its
+        # algorithmic bytes are 10 B x U x iterations; the duration is the dispatch's own (HIP events attached to it)
+        _, n_it = ctx.kernel_time("kmeans_rgbw_persist_iters")
+        iters = n_it / n_p
+        algo = 10.0 * U * iters
+        launch_ms = ms_p / n_p
+        achieved = algo / (launch_ms * 1e-3) / 1e9
+        return {"kernel": "k_rgbw_persist", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "launch_ms": round(launch_ms, 5), "launches": int(n_p),
+                "iterations_per_launch": round(iters, 2), "us_per_iteration": round(launch_ms * 1e3 / max(1.0, iters), 3),
+                "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_iteration": 10.0 * U,
+                "note": note + "; the whole K-means loop is ONE persistent launch whose points stay in LDS: algorithmic bytes = 10 B x U per iteration x "
+                               "the launch's iterations, HBM traffic (`traffic`) is a small fraction of that by construction"}
     ms_all, n_all = ctx.kernel_time("kmeans_rgbw_assign")
     ms_w, n_w = ctx.kernel_time("kmeans_rgbw_assign_working")
     if not n_w:
@@ -415,13 +430,47 @@ def main():
         import threading
         limit_s = float(os.environ.get("CNIIC_BENCH_EXTRAS_LIMIT_S", "300"))
 
+        class Progress:
+            """What the watchdog may read: JSON snapshots of the finished blocks and the name of the running one, under a lock
+            (the timer thread used to walk dictionaries the main thread was still filling)."""
+            def __init__(self, base):
+                self.lock = threading.Lock()
+                self.base = json.dumps(base)
+                self.done = {}
+                self.current = None
+
+            def begin(self, name):
+                with self.lock:
+                    self.current = name
+
+            def put(self, name, value):
+                extras[name] = value
+                snap = json.dumps(value)   # (a value that cannot be serialised fails HERE, on the main thread, inside the block's try)
+                with self.lock:
+                    self.done[name] = snap
+                    self.current = None
+
+            def rebase(self, base):
+                snap = json.dumps(base)
+                with self.lock:
+                    self.base = snap
+
+        prog = Progress(headline())
+
         def fire():
-            if rank == 0:
-                ln = headline()
-                ln.update(extras)
-                ln["extras_error"] = "watchdog: the optional blocks did not finish within %.0f s; the line carries what had" % limit_s
-                os.write(json_fd, (json.dumps(ln) + "\n").encode())
-            os._exit(0)
+            # a block hung (a GPU kernel or a collective that never returns): the line with what was finished, the stuck block's
+            # name, and a NON-ZERO exit -- a process stuck on the GPU must not read as a success
+            try:
+                if rank == 0:
+                    with prog.lock:
+                        ln = json.loads(prog.base)
+                        for k_, v_ in prog.done.items():
+                            ln[k_] = json.loads(v_)
+                        cur = prog.current
+                    ln["extras_error"] = "watchdog: the optional blocks did not finish within %.0f s (stuck in: %s); the line carries what had; exit code 3" % (limit_s, cur)
+                    os.write(json_fd, (json.dumps(ln) + "\n").encode())
+            finally:
+                os._exit(3)
         watchdog = threading.Timer(limit_s + (0.0 if rank == 0 else 10.0), fire)
         watchdog.daemon = True
         watchdog.start()
@@ -429,25 +478,29 @@ def main():
             if not args.no_extras:
                 try:
                     # the trait the reference calls is host image -> host bytes (bench.rs:33-35): the same encode with both buffers in host memory
+                    prog.begin("host_io_ms_per_step")
                     himg = img.cpu().numpy()
                     hout = np.empty(W * H * 2, np.uint8)   # (the caller's Vec<u8>, reused like a harness would)
                     ctx.encode(expr, himg, out=hout)
                     t0 = time.perf_counter()
                     for _ in range(5):
                         ctx.encode(expr, himg, out=hout)
-                    extras["host_io_ms_per_step"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+                    prog.put("host_io_ms_per_step", round((time.perf_counter() - t0) / 5 * 1e3, 3))
                     del himg, hout
                     # configs[3] on this one GPU (the N > 1 lines carry the same block over N GPUs, with their own one-rank timing)
                     F = args.frames_per_gpu
+                    prog.begin("c4_one_gpu")
                     e4 = ShardedClusterColors(ctx, K, None, dev, max_iters=args.max_iters)
                     d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=True)
                     e4.close()
-                    extras["c4_one_gpu"] = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams; frames and streams HBM-resident" % (F, F),
+                    c4blk = {"workload": "configs[3] on one GPU: %d frames 1920x1080, one palette, %d Hufman streams; frames and streams HBM-resident" % (F, F),
                                             "value": round(F * FRAME_W * FRAME_H * 2 / d4 / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3),
                                             "kmeans_iterations": int(st4["iterations"]), "unique_colours": U4, "bytes_per_px": round(nb4 / (F * FRAME_W * FRAME_H), 4),
                                             "roofline": roof4, "parity": run_c4.parity}
                     if args.cpu_sample > 0:
-                        extras["c4_one_gpu"]["cpu_baseline"] = cpu_all_cores(np, make_frames, expr)
+                        c4blk["cpu_baseline"] = cpu_all_cores(np, make_frames, expr)
+                    prog.put("c4_one_gpu", c4blk)
+                    prog.begin("batch_own_palettes")
                     # the reference's OWN batch semantics (bench.rs:24-35): the same frames, one palette EACH -- F independent encodes in
                     # one call (cniic_codec_encode_batch: the images dealt to worker streams); the all-cores CPU leg above is this workload
                     frames = make_frames(F, 0)
@@ -466,22 +519,38 @@ def main():
                                     "kmeans_iterations_mean": round(sum(s_["iterations"] for s_ in stsb) / F, 1), "bytes_per_px": round(sum(lensb) / (F * stride), 4)}
                         best.setdefault("by_streams", {})[str(streams)] = round(v, 3)
                     ctx.set_opt(_lib.OPT_BATCH_STREAMS, None)
-                    extras["batch_own_palettes"] = best
+                    prog.put("batch_own_palettes", best)
                     del frames, outb
                     # configs[2] and configs[4] as blocks of the same line (every BASELINE config driver-timed); the
                     # same functions that make the --config c3 / c5 lines
                     for name, fn, size in (("c3", run_c3, 4096), ("c5", run_c5, 16384)):
                         try:
+                            prog.begin(name)
                             blk = fn(size, 2, 6)   # (warm-up, steps: with 1 / 3 the c5 block read 1.45 .. 2.1 ms from run to run)
-                            extras[name] = {k: blk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline", "parity") if k in blk}
+                            eb = {k: blk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline", "parity") if k in blk}
                             if "stages" in blk:
-                                extras[name]["stages"] = blk["stages"]
+                                eb["stages"] = blk["stages"]
+                            prog.put(name, eb)
                         except Exception as e:
-                            extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                            prog.put(name, {"error": "%s: %s" % (type(e).__name__, e)})
+                    # the other half of the trait, driver-timed (bench.rs:45-46 decodes every image it encodes): the
+                    # decode of configs[1]'s and configs[4]'s streams, each checked against its source (delta: equal; cluster-colors: the MSE)
+                    for name, cfg in (("c2_decode", "c2"), ("c5_decode", "c5")):
+                        try:
+                            prog.begin(name)
+                            a2 = argparse.Namespace(**vars(args))
+                            a2.steps, a2.warmup = 6, 2
+                            blk = bench_decode(a2, ctx, torch, np, dev, rank, world, timed, cfg)
+                            eb = {k: blk[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "cpu_baseline", "stages", "host_io_ms_per_step") if k in blk}
+                            eb["round_trip"] = "decode(encode(img)) == img, checked on the device" if cfg == "c5" else "lossy codec: MSE against the source in config.mse_vs_source"
+                            prog.put(name, eb)
+                        except Exception as e:
+                            prog.put(name, {"error": "%s: %s" % (type(e).__name__, e)})
                 except Exception as e:   # (the headline above is measured: a failing extra is reported, not fatal)
-                    extras["extras_error"] = "%s: %s" % (type(e).__name__, e)
+                    prog.put("extras_error", "%s: %s" % (type(e).__name__, e))
             # ---- CPU baseline: oracle mode R (reference algorithm restated) on a bounded crop, 1 thread
             if args.cpu_sample > 0:
+                prog.begin("cpu_baseline")
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 import oracle_lib as O
                 s = min(args.cpu_sample, W)
@@ -496,6 +565,8 @@ def main():
                 # the HIP path on the SAME crop (the two bytes/px figures were of different images)
                 rcg, ng, stg = ctx.encode(expr, crop, max_iters=args.max_iters)
                 cpu["hip_same_crop"] = {"bytes_per_px": round(len(ng) / (s * s), 4) if rcg == 0 else None, "iterations": int(stg["iterations"]) if rcg == 0 else None}
+                prog.rebase(headline())
+                prog.begin(None)
         if world > 1 and os.environ.get("CNIIC_BENCH_MAILBOX", "0") == "1" and enc_collectives != "mailbox":
             # OPT-IN (CNIIC_BENCH_MAILBOX=1): the exchange has only ever run between processes that share one GPU, and a fault
             # in a never-exercised cross-GPU path must not cost the driver its N > 1 line.
@@ -503,20 +574,22 @@ def main():
             # direct xGMI links, k_mailbox.hip) instead of RCCL's ring; `value` above stays the RCCL figure.  Waits are bounded inside
             # the kernel (5 s here), a rank that cannot map its peers' mailboxes makes every rank skip the block.
             try:
+                prog.begin("mailbox")
                 os.environ["CNIIC_COLLECTIVE_TIMEOUT_MS"] = "5000"
                 em = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives="mailbox")
                 if em.collectives == "mailbox":
                     dtm, (nbm, stm) = timed(lambda: em.encode(img, W, H, out), args.warmup, args.steps)
                     if rank == 0:
-                        extras["mailbox"] = {"what": "the same step, the per-iteration all-reduce of the K partial sums as a one-shot exchange over IPC-mapped mailboxes",
+                        mbblk = {"what": "the same step, the per-iteration all-reduce of the K partial sums as a one-shot exchange over IPC-mapped mailboxes",
                                              "value": round(npx_total * args.steps / dtm / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(dtm / args.steps * 1e3, 3),
                                              "kmeans_iterations": int(stm["iterations"]), "same_stream_as_rccl": bool(nbm == nbytes),
                                              "speedup_vs_default_collectives": round(dt / dtm, 4)}
+                        prog.put("mailbox", mbblk)
                 elif rank == 0:
-                    extras["mailbox"] = {"unavailable": "the mailboxes could not be set up on every rank (IPC mapping or the known-answer exchange failed)"}
+                    prog.put("mailbox", {"unavailable": "the mailboxes could not be set up on every rank (IPC mapping or the known-answer exchange failed)"})
                 em.close()
             except Exception as e:
-                extras["mailbox"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                prog.put("mailbox", {"error": "%s: %s" % (type(e).__name__, e)})
             finally:
                 os.environ.pop("CNIIC_COLLECTIVE_TIMEOUT_MS", None)
         if world > 1 and not args.no_extras:
@@ -525,6 +598,7 @@ def main():
                 # own frames clustered by that rank ALONE (no collective; rank 0's is reported): the line is self-contained, its
                 # efficiency does not lean on another invocation's N = 1 figure.
                 F = args.frames_per_gpu
+                prog.begin("c4")
                 del img, out
                 e4 = ShardedClusterColors(ctx, K, dist, dev, max_iters=args.max_iters, collectives=native)  # (its own communicator: the first one is closed)
                 d4, nb4, st4, U4, roof4 = run_c4(e4, F, 1, 2, profile=False)
@@ -536,15 +610,16 @@ def main():
                 if rank == 0:
                     vN = F * FRAME_W * FRAME_H * world * 2 / d4 / 1e6
                     v1 = F * FRAME_W * FRAME_H * 2 / d1 / 1e6
-                    extras["c4"] = {"workload": "configs[3]: %d frames 1920x1080 (%d per GPU) over %d GPUs, one palette, one Hufman stream per frame" % (F * world, F, world),
+                    c4n = {"workload": "configs[3]: %d frames 1920x1080 (%d per GPU) over %d GPUs, one palette, one Hufman stream per frame" % (F * world, F, world),
                                     "value": round(vN, 3), "unit": "Mpixels/s", "ms_per_step": round(d4 / 2 * 1e3, 3), "kmeans_iterations": int(st4["iterations"]),
                                     "collectives": coll4,
                                     "one_gpu_same_run": {"what": "rank 0's %d frames clustered by rank 0 alone (its own palette, no collective), timed in this run" % F,
                                                          "value": round(v1, 3), "ms_per_step": round(d1 / 2 * 1e3, 3), "kmeans_iterations": int(st1["iterations"]),
                                                          "unique_colours": U1, "roofline": roof1},
                                     "efficiency_vs_one_gpu": round(vN / (world * v1), 4)}
+                    prog.put("c4", c4n)
             except Exception as e:   # the headline line above is already measured: an extra that fails must not take it down
-                extras["c4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                prog.put("c4", {"error": "%s: %s" % (type(e).__name__, e)})
         watchdog.cancel()
         if rank == 0:
             line = headline()

@@ -16,7 +16,7 @@ BAD_ARG, TOO_FEW_POINTS, FEW_ACTIVE, HIP, RCCL, DECODE, NOMEM, CAPACITY, UNSUPPO
 SYM_RGB, SYM_SIGNED = 1, 2
 SYNTH_UNIFORM, SYNTH_PHOTO = 0, 1
 KM_BRUTE_FORCE, KM_PROFILE, KM_NO_SKIP = 1, 2, 4
-OPT_SP_MIN_PIXELS, OPT_HUF_GPU_CODES_MIN, OPT_GPU_DECODE_MIN, OPT_DELTA_ROUTE, OPT_STAGE_TIMERS, OPT_FRAME_TREES_HOST, OPT_BATCH_STREAMS, OPT_KM_MAX_BLOCKS = range(1, 9)
+OPT_SP_MIN_PIXELS, OPT_HUF_GPU_CODES_MIN, OPT_GPU_DECODE_MIN, OPT_DELTA_ROUTE, OPT_STAGE_TIMERS, OPT_FRAME_TREES_HOST, OPT_BATCH_STREAMS, OPT_KM_MAX_BLOCKS, OPT_KM_LOOP = range(1, 10)
 
 # every symbol include/cniic_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

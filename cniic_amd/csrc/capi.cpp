@@ -96,6 +96,7 @@ void cniic_ctx_destroy(cniic_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->poll_ev) if (e) (void)hipEventDestroy(e);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned_ps) (void)hipHostFree(c->pinned_ps);
     if (c->pinned_res) (void)hipHostFree(c->pinned_res);
     if (c->pinned_huf) (void)hipHostFree(c->pinned_huf);
     if (c->res_ev) (void)hipEventDestroy(c->res_ev);
@@ -165,7 +166,7 @@ int32_t cniic_ctx_get_opt(cniic_ctx *c, int32_t opt, uint64_t *value) {
     LOCK(c);
     static const struct { const char *env; uint64_t dflt; } k[CNIIC_OPT_COUNT] = {
         {nullptr, 0}, {"CNIIC_SP_MIN_PIXELS", 1ull << 20}, {"CNIIC_HUF_GPU_CODES_MIN", 32768}, {"CNIIC_GPU_DECODE_MIN", 1ull << 14},
-        {"CNIIC_DELTA_ROUTE", 0}, {nullptr, 0}, {"CNIIC_FRAME_TREES_HOST", 0}, {nullptr, 8}, {"CNIIC_KM_MAX_BLOCKS", 0}};
+        {"CNIIC_DELTA_ROUTE", 0}, {nullptr, 0}, {"CNIIC_FRAME_TREES_HOST", 0}, {nullptr, 8}, {"CNIIC_KM_MAX_BLOCKS", 0}, {"CNIIC_KM_LOOP", 0}};
     if (opt <= 0 || opt >= CNIIC_OPT_COUNT) return c->fail(CNIIC_ERR_BAD_ARG, "ctx_get_opt: unknown option %d", opt);
     *value = opt == CNIIC_OPT_STAGE_TIMERS ? (c->timers ? 1 : 0) : c->opt(opt, k[opt].env, k[opt].dflt);
     return CNIIC_OK;
@@ -924,6 +925,7 @@ int32_t cniic_codec_encode_batch(cniic_ctx *c, const char *expr, const cniic_kme
         // several images in flight: half-size K-means grids, so that two images' launches are resident together (measured on 64 frames
         // 1920 x 1080 with 8 workers: 768 blocks 0.885 ms per frame, 384: 0.729, 192: 0.80, 96: 1.17)
         if (S > 1 && !((c->opt_set >> CNIIC_OPT_KM_MAX_BLOCKS) & 1u) && !getenv("CNIIC_KM_MAX_BLOCKS")) { wk->opt_val[CNIIC_OPT_KM_MAX_BLOCKS] = 384; wk->opt_set |= 1u << CNIIC_OPT_KM_MAX_BLOCKS; }
+        wk->ps_div = S;                        // ... and the persistent K-means launch an S-th of the CUs, so that S of them are resident side by side
         wk->scan_xy.release();                 // ... and its injected scan, as a view of this context's table
         wk->scan_w = wk->scan_h = 0;
         if (c->scan_xy.p) { wk->scan_xy.view(c->scan_xy.p, c->scan_xy.bytes); wk->scan_w = c->scan_w; wk->scan_h = c->scan_h; }

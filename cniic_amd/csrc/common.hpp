@@ -145,6 +145,8 @@ struct Ctx {
     bool   dense27_clean = false;
     DevBuf hilbert_lut;     // state-machine tables of the 2^n Hilbert scan (k_hilbert.hip)
     void  *pinned = nullptr; // 4 KiB of pinned host memory: two KmDevState slots for lagged convergence polling
+    void  *pinned_ps = nullptr;  // pinned: how the persistent K-means launch ended (PsExit, k_kmeans_persist.hip)
+    uint32_t ps_div = 1;         // the persistent K-means launch takes 1 / ps_div of the CUs (worker contexts of a batch encode)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     void  *pinned_res = nullptr;  // pinned landing area of K-means result blocks (grown on demand)
     uint64_t pinned_res_bytes = 0;

@@ -87,7 +87,10 @@ int32_t     cniic_memcpy(cniic_ctx *ctx, void *dst, const void *src, uint64_t by
 #define CNIIC_OPT_KM_MAX_BLOCKS      8  /* cluster-colors: cap on the K-means assign kernel's grid (a multiple of 3; 0 = none, 768 blocks  */
                                         /* on large inputs).  A smaller grid lets the launches of several contexts share the machine:     */
                                         /* cniic_codec_encode_batch gives its workers 384 unless this is set.  CNIIC_KM_MAX_BLOCKS          */
-#define CNIIC_OPT_COUNT              9
+#define CNIIC_OPT_KM_LOOP             9  /* cluster-colors (K <= 256, one GPU): 0 = the K-means loop as ONE persistent launch with the       */
+                                        /* points resident in LDS (default; falls back by itself when its grid cannot be resident),     */
+                                        /* 1 = one launch per iteration.  CNIIC_KM_LOOP                                                    */
+#define CNIIC_OPT_COUNT              10
 int32_t     cniic_ctx_set_opt(cniic_ctx *ctx, int32_t opt, uint64_t value);
 int32_t     cniic_ctx_unset_opt(cniic_ctx *ctx, int32_t opt);
 int32_t     cniic_ctx_get_opt(cniic_ctx *ctx, int32_t opt, uint64_t *value);

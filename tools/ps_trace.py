@@ -1,0 +1,61 @@
+"""Per-iteration timeline of the persistent colour K-means launch (k_kmeans_persist.hip) on the headline workload:
+    CNIIC_USE_TESTING_LIB=1 python tools/ps_trace.py [size] [K] [out.csv]
+Block 0 stamps the 100 MHz clock when an iteration's centroids stand; the library writes the differences (CNIIC_KM_PS_TRACE)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("CNIIC_USE_TESTING_LIB", "1")
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "ps_trace.csv")
+os.environ["CNIIC_KM_PS_TRACE"] = path
+bpath = path.replace(".csv", "_blocks.csv")
+if os.environ.get("PS_BLOCKS_TRACE", "1") == "1":
+    os.environ["CNIIC_KM_PS_BLOCK_TRACE"] = bpath
+os.environ.setdefault("CNIIC_KM_PS_REQUIRE", "1")
+
+import torch
+
+import cniic_amd
+from cniic_amd import _lib, synth
+
+dev = torch.device("cuda:0")
+with cniic_amd.Context(0) as ctx:
+    img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev)
+    ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
+    out = torch.empty(size * size * 2, dtype=torch.uint8, device=dev)
+    expr = "cluster-colors(%d)" % K
+    for _ in range(3):
+        rc, n, st = ctx.encode(expr, img, w=size, h=size, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        rc, n, st = ctx.encode(expr, img, w=size, h=size, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print("encode %.3f ms, %d bytes, %s" % (dt * 1e3, n, st))
+rows = [l.strip().split(",") for l in open(path)][1:]
+us = [float(r[1]) for r in rows]
+nm = [int(r[2]) for r in rows]
+full = [u for u, m in zip(us[1:], nm[1:]) if m > 64 or m < 0]
+skip = [u for u, m in zip(us[1:], nm[1:]) if 0 <= m <= 64]
+print("iterations %d, loop %.1f us: first %.1f us | full x%d mean %.2f us | skip x%d mean %.2f us" % (
+    len(us), sum(us), us[0], len(full), sum(full) / max(1, len(full)), len(skip), sum(skip) / max(1, len(skip))))
+print(" ".join("%.1f" % u for u in us))
+
+if os.path.exists(bpath):
+    import collections
+    per = collections.defaultdict(list)
+    for l in list(open(bpath))[1:]:
+        g, i, a_, f_, b_, u_ = l.strip().split(",")
+        per[int(i)].append((float(a_), float(f_), float(b_), float(u_)))
+    print("iteration: assign mean / max | flush mean | barrier min / mean | update mean   (us, over the blocks)")
+    for i in sorted(per):
+        v = per[i]
+        n = len(v)
+        print("%3d: assign %6.2f / %6.2f | flush %5.2f | barrier %5.2f / %5.2f | update %5.2f" % (
+            i, sum(x[0] for x in v) / n, max(x[0] for x in v), sum(x[1] for x in v) / n, min(x[2] for x in v), sum(x[2] for x in v) / n, sum(x[3] for x in v) / n))
