@@ -25,11 +25,10 @@
 namespace cniic {
 
 constexpr int kPsThreads = 1024, kPsWaves = kPsThreads / 64;
-constexpr uint32_t kPsScap = 128;                      // entries of a shared super-cell list (a longer list: the cell builds from the table)
 constexpr uint32_t kPsAccWords = 5 * 256;              // u64 accumulators (K <= 256)
-// dynamic LDS: [acc u64 5 x 256 | tab uint2 256 | S uint2 kPsSlots x 128 | wmask u64 16 x 4 | per block: cstart u32[C + 1], ccell u16[C], rec u32[C][10], points u32[...]]
-constexpr uint32_t kPsOffTab = kPsAccWords * 8, kPsOffS = kPsOffTab + 256 * 8, kPsOffMask = kPsOffS + kPsSlots * kPsScap * 8;
-static_assert(kPsOffCell == kPsOffMask + kPsWaves * 4 * 8, "ps_cell_bytes / kPsOffCell (kmeans_rgbw.hpp) describe this layout");
+// dynamic LDS: [acc u64 5 x 256 | tab uint2 256 | ids u8 kPsSlotsMax x kPsScap | per block (ps_cell_bytes): first points, records, cell ids, work list, list slots | points u32[...]]
+constexpr uint32_t kPsOffTab = kPsAccWords * 8, kPsOffS = kPsOffTab + 256 * 8;
+static_assert(kPsOffCell == kPsOffS + kPsSlotsMax * kPsScap, "ps_cell_bytes / kPsOffCell (kmeans_rgbw.hpp) describe this layout");
 
 __device__ __forceinline__ uint32_t ps_xcc_id() {
     uint32_t v;
@@ -80,80 +79,108 @@ __device__ __forceinline__ bool ps_barrier_xcd(PsBar *b, uint32_t x, uint32_t nx
     return ok;
 }
 
-// ---------------------------------------------------------------- the block ranges
-// Block g owns the cells [mb0, mb1) of the compacted list (equal estimated cost, as k_wave_ranges deals them to waves), its points are
-// consecutive in the cell-major arrays; the first [mb0, msplit) have their packed words in the block's LDS -- as many whole cells as
-// fit behind the block's descriptors and records.  fail: a block would own more cells than its LDS can describe (then no block starts).
-__global__ __launch_bounds__(1024) void k_ps_ranges(const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ ne_count,
-                                                    uint32_t G, uint32_t dyn_bytes, PsRange *__restrict__ ranges, uint32_t *__restrict__ fail) {
-    __shared__ uint32_t s_b[1025];
-    const uint32_t M = *ne_count;
+// ---------------------------------------------------------------- who owns what
+// The compacted list of non-empty cells is cut into G x kPsChunks consecutive chunks of equal estimated cost (the classic loop's cost
+// model: ne_cost) and block b owns chunks b, G + b, 2 G + b, ...: equal work per block by construction, and a region of colour space --
+// what one moved centroid dirties late in a run is a hundred or two ADJACENT cells -- is spread over as many blocks as it has chunks
+// instead of landing on one or two (profiles/r05_persist_v1_block_phases.txt: with one contiguous range per block the slowest block of a
+// skip iteration did 25 us of work while the mean was 2).  cb[i] = first cell of chunk i, cb[G kPsChunks] = M.
+// fail: a block would own more cells than its LDS can describe (then no block starts and the classic loop runs).
+__global__ __launch_bounds__(1024) void k_ps_ranges(const uint32_t *__restrict__ ne_cost, const uint32_t *__restrict__ ne_count, uint32_t G, uint32_t dyn_bytes,
+                                                    uint32_t *__restrict__ cb, uint32_t *__restrict__ fail) {
+    const uint32_t M = *ne_count, NC = G * kPsChunks;
     const uint64_t total = ne_cost[M];
-    for (uint32_t g = threadIdx.x; g <= G; g += blockDim.x) {
-        const uint64_t c_lo = total * g / G;
+    for (uint32_t g = threadIdx.x; g <= NC; g += blockDim.x) {
+        const uint64_t c_lo = total * g / NC;
         uint32_t a = 0, b = M;   // first cell whose cost prefix is >= c_lo
         while (a < b) { const uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_lo) a = mid + 1; else b = mid; }
-        s_b[g] = g == G ? M : a;
+        cb[g] = g == NC ? M : a;
     }
-    __syncthreads();
+    __syncthreads();   // (one block: its own stores are visible to it behind the barrier)
     for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
-        const uint32_t mb0 = s_b[g], mb1 = s_b[g + 1], C = mb1 - mb0;
-        uint32_t msplit = mb0;
+        uint32_t C = 0;
+        for (uint32_t r = 0; r < kPsChunks; r++) C += cb[r * G + g + 1] - cb[r * G + g];
         if (C > kPsMaxCells || kPsOffCell + ps_cell_bytes(C) > dyn_bytes) atomicAdd(fail, 1u);
-        else {
-            const uint32_t cap = (dyn_bytes - kPsOffCell - ps_cell_bytes(C)) / 4u, q0 = ne_start[mb0];
-            uint32_t a = mb0, b = mb1;   // the last m in [mb0, mb1] whose points before it fit
-            while (a < b) { const uint32_t mid = (a + b + 1) >> 1; if (ne_start[mid] - q0 <= cap) a = mid; else b = mid - 1; }
-            msplit = a;
-        }
-        ranges[g] = PsRange{mb0, mb1, msplit, 0u};
     }
 }
 
-// ---------------------------------------------------------------- a cell's candidates as a bitmask of cluster ids
-// The members of `list` (ascending id; n entries) that can be nearest somewhere in cell c's cube: pivot = the member nearest the cube's
-// centre, kept = whoever the pivot does not dominate over the whole cube (Dominance, kmeans_rgbw.hpp).  The mask, the pivot's colour and
-// id go into the cell's record (skip schedule).  TABLE: `list` is the block's centroid table itself (position = id: the ballots ARE the
-// mask words, and the mask is complete -- it holds every centroid of the table the pivot does not dominate).
-template <bool TABLE>
-__device__ __forceinline__ uint32_t ps_build(const uint2 *list, uint32_t n, uint32_t c, int lane, unsigned long long *wm, uint32_t *rec, unsigned long long (&nm)[4]) {
+// ---- reductions inside a ROW of 16 lanes (a DPP row: rotations stay inside it), the result in every lane of the row
+template <class Op> __device__ __forceinline__ uint32_t row_allreduce(uint32_t v, Op op) {
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    return v;
+}
+__device__ __forceinline__ uint32_t row_min(uint32_t v) { return row_allreduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint32_t row_max(uint32_t v) { return row_allreduce(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ __forceinline__ uint32_t row_sum(uint32_t v) { return row_allreduce(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+
+// ---------------------------------------------------------------- candidates
+// squared distance from colour key ck to the centre of the cube at low corner `lo` (packed) with half side h: |v|^2 - 2 v.c + |c|^2
+__device__ __forceinline__ uint32_t ps_centre_dist(uint32_t ck, uint32_t cpk, uint32_t cc) { return dot4u8(ck, ck, cc) - 2u * dot4u8(ck, cpk, 0); }
+
+// The super-cell lists of the block, all at once: thread = (slot, centroid).  List `slot` = the ids (ascending) of the centroids that
+// can be nearest somewhere in super-cell ssup[slot]: pivot = the centroid nearest the cube's centre, kept = whoever the pivot does not
+// dominate over the whole cube (Dominance, kmeans_rgbw.hpp).  A list of more than kPsScap ids is not kept: its cells build from the table.
+__device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uint32_t nslots, const uint16_t *ssup, uint32_t *s_piv, uint32_t (*s_cnt)[4], uint32_t *s_nS,
+                                               uint8_t *Sids, uint32_t tid, int lane) {
+    constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
+    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
+        const uint32_t slot = p >> 8, k = p & 255u;
+        const CellBox bx = super_box(ssup[slot]);
+        const uint32_t cpk = pack_rgb(bx.r0 + 16, bx.g0 + 16, bx.b0 + 16), cc = dot4u8(cpk, cpk, 0);
+        const uint32_t key = k < K ? (ps_centre_dist(tab[k].x, cpk, cc) << 8) | k : 0xffffffffu;
+        const uint32_t m = wave_reduce_min(key);
+        if (lane == 0) atomicMin(&s_piv[slot], m);
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
+        const uint32_t slot = p >> 8, k = p & 255u;
+        Dominance dm;
+        dm.set(super_box(ssup[slot]), ext, tab[s_piv[slot] & 255u].x);
+        const bool keep = k < K && dm.worst(tab[k < K ? k : 0].x) >= 0;
+        const unsigned long long bm = __ballot(keep);
+        if (lane == 0) s_cnt[slot][(p >> 6) & 3u] = (uint32_t)__popcll(bm);
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
+        const uint32_t slot = p >> 8, k = p & 255u, q = (p >> 6) & 3u;
+        Dominance dm;
+        dm.set(super_box(ssup[slot]), ext, tab[s_piv[slot] & 255u].x);
+        const bool keep = k < K && dm.worst(tab[k < K ? k : 0].x) >= 0;
+        const unsigned long long bm = __ballot(keep);
+        uint32_t before = 0;
+        for (uint32_t t = 0; t < q; t++) before += s_cnt[slot][t];
+        const uint32_t pos = before + lanes_below(bm);
+        if (keep && pos < kPsScap) Sids[slot * kPsScap + pos] = (uint8_t)k;
+        if (q == 3 && lane == 0) s_nS[slot] = before + (uint32_t)__popcll(bm);
+    }
+    __syncthreads();
+    if (tid < nslots) s_piv[tid] = 0xffffffffu;   // for the next build
+}
+
+// One cell's candidates from a list of ids (or the whole table), by the 16 lanes of a row: pivot = the member nearest the cube's centre
+// (lowest id on ties), kept = the members the pivot does not dominate over the cell's cube; the mask (bit k <=> centroid k) into the
+// cell's record.  Returns the pivot's id; every lane of the row calls it with the same arguments.
+__device__ __forceinline__ uint32_t ps_row_build(const uint2 *tab, const uint8_t *ids, uint32_t n, bool from_table, uint32_t c, uint32_t l16, uint32_t *rec) {
     constexpr int32_t ext = (1 << kCellShift) - 1;
     const CellBox bx = cell_box(c);
-    const uint32_t pe = nearest_to_centre(list, n, bx, ext, lane);
-    const uint2 pvc = list[pe];
-    const uint32_t pv = (uint32_t)__builtin_amdgcn_readfirstlane((int)pvc.x), pid = 255u - ((uint32_t)__builtin_amdgcn_readfirstlane((int)pvc.y) & 255u);
-    Dominance dm;
-    dm.set(bx, ext, pv);
-    if constexpr (TABLE) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const uint32_t k = 64 * w + lane;
-            nm[w] = __ballot(k < n && dm.worst(list[k < n ? k : 0].x) >= 0);
-        }
-    } else {
-        if (lane < 4) wm[lane] = 0ull;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-            const uint32_t e = e0 + lane;
-            if (e < n) {
-                const uint2 cc = list[e];
-                if (dm.worst(cc.x) >= 0) { const uint32_t k = 255u - (cc.y & 255u); atomicOr(&wm[k >> 6], 1ull << (k & 63)); }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t *w32 = reinterpret_cast<const uint32_t *>(wm);
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-            nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w32[2 * w + 1]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)w32[2 * w]);
+    const uint32_t cpk = pack_rgb(bx.r0 + 4, bx.g0 + 4, bx.b0 + 4), cc = dot4u8(cpk, cpk, 0);
+    uint32_t best = 0xffffffffu;
+    for (uint32_t e = l16; e < n; e += 16) {
+        const uint32_t k = from_table ? e : ids[e];
+        best = min(best, (ps_centre_dist(tab[k].x, cpk, cc) << 8) | k);
     }
-    uint32_t wv = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++)
-        if (lane == t) wv = (uint32_t)(nm[t >> 1] >> (32 * (t & 1)));
-    if (lane < 8) rec[2 + lane] = wv;
-    if (lane == 8) rec[0] = pv;
-    if (lane == 9) rec[1] = c | (pid << 16) | (TABLE ? kRecComplete : 0u);
-    return (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
+    const uint32_t pid = row_min(best) & 255u;
+    Dominance dm;
+    dm.set(bx, ext, tab[pid].x);
+    if (l16 < 8) rec[2 + l16] = 0u;
+    for (uint32_t e = l16; e < n; e += 16) {
+        const uint32_t k = from_table ? e : ids[e];
+        if (dm.worst(tab[k].x) >= 0) atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31));
+    }
+    return pid;
 }
 
 // ---------------------------------------------------------------- sweeps
@@ -191,7 +218,7 @@ __device__ __forceinline__ void ps_book_move(unsigned long long *acc, uint32_t K
 // first mover's (old, new) pair are summed in the wave and booked by one lane, round by round (ten LDS atomics per point on the same
 // ten words run one lane at a time).
 template <typename StoreLabel>
-__device__ __forceinline__ void ps_sweep(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
+__device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
                                          const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
                                          bool agg, StoreLabel store_label) {
     uint32_t key[kSweep], cur[kSweep], wt[kSweep];
@@ -210,7 +237,7 @@ __device__ __forceinline__ void ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
         bool same = true;
 #pragma unroll
         for (int u = 0; u < kSweep; u++) same = same & ((base + u * 64 + lane >= e) | (cur[u] == only));
-        if (__ballot(!same) == 0ull) return;
+        if (__ballot(!same) == 0ull) return true;
     }
     uint32_t best[kSweep];
     ps_best(key, nm, tab, best);
@@ -222,11 +249,11 @@ __device__ __forceinline__ void ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
         mv[u] = (base + u * 64 + lane < e) & ((best[u] >> 8) > (kc >> 8));  // strictly closer (kmeans.rs:375)
         any = any | mv[u];
     }
-    if (!__ballot(any)) return;
+    if (!__ballot(any)) return false;
     if (__ballot(heavy & any)) {   // a pixel count of 255 and more is looked up (rare in a photograph)
 #pragma unroll
         for (int u = 0; u < kSweep; u++)
-            if (mv[u] && wt[u] == 255u) wt[u] = cwq[base + u * 64 + lane];
+            if (mv[u] && wt[u] == 255u) wt[u] = cwq[base + u * 64 + lane - s0];
     }
     uint32_t nl[kSweep];
 #pragma unroll
@@ -243,7 +270,7 @@ __device__ __forceinline__ void ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
 #pragma unroll 1
             for (int round = 0; round < 6; round++) {
                 const unsigned long long b0 = __ballot(mv[0]), b1 = __ballot(mv[1]), b2 = __ballot(mv[2]), b3 = __ballot(mv[3]);
-                if (!(b0 | b1 | b2 | b3)) return;
+                if (!(b0 | b1 | b2 | b3)) return false;
                 uint32_t pn, po;
                 if (b0) { const int l = __builtin_ctzll(b0); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[0], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[0], l); }
                 else if (b1) { const int l = __builtin_ctzll(b1); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[1], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[1], l); }
@@ -281,15 +308,31 @@ __device__ __forceinline__ void ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
 #pragma unroll
     for (int u = 0; u < kSweep; u++)
         if (mv[u]) ps_book_move(acc, K, key[u], wt[u], cur[u], nl[u]);
+    return false;
 }
 
-// The sweep of iteration 0: colours, pixel counts and the initial labels (init_assignment, kmeans.rs:61-78) come from the cell-major
-// arrays, EVERY point adds to the sums of the cluster it ends in (the running sums start at zero), and the packed word of every point
-// is written to its home.  A sweep lies inside one 8^3 cell and its points join one, two, three clusters: round by round, the cluster of
-// the first point still to be booked, every point that joins it summed in the wave, one lane adds the totals.
-template <typename StoreWord>
-__device__ __forceinline__ void ps_sweep_first(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep], uint32_t base, uint32_t e, int lane,
-                                               const unsigned long long (&nm)[4], const uint2 *tab, uint32_t K, unsigned long long *acc, uint32_t &moved, StoreWord store_word) {
+// The sweep of iteration 0 over the packed words the block loaded at entry (colour, pixel count, the initial label of init_assignment,
+// kmeans.rs:61-78): EVERY point adds to the sums of the cluster it ends in (the running sums start at zero).  A sweep lies inside one
+// 8^3 cell and its points join one, two, three clusters: round by round, the cluster of the first point still to be booked, every
+// point that joins it summed in the wave, one lane adds the totals.
+template <typename StoreLabel>
+__device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4],
+                                               const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
+                                               StoreLabel store_label) {
+    uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+    bool heavy = false;
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        p[u] = pk_key(wd[u], cbk);
+        cur[u] = wd[u] >> 24;
+        wt[u] = (wd[u] >> 16) & 255u;
+        heavy = heavy | (wt[u] == 255u);
+    }
+    if (__ballot(heavy)) {   // a pixel count of 255 and more is looked up
+#pragma unroll
+        for (int u = 0; u < kSweep; u++)
+            if (wt[u] == 255u && base + u * 64 + lane < e) wt[u] = cwq[base + u * 64 + lane - s0];
+    }
     uint32_t best[kSweep];
     ps_best(p, nm, tab, best);
     uint32_t nl[kSweep];
@@ -302,8 +345,7 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&p)[kSweep], cons
         if (rem[u]) {
             const uint2 cc = tab[cur[u]];
             const uint32_t kc = (dot4u8(p[u], cc.x, 0) << 9) + cc.y;
-            if ((best[u] >> 8) > (kc >> 8)) { nl[u] = 255u - (best[u] & 255u); moved++; }  // strictly closer (kmeans.rs:375)
-            store_word(idx, pk_make(p[u], wt[u], nl[u]));
+            if ((best[u] >> 8) > (kc >> 8)) { nl[u] = 255u - (best[u] & 255u); moved++; store_label(idx, nl[u]); }  // strictly closer (kmeans.rs:375)
         }
     }
     static_assert(kSweep == 4, "four slots per lane");
@@ -349,43 +391,44 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&p)[kSweep], cons
     }
 }
 
-// the 64 x kSweep entries from position `from` (global, cell-major) of the classic arrays as buffer loads; entries at `end` and beyond read 0
-__device__ __forceinline__ void ps_load_first(const uint32_t *__restrict__ ckeys, const uint8_t *__restrict__ labels, const uint32_t *__restrict__ cweight,
-                                              uint32_t from, uint32_t end, int lane, uint32_t (&p)[kSweep], uint32_t (&cur)[kSweep], uint32_t (&wt)[kSweep]) {
-    const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)from), e = (uint32_t)__builtin_amdgcn_readfirstlane((int)end);
-    const uint32_t lim = e > f ? e : 0u;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(ckeys), 0, (int)(lim * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(labels), 0, (int)lim, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(cweight), 0, (int)(lim * 4u), 0x00020000);
-    const uint32_t q = f + (uint32_t)lane;
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        p[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rk, (int)(q * 4u + u * 256u), 0, 0);
-        cur[u] = (uint32_t)(uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rl, (int)(q + u * 64u), 0, 0);
-        wt[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rw, (int)(q * 4u + u * 256u), 0, 0);
-    }
-}
+// -DCNIIC_PS_PHASES: wave-clock totals per phase of k_rgbw_persist (a measuring build, never the shipped one):
+// 0 lists, 1 classify, 2 draw + descriptors, 3 mask, 4 point words, 5 sweep, 6 cell tail, 7 flush .. barrier .. update, 8 cells swept
+#ifdef CNIIC_PS_PHASES
+__device__ unsigned long long g_ps_phase[16];
+#define PS_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
+#define PS_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
+#else
+#define PS_PHASE(i) do {} while (0)
+#define PS_COUNT(i, v) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------- the kernel
+// What only the launch's last instructions (or a rare branch) need sits in pinned host memory behind one pointer: as kernel arguments
+// those thirty scalar registers would be alive across the whole loop (the first build spilled 136 scalar registers into vector ones and
+// three of those to scratch).
+struct PsCold {
+    PsExit exit;                          // how the launch ended (the host reads it)
+    uint2 *cconst_g;                      // results, written by block 0 on a regular exit
+    uint32_t *cent_g;
+    uint64_t *members_out, *wsum_out;
+    const uint32_t *keys;                 // canonical point list (empty-cluster reseed) ...
+    GIdx gx;                              // ... or the index of all occupied colours
+    uint64_t seed, U;
+};
 struct PsArgs {
     const uint32_t *ckeys, *cweight;      // cell-major colours and pixel counts
     uint8_t *labels;                      // cell-major labels: the initial assignment on entry, the result on a regular exit
     const uint32_t *ne_cell, *ne_start;   // compacted non-empty cells: id, first position
-    const PsRange *ranges;
+    const uint32_t *cb;                   // chunk boundaries (k_ps_ranges)
     const uint32_t *ranges_fail;
     uint32_t *pk;                         // packed words of the points that do not fit their block's LDS, by cell-major position
     const uint2 *cconst0;                 // the initial centroids (k_rgbw_init_cent)
     unsigned long long *partials;         // 3 x kPsPartWords, zero on entry
     PsBar *bar;                           // zero on entry
-    uint2 *cconst_g;                      // results, written by block 0 on a regular exit
-    uint32_t *cent_g;
-    uint64_t *members_out, *wsum_out;
     KmDevState *st_rw;
-    PsExit *exit_host;                    // pinned: how the launch ended
-    const uint32_t *keys;                 // canonical point list (empty-cluster reseed) ...
-    GIdx gx;                              // ... or the index of all occupied colours
-    uint64_t seed, max_iters, U;
-    uint32_t K, max_skip, agg_iters, test_abort_at;
+    PsCold *cold;                         // pinned
+    uint64_t max_iters;
+    uint32_t K, max_skip, agg_iters, test_abort_at, lds_budget;
     unsigned long long timeout_ticks;
     unsigned long long *iter_ts;          // block 0's clock (100 MHz) when iteration j's centroids stood, [0] at entry; kPsTsCap entries, or null
     unsigned long long *blk_ts;           // measuring runs (CNIIC_KM_PS_BLOCK_TRACE): [block][iteration < 128][4] clock at: assign done, flushed, through the barrier, centroids stand
@@ -393,39 +436,112 @@ struct PsArgs {
 
 __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     extern __shared__ __align__(16) unsigned long long lds[];
-    __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active, s_ok, s_nx, s_nxcd;
+    __shared__ uint32_t s_moved, s_nmoved, s_reseed, s_active, s_ok, s_nx, s_nxcd, s_qn, s_qhead, s_Cres, s_nslots;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
-    __shared__ uint32_t s_nS[kPsSlots];
     __shared__ unsigned long long s_mm[4], s_evals, s_changed, s_pev;
-    const uint32_t tid = threadIdx.x, K = a.K;
+    __shared__ uint32_t s_piv[kPsSlotsMax], s_cnt[kPsSlotsMax][4], s_nS[kPsSlotsMax];
+    __shared__ uint16_t s_ssup[kPsSlotsMax];
+    __shared__ uint32_t s_cbase[kPsChunks + 1], s_cm0[kPsChunks], s_scan[kPsThreads / 64];
+    const uint32_t tid = threadIdx.x, K = a.K, G = gridDim.x;
     const int lane = tid & 63, wid = tid >> 6;
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds) + kPsOffTab);
-    uint2 *Sbase = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds) + kPsOffS);
-    unsigned long long *wmask = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(lds) + kPsOffMask) + wid * 4;
+    uint8_t *Sids = reinterpret_cast<uint8_t *>(lds) + kPsOffS;
     if (*a.ranges_fail) {   // (the same word for every block: nobody starts, nobody waits)
-        if (blockIdx.x == 0 && tid == 0) { a.exit_host->status = kPsStatusRanges; __threadfence_system(); }
+        if (blockIdx.x == 0 && tid == 0) { a.cold->exit.status = kPsStatusRanges; __threadfence_system(); }
         return;
     }
-    const PsRange rg = a.ranges[blockIdx.x];
-    const uint32_t C = rg.mb1 - rg.mb0, Cres = rg.msplit - rg.mb0;
-    uint32_t *cstart = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds) + kPsOffCell);   // [C + 1] first point of a cell, relative to the block's
-    uint16_t *ccell = reinterpret_cast<uint16_t *>(cstart + C + 1);                                   // [C] cell ids
-    uint32_t *recs = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(cstart) + ps_desc_bytes(C));   // [C][kPsRecWords]
-    uint32_t *pts = recs + (size_t)kPsRecWords * C;                                                   // the resident points' words
-    const uint32_t q0 = a.ne_start[rg.mb0], nq = a.ne_start[rg.mb1] - q0, nres = a.ne_start[rg.msplit] - q0;
-    uint32_t *pkq = a.pk + q0;                   // the same positions in memory (used from nres on)
-    const uint32_t *cwq = a.cweight + q0;
-    for (uint32_t i = tid; i <= C; i += kPsThreads) cstart[i] = a.ne_start[rg.mb0 + i] - q0;
-    for (uint32_t i = tid; i < C; i += kPsThreads) ccell[i] = (uint16_t)a.ne_cell[rg.mb0 + i];
+    // ---- the block's cells: chunks b, G + b, 2 G + b, ... of the compacted list, in that order
+    if (tid < kPsChunks) {
+        const uint32_t m0 = a.cb[tid * G + blockIdx.x], m1 = a.cb[tid * G + blockIdx.x + 1];
+        s_cm0[tid] = m0;
+        s_cbase[tid + 1] = m1 - m0;
+    }
+    if (tid == 0) {
+        s_cbase[0] = 0;
+        s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_mm[0] = s_mm[1] = s_mm[2] = s_mm[3] = 0ull; s_qn = 0; s_qhead = 0; s_Cres = 0; s_nslots = 0;
+    }
+    __syncthreads();
+    if (tid == 0)
+        for (uint32_t r = 0; r < kPsChunks; r++) s_cbase[r + 1] += s_cbase[r];
+    __syncthreads();
+    const uint32_t C = s_cbase[kPsChunks], Cr = (C + 3u) & ~3u;
+    uint8_t *cellb = reinterpret_cast<uint8_t *>(lds) + kPsOffCell;
+    uint32_t *cstart = reinterpret_cast<uint32_t *>(cellb);                     // [Cr + 4] first point of a cell in the block's own numbering ([C]: all its points)
+    uint32_t *gstart = cstart + Cr + 4;                                          // [Cr] ... and in the cell-major arrays
+    uint32_t *recs = gstart + Cr;                                                // [Cr][kPsRecWords] skip records
+    uint16_t *ccell = reinterpret_cast<uint16_t *>(recs + (size_t)kPsRecWords * Cr);   // [Cr] cell ids
+    uint16_t *queue = ccell + Cr;                                                // [Cr] cells to sweep in this iteration
+    uint8_t *cslot = reinterpret_cast<uint8_t *>(queue + Cr);                    // [Cr] which shared list (255: none, the table)
+    uint32_t *pts = reinterpret_cast<uint32_t *>(cslot + Cr);                    // the resident points' words
+    const uint32_t cap = (a.lds_budget - kPsOffCell - ps_cell_bytes(C)) / 4u;    // (k_ps_ranges made sure the budget covers the descriptors)
+    {
+        uint32_t np = 0, r = 0, cid = 0;
+        const bool mine = tid < C;
+        if (mine) {
+            while (tid >= s_cbase[r + 1]) r++;
+            const uint32_t m = s_cm0[r] + (tid - s_cbase[r]);
+            cid = a.ne_cell[m];
+            const uint32_t gs = a.ne_start[m];
+            np = a.ne_start[m + 1] - gs;
+            ccell[tid] = (uint16_t)cid;
+            gstart[tid] = gs;
+            uint32_t *rec = recs + (size_t)kPsRecWords * tid;
+            rec[0] = 0u; rec[1] = 0xffffu;   // (no pivot yet; the cell's common label: unknown)
+        }
+        const uint32_t off = block_exclusive_scan<kPsThreads>(np, s_scan);
+        if (mine) cstart[tid] = off;
+        if (tid == (C ? C - 1 : 0)) cstart[C] = C ? off + np : 0u;
+        __syncthreads();
+        // the distinct super-cells of the range, in order: a shared list each (the first kPsSlotsMax of them)
+        const bool flag = mine && (tid == s_cbase[r] || ((uint32_t)ccell[tid - 1] >> kSuperShift) != (cid >> kSuperShift));
+        const uint32_t before = block_exclusive_scan<kPsThreads>(flag ? 1u : 0u, s_scan);
+        if (mine) {
+            const uint32_t sidx = before + (flag ? 1u : 0u) - 1u;
+            cslot[tid] = sidx < kPsSlotsMax ? (uint8_t)sidx : (uint8_t)255;
+            if (flag && sidx < kPsSlotsMax) s_ssup[sidx] = (uint16_t)(cid >> kSuperShift);
+            if (tid == C - 1) s_nslots = min(sidx + 1u, kPsSlotsMax);
+            if (cstart[tid + 1] <= cap && (tid + 1 == C || cstart[tid + 2] > cap)) s_Cres = tid + 1;   // the cells whose points fit the LDS behind the descriptors
+        }
+    }
     for (uint32_t i = tid; i < 5 * K; i += kPsThreads) acc[i] = 0ull;
     for (uint32_t i = tid; i < K; i += kPsThreads) tab[i] = a.cconst0[i];
+    if (tid < kPsSlotsMax) s_piv[tid] = 0xffffffffu;
+    __syncthreads();
+    // ---- the block's points: colour, pixel count and the initial label (init_assignment, kmeans.rs:61-78) of every point of its cells,
+    // as one packed word each, into LDS (the cells that fit) or the packed array in memory; a wave per cell, four loads in flight per array
+    {
+        const uint32_t Cres0 = s_Cres;
+        for (uint32_t i = wid; i < C; i += kPsWaves) {
+            const uint32_t s = cstart[i], n = cstart[i + 1] - s, gs = gstart[i];
+            const uint32_t cbk = cell_base_key(ccell[i]);
+            (void)cbk;
+            for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+                uint32_t kk[4], ww[4], ll[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + u * 64 + lane;
+                    const bool in = t < n;
+                    kk[u] = in ? a.ckeys[gs + t] : 0u;
+                    ww[u] = in ? a.cweight[gs + t] : 0u;
+                    ll[u] = in ? (uint32_t)a.labels[gs + t] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + u * 64 + lane;
+                    if (t < n) {
+                        const uint32_t w = pk_make(kk[u], ww[u], ll[u]);
+                        if (i < Cres0) pts[s + t] = w; else a.pk[gs + t] = w;
+                    }
+                }
+            }
+        }
+    }
     if (tid == 0) {
-        s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_mm[0] = s_mm[1] = s_mm[2] = s_mm[3] = 0ull; s_cell = 0;
         // census: how many blocks does my XCD hold, how many XCDs are in use?  (nothing about placement is assumed)
         const uint32_t x = ps_xcc_id();
         __hip_atomic_fetch_add(&a.bar->xblocks[x].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool ok = ps_barrier_flat(a.bar, gridDim.x, a.timeout_ticks);
+        const bool ok = ps_barrier_flat(a.bar, G, a.timeout_ticks);
         uint32_t n = 0;
         for (int i = 0; i < 8; i++) n += ps_ld(&a.bar->xblocks[i].v) != 0;
         s_nx = ps_ld(&a.bar->xblocks[x].v);
@@ -435,13 +551,11 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     }
     __syncthreads();
     if (!s_ok) {
-        if (tid == 0) { a.exit_host->status = kPsStatusAborted; __threadfence_system(); }
+        if (tid == 0) { a.cold->exit.status = kPsStatusAborted; __threadfence_system(); }
         return;
     }
-    // the super-cells of the block's range: its cells are consecutive in super-cell-major order; the first kPsSlots get a shared list
-    const uint32_t sup_first = C ? (uint32_t)ccell[0] >> kSuperShift : 0u;
-    const uint32_t nsl = C ? min(((uint32_t)ccell[C - 1] >> kSuperShift) - sup_first + 1u, kPsSlots) : 0u;
-    const unsigned long long lt_mask = (1ull << lane) - 1;
+    const uint32_t Cres = s_Cres, nslots = s_nslots;
+    const uint32_t row = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
     // running sums of cluster k = tid (kmeans.rs: the members of every cluster, as sums): registers, the same in every block
     unsigned long long run[5] = {0, 0, 0, 0, 0};
     uint32_t moved = 0;
@@ -449,150 +563,148 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     uint32_t j = 0;              // the iteration whose assign step runs
     uint32_t nS = K;             // centroids the last update moved
     unsigned long long reseeds_total = 0, evals_total = 0;
+    // a cell's record is complete, its mask words stand in rec[2..9]: the pivot's id and the complete flag into word 1 (the cell's common
+    // label stays), and the cell goes on the work list unless ONE candidate is left and every point already carries it (nothing can move:
+    // the lone candidate beats every other centroid for every colour of the cube)
+    auto classified = [&](uint32_t i, uint32_t *rec, uint32_t pid, bool complete, bool force) {
+        const uint32_t w = l16 < 8 ? rec[2 + l16] : 0u;
+        const uint32_t cnt = row_sum((uint32_t)__popc(w));
+        const uint32_t only = row_max(w ? 32u * l16 + (uint32_t)__builtin_ctz(w) : 0u);
+        if (l16 == 0) {
+            const uint32_t ul = rec[1] & 0xffffu;
+            rec[1] = ul | (pid << 16) | (complete ? kRecComplete : 0u);
+            if (force || !(cnt == 1 && ul == only)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
+        }
+    };
+#ifdef CNIIC_PS_PHASES
+    long long t_ph = clock64();
+    unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         const bool first = j == 0;
         const bool skip_mode = !first && a.max_skip && nS <= a.max_skip;
+        PS_PHASE(7);
         if (!skip_mode) {
             // ============================================================= FULL schedule: every cell's candidates anew
-            if ((uint32_t)wid < nsl) {
-                const uint32_t n = build_super(tab, K, sup_first + wid, lane, lt_mask, Sbase + (size_t)wid * kPsScap, kPsScap);
-                if (lane == 0) s_nS[wid] = n;
-            }
-            __syncthreads();
-            for (;;) {
-                uint32_t i = 0;
-                if (lane == 0) i = atomicAdd(&s_cell, 1u);
-                i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-                if (i >= C) break;
-                const uint32_t c = ccell[i], s = cstart[i], e = cstart[i + 1];
-                uint32_t *rec = recs + (size_t)kPsRecWords * i;
-                const uint32_t slot = (c >> kSuperShift) - sup_first;
-                unsigned long long nm[4];
-                uint32_t ncand;
-                const uint32_t nSl = slot < kPsSlots ? s_nS[slot] : 0xffffffffu;
-                if (nSl <= kPsScap) ncand = ps_build<false>(Sbase + (size_t)slot * kPsScap, nSl, c, lane, wmask, rec, nm);
-                else ncand = ps_build<true>(tab, K, c, lane, wmask, rec, nm);
-                const uint32_t cbk = cell_base_key(c);
-                const bool res = i < Cres;
-                if (first) {
-                    uint32_t p[kSweep], cur[kSweep], wt[kSweep];
-                    ps_load_first(a.ckeys, a.labels, a.cweight, q0 + s, q0 + e, lane, p, cur, wt);
-                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                        uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-                        ps_load_first(a.ckeys, a.labels, a.cweight, q0 + base + 64 * kSweep, q0 + e, lane, pn, curn, wtn);
-                        if (res) ps_sweep_first(p, cur, wt, base, e, lane, nm, tab, K, acc, moved, [&](uint32_t idx, uint32_t w) { pts[idx] = w; });
-                        else ps_sweep_first(p, cur, wt, base, e, lane, nm, tab, K, acc, moved, [&](uint32_t idx, uint32_t w) { pkq[idx] = w; });
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
-                    }
-                } else if (res) {
-                    const bool agg = j <= a.agg_iters;
-                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                        uint32_t wd[kSweep];
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
-                        ps_sweep(wd, base, e, lane, nm, ncand, tab, K, cbk, cwq, acc, moved, agg, [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pts)[4 * idx + 3] = (uint8_t)l; });
-                    }
-                } else {
-                    const bool agg = j <= a.agg_iters;
-                    uint32_t wd[kSweep];
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? pkq[idx] : 0u; }
-                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                        uint32_t wn[kSweep];
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + 64 * kSweep + u * 64 + lane; wn[u] = idx < e ? pkq[idx] : 0u; }
-                        ps_sweep(wd, base, e, lane, nm, ncand, tab, K, cbk, cwq, acc, moved, agg, [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pkq)[4 * (size_t)idx + 3] = (uint8_t)l; });
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) wd[u] = wn[u];
-                    }
+            ps_build_lists(tab, K, nslots, s_ssup, s_piv, s_cnt, s_nS, Sids, tid, lane);
+            PS_PHASE(0);
+            if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 4] = wall_clock64();
+            for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {   // a row of 16 lanes per cell
+                const uint32_t i = i0 + row;
+                if (i < C) {
+                    const uint32_t c = ccell[i], slot = cslot[i];
+                    const uint32_t nl = slot != 255u ? s_nS[slot] : 0xffffffffu;
+                    const bool from_table = nl > kPsScap;
+                    uint32_t *rec = recs + (size_t)kPsRecWords * i;
+                    const uint32_t pid = ps_row_build(tab, Sids + (from_table ? 0u : slot * kPsScap), from_table ? K : nl, from_table, c, l16, rec);
+                    if (l16 == 0) rec[0] = tab[pid].x;
+                    classified(i, rec, pid, from_table, first);
                 }
-                evals += (unsigned long long)(e - s) * (ncand + 1);
             }
         } else {
             // ============================================================= SKIP schedule (at most max_skip centroids moved)
             // A cell none of whose candidates moved and whose pivot still dominates every moved centroid repeats all its decisions.
-            // Cells are dealt to the waves with a stride (what survives the test is clustered around the centroids that moved); eight
-            // cells are tested together, lane = (cell, one of eight moved centroids).
-            const uint32_t k1 = (uint32_t)lane < nS ? s_mlist[lane] : 0xffffffffu;
-            const uint32_t ck1 = k1 != 0xffffffffu ? tab[k1].x : 0u;
-            for (uint32_t t0 = 0; (uint32_t)wid + kPsWaves * t0 < C; t0 += 8) {
-                const uint32_t ci = (uint32_t)lane >> 3, ic = (uint32_t)wid + kPsWaves * (t0 + ci);
-                const bool cell_ok = ic < C;
-                const uint32_t *rc = recs + (size_t)kPsRecWords * (cell_ok ? ic : 0u);
-                Dominance dmv;
-                dmv.set(cell_box(rc[1] & 0x7fffu), (1 << kCellShift) - 1, rc[0]);
+            for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {
+                const uint32_t i = i0 + row;
+                const bool ok = i < C;
+                uint32_t *rec = recs + (size_t)kPsRecWords * (ok ? i : 0u);
+                const uint32_t r1 = rec[1], pid = (r1 >> 16) & 255u, c = ccell[ok ? i : 0u];
+                Dominance dm;
+                dm.set(cell_box(c), (1 << kCellShift) - 1, rec[0]);
                 bool dv = false;
-                for (uint32_t j0 = 0; j0 < nS; j0 += 8) {
-                    const uint32_t jj = j0 + ((uint32_t)lane & 7u);
-                    const bool has = jj < nS;
-                    const uint32_t k = has ? s_mlist[jj] : 0u;
-                    const bool in = ((rc[2 + (k >> 5)] >> (k & 31)) & 1u) != 0;
-                    dv = dv | (has & (in | (dmv.worst(tab[k].x) >= 0)));   // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                for (uint32_t jj = l16; jj < nS; jj += 16) {
+                    const uint32_t k = s_mlist[jj];
+                    const bool in = ((rec[2 + (k >> 5)] >> (k & 31)) & 1u) != 0;
+                    dv = dv | in | (dm.worst(tab[k].x) >= 0);   // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
                 }
-                const unsigned long long dirty8 = __ballot(dv && cell_ok);
-                if (!dirty8) continue;
-#pragma unroll 1
-                for (uint32_t bi = 0; bi < 8; bi++) {
-                    if (!((dirty8 >> (8 * bi)) & 0xffull)) continue;
-                    const uint32_t i = (uint32_t)wid + kPsWaves * (t0 + bi);
-                    uint32_t *rec = recs + (size_t)kPsRecWords * i;
-                    const uint32_t pvt = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[0]), cw = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[1]);
-                    const uint32_t c = cw & 0x7fffu, pid = (cw >> 16) & 255u;
-                    const uint32_t s = cstart[i], e = cstart[i + 1];
-                    constexpr int32_t ext = (1 << kCellShift) - 1;
-                    const CellBox bx = cell_box(c);
-                    // A COMPLETE mask whose pivot has not moved: every centroid that has not moved keeps its verdict against it; the moved
+                const unsigned long long bm = __ballot(dv && ok);
+                if (!bm) continue;
+                if ((bm >> (16 * row)) & 0xffffull) {
+                    // A COMPLETE mask whose pivot has not moved: every centroid that has not moved keeps its verdict against it, the moved
                     // ones are tested here.  Otherwise the mask is rebuilt from the whole table with a fresh pivot (and is complete then).
-                    const bool keep_pivot = (cw & kRecComplete) && ((s_mm[pid >> 6] >> (pid & 63)) & 1ull) == 0ull;
-                    unsigned long long nm[4];
-                    uint32_t ncand;
-                    if (keep_pivot) {
-                        Dominance dm;
-                        dm.set(bx, ext, pvt);
-                        unsigned long long f1 = __ballot(k1 != 0xffffffffu && dm.worst(ck1) >= 0);
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            const unsigned long long om = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)rec[3 + 2 * w]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[2 + 2 * w]);
-                            nm[w] = om & ~s_mm[w];
+                    const bool keep = (r1 & kRecComplete) && ((s_mm[pid >> 6] >> (pid & 63)) & 1ull) == 0ull;
+                    if (keep) {
+                        if (l16 < 8) rec[2 + l16] &= ~reinterpret_cast<const uint32_t *>(s_mm)[l16];
+                        for (uint32_t jj = l16; jj < nS; jj += 16) {
+                            const uint32_t k = s_mlist[jj];
+                            if (dm.worst(tab[k].x) >= 0) atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31));
                         }
-                        while (f1) {
-                            const int l = __builtin_ctzll(f1);
-                            f1 &= f1 - 1;
-                            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)k1, l);
-                            const unsigned long long b = 1ull << (k & 63);
-                            const uint32_t w = (k >> 6) & 3;
-                            nm[0] |= w == 0 ? b : 0ull; nm[1] |= w == 1 ? b : 0ull; nm[2] |= w == 2 ? b : 0ull; nm[3] |= w == 3 ? b : 0ull;
-                        }
-#pragma unroll
-                        for (int w = 0; w < 4; w++) nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nm[w] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nm[w]);
-                        uint32_t wv = 0;
-#pragma unroll
-                        for (int t = 0; t < 8; t++)
-                            if (lane == t) wv = (uint32_t)(nm[t >> 1] >> (32 * (t & 1)));
-                        if (lane < 8) rec[2 + lane] = wv;
-                        ncand = (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
-                    } else ncand = ps_build<true>(tab, K, c, lane, wmask, rec, nm);
-                    const uint32_t cbk = cell_base_key(c);
-                    if (i < Cres) {
-                        for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                            uint32_t wd[kSweep];
-#pragma unroll
-                            for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
-                            ps_sweep(wd, base, e, lane, nm, ncand, tab, K, cbk, cwq, acc, moved, false, [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pts)[4 * idx + 3] = (uint8_t)l; });
-                        }
+                        classified(i, rec, pid, true, false);
                     } else {
-                        for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                            uint32_t wd[kSweep];
-#pragma unroll
-                            for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + u * 64 + lane; wd[u] = idx < e ? pkq[idx] : 0u; }
-                            ps_sweep(wd, base, e, lane, nm, ncand, tab, K, cbk, cwq, acc, moved, false, [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pkq)[4 * (size_t)idx + 3] = (uint8_t)l; });
-                        }
+                        const uint32_t npid = ps_row_build(tab, Sids, K, true, c, l16, rec);
+                        if (l16 == 0) rec[0] = tab[npid].x;
+                        classified(i, rec, npid, true, false);
                     }
-                    evals += (unsigned long long)(e - s) * (ncand + 1);
                 }
             }
         }
+        __syncthreads();   // the work list is complete
+        PS_PHASE(1);
+        if (a.blk_ts && tid == 0 && j < 128) { a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 5] = wall_clock64(); a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 6] = s_qn; }
+        // ------------------------------------------------------------- sweeps: the waves draw cells from the list
+        {
+            const uint32_t qn = s_qn;
+            const bool agg = !first && j <= a.agg_iters;
+            for (;;) {
+                uint32_t qi = 0;
+                if (lane == 0) qi = atomicAdd(&s_qhead, 1u);
+                qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+                if (qi >= qn) break;
+                const uint32_t i = queue[qi];
+                const uint32_t c = ccell[i], s = cstart[i], e = cstart[i + 1], gs = gstart[i];
+                uint32_t *rec = recs + (size_t)kPsRecWords * i;
+                PS_PHASE(2);
+                PS_COUNT(8, 1);
+                const uint32_t mw = lane < 8 ? rec[2 + lane] : 0u;
+                unsigned long long nm[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+                    nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * w + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * w);
+                const uint32_t ncand = (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
+                const uint32_t cbk = cell_base_key(c);
+                const bool res = i < Cres;
+                PS_PHASE(3);
+                const uint32_t *cwc = a.cweight + gs;
+                uint32_t *pkc = a.pk + gs;
+                bool uniform = !first;   // every sweep of the cell left through the one-candidate exit: all its points carry that candidate
+                if (res) {
+                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                        uint32_t wd[kSweep];
+#pragma unroll
+                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
+#ifdef CNIIC_PS_PHASES
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                        PS_PHASE(4);
+                        auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pts)[4 * idx + 3] = (uint8_t)l; };
+                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
+                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, tab, K, cbk, cwc, acc, moved, agg, st) && uniform;
+                        PS_PHASE(5);
+                    }
+                } else {
+                    uint32_t wd[kSweep];
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? pkc[idx - s] : 0u; }
+                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                        uint32_t wn[kSweep];
+#pragma unroll
+                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + 64 * kSweep + u * 64 + lane; wn[u] = idx < e ? pkc[idx - s] : 0u; }
+                        auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pkc)[4 * (size_t)(idx - s) + 3] = (uint8_t)l; };
+                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
+                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, tab, K, cbk, cwc, acc, moved, agg, st) && uniform;
+#pragma unroll
+                        for (int u = 0; u < kSweep; u++) wd[u] = wn[u];
+                    }
+                }
+                if (lane == 0) {
+                    const uint32_t only = nm[0] ? (uint32_t)__builtin_ctzll(nm[0]) : nm[1] ? 64u + (uint32_t)__builtin_ctzll(nm[1]) : nm[2] ? 128u + (uint32_t)__builtin_ctzll(nm[2]) : 192u + (uint32_t)__builtin_ctzll(nm[3]);
+                    rec[1] = (rec[1] & 0xffff0000u) | (uniform && ncand == 1 ? only : 0xffffu);
+                }
+                evals += (unsigned long long)(e - s) * (ncand + 1);
+                PS_PHASE(6);
+            }
+        }
+        PS_PHASE(9);
         // ------------------------------------------------------------- this iteration's deltas leave the block
         moved = wave_reduce_sum(moved);
         if (lane == 0) {
@@ -601,7 +713,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         }
         moved = 0; evals = 0;
         __syncthreads();
-        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 4 + 0] = wall_clock64();
+        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 0] = wall_clock64();
         unsigned long long *Pcur = a.partials + (size_t)(j % 3) * kPsPartWords;
         for (uint32_t i = tid; i < 5 * K; i += kPsThreads) {
             const unsigned long long v = acc[i];
@@ -610,11 +722,11 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         if (tid == 0) {
             if (s_moved) __hip_atomic_fetch_add(&Pcur[5 * (size_t)K], (unsigned long long)s_moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (s_evals) __hip_atomic_fetch_add(&Pcur[5 * (size_t)K + 1], s_evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_moved = 0; s_evals = 0; s_cell = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_mm[0] = s_mm[1] = s_mm[2] = s_mm[3] = 0ull;
+            s_moved = 0; s_evals = 0; s_qn = 0; s_qhead = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_mm[0] = s_mm[1] = s_mm[2] = s_mm[3] = 0ull;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's atomics have been performed before its block arrives
         __syncthreads();
-        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 4 + 1] = wall_clock64();
+        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 1] = wall_clock64();
         if (tid == 0) {
             bool ok = ps_barrier_xcd(a.bar, ps_xcc_id(), s_nx, s_nxcd, a.timeout_ticks);
 #ifdef CNIIC_TESTING
@@ -624,10 +736,10 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         }
         __syncthreads();
         if (!s_ok) {
-            if (tid == 0) { a.exit_host->status = kPsStatusAborted; __threadfence_system(); }
+            if (tid == 0) { a.cold->exit.status = kPsStatusAborted; __threadfence_system(); }
             return;
         }
-        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 4 + 2] = wall_clock64();
+        if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 2] = wall_clock64();
         j++;
         // ------------------------------------------------------------- finish iteration j - 1: Point::mean for ColorCount (clusterc.rs:83-113)
         // + empty-cluster reseed (kmeans.rs:110-137), redundantly in every block: the sums are the same everywhere
@@ -645,8 +757,10 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
             for (int i = 0; i < 5; i++) run[i] += d[i];
             uint32_t ck;
             if (run[4] == 0) {
-                const uint64_t ri = reseed_index(a.seed, j - 1, k, a.U);  // fake_clone of the stolen point
-                ck = a.gx.bits ? gidx_select(a.gx, ri) : a.keys[ri];
+                const PsCold *cd = a.cold;
+                const uint64_t ri = reseed_index(cd->seed, j - 1, k, cd->U);  // fake_clone of the stolen point
+                const GIdx gx = cd->gx;
+                ck = gx.bits ? gidx_select(gx, ri) : cd->keys[ri];
                 atomicAdd(&s_reseed, 1u);
             } else {
                 const uint32_t r = div_floor_small(run[0], run[3]) & 255, g = div_floor_small(run[1], run[3]) & 255, b = div_floor_small(run[2], run[3]) & 255;
@@ -665,7 +779,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
             s_pev = ps_aread(&Pcur[5 * (size_t)K + 1]);
         }
         __syncthreads();
-        if (a.blk_ts && tid == 0 && j <= 128) a.blk_ts[((size_t)blockIdx.x * 128 + j - 1) * 4 + 3] = wall_clock64();
+        if (a.blk_ts && tid == 0 && j <= 128) a.blk_ts[((size_t)blockIdx.x * 128 + j - 1) * 8 + 3] = wall_clock64();
         const unsigned long long changed = s_changed;
         nS = s_nmoved;
         reseeds_total += s_reseed;
@@ -678,45 +792,34 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
             if (a.iter_ts && j < kPsTsCap) a.iter_ts[j] = wall_clock64();
             if (fin) {
                 sw->moved_last = changed; sw->reseeds = reseeds_total; sw->active = s_active; sw->pair_evals = evals_total; sw->iter = j; sw->done = 1;
-                PsExit *x = a.exit_host;
+                PsExit *x = &a.cold->exit;
                 x->iter = j; x->moved_last = changed; x->reseeds = reseeds_total; x->active = s_active; x->pair_evals = evals_total;
             }
         }
         if (fin) break;   // converged (kmeans.rs:26-32) or the iteration cap: every block sees the same sums and leaves together
     }
+#ifdef CNIIC_PS_PHASES
+    if (lane == 0)
+        for (int i = 0; i < 16; i++)
+            if (ph_[i]) atomicAdd(&g_ps_phase[i], ph_[i]);
+#endif
     // ----------------------------------------------------------------- results
     if (blockIdx.x == 0 && tid < K) {
+        const PsCold *cd = a.cold;
         const uint2 cc = tab[tid];
-        a.cent_g[tid] = cc.x;
-        a.cconst_g[tid] = cc;
-        a.members_out[tid] = run[4];
-        a.wsum_out[tid] = run[3];
+        cd->cent_g[tid] = cc.x;
+        cd->cconst_g[tid] = cc;
+        cd->members_out[tid] = run[4];
+        cd->wsum_out[tid] = run[3];
     }
-    // the labels of the block's points, four per thread and store where the block's range allows
-    {
-        const uint64_t g_lo = q0, g_hi = (uint64_t)q0 + nq;
-        for (uint64_t g4 = (g_lo & ~3ull) + 4ull * tid; g4 < g_hi; g4 += 4ull * kPsThreads) {
-            uint32_t lb[4];
-            bool in[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const uint64_t g = g4 + t;
-                in[t] = g >= g_lo && g < g_hi;
-                const uint32_t idx = in[t] ? (uint32_t)(g - g_lo) : 0u;
-                lb[t] = 0u;
-                if (in[t]) { if (idx < nres) lb[t] = pts[idx] >> 24; else lb[t] = pkq[idx] >> 24; }
-            }
-            if (in[0] && in[3]) *reinterpret_cast<uint32_t *>(a.labels + g4) = lb[0] | (lb[1] << 8) | (lb[2] << 16) | (lb[3] << 24);
-            else {
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (in[t]) a.labels[g4 + t] = (uint8_t)lb[t];
-            }
-        }
+    for (uint32_t i = wid; i < C; i += kPsWaves) {   // the labels of the block's points, a wave per cell
+        const uint32_t s = cstart[i], n = cstart[i + 1] - s, gs = gstart[i];
+        if (i < Cres) { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(pts[s + t] >> 24); }
+        else { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(a.pk[gs + t] >> 24); }
     }
     if (blockIdx.x == 0) {
         __syncthreads();
-        if (tid == 0) { __threadfence_system(); a.exit_host->status = kPsStatusDone; __threadfence_system(); }
+        if (tid == 0) { __threadfence_system(); a.cold->exit.status = kPsStatusDone; __threadfence_system(); }
     }
 }
 
@@ -757,7 +860,7 @@ int ps_prepare(KmRgbwState *s) {
         attr_set[c->device] = true;
     }
     const uint64_t o_bar = 0, o_part = (sizeof(PsBar) + 255) & ~255ull, o_fail = o_part + ((3 * (uint64_t)kPsPartWords * 8 + 255) & ~255ull);
-    const uint64_t o_rng = o_fail + 256, total = o_rng + (uint64_t)G * sizeof(PsRange);
+    const uint64_t o_rng = o_fail + 256, total = o_rng + ((uint64_t)G * kPsChunks + 1) * 4;
     CNIIC_HIP_TRY(c, s->ps_arena.alloc(total));
     CNIIC_HIP_TRY(c, hipMemsetAsync(s->ps_arena.p, 0, o_rng, c->stream));
     CNIIC_HIP_TRY(c, s->ps_pk.alloc(std::max<uint64_t>(s->U, 1) * 4));
@@ -767,8 +870,9 @@ int ps_prepare(KmRgbwState *s) {
     uint8_t *a = s->ps_arena.as<uint8_t>();
     uint32_t budget = kPsDynBytes;   // (the tests shrink it: CNIIC_TEST_PS_LDS_BYTES leaves most cells' points in memory)
     if (const char *e = test_env("CNIIC_TEST_PS_LDS_BYTES")) budget = std::min<uint32_t>(kPsDynBytes, (uint32_t)atoi(e));
-    hipLaunchKernelGGL(k_ps_ranges, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)s->ne_cost.as<uint32_t>(), (const uint32_t *)s->ne_start.as<uint32_t>(),
-                       (const uint32_t *)s->ne_count.as<uint32_t>(), G, budget, reinterpret_cast<PsRange *>(a + o_rng), reinterpret_cast<uint32_t *>(a + o_fail));
+    s->ps_budget = budget;
+    hipLaunchKernelGGL(k_ps_ranges, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)s->ne_cost.as<uint32_t>(), (const uint32_t *)s->ne_count.as<uint32_t>(), G, budget,
+                       reinterpret_cast<uint32_t *>(a + o_rng), reinterpret_cast<uint32_t *>(a + o_fail));
     CNIIC_HIP_TRY(c, hipGetLastError());
     s->ps = true;
     return CNIIC_OK;
@@ -785,9 +889,11 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
     const int dev = c->device >= 0 && c->device < 16 ? c->device : 0, G = (int)s->ps_blocks;
     if (g_ps_cus_in_use[dev].fetch_add(G) + G > ps_cu_count(c->device)) { g_ps_cus_in_use[dev].fetch_sub(G); return CNIIC_OK; }
     struct Release { int dev, G; ~Release() { g_ps_cus_in_use[dev].fetch_sub(G); } } release{dev, G};
-    if (!c->pinned_ps) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned_ps, 256, hipHostMallocDefault));
-    PsExit *xh = static_cast<PsExit *>(c->pinned_ps);
-    memset(xh, 0, sizeof *xh);
+    if (!c->pinned_ps) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned_ps, 1024, hipHostMallocDefault));
+    static_assert(sizeof(PsCold) <= 1024, "the pinned block holds a PsCold");
+    PsCold *cold = static_cast<PsCold *>(c->pinned_ps);
+    memset(cold, 0, sizeof *cold);
+    PsExit *xh = &cold->exit;
     uint8_t *ar = s->ps_arena.as<uint8_t>();
     DevBuf ts;
     const bool want_ts = s->profile || test_env("CNIIC_KM_PS_TRACE");
@@ -795,12 +901,13 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
     PsArgs a{};
     a.ckeys = s->ckeys.as<uint32_t>(); a.cweight = s->cweight.as<uint32_t>(); a.labels = s->labels.as<uint8_t>();
     a.ne_cell = s->ne_cell.as<uint32_t>(); a.ne_start = s->ne_start.as<uint32_t>();
-    a.ranges = reinterpret_cast<const PsRange *>(ar + s->ps_o_rng); a.ranges_fail = reinterpret_cast<const uint32_t *>(ar + s->ps_o_fail);
+    a.cb = reinterpret_cast<const uint32_t *>(ar + s->ps_o_rng); a.ranges_fail = reinterpret_cast<const uint32_t *>(ar + s->ps_o_fail);
+    a.lds_budget = s->ps_budget;
     a.pk = s->ps_pk.as<uint32_t>(); a.cconst0 = s->cconst.as<uint2>();
     a.partials = reinterpret_cast<unsigned long long *>(ar + s->ps_o_part); a.bar = reinterpret_cast<PsBar *>(ar);
-    a.cconst_g = s->cconst.as<uint2>(); a.cent_g = s->cent.as<uint32_t>(); a.members_out = s->members_last.as<uint64_t>(); a.wsum_out = s->wsum_last.as<uint64_t>();
-    a.st_rw = s->dstate.as<KmDevState>(); a.exit_host = xh;
-    a.keys = s->keys; a.gx = s->gidx; a.seed = s->seed; a.max_iters = s->max_iters; a.U = s->gidx.bits ? s->gidx.U : s->U;
+    cold->cconst_g = s->cconst.as<uint2>(); cold->cent_g = s->cent.as<uint32_t>(); cold->members_out = s->members_last.as<uint64_t>(); cold->wsum_out = s->wsum_last.as<uint64_t>();
+    cold->keys = s->keys; cold->gx = s->gidx; cold->seed = s->seed; cold->U = s->gidx.bits ? s->gidx.U : s->U;
+    a.st_rw = s->dstate.as<KmDevState>(); a.cold = cold; a.max_iters = s->max_iters;
     a.K = s->K; a.max_skip = s->no_skip ? 0u : s->max_skip; a.agg_iters = s->agg_launches;
     a.test_abort_at = 0;
     if (const char *e = test_env("CNIIC_TEST_PS_ABORT_AT")) a.test_abort_at = (uint32_t)atoi(e);
@@ -810,7 +917,7 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
     a.iter_ts = want_ts ? ts.as<unsigned long long>() : nullptr;
     DevBuf bts;
     const char *bt_path = test_env("CNIIC_KM_PS_BLOCK_TRACE");
-    if (bt_path) { CNIIC_HIP_TRY(c, bts.alloc((uint64_t)G * 128 * 4 * 8)); CNIIC_HIP_TRY(c, hipMemsetAsync(bts.p, 0, (uint64_t)G * 128 * 4 * 8, c->stream)); a.blk_ts = bts.as<unsigned long long>(); }
+    if (bt_path) { CNIIC_HIP_TRY(c, bts.alloc((uint64_t)G * 128 * 8 * 8)); CNIIC_HIP_TRY(c, hipMemsetAsync(bts.p, 0, (uint64_t)G * 128 * 8 * 8, c->stream)); a.blk_ts = bts.as<unsigned long long>(); }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->profile) { CNIIC_HIP_TRY(c, hipEventCreate(&e0)); CNIIC_HIP_TRY(c, hipEventCreate(&e1)); }
     hipExtLaunchKernelGGL(k_rgbw_persist, dim3((uint32_t)G), dim3(kPsThreads), kPsDynBytes, c->stream, e0, e1, 0, a);
@@ -854,18 +961,30 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
         }
     }
     if (bt_path) {   // per block and iteration: microseconds in the assign step, the flush, the barrier, the update (the clock starts where the previous iteration's centroids stood)
-        std::vector<unsigned long long> b((size_t)G * 128 * 4);
+        std::vector<unsigned long long> b((size_t)G * 128 * 8);
         CNIIC_HIP_TRY(c, hipMemcpy(b.data(), bts.p, b.size() * 8, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(bt_path, "w")) {
-            fprintf(f, "block,iteration,assign_us,flush_us,barrier_us,update_us\n");
+            fprintf(f, "block,iteration,assign_us,flush_us,barrier_us,update_us,lists_us,classify_us,sweeps_us,cells_swept\n");
             for (int g = 0; g < G; g++)
                 for (uint64_t i = 1; i < xh->iter && i < 128; i++) {
-                    const unsigned long long *r = &b[((size_t)g * 128 + i) * 4], start = b[((size_t)g * 128 + i - 1) * 4 + 3];
-                    fprintf(f, "%d,%llu,%.2f,%.2f,%.2f,%.2f\n", g, (unsigned long long)i, (r[0] - start) / 100.0, (r[1] - r[0]) / 100.0, (r[2] - r[1]) / 100.0, (r[3] - r[2]) / 100.0);
+                    const unsigned long long *r = &b[((size_t)g * 128 + i) * 8], start = b[((size_t)g * 128 + i - 1) * 8 + 3];
+                    const unsigned long long l_end = r[4] ? r[4] : start;   // (skip schedule: no lists)
+                    fprintf(f, "%d,%llu,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f,%.2f,%llu\n", g, (unsigned long long)i, (r[0] - start) / 100.0, (r[1] - r[0]) / 100.0, (r[2] - r[1]) / 100.0, (r[3] - r[2]) / 100.0,
+                            (l_end - start) / 100.0, (r[5] - l_end) / 100.0, (r[0] - r[5]) / 100.0, r[6]);
                 }
             fclose(f);
         }
     }
+#ifdef CNIIC_PS_PHASES
+    {
+        unsigned long long ph[16], zero[16] = {0};
+        CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ps_phase), sizeof ph));
+        CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ps_phase), zero, sizeof zero));
+        const double w = (double)G * kPsWaves;
+        fprintf(stderr, "persist phases (wave clocks per wave, %llu iterations): lists %.0f classify %.0f | draw+desc %.0f mask %.0f words %.0f sweep %.0f tail %.0f wait-for-others %.0f | sync+update %.0f | cells swept per wave %.1f\n",
+                (unsigned long long)xh->iter, ph[0] / w, ph[1] / w, ph[2] / w, ph[3] / w, ph[4] / w, ph[5] / w, ph[6] / w, ph[9] / w, ph[7] / w, ph[8] / w);
+    }
+#endif
     *ran = true;
     return CNIIC_OK;
 }

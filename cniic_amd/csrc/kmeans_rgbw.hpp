@@ -78,21 +78,23 @@ struct KmRgbwState {
     DevBuf ps_arena;             // [PsBar | 3 x kPsPartWords sums | fail word | PsRange[ps_blocks]]
     DevBuf ps_pk;                // packed words of the points that do not fit their block's LDS
     uint64_t ps_o_part = 0, ps_o_fail = 0, ps_o_rng = 0;
+    uint32_t ps_budget = 0;      // bytes of dynamic LDS the block ranges were made for
 };
 
 // ---- k_kmeans_persist.hip: the LDS of a block and what the launch shares with its set-up
-constexpr uint32_t kPsSlots = 4;                        // shared super-cell lists of a block (its range rarely spans more super-cells)
-constexpr uint32_t kPsRecWords = 10;                    // a cell's skip record: pivot colour, cell | pivot id << 16 | kRecComplete, 8 mask words
+constexpr uint32_t kPsChunks = 16;                      // chunks of the cell list a block owns (interleaved with the other blocks')
+constexpr uint32_t kPsSlotsMax = 32;                    // shared super-cell lists of a block (cells of further super-cells build from the table)
+constexpr uint32_t kPsScap = 128;                       // ids a shared list holds (a longer list: its cells build from the table)
+constexpr uint32_t kPsRecWords = 10;                    // a cell's record: pivot colour, common label | pivot id << 16 | kRecComplete, 8 mask words
 constexpr uint32_t kPsMaxCells = 1024;                  // cells a block may own
-constexpr uint32_t kPsOffCell = 5 * 256 * 8 + 256 * 8 + kPsSlots * 128 * 8 + 16 * 4 * 8;   // accumulators, table, shared lists, the waves' mask words
-constexpr uint32_t kPsDynBytes = 160 * 1024 - 1536;     // the launch's dynamic LDS (the kernel's static variables take the rest)
+constexpr uint32_t kPsOffCell = 5 * 256 * 8 + 256 * 8 + kPsSlotsMax * kPsScap;   // accumulators, table, the shared lists' ids
+constexpr uint32_t kPsDynBytes = 160 * 1024 - 3072;     // the launch's dynamic LDS (the kernel's static variables take the rest)
 constexpr uint32_t kPsPartWords = 5 * 256 + 8;          // u64 words of one buffer of sums (5K + 2, padded)
 constexpr uint32_t kPsTsCap = 1024;                     // iterations whose end block 0 timestamps
-__host__ __device__ constexpr uint32_t ps_desc_bytes(uint32_t C) { return ((C + 1) * 4u + C * 2u + 7u) & ~7u; }     // first points u32[C + 1], cell ids u16[C]
-__host__ __device__ constexpr uint32_t ps_cell_bytes(uint32_t C) { return ps_desc_bytes(C) + C * kPsRecWords * 4u; }
+// per cell (C rounded up to a multiple of 4): first point u32 (own numbering; + 4 words), first point u32 (cell-major), record, id u16, work list u16, list slot u8
+__host__ __device__ constexpr uint32_t ps_cell_bytes(uint32_t C) { return 16u + ((C + 3u) & ~3u) * (4u + 4u + kPsRecWords * 4u + 2u + 2u + 1u); }
 struct alignas(128) PsLine { uint32_t v; uint32_t pad[31]; };
 struct PsBar { PsLine xcount[8], xgen[8], xblocks[8], top, topgen, count, gen, abort_; };   // every counter on a line of its own
-struct PsRange { uint32_t mb0, mb1, msplit, pad; };    // cells [mb0, mb1) of the compacted list; [mb0, msplit): points resident in LDS
 constexpr uint32_t kPsStatusDone = 1, kPsStatusAborted = 2, kPsStatusRanges = 3;
 struct PsExit { uint32_t status, pad; uint64_t iter, moved_last, reseeds, active, pair_evals; };   // pinned: how the launch ended
 int ps_prepare(KmRgbwState *s);

@@ -54,13 +54,13 @@ def test_any_grid_gives_the_oracles_run(ctx, monkeypatch, K, shape, blocks):
     run_both(ctx, synth_img(*shape, seed=11 + K), K)
 
 
-@pytest.mark.parametrize("lds_bytes", ["20000", "26000", "60000"])
+@pytest.mark.parametrize("lds_bytes", ["30000", "40000", "100000"])
 @pytest.mark.parametrize("no_skip", [False, True])
 def test_points_that_do_not_fit_lds_live_in_memory(ctx, monkeypatch, lds_bytes, no_skip):
-    """a block's LDS budget shrunk until most (20000: all) of its cells keep their packed words in memory"""
+    """a block's LDS budget shrunk until most of its cells keep their packed words in memory (30000: a few hundred points stay)"""
     from cniic_amd import _lib
     monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")
-    monkeypatch.setenv("CNIIC_KM_PS_BLOCKS", "4")
+    monkeypatch.setenv("CNIIC_KM_PS_BLOCKS", "8")
     monkeypatch.setenv("CNIIC_TEST_PS_LDS_BYTES", lds_bytes)
     run_both(ctx, synth_img(300, 260, seed=5), 64, flags=_lib.KM_NO_SKIP if no_skip else 0)
 
@@ -69,6 +69,7 @@ def test_points_that_do_not_fit_lds_live_in_memory(ctx, monkeypatch, lds_bytes, 
 def test_a_barrier_that_gives_up_hands_over_to_the_launch_per_iteration_loop(ctx, monkeypatch, abort_at):
     """CNIIC_TEST_PS_ABORT_AT: every block leaves at that barrier as if its wait had run out; nothing the classic loop reads was
     written, and it produces the oracle's run"""
+    monkeypatch.delenv("CNIIC_KM_PS_REQUIRE", raising=False)
     monkeypatch.setenv("CNIIC_TEST_PS_ABORT_AT", abort_at)
     run_both(ctx, synth_img(128, 128, seed=3), 32)
     monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")      # ... and with REQUIRE the same abort is an error: the knob does what it says
@@ -82,8 +83,14 @@ def test_a_range_with_too_many_cells_is_refused_before_any_block_starts(ctx, mon
     """one block for an image of several thousand non-empty cells: k_ps_ranges raises the fail word, the launch leaves at once"""
     from cniic_amd import synth
     img = synth.uniform(256, 256, synth.SEED0 + 9)           # uniform noise: ~all 32768 cells occupied
+    monkeypatch.delenv("CNIIC_KM_PS_REQUIRE", raising=False)
     monkeypatch.setenv("CNIIC_KM_PS_BLOCKS", "1")
     run_both(ctx, img, 16, max_iters=6)
+    monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")           # (and with REQUIRE the refusal is an error: the fail word did its work)
+    from cniic_amd import _lib
+    keys, counts = O.count_freqs(keys_of(img))
+    rc, _ = ctx.kmeans_rgbw(keys, counts.astype(np.uint32), 16, max_iters=6, allow=(_lib.HIP,))
+    assert rc == _lib.HIP
 
 
 @pytest.mark.parametrize("max_iters", [1, 2, 5])

@@ -51,11 +51,12 @@ if os.path.exists(bpath):
     import collections
     per = collections.defaultdict(list)
     for l in list(open(bpath))[1:]:
-        g, i, a_, f_, b_, u_ = l.strip().split(",")
-        per[int(i)].append((float(a_), float(f_), float(b_), float(u_)))
-    print("iteration: assign mean / max | flush mean | barrier min / mean | update mean   (us, over the blocks)")
+        f = l.strip().split(",")
+        per[int(f[1])].append([float(x) for x in f[2:]])
+    print("iteration: assign mean / max = lists + classify + sweeps (mean; cells swept mean / max) | flush mean | barrier min / mean | update mean   (us, over the blocks)")
     for i in sorted(per):
         v = per[i]
         n = len(v)
-        print("%3d: assign %6.2f / %6.2f | flush %5.2f | barrier %5.2f / %5.2f | update %5.2f" % (
-            i, sum(x[0] for x in v) / n, max(x[0] for x in v), sum(x[1] for x in v) / n, min(x[2] for x in v), sum(x[2] for x in v) / n, sum(x[3] for x in v) / n))
+        m = lambda k: sum(x[k] for x in v) / n
+        print("%3d: assign %6.2f / %6.2f = %5.2f + %5.2f + %5.2f (%5.1f / %3d) | flush %5.2f | barrier %5.2f / %5.2f | update %5.2f" % (
+            i, m(0), max(x[0] for x in v), m(4), m(5), m(6), m(7), max(x[7] for x in v), m(1), min(x[2] for x in v), m(2), m(3)))
