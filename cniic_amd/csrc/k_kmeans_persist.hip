@@ -28,7 +28,7 @@ constexpr int kPsThreads = 1024, kPsWaves = kPsThreads / 64;
 constexpr uint32_t kPsAccWords = 5 * 256;              // u64 accumulators (K <= 256)
 // dynamic LDS: [acc u64 5 x 256 | tab uint2 256 | ids u8 kPsSlotsMax x kPsScap | per block (ps_cell_bytes): first points, records, cell ids, work list, list slots | points u32[...]]
 constexpr uint32_t kPsOffTab = kPsAccWords * 8, kPsOffS = kPsOffTab + 256 * 8;
-static_assert(kPsOffCell == kPsOffS + kPsSlotsMax * kPsScap, "ps_cell_bytes / kPsOffCell (kmeans_rgbw.hpp) describe this layout");
+static_assert(kPsOffCell == kPsOffS + kPsSlotsMax * kPsScap * 4, "ps_cell_bytes / kPsOffCell (kmeans_rgbw.hpp) describe this layout");
 
 __device__ __forceinline__ uint32_t ps_xcc_id() {
     uint32_t v;
@@ -120,68 +120,122 @@ __device__ __forceinline__ uint32_t row_sum(uint32_t v) { return row_allreduce(v
 // squared distance from colour key ck to the centre of the cube at low corner `lo` (packed) with half side h: |v|^2 - 2 v.c + |c|^2
 __device__ __forceinline__ uint32_t ps_centre_dist(uint32_t ck, uint32_t cpk, uint32_t cc) { return dot4u8(ck, ck, cc) - 2u * dot4u8(ck, cpk, 0); }
 
-// The super-cell lists of the block, all at once: thread = (slot, centroid).  List `slot` = the ids (ascending) of the centroids that
-// can be nearest somewhere in super-cell ssup[slot]: pivot = the centroid nearest the cube's centre, kept = whoever the pivot does not
-// dominate over the whole cube (Dominance, kmeans_rgbw.hpp).  A list of more than kPsScap ids is not kept: its cells build from the table.
-__device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uint32_t nslots, const uint16_t *ssup, uint32_t *s_piv, uint32_t (*s_cnt)[4], uint32_t *s_nS,
-                                               uint8_t *Sids, uint32_t tid, int lane) {
+// The super-cell lists of the block, a wave per list.  List `slot` = the centroids (ascending id) that can be nearest somewhere in
+// super-cell ssup[slot]: pivot = the centroid nearest the cube's centre, kept = whoever the pivot does not dominate over the whole cube
+// (Dominance, kmeans_rgbw.hpp).  An entry is id << 24 | colour: the per-cell builds read ONE word per member, all of a lane's members
+// at once.  A list of more than kPsScap members is not kept: its cells build from the table.
+__device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uint32_t nslots, const uint16_t *ssup, uint32_t *s_nS, uint32_t *Sent, int wid, int lane) {
     constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
-    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
-        const uint32_t slot = p >> 8, k = p & 255u;
-        const CellBox bx = super_box(ssup[slot]);
+    for (uint32_t slot = (uint32_t)wid; slot < nslots; slot += kPsWaves) {
+        const CellBox bx = super_box((uint32_t)__builtin_amdgcn_readfirstlane((int)ssup[slot]));
         const uint32_t cpk = pack_rgb(bx.r0 + 16, bx.g0 + 16, bx.b0 + 16), cc = dot4u8(cpk, cpk, 0);
-        const uint32_t key = k < K ? (ps_centre_dist(tab[k].x, cpk, cc) << 8) | k : 0xffffffffu;
-        const uint32_t m = wave_reduce_min(key);
-        if (lane == 0) atomicMin(&s_piv[slot], m);
-    }
-    __syncthreads();
-    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
-        const uint32_t slot = p >> 8, k = p & 255u;
+        uint32_t ck[4], best = 0xffffffffu;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t k = 64u * r + (uint32_t)lane;
+            ck[r] = k < K ? tab[k].x : 0u;
+            if (k < K) best = min(best, (ps_centre_dist(ck[r], cpk, cc) << 8) | k);
+        }
+        const uint32_t piv = wave_reduce_min(best) & 255u;
         Dominance dm;
-        dm.set(super_box(ssup[slot]), ext, tab[s_piv[slot] & 255u].x);
-        const bool keep = k < K && dm.worst(tab[k < K ? k : 0].x) >= 0;
-        const unsigned long long bm = __ballot(keep);
-        if (lane == 0) s_cnt[slot][(p >> 6) & 3u] = (uint32_t)__popcll(bm);
+        dm.set(bx, ext, (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[piv].x));
+        uint32_t n = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t k = 64u * r + (uint32_t)lane;
+            const bool keep = k < K && dm.worst(ck[r]) >= 0;
+            const unsigned long long bm = __ballot(keep);
+            const uint32_t pos = n + lanes_below(bm);
+            if (keep && pos < kPsScap) Sent[slot * kPsScap + pos] = (k << 24) | ck[r];
+            n += (uint32_t)__popcll(bm);
+        }
+        if (lane == 0) s_nS[slot] = n;
     }
     __syncthreads();
-    for (uint32_t p = tid; p < nslots * 256u; p += kPsThreads) {
-        const uint32_t slot = p >> 8, k = p & 255u, q = (p >> 6) & 3u;
-        Dominance dm;
-        dm.set(super_box(ssup[slot]), ext, tab[s_piv[slot] & 255u].x);
-        const bool keep = k < K && dm.worst(tab[k < K ? k : 0].x) >= 0;
-        const unsigned long long bm = __ballot(keep);
-        uint32_t before = 0;
-        for (uint32_t t = 0; t < q; t++) before += s_cnt[slot][t];
-        const uint32_t pos = before + lanes_below(bm);
-        if (keep && pos < kPsScap) Sids[slot * kPsScap + pos] = (uint8_t)k;
-        if (q == 3 && lane == 0) s_nS[slot] = before + (uint32_t)__popcll(bm);
-    }
-    __syncthreads();
-    if (tid < nslots) s_piv[tid] = 0xffffffffu;   // for the next build
 }
 
-// One cell's candidates from a list of ids (or the whole table), by the 16 lanes of a row: pivot = the member nearest the cube's centre
-// (lowest id on ties), kept = the members the pivot does not dominate over the cell's cube; the mask (bit k <=> centroid k) into the
-// cell's record.  Returns the pivot's id; every lane of the row calls it with the same arguments.
-__device__ __forceinline__ uint32_t ps_row_build(const uint2 *tab, const uint8_t *ids, uint32_t n, bool from_table, uint32_t c, uint32_t l16, uint32_t *rec) {
+// A cell's record once its mask words stand in rec[2..9] (every lane of the cell's row calls this): the number of candidates, up to
+// four of their ids as bytes of rec[10] (what a sweep reads instead of walking the mask), and the pivot's id / the complete flag in
+// word 1 (the cell's common label stays).  Returns (row-uniform) whether the cell must be swept: not if ONE candidate is left and every
+// point already carries it (the lone candidate beats every other centroid for every colour of the cube: nothing can move).
+__device__ __forceinline__ bool ps_row_finish(uint32_t *rec, uint32_t l16, uint32_t pid, bool complete) {
+    const uint32_t w = l16 < 8 ? rec[2 + l16] : 0u;
+    const uint32_t pc = (uint32_t)__popc(w);
+    uint32_t inc = pc;   // inclusive scan inside the row (lanes 8..15 add nothing)
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);   // row_shr:1
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);   // row_shr:2
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);   // row_shr:4
+    const uint32_t cnt = row_max(inc);
+    uint32_t pos = inc - pc, ww = w;
+    uint8_t *c4 = reinterpret_cast<uint8_t *>(rec + 10);
+    while (ww && pos < 4) {
+        c4[pos] = (uint8_t)(32u * l16 + (uint32_t)__builtin_ctz(ww));
+        ww &= ww - 1;
+        pos++;
+    }
+    const uint32_t r1 = rec[1];
+    if (l16 == 0) rec[1] = (r1 & 0xffffu) | (pid << 16) | (min(cnt, 127u) << 24) | (complete ? kRecComplete : 0u);
+    const uint32_t only = rec[10] & 255u;   // (behind the byte stores of this wave: the LDS serves a wave in order)
+    return !(cnt == 1 && (r1 & 0xffffu) == only);
+}
+
+// One cell's candidates from its super-cell's list, by the 16 lanes of a row: every lane takes the members l16, l16 + 16, ... (at most
+// kPsScap / 16, all read at once), pivot = the member nearest the cube's centre (lowest id on ties), kept = the members the pivot does not
+// dominate over the cell's cube; the mask (bit k <=> centroid k) into the cell's record.  Returns the pivot's id.
+__device__ __forceinline__ uint32_t ps_row_build_list(const uint2 *tab, const uint32_t *ent, uint32_t n, uint32_t c, uint32_t l16, uint32_t *rec) {
     constexpr int32_t ext = (1 << kCellShift) - 1;
+    constexpr int PER = kPsScap / 16;
     const CellBox bx = cell_box(c);
     const uint32_t cpk = pack_rgb(bx.r0 + 4, bx.g0 + 4, bx.b0 + 4), cc = dot4u8(cpk, cpk, 0);
+    uint32_t en[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) en[t] = l16 + 16u * t < n ? ent[l16 + 16u * t] : 0xffffffffu;
     uint32_t best = 0xffffffffu;
-    for (uint32_t e = l16; e < n; e += 16) {
-        const uint32_t k = from_table ? e : ids[e];
-        best = min(best, (ps_centre_dist(tab[k].x, cpk, cc) << 8) | k);
-    }
+#pragma unroll
+    for (int t = 0; t < PER; t++)
+        if (l16 + 16u * t < n) best = min(best, (ps_centre_dist(en[t] & 0xffffffu, cpk, cc) << 8) | (en[t] >> 24));
     const uint32_t pid = row_min(best) & 255u;
     Dominance dm;
     dm.set(bx, ext, tab[pid].x);
     if (l16 < 8) rec[2 + l16] = 0u;
-    for (uint32_t e = l16; e < n; e += 16) {
-        const uint32_t k = from_table ? e : ids[e];
-        if (dm.worst(tab[k].x) >= 0) atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31));
-    }
+#pragma unroll
+    for (int t = 0; t < PER; t++)
+        if (l16 + 16u * t < n && dm.worst(en[t] & 0xffffffu) >= 0) { const uint32_t k = en[t] >> 24; atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31)); }
+    if (l16 == 0) rec[0] = tab[pid].x;
     return pid;
 }
+// ... and from the whole table (a list that did not fit; a dirty cell of the skip schedule whose mask is not complete or whose pivot moved)
+__device__ __forceinline__ uint32_t ps_row_build_table(const uint2 *tab, uint32_t K, uint32_t c, uint32_t l16, uint32_t *rec) {
+    constexpr int32_t ext = (1 << kCellShift) - 1;
+    const CellBox bx = cell_box(c);
+    const uint32_t cpk = pack_rgb(bx.r0 + 4, bx.g0 + 4, bx.b0 + 4), cc = dot4u8(cpk, cpk, 0);
+    uint32_t best = 0xffffffffu;
+    for (uint32_t k = l16; k < K; k += 16) best = min(best, (ps_centre_dist(tab[k].x, cpk, cc) << 8) | k);
+    const uint32_t pid = row_min(best) & 255u;
+    Dominance dm;
+    dm.set(bx, ext, tab[pid].x);
+    if (l16 < 8) rec[2 + l16] = 0u;
+    for (uint32_t k = l16; k < K; k += 16)
+        if (dm.worst(tab[k].x) >= 0) atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31));
+    if (l16 == 0) rec[0] = tab[pid].x;
+    return pid;
+}
+
+// -DCNIIC_PS_PHASES: wave-clock totals per phase of k_rgbw_persist (a measuring build, never the shipped one):
+// 0 lists, 1 classify, 2 draw + descriptors, 3 mask, 4 point words, 5 sweep, 6 cell tail, 7 flush .. barrier .. update, 8 cells swept;
+// inside a sweep: 10 unpack + one-candidate exit, 11 table reads + scores, 12 who moves, 13 labels, 14 booking
+#ifdef CNIIC_PS_PHASES
+__device__ unsigned long long g_ps_phase[16];
+#define PS_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
+#define PS_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
+#define PS_PROF_PARAMS , unsigned long long (&ph_)[16], long long &t_ph
+#define PS_PROF_ARGS , ph_, t_ph
+#else
+#define PS_PHASE(i) do {} while (0)
+#define PS_COUNT(i, v) do {} while (0)
+#define PS_PROF_PARAMS
+#define PS_PROF_ARGS
+#endif
 
 // ---------------------------------------------------------------- sweeps
 // best packed key (distance | 255 - id) of every slot's colour over the candidates of the mask: the set bits are walked on the scalar
@@ -219,8 +273,8 @@ __device__ __forceinline__ void ps_book_move(unsigned long long *acc, uint32_t K
 // ten words run one lane at a time).
 template <typename StoreLabel>
 __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
-                                         const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
-                                         bool agg, StoreLabel store_label) {
+                                         uint32_t cand4, const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
+                                         bool agg, StoreLabel store_label PS_PROF_PARAMS) {
     uint32_t key[kSweep], cur[kSweep], wt[kSweep];
     bool heavy = false;
 #pragma unroll
@@ -233,23 +287,46 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
     if (ncand == 1) {
         // More than half of the cells lie inside one cluster's region: ONE candidate, and as a rule every point already carries its
         // label; the lone candidate beats every other centroid for every colour of the cube, so nothing can move.
-        const uint32_t only = nm[0] ? (uint32_t)__builtin_ctzll(nm[0]) : nm[1] ? 64u + (uint32_t)__builtin_ctzll(nm[1]) : nm[2] ? 128u + (uint32_t)__builtin_ctzll(nm[2]) : 192u + (uint32_t)__builtin_ctzll(nm[3]);
+        const uint32_t only = cand4 & 255u;
         bool same = true;
 #pragma unroll
         for (int u = 0; u < kSweep; u++) same = same & ((base + u * 64 + lane >= e) | (cur[u] == only));
-        if (__ballot(!same) == 0ull) return true;
+        if (__ballot(!same) == 0ull) { PS_PHASE(10); return true; }
     }
+    PS_PHASE(10);
+    // every table entry the sweep needs is asked for before the first one is used: the candidates' (up to four, their ids are bytes of the
+    // record's last word) and the four current centroids'
+    uint2 ccur[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) ccur[u] = tab[cur[u]];
     uint32_t best[kSweep];
-    ps_best(key, nm, tab, best);
+    if (ncand <= 4) {
+        const uint2 c0 = tab[cand4 & 255u], c1 = tab[(cand4 >> 8) & 255u], c2 = tab[(cand4 >> 16) & 255u], c3 = tab[cand4 >> 24];
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) best[u] = (dot4u8(key[u], c0.x, 0) << 9) + c0.y;
+        if (ncand > 1) {
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(key[u], c1.x, 0) << 9) + c1.y);
+        }
+        if (ncand > 2) {
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(key[u], c2.x, 0) << 9) + c2.y);
+        }
+        if (ncand > 3) {
+#pragma unroll
+            for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(key[u], c3.x, 0) << 9) + c3.y);
+        }
+    } else ps_best(key, nm, tab, best);
+    PS_PHASE(11);
     bool mv[kSweep], any = false;
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
-        const uint2 cc = tab[cur[u]];
-        const uint32_t kc = (dot4u8(key[u], cc.x, 0) << 9) + cc.y;
+        const uint32_t kc = (dot4u8(key[u], ccur[u].x, 0) << 9) + ccur[u].y;
         mv[u] = (base + u * 64 + lane < e) & ((best[u] >> 8) > (kc >> 8));  // strictly closer (kmeans.rs:375)
         any = any | mv[u];
     }
-    if (!__ballot(any)) return false;
+    if (!__ballot(any)) { PS_PHASE(12); return false; }
+    PS_PHASE(12);
     if (__ballot(heavy & any)) {   // a pixel count of 255 and more is looked up (rare in a photograph)
 #pragma unroll
         for (int u = 0; u < kSweep; u++)
@@ -261,6 +338,7 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
         nl[u] = mv[u] ? 255u - (best[u] & 255u) : cur[u];
         if (mv[u]) { store_label(base + u * 64 + lane, nl[u]); moved++; }
     }
+    PS_PHASE(13);
     if (agg) {
         static_assert(kSweep == 4, "four slots per lane");
         uint32_t nmv = 0;
@@ -308,6 +386,7 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
 #pragma unroll
     for (int u = 0; u < kSweep; u++)
         if (mv[u]) ps_book_move(acc, K, key[u], wt[u], cur[u], nl[u]);
+    PS_PHASE(14);
     return false;
 }
 
@@ -391,17 +470,6 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uin
     }
 }
 
-// -DCNIIC_PS_PHASES: wave-clock totals per phase of k_rgbw_persist (a measuring build, never the shipped one):
-// 0 lists, 1 classify, 2 draw + descriptors, 3 mask, 4 point words, 5 sweep, 6 cell tail, 7 flush .. barrier .. update, 8 cells swept
-#ifdef CNIIC_PS_PHASES
-__device__ unsigned long long g_ps_phase[16];
-#define PS_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
-#define PS_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
-#else
-#define PS_PHASE(i) do {} while (0)
-#define PS_COUNT(i, v) do {} while (0)
-#endif
-
 // ---------------------------------------------------------------- the kernel
 // What only the launch's last instructions (or a rare branch) need sits in pinned host memory behind one pointer: as kernel arguments
 // those thirty scalar registers would be alive across the whole loop (the first build spilled 136 scalar registers into vector ones and
@@ -439,14 +507,14 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     __shared__ uint32_t s_moved, s_nmoved, s_reseed, s_active, s_ok, s_nx, s_nxcd, s_qn, s_qhead, s_Cres, s_nslots;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ unsigned long long s_mm[4], s_evals, s_changed, s_pev;
-    __shared__ uint32_t s_piv[kPsSlotsMax], s_cnt[kPsSlotsMax][4], s_nS[kPsSlotsMax];
+    __shared__ uint32_t s_nS[kPsSlotsMax], s_mcol[kMaxMovedSkip];
     __shared__ uint16_t s_ssup[kPsSlotsMax];
     __shared__ uint32_t s_cbase[kPsChunks + 1], s_cm0[kPsChunks], s_scan[kPsThreads / 64];
     const uint32_t tid = threadIdx.x, K = a.K, G = gridDim.x;
     const int lane = tid & 63, wid = tid >> 6;
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(lds) + kPsOffTab);
-    uint8_t *Sids = reinterpret_cast<uint8_t *>(lds) + kPsOffS;
+    uint32_t *Sent = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds) + kPsOffS);
     if (*a.ranges_fail) {   // (the same word for every block: nobody starts, nobody waits)
         if (blockIdx.x == 0 && tid == 0) { a.cold->exit.status = kPsStatusRanges; __threadfence_system(); }
         return;
@@ -475,38 +543,56 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     uint8_t *cslot = reinterpret_cast<uint8_t *>(queue + Cr);                    // [Cr] which shared list (255: none, the table)
     uint32_t *pts = reinterpret_cast<uint32_t *>(cslot + Cr);                    // the resident points' words
     const uint32_t cap = (a.lds_budget - kPsOffCell - ps_cell_bytes(C)) / 4u;    // (k_ps_ranges made sure the budget covers the descriptors)
-    {
-        uint32_t np = 0, r = 0, cid = 0;
-        const bool mine = tid < C;
-        if (mine) {
-            while (tid >= s_cbase[r + 1]) r++;
-            const uint32_t m = s_cm0[r] + (tid - s_cbase[r]);
-            cid = a.ne_cell[m];
-            const uint32_t gs = a.ne_start[m];
-            np = a.ne_start[m + 1] - gs;
-            ccell[tid] = (uint16_t)cid;
-            gstart[tid] = gs;
-            uint32_t *rec = recs + (size_t)kPsRecWords * tid;
-            rec[0] = 0u; rec[1] = 0xffffu;   // (no pivot yet; the cell's common label: unknown)
+    {   // two cells per thread: 2 tid and 2 tid + 1 (a block owns at most kPsMaxCells = 2 x kPsThreads)
+        uint32_t np[2] = {0, 0}, cid[2] = {0, 0}, rr[2] = {0, 0};
+        bool mine[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t i = 2 * tid + q;
+            mine[q] = i < C;
+            if (mine[q]) {
+                uint32_t r = 0;
+                while (i >= s_cbase[r + 1]) r++;
+                rr[q] = r;
+                const uint32_t m = s_cm0[r] + (i - s_cbase[r]);
+                cid[q] = a.ne_cell[m];
+                const uint32_t gs = a.ne_start[m];
+                np[q] = a.ne_start[m + 1] - gs;
+                ccell[i] = (uint16_t)cid[q];
+                gstart[i] = gs;
+                uint32_t *rec = recs + (size_t)kPsRecWords * i;
+                rec[0] = 0u; rec[1] = 0xffffu; rec[10] = 0u;   // (no pivot yet; the cell's common label: unknown)
+            }
         }
-        const uint32_t off = block_exclusive_scan<kPsThreads>(np, s_scan);
-        if (mine) cstart[tid] = off;
-        if (tid == (C ? C - 1 : 0)) cstart[C] = C ? off + np : 0u;
+        const uint32_t off = block_exclusive_scan<kPsThreads>(np[0] + np[1], s_scan);
+        if (mine[0]) cstart[2 * tid] = off;
+        if (mine[1]) cstart[2 * tid + 1] = off + np[0];
+        if (tid == (C ? (C - 1) / 2 : 0)) cstart[C] = C ? off + np[0] + np[1] : 0u;
         __syncthreads();
         // the distinct super-cells of the range, in order: a shared list each (the first kPsSlotsMax of them)
-        const bool flag = mine && (tid == s_cbase[r] || ((uint32_t)ccell[tid - 1] >> kSuperShift) != (cid >> kSuperShift));
-        const uint32_t before = block_exclusive_scan<kPsThreads>(flag ? 1u : 0u, s_scan);
-        if (mine) {
-            const uint32_t sidx = before + (flag ? 1u : 0u) - 1u;
-            cslot[tid] = sidx < kPsSlotsMax ? (uint8_t)sidx : (uint8_t)255;
-            if (flag && sidx < kPsSlotsMax) s_ssup[sidx] = (uint16_t)(cid >> kSuperShift);
-            if (tid == C - 1) s_nslots = min(sidx + 1u, kPsSlotsMax);
-            if (cstart[tid + 1] <= cap && (tid + 1 == C || cstart[tid + 2] > cap)) s_Cres = tid + 1;   // the cells whose points fit the LDS behind the descriptors
+        bool flag[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t i = 2 * tid + q;
+            flag[q] = mine[q] && (i == s_cbase[rr[q]] || ((uint32_t)ccell[i - 1] >> kSuperShift) != (cid[q] >> kSuperShift));
+        }
+        const uint32_t before = block_exclusive_scan<kPsThreads>((flag[0] ? 1u : 0u) + (flag[1] ? 1u : 0u), s_scan);
+        uint32_t run_f = before;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t i = 2 * tid + q;
+            run_f += flag[q] ? 1u : 0u;
+            if (mine[q]) {
+                const uint32_t sidx = run_f - 1u;
+                cslot[i] = sidx < kPsSlotsMax ? (uint8_t)sidx : (uint8_t)255;
+                if (flag[q] && sidx < kPsSlotsMax) s_ssup[sidx] = (uint16_t)(cid[q] >> kSuperShift);
+                if (i == C - 1) s_nslots = min(sidx + 1u, kPsSlotsMax);
+                if (cstart[i + 1] <= cap && (i + 1 == C || cstart[i + 2] > cap)) s_Cres = i + 1;   // the cells whose points fit the LDS behind the descriptors
+            }
         }
     }
     for (uint32_t i = tid; i < 5 * K; i += kPsThreads) acc[i] = 0ull;
     for (uint32_t i = tid; i < K; i += kPsThreads) tab[i] = a.cconst0[i];
-    if (tid < kPsSlotsMax) s_piv[tid] = 0xffffffffu;
     __syncthreads();
     // ---- the block's points: colour, pixel count and the initial label (init_assignment, kmeans.rs:61-78) of every point of its cells,
     // as one packed word each, into LDS (the cells that fit) or the packed array in memory; a wave per cell, four loads in flight per array
@@ -563,19 +649,6 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     uint32_t j = 0;              // the iteration whose assign step runs
     uint32_t nS = K;             // centroids the last update moved
     unsigned long long reseeds_total = 0, evals_total = 0;
-    // a cell's record is complete, its mask words stand in rec[2..9]: the pivot's id and the complete flag into word 1 (the cell's common
-    // label stays), and the cell goes on the work list unless ONE candidate is left and every point already carries it (nothing can move:
-    // the lone candidate beats every other centroid for every colour of the cube)
-    auto classified = [&](uint32_t i, uint32_t *rec, uint32_t pid, bool complete, bool force) {
-        const uint32_t w = l16 < 8 ? rec[2 + l16] : 0u;
-        const uint32_t cnt = row_sum((uint32_t)__popc(w));
-        const uint32_t only = row_max(w ? 32u * l16 + (uint32_t)__builtin_ctz(w) : 0u);
-        if (l16 == 0) {
-            const uint32_t ul = rec[1] & 0xffffu;
-            rec[1] = ul | (pid << 16) | (complete ? kRecComplete : 0u);
-            if (force || !(cnt == 1 && ul == only)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
-        }
-    };
 #ifdef CNIIC_PS_PHASES
     long long t_ph = clock64();
     unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -586,24 +659,36 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         PS_PHASE(7);
         if (!skip_mode) {
             // ============================================================= FULL schedule: every cell's candidates anew
-            ps_build_lists(tab, K, nslots, s_ssup, s_piv, s_cnt, s_nS, Sids, tid, lane);
-            PS_PHASE(0);
+            ps_build_lists(tab, K, nslots, s_ssup, s_nS, Sent, wid, lane);
             if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 4] = wall_clock64();
+            PS_PHASE(0);
             for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {   // a row of 16 lanes per cell
                 const uint32_t i = i0 + row;
                 if (i < C) {
                     const uint32_t c = ccell[i], slot = cslot[i];
                     const uint32_t nl = slot != 255u ? s_nS[slot] : 0xffffffffu;
-                    const bool from_table = nl > kPsScap;
                     uint32_t *rec = recs + (size_t)kPsRecWords * i;
-                    const uint32_t pid = ps_row_build(tab, Sids + (from_table ? 0u : slot * kPsScap), from_table ? K : nl, from_table, c, l16, rec);
-                    if (l16 == 0) rec[0] = tab[pid].x;
-                    classified(i, rec, pid, from_table, first);
+                    bool needs;
+                    if (nl <= kPsScap) {
+                        const uint32_t pid = ps_row_build_list(tab, Sent + slot * kPsScap, nl, c, l16, rec);
+                        needs = ps_row_finish(rec, l16, pid, false);
+                    } else {
+                        const uint32_t pid = ps_row_build_table(tab, K, c, l16, rec);
+                        needs = ps_row_finish(rec, l16, pid, true);
+                    }
+                    if (l16 == 0 && (needs || first)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
                 }
             }
         } else {
             // ============================================================= SKIP schedule (at most max_skip centroids moved)
             // A cell none of whose candidates moved and whose pivot still dominates every moved centroid repeats all its decisions.
+            uint32_t mk[4], mc[4];   // the lane's share of the moved centroids: ids and colours
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t jj = l16 + 16u * t;
+                mk[t] = jj < nS ? s_mlist[jj] : 0xffffffffu;
+                mc[t] = jj < nS ? s_mcol[jj] : 0u;
+            }
             for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {
                 const uint32_t i = i0 + row;
                 const bool ok = i < C;
@@ -612,10 +697,12 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                 Dominance dm;
                 dm.set(cell_box(c), (1 << kCellShift) - 1, rec[0]);
                 bool dv = false;
-                for (uint32_t jj = l16; jj < nS; jj += 16) {
-                    const uint32_t k = s_mlist[jj];
-                    const bool in = ((rec[2 + (k >> 5)] >> (k & 31)) & 1u) != 0;
-                    dv = dv | in | (dm.worst(tab[k].x) >= 0);   // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (mk[t] != 0xffffffffu) {
+                        const bool in = ((rec[2 + (mk[t] >> 5)] >> (mk[t] & 31)) & 1u) != 0;
+                        dv = dv | in | (dm.worst(mc[t]) >= 0);   // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
+                    }
                 }
                 const unsigned long long bm = __ballot(dv && ok);
                 if (!bm) continue;
@@ -623,85 +710,105 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     // A COMPLETE mask whose pivot has not moved: every centroid that has not moved keeps its verdict against it, the moved
                     // ones are tested here.  Otherwise the mask is rebuilt from the whole table with a fresh pivot (and is complete then).
                     const bool keep = (r1 & kRecComplete) && ((s_mm[pid >> 6] >> (pid & 63)) & 1ull) == 0ull;
+                    bool needs;
                     if (keep) {
                         if (l16 < 8) rec[2 + l16] &= ~reinterpret_cast<const uint32_t *>(s_mm)[l16];
-                        for (uint32_t jj = l16; jj < nS; jj += 16) {
-                            const uint32_t k = s_mlist[jj];
-                            if (dm.worst(tab[k].x) >= 0) atomicOr(&rec[2 + (k >> 5)], 1u << (k & 31));
-                        }
-                        classified(i, rec, pid, true, false);
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            if (mk[t] != 0xffffffffu && dm.worst(mc[t]) >= 0) atomicOr(&rec[2 + (mk[t] >> 5)], 1u << (mk[t] & 31));
+                        needs = ps_row_finish(rec, l16, pid, true);
                     } else {
-                        const uint32_t npid = ps_row_build(tab, Sids, K, true, c, l16, rec);
-                        if (l16 == 0) rec[0] = tab[npid].x;
-                        classified(i, rec, npid, true, false);
+                        const uint32_t npid = ps_row_build_table(tab, K, c, l16, rec);
+                        needs = ps_row_finish(rec, l16, npid, true);
                     }
+                    if (l16 == 0 && needs) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
                 }
             }
         }
         __syncthreads();   // the work list is complete
-        PS_PHASE(1);
         if (a.blk_ts && tid == 0 && j < 128) { a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 5] = wall_clock64(); a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 6] = s_qn; }
-        // ------------------------------------------------------------- sweeps: the waves draw cells from the list
+        PS_PHASE(1);
+        // ------------------------------------------------------------- sweeps: list entry wid, wid + 16, ... is this wave's
         {
             const uint32_t qn = s_qn;
             const bool agg = !first && j <= a.agg_iters;
-            for (;;) {
-                uint32_t qi = 0;
-                if (lane == 0) qi = atomicAdd(&s_qhead, 1u);
-                qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
-                if (qi >= qn) break;
-                const uint32_t i = queue[qi];
-                const uint32_t c = ccell[i], s = cstart[i], e = cstart[i + 1], gs = gstart[i];
-                uint32_t *rec = recs + (size_t)kPsRecWords * i;
+            // the wave's cells, 64 at a time: lane t holds the t-th one's index, first and last point, position in the cell-major arrays and id
+            const uint32_t nall = qn > (uint32_t)wid ? (qn - (uint32_t)wid + kPsWaves - 1) / kPsWaves : 0u;
+            for (uint32_t tb = 0; tb < nall; tb += 64) {
+            uint32_t vi = 0, vs = 0, ve = 0, vg = 0, vc = 0;
+            const uint32_t nmine = min(nall - tb, 64u);
+            if ((uint32_t)lane < nmine) {
+                vi = queue[(uint32_t)wid + kPsWaves * (tb + (uint32_t)lane)];
+                vs = cstart[vi]; ve = cstart[vi + 1]; vg = gstart[vi]; vc = ccell[vi];
+            }
+            // one cell ahead: the record (lane l < 11 holds word l) and the words of the first sweep
+            auto fetch = [&](uint32_t t, uint32_t &rw, uint32_t (&wd)[kSweep]) {
+                const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)vi, (int)t), s = (uint32_t)__builtin_amdgcn_readlane((int)vs, (int)t);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ve, (int)t), gs = (uint32_t)__builtin_amdgcn_readlane((int)vg, (int)t);
+                rw = lane < (int)kPsRecWords ? recs[(size_t)kPsRecWords * i + lane] : 0u;
+                if (i < Cres) {
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? a.pk[gs + (idx - s)] : 0u; }
+                }
+            };
+            uint32_t rw = 0, wd[kSweep] = {0, 0, 0, 0};
+            if (nmine) fetch(0, rw, wd);
+            for (uint32_t t = 0; t < nmine; t++) {
+                const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)vi, (int)t), s = (uint32_t)__builtin_amdgcn_readlane((int)vs, (int)t);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ve, (int)t), gs = (uint32_t)__builtin_amdgcn_readlane((int)vg, (int)t);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)vc, (int)t);
+                uint32_t rwn = 0, wn[kSweep] = {0, 0, 0, 0};
+                if (t + 1 < nmine) fetch(t + 1, rwn, wn);
                 PS_PHASE(2);
                 PS_COUNT(8, 1);
-                const uint32_t mw = lane < 8 ? rec[2 + lane] : 0u;
                 unsigned long long nm[4];
 #pragma unroll
                 for (int w = 0; w < 4; w++)
-                    nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * w + 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)mw, 2 * w);
+                    nm[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rw, 3 + 2 * w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rw, 2 + 2 * w);
+                const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)rw, 1), cand4 = (uint32_t)__builtin_amdgcn_readlane((int)rw, 10);
                 const uint32_t ncand = (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
                 const uint32_t cbk = cell_base_key(c);
                 const bool res = i < Cres;
-                PS_PHASE(3);
                 const uint32_t *cwc = a.cweight + gs;
                 uint32_t *pkc = a.pk + gs;
+                uint32_t *rec = recs + (size_t)kPsRecWords * i;
                 bool uniform = !first;   // every sweep of the cell left through the one-candidate exit: all its points carry that candidate
-                if (res) {
-                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                        uint32_t wd[kSweep];
+                PS_PHASE(3);
+                for (uint32_t base = s; base < e; base += 64 * kSweep) {
+                    uint32_t w2[kSweep] = {0, 0, 0, 0};
+                    if (base + 64 * kSweep < e) {   // (a cell of more than 256 points: its next sweep's words now)
+                        if (res) {
 #pragma unroll
-                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
-#ifdef CNIIC_PS_PHASES
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                        PS_PHASE(4);
+                            for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + 64 * kSweep + u * 64 + lane; w2[u] = idx < e ? pts[idx] : 0u; }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + 64 * kSweep + u * 64 + lane; w2[u] = idx < e ? pkc[idx - s] : 0u; }
+                        }
+                    }
+                    PS_PHASE(4);
+                    if (res) {
                         auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pts)[4 * idx + 3] = (uint8_t)l; };
                         if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
-                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, tab, K, cbk, cwc, acc, moved, agg, st) && uniform;
-                        PS_PHASE(5);
-                    }
-                } else {
-                    uint32_t wd[kSweep];
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? pkc[idx - s] : 0u; }
-                    for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                        uint32_t wn[kSweep];
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) { const uint32_t idx = base + 64 * kSweep + u * 64 + lane; wn[u] = idx < e ? pkc[idx - s] : 0u; }
+                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, agg, st PS_PROF_ARGS) && uniform;
+                    } else {
                         auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pkc)[4 * (size_t)(idx - s) + 3] = (uint8_t)l; };
                         if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
-                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, tab, K, cbk, cwc, acc, moved, agg, st) && uniform;
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) wd[u] = wn[u];
+                        else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, agg, st PS_PROF_ARGS) && uniform;
                     }
+                    PS_PHASE(5);
+#pragma unroll
+                    for (int u = 0; u < kSweep; u++) wd[u] = w2[u];
                 }
-                if (lane == 0) {
-                    const uint32_t only = nm[0] ? (uint32_t)__builtin_ctzll(nm[0]) : nm[1] ? 64u + (uint32_t)__builtin_ctzll(nm[1]) : nm[2] ? 128u + (uint32_t)__builtin_ctzll(nm[2]) : 192u + (uint32_t)__builtin_ctzll(nm[3]);
-                    rec[1] = (rec[1] & 0xffff0000u) | (uniform && ncand == 1 ? only : 0xffffu);
-                }
+                if (lane == 0) rec[1] = (r1 & 0xffff0000u) | (uniform && ncand == 1 ? cand4 & 255u : 0xffffu);
                 evals += (unsigned long long)(e - s) * (ncand + 1);
+                rw = rwn;
+#pragma unroll
+                for (int u = 0; u < kSweep; u++) wd[u] = wn[u];
                 PS_PHASE(6);
+            }
             }
         }
         PS_PHASE(9);
@@ -771,7 +878,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
             tab[k] = make_cconst(ck, k, 8);
             if (ck != oldc) {
                 const uint32_t pos = atomicAdd(&s_nmoved, 1u);
-                if (pos < kMaxMovedSkip) s_mlist[pos] = k;
+                if (pos < kMaxMovedSkip) { s_mlist[pos] = k; s_mcol[pos] = ck; }
                 atomicOr(&s_mm[(k >> 6) & 3], 1ull << (k & 63));
             }
         } else if (tid == kPsThreads - 1) {
@@ -981,8 +1088,9 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
         CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ps_phase), sizeof ph));
         CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ps_phase), zero, sizeof zero));
         const double w = (double)G * kPsWaves;
-        fprintf(stderr, "persist phases (wave clocks per wave, %llu iterations): lists %.0f classify %.0f | draw+desc %.0f mask %.0f words %.0f sweep %.0f tail %.0f wait-for-others %.0f | sync+update %.0f | cells swept per wave %.1f\n",
-                (unsigned long long)xh->iter, ph[0] / w, ph[1] / w, ph[2] / w, ph[3] / w, ph[4] / w, ph[5] / w, ph[6] / w, ph[9] / w, ph[7] / w, ph[8] / w);
+        fprintf(stderr, "persist phases (wave clocks per wave, %llu iterations): lists %.0f classify %.0f | draw+desc %.0f mask %.0f words %.0f sweep %.0f tail %.0f wait-for-others %.0f | sync+update %.0f | cells swept per wave %.1f"
+                        " | in the sweeps: unpack+exit %.0f scores %.0f movers? %.0f labels %.0f booking %.0f\n",
+                (unsigned long long)xh->iter, ph[0] / w, ph[1] / w, ph[2] / w, ph[3] / w, ph[4] / w, ph[5] / w, ph[6] / w, ph[9] / w, ph[7] / w, ph[8] / w, ph[10] / w, ph[11] / w, ph[12] / w, ph[13] / w, ph[14] / w);
     }
 #endif
     *ran = true;

@@ -84,10 +84,10 @@ struct KmRgbwState {
 // ---- k_kmeans_persist.hip: the LDS of a block and what the launch shares with its set-up
 constexpr uint32_t kPsChunks = 16;                      // chunks of the cell list a block owns (interleaved with the other blocks')
 constexpr uint32_t kPsSlotsMax = 32;                    // shared super-cell lists of a block (cells of further super-cells build from the table)
-constexpr uint32_t kPsScap = 128;                       // ids a shared list holds (a longer list: its cells build from the table)
-constexpr uint32_t kPsRecWords = 10;                    // a cell's record: pivot colour, common label | pivot id << 16 | kRecComplete, 8 mask words
-constexpr uint32_t kPsMaxCells = 1024;                  // cells a block may own
-constexpr uint32_t kPsOffCell = 5 * 256 * 8 + 256 * 8 + kPsSlotsMax * kPsScap;   // accumulators, table, the shared lists' ids
+constexpr uint32_t kPsScap = 96;                        // members a shared list holds (a longer list: its cells build from the table)
+constexpr uint32_t kPsRecWords = 11;                    // a cell's record: pivot colour, common label | pivot id << 16 | candidates << 24 | kRecComplete, 8 mask words, four candidate ids
+constexpr uint32_t kPsMaxCells = 2048;                  // cells a block may own (two per thread of its set-up)
+constexpr uint32_t kPsOffCell = 5 * 256 * 8 + 256 * 8 + kPsSlotsMax * kPsScap * 4;   // accumulators, table, the shared lists (id << 24 | colour)
 constexpr uint32_t kPsDynBytes = 160 * 1024 - 3072;     // the launch's dynamic LDS (the kernel's static variables take the rest)
 constexpr uint32_t kPsPartWords = 5 * 256 + 8;          // u64 words of one buffer of sums (5K + 2, padded)
 constexpr uint32_t kPsTsCap = 1024;                     // iterations whose end block 0 timestamps
