@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t ps_centre_dist(uint32_t ck, uint32_t cpk, ui
 // super-cell ssup[slot]: pivot = the centroid nearest the cube's centre, kept = whoever the pivot does not dominate over the whole cube
 // (Dominance, kmeans_rgbw.hpp).  An entry is id << 24 | colour: the per-cell builds read ONE word per member, all of a lane's members
 // at once.  A list of more than kPsScap members is not kept: its cells build from the table.
-__device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uint32_t nslots, const uint16_t *ssup, uint32_t *s_nS, uint32_t *Sent, int wid, int lane) {
+__device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uint32_t nslots, const uint16_t *ssup, uint32_t *s_nS, uint32_t *s_lpiv, uint32_t *Sent, int wid, int lane) {
     constexpr int32_t ext = (1 << (kCellShift + 2)) - 1;
     for (uint32_t slot = (uint32_t)wid; slot < nslots; slot += kPsWaves) {
         const CellBox bx = super_box((uint32_t)__builtin_amdgcn_readfirstlane((int)ssup[slot]));
@@ -149,16 +149,22 @@ __device__ __forceinline__ void ps_build_lists(const uint2 *tab, uint32_t K, uin
             if (keep && pos < kPsScap) Sent[slot * kPsScap + pos] = (k << 24) | ck[r];
             n += (uint32_t)__popcll(bm);
         }
-        if (lane == 0) s_nS[slot] = n;
+        if (lane == 0) { s_nS[slot] = n; s_lpiv[slot] = piv; }
     }
     __syncthreads();
 }
+
+// word 1 of a cell's record: bits 0..8 the label all its points carry (kPsUlMask: not known), bit 9 the mask holds EVERY centroid of the table
+// the cell's pivot does not dominate (built from the table), bits 16..23 the cell's pivot, bits 24..31 the pivot of the super-cell list the
+// mask was built from.  A mask stays a base for the incremental update of the skip schedule while the cell's pivot has not moved and
+// -- unless complete -- the list's pivot has not either: what the list left out was dominated by THAT centroid over the whole super-cell.
+constexpr uint32_t kPsUlMask = 0x1ffu, kPsComplete = 0x200u;
 
 // A cell's record once its mask words stand in rec[2..9] (every lane of the cell's row calls this): the number of candidates, up to
 // four of their ids as bytes of rec[10] (what a sweep reads instead of walking the mask), and the pivot's id / the complete flag in
 // word 1 (the cell's common label stays).  Returns (row-uniform) whether the cell must be swept: not if ONE candidate is left and every
 // point already carries it (the lone candidate beats every other centroid for every colour of the cube: nothing can move).
-__device__ __forceinline__ bool ps_row_finish(uint32_t *rec, uint32_t l16, uint32_t pid, bool complete) {
+__device__ __forceinline__ bool ps_row_finish(uint32_t *rec, uint32_t l16, uint32_t pid, uint32_t lpid, bool complete) {
     const uint32_t w = l16 < 8 ? rec[2 + l16] : 0u;
     const uint32_t pc = (uint32_t)__popc(w);
     uint32_t inc = pc;   // inclusive scan inside the row (lanes 8..15 add nothing)
@@ -174,9 +180,9 @@ __device__ __forceinline__ bool ps_row_finish(uint32_t *rec, uint32_t l16, uint3
         pos++;
     }
     const uint32_t r1 = rec[1];
-    if (l16 == 0) rec[1] = (r1 & 0xffffu) | (pid << 16) | (min(cnt, 127u) << 24) | (complete ? kRecComplete : 0u);
+    if (l16 == 0) rec[1] = (r1 & kPsUlMask) | (pid << 16) | (lpid << 24) | (complete ? kPsComplete : 0u);
     const uint32_t only = rec[10] & 255u;   // (behind the byte stores of this wave: the LDS serves a wave in order)
-    return !(cnt == 1 && (r1 & 0xffffu) == only);
+    return !(cnt == 1 && (r1 & kPsUlMask) == only);
 }
 
 // One cell's candidates from its super-cell's list, by the 16 lanes of a row: every lane takes the members l16, l16 + 16, ... (at most
@@ -256,6 +262,16 @@ __device__ __forceinline__ void ps_best(const uint32_t (&key)[kSweep], const uns
     }
 }
 
+// ---- the resident point word (its own format: the sweep's common path is two instructions to unpack a point)
+//   bits 0..2 / 8..10 / 16..18   the colour inside its 8^3 cell, b / g / r, each in the byte lane the key has it in: key = cell base | (w & 0x070707)
+//   bits 24..31                  255 - label: what the low byte of a packed score holds, so "the best candidate is not my cluster" is one compare
+//   bits 3..7, 11..13            the pixel count's low five and high three bits; 255 = look it up (needed only when a point moves)
+__device__ __forceinline__ uint32_t ps_pack(uint32_t key, uint32_t w, uint32_t label) {
+    const uint32_t wc = min(w, 255u);
+    return (key & 0x070707u) | ((wc & 31u) << 3) | ((wc >> 5) << 11) | ((255u - label) << 24);
+}
+__device__ __forceinline__ uint32_t ps_wt(uint32_t w) { return ((w >> 3) & 31u) | ((w >> 6) & 0xe0u); }
+
 // the signed deltas of one mover into the block's accumulators (clusterc.rs:92-98: sums of channel x count, of counts, of members)
 __device__ __forceinline__ void ps_book_move(unsigned long long *acc, uint32_t K, uint32_t pp, uint64_t w, uint32_t ol, uint32_t nl) {
     const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
@@ -265,41 +281,9 @@ __device__ __forceinline__ void ps_book_move(unsigned long long *acc, uint32_t K
     atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w); atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
 }
 
-// One sweep of an iteration after the first: the 64 x kSweep packed words w (positions base + 64 u + lane of the block's point range,
-// those below e) against the candidates of the mask.  Stay unless another centroid is STRICTLY closer (kmeans.rs:375), lowest id among
-// equals (the key's low byte).  A mover's label byte is rewritten in place (st: the words' home, LDS or memory), its deltas booked.
-// agg (the first iterations after iteration 0, where centroids still travel and whole cells change hands): the movers that share the
-// first mover's (old, new) pair are summed in the wave and booked by one lane, round by round (ten LDS atomics per point on the same
-// ten words run one lane at a time).
-template <typename StoreLabel>
-__device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
-                                         uint32_t cand4, const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
-                                         bool agg, StoreLabel store_label PS_PROF_PARAMS) {
-    uint32_t key[kSweep], cur[kSweep], wt[kSweep];
-    bool heavy = false;
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        key[u] = pk_key(wd[u], cbk);
-        cur[u] = wd[u] >> 24;
-        wt[u] = (wd[u] >> 16) & 255u;
-        heavy = heavy | (wt[u] == 255u);
-    }
-    if (ncand == 1) {
-        // More than half of the cells lie inside one cluster's region: ONE candidate, and as a rule every point already carries its
-        // label; the lone candidate beats every other centroid for every colour of the cube, so nothing can move.
-        const uint32_t only = cand4 & 255u;
-        bool same = true;
-#pragma unroll
-        for (int u = 0; u < kSweep; u++) same = same & ((base + u * 64 + lane >= e) | (cur[u] == only));
-        if (__ballot(!same) == 0ull) { PS_PHASE(10); return true; }
-    }
-    PS_PHASE(10);
-    // every table entry the sweep needs is asked for before the first one is used: the candidates' (up to four, their ids are bytes of the
-    // record's last word) and the four current centroids'
-    uint2 ccur[kSweep];
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) ccur[u] = tab[cur[u]];
-    uint32_t best[kSweep];
+// the best packed score of every slot's colour over a cell's candidates: up to four ids as bytes of the record's last word (their
+// table entries asked for together), more than four by walking the mask on the scalar unit
+__device__ __forceinline__ void ps_scores(const uint32_t (&key)[kSweep], const unsigned long long (&nm)[4], uint32_t ncand, uint32_t cand4, const uint2 *tab, uint32_t (&best)[kSweep]) {
     if (ncand <= 4) {
         const uint2 c0 = tab[cand4 & 255u], c1 = tab[(cand4 >> 8) & 255u], c2 = tab[(cand4 >> 16) & 255u], c3 = tab[cand4 >> 24];
 #pragma unroll
@@ -317,27 +301,67 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
             for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(key[u], c3.x, 0) << 9) + c3.y);
         }
     } else ps_best(key, nm, tab, best);
+}
+
+// One sweep of an iteration after the first: the 64 x kSweep point words wd (positions base + 64 u + lane of the block's point range,
+// those below e) against the cell's candidates.  Stay unless another centroid is STRICTLY closer (kmeans.rs:375), lowest id among
+// equals (the score's low byte).  The common path never looks at a point's own centroid: its score is among the candidates', so the
+// best one carrying the point's label means "stays"; only points whose best candidate is somebody else compare with their own
+// centroid (a tie keeps them).  A mover's label byte is rewritten in place (store_label: the words' home, LDS or memory), its signed
+// deltas booked, one mover per lane and pass.  agg (the first iterations after iteration 0, where centroids still travel and whole
+// cells change hands): the movers that share the first mover's (old, new) pair are summed in the wave and booked by one lane.
+// Returns true if the sweep left through the one-candidate exit (every point carries the lone candidate).
+template <typename StoreLabel>
+__device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
+                                         uint32_t cand4, const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
+                                         bool agg, StoreLabel store_label PS_PROF_PARAMS) {
+    uint32_t key[kSweep], lc[kSweep];
+    bool valid[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {
+        key[u] = cbk | (wd[u] & 0x070707u);
+        lc[u] = wd[u] >> 24;
+        valid[u] = base + u * 64 + lane < e;
+    }
+    if (ncand == 1) {
+        // More than half of the cells lie inside one cluster's region: ONE candidate, and as a rule every point already carries its
+        // label; the lone candidate beats every other centroid for every colour of the cube, so nothing can move.
+        const uint32_t onlyc = 255u - (cand4 & 255u);
+        bool same = true;
+#pragma unroll
+        for (int u = 0; u < kSweep; u++) same = same & (!valid[u] | (lc[u] == onlyc));
+        if (__ballot(!same) == 0ull) { PS_PHASE(10); return true; }
+    }
+    PS_PHASE(10);
+    uint32_t best[kSweep];
+    ps_scores(key, nm, ncand, cand4, tab, best);
     PS_PHASE(11);
     bool mv[kSweep], any = false;
 #pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        const uint32_t kc = (dot4u8(key[u], ccur[u].x, 0) << 9) + ccur[u].y;
-        mv[u] = (base + u * 64 + lane < e) & ((best[u] >> 8) > (kc >> 8));  // strictly closer (kmeans.rs:375)
+    for (int u = 0; u < kSweep; u++) { mv[u] = valid[u] & ((best[u] & 255u) != lc[u]); any = any | mv[u]; }
+    if (!__ballot(any)) { PS_PHASE(12); return false; }
+    any = false;
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) {   // (the few whose best candidate is not their own cluster: strictly closer, kmeans.rs:375?)
+        const uint2 cc = tab[255u - lc[u]];
+        const uint32_t kc = (dot4u8(key[u], cc.x, 0) << 9) + cc.y;
+        mv[u] = mv[u] & ((best[u] >> 8) > (kc >> 8));
         any = any | mv[u];
     }
     if (!__ballot(any)) { PS_PHASE(12); return false; }
     PS_PHASE(12);
-    if (__ballot(heavy & any)) {   // a pixel count of 255 and more is looked up (rare in a photograph)
+    uint32_t wt[kSweep];
+    bool heavy = false;
+#pragma unroll
+    for (int u = 0; u < kSweep; u++) { wt[u] = ps_wt(wd[u]); heavy = heavy | (mv[u] & (wt[u] == 255u)); }
+    if (__ballot(heavy)) {   // a pixel count of 255 and more is looked up (rare in a photograph)
 #pragma unroll
         for (int u = 0; u < kSweep; u++)
             if (mv[u] && wt[u] == 255u) wt[u] = cwq[base + u * 64 + lane - s0];
     }
-    uint32_t nl[kSweep];
 #pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        nl[u] = mv[u] ? 255u - (best[u] & 255u) : cur[u];
-        if (mv[u]) { store_label(base + u * 64 + lane, nl[u]); moved++; }
-    }
+    for (int u = 0; u < kSweep; u++)
+        if (mv[u]) { store_label(base + u * 64 + lane, best[u] & 255u); moved++; }
     PS_PHASE(13);
     if (agg) {
         static_assert(kSweep == 4, "four slots per lane");
@@ -349,16 +373,16 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
             for (int round = 0; round < 6; round++) {
                 const unsigned long long b0 = __ballot(mv[0]), b1 = __ballot(mv[1]), b2 = __ballot(mv[2]), b3 = __ballot(mv[3]);
                 if (!(b0 | b1 | b2 | b3)) return false;
-                uint32_t pn, po;
-                if (b0) { const int l = __builtin_ctzll(b0); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[0], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[0], l); }
-                else if (b1) { const int l = __builtin_ctzll(b1); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[1], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[1], l); }
-                else if (b2) { const int l = __builtin_ctzll(b2); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[2], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[2], l); }
-                else { const int l = __builtin_ctzll(b3); pn = (uint32_t)__builtin_amdgcn_readlane((int)nl[3], l); po = (uint32_t)__builtin_amdgcn_readlane((int)cur[3], l); }
+                uint32_t pn, po;   // (as low bytes of scores: 255 - id)
+                if (b0) { const int l = __builtin_ctzll(b0); pn = (uint32_t)__builtin_amdgcn_readlane((int)best[0], l) & 255u; po = (uint32_t)__builtin_amdgcn_readlane((int)lc[0], l); }
+                else if (b1) { const int l = __builtin_ctzll(b1); pn = (uint32_t)__builtin_amdgcn_readlane((int)best[1], l) & 255u; po = (uint32_t)__builtin_amdgcn_readlane((int)lc[1], l); }
+                else if (b2) { const int l = __builtin_ctzll(b2); pn = (uint32_t)__builtin_amdgcn_readlane((int)best[2], l) & 255u; po = (uint32_t)__builtin_amdgcn_readlane((int)lc[2], l); }
+                else { const int l = __builtin_ctzll(b3); pn = (uint32_t)__builtin_amdgcn_readlane((int)best[3], l) & 255u; po = (uint32_t)__builtin_amdgcn_readlane((int)lc[3], l); }
                 uint32_t cnt = 0;
                 bool mt[kSweep];
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) {
-                    mt[u] = mv[u] && nl[u] == pn && cur[u] == po;
+                    mt[u] = mv[u] && (best[u] & 255u) == pn && lc[u] == po;
                     cnt += (uint32_t)__popcll(__ballot(mt[u]));
                     mv[u] = mv[u] && !mt[u];
                 }
@@ -367,6 +391,7 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
                     for (int u = 0; u < kSweep; u++) mv[u] = mv[u] || mt[u];
                     break;
                 }
+                const size_t kn = 255u - pn, ko = 255u - po;
                 auto book = [&](int shift, uint32_t mask, size_t at_new, size_t at_old) {
                     unsigned long long v = 0;
 #pragma unroll
@@ -375,36 +400,47 @@ __device__ __forceinline__ bool ps_sweep(const uint32_t (&wd)[kSweep], uint32_t 
                     v = wave_reduce_sum64(v);
                     if (lane == 0) { atomicAdd(&acc[at_new], v); atomicAdd(&acc[at_old], 0ull - v); }
                 };
-                book(16, 255u, 3 * (size_t)pn + 0, 3 * (size_t)po + 0);
-                book(8, 255u, 3 * (size_t)pn + 1, 3 * (size_t)po + 1);
-                book(0, 255u, 3 * (size_t)pn + 2, 3 * (size_t)po + 2);
-                book(0, 0u, 3 * (size_t)K + pn, 3 * (size_t)K + po);
-                if (lane == 0) { atomicAdd(&acc[4 * K + pn], (unsigned long long)cnt); atomicAdd(&acc[4 * K + po], 0ull - (unsigned long long)cnt); }
+                book(16, 255u, 3 * kn + 0, 3 * ko + 0);
+                book(8, 255u, 3 * kn + 1, 3 * ko + 1);
+                book(0, 255u, 3 * kn + 2, 3 * ko + 2);
+                book(0, 0u, 3 * (size_t)K + kn, 3 * (size_t)K + ko);
+                if (lane == 0) { atomicAdd(&acc[4 * K + kn], (unsigned long long)cnt); atomicAdd(&acc[4 * K + ko], 0ull - (unsigned long long)cnt); }
             }
         }
     }
-#pragma unroll
-    for (int u = 0; u < kSweep; u++)
-        if (mv[u]) ps_book_move(acc, K, key[u], wt[u], cur[u], nl[u]);
+    // one mover per lane and pass (as four exec-masked bodies every slot with a single mover in the wave cost the whole booking sequence)
+    for (;;) {
+        const bool has = mv[0] | mv[1] | mv[2] | mv[3];
+        if (!__ballot(has)) break;
+        if (has) {
+            const int u = mv[0] ? 0 : mv[1] ? 1 : mv[2] ? 2 : 3;
+            const uint32_t kk = u == 0 ? key[0] : u == 1 ? key[1] : u == 2 ? key[2] : key[3];
+            const uint32_t ww = u == 0 ? wt[0] : u == 1 ? wt[1] : u == 2 ? wt[2] : wt[3];
+            const uint32_t bb = u == 0 ? best[0] : u == 1 ? best[1] : u == 2 ? best[2] : best[3];
+            const uint32_t oo = u == 0 ? lc[0] : u == 1 ? lc[1] : u == 2 ? lc[2] : lc[3];
+            ps_book_move(acc, K, kk, ww, 255u - oo, 255u - (bb & 255u));
+            mv[0] = mv[0] & (u != 0); mv[1] = mv[1] & (u != 1); mv[2] = mv[2] & (u != 2); mv[3] = false | (mv[3] & (u != 3));
+        }
+    }
     PS_PHASE(14);
     return false;
 }
 
-// The sweep of iteration 0 over the packed words the block loaded at entry (colour, pixel count, the initial label of init_assignment,
+// The sweep of iteration 0 over the point words the block loaded at entry (colour, pixel count, the initial label of init_assignment,
 // kmeans.rs:61-78): EVERY point adds to the sums of the cluster it ends in (the running sums start at zero).  A sweep lies inside one
 // 8^3 cell and its points join one, two, three clusters: round by round, the cluster of the first point still to be booked, every
 // point that joins it summed in the wave, one lane adds the totals.
 template <typename StoreLabel>
-__device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4],
-                                               const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
+__device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uint32_t base, uint32_t e, uint32_t s0, int lane, const unsigned long long (&nm)[4], uint32_t ncand,
+                                               uint32_t cand4, const uint2 *tab, uint32_t K, uint32_t cbk, const uint32_t *__restrict__ cwq, unsigned long long *acc, uint32_t &moved,
                                                StoreLabel store_label) {
-    uint32_t p[kSweep], cur[kSweep], wt[kSweep];
+    uint32_t p[kSweep], lc[kSweep], wt[kSweep];
     bool heavy = false;
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
-        p[u] = pk_key(wd[u], cbk);
-        cur[u] = wd[u] >> 24;
-        wt[u] = (wd[u] >> 16) & 255u;
+        p[u] = cbk | (wd[u] & 0x070707u);
+        lc[u] = wd[u] >> 24;
+        wt[u] = ps_wt(wd[u]);
         heavy = heavy | (wt[u] == 255u);
     }
     if (__ballot(heavy)) {   // a pixel count of 255 and more is looked up
@@ -413,18 +449,18 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uin
             if (wt[u] == 255u && base + u * 64 + lane < e) wt[u] = cwq[base + u * 64 + lane - s0];
     }
     uint32_t best[kSweep];
-    ps_best(p, nm, tab, best);
-    uint32_t nl[kSweep];
+    ps_scores(p, nm, ncand, cand4, tab, best);
+    uint32_t nl[kSweep];   // 255 - the cluster a point ends in
     bool rem[kSweep];
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
         const uint32_t idx = base + u * 64 + lane;
-        nl[u] = cur[u];
+        nl[u] = lc[u];
         rem[u] = idx < e;
-        if (rem[u]) {
-            const uint2 cc = tab[cur[u]];
+        if (rem[u] && (best[u] & 255u) != lc[u]) {
+            const uint2 cc = tab[255u - lc[u]];
             const uint32_t kc = (dot4u8(p[u], cc.x, 0) << 9) + cc.y;
-            if ((best[u] >> 8) > (kc >> 8)) { nl[u] = 255u - (best[u] & 255u); moved++; store_label(idx, nl[u]); }  // strictly closer (kmeans.rs:375)
+            if ((best[u] >> 8) > (kc >> 8)) { nl[u] = best[u] & 255u; moved++; store_label(idx, nl[u]); }  // strictly closer (kmeans.rs:375)
         }
     }
     static_assert(kSweep == 4, "four slots per lane");
@@ -445,6 +481,7 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uin
             cnt += (uint32_t)__popcll(__ballot(match));
             rem[u] = rem[u] && !match;
         }
+        const size_t kn = 255u - pn;
         auto book = [&](int shift, uint32_t mask, size_t at) {
             unsigned long long v = 0;
 #pragma unroll
@@ -453,16 +490,16 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uin
             v = wave_reduce_sum64(v);
             if (lane == 0) atomicAdd(&acc[at], v);
         };
-        book(16, 255u, 3 * (size_t)pn + 0);
-        book(8, 255u, 3 * (size_t)pn + 1);
-        book(0, 255u, 3 * (size_t)pn + 2);
-        book(0, 0u, 3 * (size_t)K + pn);
-        if (lane == 0) atomicAdd(&acc[4 * K + pn], (unsigned long long)cnt);
+        book(16, 255u, 3 * kn + 0);
+        book(8, 255u, 3 * kn + 1);
+        book(0, 255u, 3 * kn + 2);
+        book(0, 0u, 3 * (size_t)K + kn);
+        if (lane == 0) atomicAdd(&acc[4 * K + kn], (unsigned long long)cnt);
     }
 #pragma unroll
     for (int u = 0; u < kSweep; u++) {
         if (rem[u]) {
-            const uint32_t pp = p[u], n_ = nl[u];
+            const uint32_t pp = p[u], n_ = 255u - nl[u];
             const uint64_t w = wt[u];
             atomicAdd(&acc[3 * n_ + 0], ((pp >> 16) & 255) * w); atomicAdd(&acc[3 * n_ + 1], ((pp >> 8) & 255) * w); atomicAdd(&acc[3 * n_ + 2], (pp & 255) * w);
             atomicAdd(&acc[3 * K + n_], (unsigned long long)w); atomicAdd(&acc[4 * K + n_], 1ull);
@@ -470,7 +507,6 @@ __device__ __forceinline__ void ps_sweep_first(const uint32_t (&wd)[kSweep], uin
     }
 }
 
-// ---------------------------------------------------------------- the kernel
 // What only the launch's last instructions (or a rare branch) need sits in pinned host memory behind one pointer: as kernel arguments
 // those thirty scalar registers would be alive across the whole loop (the first build spilled 136 scalar registers into vector ones and
 // three of those to scratch).
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     __shared__ uint32_t s_moved, s_nmoved, s_reseed, s_active, s_ok, s_nx, s_nxcd, s_qn, s_qhead, s_Cres, s_nslots;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ unsigned long long s_mm[4], s_evals, s_changed, s_pev;
-    __shared__ uint32_t s_nS[kPsSlotsMax], s_mcol[kMaxMovedSkip];
+    __shared__ uint32_t s_nS[kPsSlotsMax], s_lpiv[kPsSlotsMax], s_mcol[kMaxMovedSkip];
     __shared__ uint16_t s_ssup[kPsSlotsMax];
     __shared__ uint32_t s_cbase[kPsChunks + 1], s_cm0[kPsChunks], s_scan[kPsThreads / 64];
     const uint32_t tid = threadIdx.x, K = a.K, G = gridDim.x;
@@ -561,7 +597,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                 ccell[i] = (uint16_t)cid[q];
                 gstart[i] = gs;
                 uint32_t *rec = recs + (size_t)kPsRecWords * i;
-                rec[0] = 0u; rec[1] = 0xffffu; rec[10] = 0u;   // (no pivot yet; the cell's common label: unknown)
+                rec[0] = 0u; rec[1] = kPsUlMask; rec[10] = 0u;   // (no pivot yet; the cell's common label: unknown)
             }
         }
         const uint32_t off = block_exclusive_scan<kPsThreads>(np[0] + np[1], s_scan);
@@ -616,7 +652,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                 for (int u = 0; u < 4; u++) {
                     const uint32_t t = t0 + u * 64 + lane;
                     if (t < n) {
-                        const uint32_t w = pk_make(kk[u], ww[u], ll[u]);
+                        const uint32_t w = ps_pack(kk[u], ww[u], ll[u]);
                         if (i < Cres0) pts[s + t] = w; else a.pk[gs + t] = w;
                     }
                 }
@@ -641,6 +677,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         return;
     }
     const uint32_t Cres = s_Cres, nslots = s_nslots;
+    if (a.blk_ts && tid == 0) { a.blk_ts[((size_t)blockIdx.x * 128 + 0) * 8 + 7] = C; a.blk_ts[((size_t)blockIdx.x * 128 + 1) * 8 + 7] = cstart[C]; a.blk_ts[((size_t)blockIdx.x * 128 + 2) * 8 + 7] = nslots; }
     const uint32_t row = (uint32_t)lane >> 4, l16 = (uint32_t)lane & 15u;
     // running sums of cluster k = tid (kmeans.rs: the members of every cluster, as sums): registers, the same in every block
     unsigned long long run[5] = {0, 0, 0, 0, 0};
@@ -659,7 +696,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         PS_PHASE(7);
         if (!skip_mode) {
             // ============================================================= FULL schedule: every cell's candidates anew
-            ps_build_lists(tab, K, nslots, s_ssup, s_nS, Sent, wid, lane);
+            ps_build_lists(tab, K, nslots, s_ssup, s_nS, s_lpiv, Sent, wid, lane);
             if (a.blk_ts && tid == 0 && j < 128) a.blk_ts[((size_t)blockIdx.x * 128 + j) * 8 + 4] = wall_clock64();
             PS_PHASE(0);
             for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {   // a row of 16 lanes per cell
@@ -671,17 +708,18 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     bool needs;
                     if (nl <= kPsScap) {
                         const uint32_t pid = ps_row_build_list(tab, Sent + slot * kPsScap, nl, c, l16, rec);
-                        needs = ps_row_finish(rec, l16, pid, false);
+                        needs = ps_row_finish(rec, l16, pid, s_lpiv[slot], false);
                     } else {
                         const uint32_t pid = ps_row_build_table(tab, K, c, l16, rec);
-                        needs = ps_row_finish(rec, l16, pid, true);
+                        needs = ps_row_finish(rec, l16, pid, 0u, true);
                     }
                     if (l16 == 0 && (needs || first)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
                 }
             }
         } else {
             // ============================================================= SKIP schedule (at most max_skip centroids moved)
-            // A cell none of whose candidates moved and whose pivot still dominates every moved centroid repeats all its decisions.
+            // A cell none of whose candidates moved and whose pivot still dominates every moved centroid repeats all its decisions.  The
+            // test, a row of 16 lanes per cell; what fails it goes on the list and is worked on by a whole wave below.
             uint32_t mk[4], mc[4];   // the lane's share of the moved centroids: ids and colours
 #pragma unroll
             for (int t = 0; t < 4; t++) {
@@ -692,11 +730,11 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
             for (uint32_t i0 = (uint32_t)wid * 4; i0 < C; i0 += kPsWaves * 4) {
                 const uint32_t i = i0 + row;
                 const bool ok = i < C;
-                uint32_t *rec = recs + (size_t)kPsRecWords * (ok ? i : 0u);
-                const uint32_t r1 = rec[1], pid = (r1 >> 16) & 255u, c = ccell[ok ? i : 0u];
+                const uint32_t *rec = recs + (size_t)kPsRecWords * (ok ? i : 0u);
+                const uint32_t r1 = rec[1], lp = r1 >> 24, c = ccell[ok ? i : 0u];
                 Dominance dm;
                 dm.set(cell_box(c), (1 << kCellShift) - 1, rec[0]);
-                bool dv = false;
+                bool dv = !(r1 & kPsComplete) && ((s_mm[lp >> 6] >> (lp & 63)) & 1ull) != 0ull;   // the list the mask came from lost its pivot
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (mk[t] != 0xffffffffu) {
@@ -705,24 +743,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     }
                 }
                 const unsigned long long bm = __ballot(dv && ok);
-                if (!bm) continue;
-                if ((bm >> (16 * row)) & 0xffffull) {
-                    // A COMPLETE mask whose pivot has not moved: every centroid that has not moved keeps its verdict against it, the moved
-                    // ones are tested here.  Otherwise the mask is rebuilt from the whole table with a fresh pivot (and is complete then).
-                    const bool keep = (r1 & kRecComplete) && ((s_mm[pid >> 6] >> (pid & 63)) & 1ull) == 0ull;
-                    bool needs;
-                    if (keep) {
-                        if (l16 < 8) rec[2 + l16] &= ~reinterpret_cast<const uint32_t *>(s_mm)[l16];
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-                            if (mk[t] != 0xffffffffu && dm.worst(mc[t]) >= 0) atomicOr(&rec[2 + (mk[t] >> 5)], 1u << (mk[t] & 31));
-                        needs = ps_row_finish(rec, l16, pid, true);
-                    } else {
-                        const uint32_t npid = ps_row_build_table(tab, K, c, l16, rec);
-                        needs = ps_row_finish(rec, l16, npid, true);
-                    }
-                    if (l16 == 0 && needs) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
-                }
+                if (l16 == 0 && ((bm >> (16 * row)) & 0xffffull)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
             }
         }
         __syncthreads();   // the work list is complete
@@ -732,20 +753,78 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
         {
             const uint32_t qn = s_qn;
             const bool agg = !first && j <= a.agg_iters;
-            // the wave's cells, 64 at a time: lane t holds the t-th one's index, first and last point, position in the cell-major arrays and id
-            const uint32_t nall = qn > (uint32_t)wid ? (qn - (uint32_t)wid + kPsWaves - 1) / kPsWaves : 0u;
-            for (uint32_t tb = 0; tb < nall; tb += 64) {
-            uint32_t vi = 0, vs = 0, ve = 0, vg = 0, vc = 0;
-            const uint32_t nmine = min(nall - tb, 64u);
-            if ((uint32_t)lane < nmine) {
-                vi = queue[(uint32_t)wid + kPsWaves * (tb + (uint32_t)lane)];
-                vs = cstart[vi]; ve = cstart[vi + 1]; vg = gstart[vi]; vc = ccell[vi];
-            }
-            // one cell ahead: the record (lane l < 11 holds word l) and the words of the first sweep
-            auto fetch = [&](uint32_t t, uint32_t &rw, uint32_t (&wd)[kSweep]) {
-                const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)vi, (int)t), s = (uint32_t)__builtin_amdgcn_readlane((int)vs, (int)t);
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ve, (int)t), gs = (uint32_t)__builtin_amdgcn_readlane((int)vg, (int)t);
-                rw = lane < (int)kPsRecWords ? recs[(size_t)kPsRecWords * i + lane] : 0u;
+            for (;;) {   // the waves draw cells from the list (what a cell costs depends on how many of its points move)
+                uint32_t qi = 0;
+                if (lane == 0) qi = atomicAdd(&s_qhead, 1u);
+                qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+                if (qi >= qn) break;
+                const uint32_t i = queue[qi];
+                const uint32_t s = cstart[i], e = cstart[i + 1], gs = gstart[i], c = ccell[i];
+                uint32_t rw = lane < (int)kPsRecWords ? recs[(size_t)kPsRecWords * i + lane] : 0u;
+                if (skip_mode) {
+                    // ---- a dirty cell of the skip schedule: its mask brought up to date by the whole wave.  A mask whose pivot (and, unless
+                    // complete, whose list's pivot) has not moved keeps every verdict on the centroids that have not moved: the moved ones
+                    // are tested, one per lane.  Otherwise: from the whole table with a fresh pivot, position = id, the ballots ARE the mask.
+                    constexpr int32_t ext = (1 << kCellShift) - 1;
+                    const uint32_t r1o = (uint32_t)__builtin_amdgcn_readlane((int)rw, 1), pido = (r1o >> 16) & 255u, lpo = r1o >> 24;
+                    const bool keep = ((s_mm[pido >> 6] >> (pido & 63)) & 1ull) == 0ull && ((r1o & kPsComplete) || ((s_mm[lpo >> 6] >> (lpo & 63)) & 1ull) == 0ull);
+                    const CellBox bx = cell_box(c);
+                    unsigned long long um[4];
+                    uint32_t npid = pido, npv = (uint32_t)__builtin_amdgcn_readlane((int)rw, 0);
+                    bool complete = (r1o & kPsComplete) != 0;
+                    if (keep) {
+                        Dominance dm;
+                        dm.set(bx, ext, npv);
+                        const uint32_t k1 = (uint32_t)lane < nS ? s_mlist[lane] : 0xffffffffu;
+                        const uint32_t ck1 = (uint32_t)lane < nS ? s_mcol[lane] : 0u;
+                        unsigned long long f1 = __ballot(k1 != 0xffffffffu && dm.worst(ck1) >= 0);
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            um[w] = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)rw, 3 + 2 * w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rw, 2 + 2 * w)) & ~s_mm[w];
+                        while (f1) {
+                            const int l = __builtin_ctzll(f1);
+                            f1 &= f1 - 1;
+                            const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)k1, l);
+                            const unsigned long long bit = 1ull << (k & 63);
+                            const uint32_t w = (k >> 6) & 3;
+                            um[0] |= w == 0 ? bit : 0ull; um[1] |= w == 1 ? bit : 0ull; um[2] |= w == 2 ? bit : 0ull; um[3] |= w == 3 ? bit : 0ull;
+                        }
+                    } else {
+                        npid = nearest_to_centre(tab, K, bx, ext, lane);
+                        npv = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[npid].x);
+                        Dominance dm;
+                        dm.set(bx, ext, npv);
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const uint32_t k = 64 * w + lane;
+                            um[w] = __ballot(k < K && dm.worst(tab[k < K ? k : 0].x) >= 0);
+                        }
+                        complete = true;
+                    }
+#pragma unroll
+                    for (int w = 0; w < 4; w++) um[w] = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(um[w] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)um[w]);
+                    // up to four candidate ids as bytes (scalar unit), the record's words rebuilt in the lanes that hold them
+                    uint32_t c4 = 0, got = 0;
+                    {
+                        unsigned long long t4[4] = {um[0], um[1], um[2], um[3]};
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            while (t4[w] && got < 4) { c4 |= (64u * w + (uint32_t)__builtin_ctzll(t4[w])) << (8 * got); t4[w] &= t4[w] - 1; got++; }
+                    }
+                    const uint32_t r1n = (r1o & kPsUlMask) | (npid << 16) | (complete ? kPsComplete : (r1o & 0xff000000u));
+                    uint32_t nw = rw;
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                        if (lane == 2 + t) nw = (uint32_t)(um[t >> 1] >> (32 * (t & 1)));
+                    if (lane == 0) nw = npv;
+                    if (lane == 1) nw = r1n;
+                    if (lane == 10) nw = c4;
+                    rw = nw;
+                    if (lane < (int)kPsRecWords) recs[(size_t)kPsRecWords * i + lane] = rw;
+                    const uint32_t ncd = (uint32_t)(__popcll(um[0]) + __popcll(um[1]) + __popcll(um[2]) + __popcll(um[3]));
+                    if (ncd == 1 && (r1o & kPsUlMask) == (c4 & 255u)) continue;   // one candidate, and every point carries it: nothing can move
+                }
+                uint32_t wd[kSweep];
                 if (i < Cres) {
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? pts[idx] : 0u; }
@@ -753,15 +832,6 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) { const uint32_t idx = s + u * 64 + lane; wd[u] = idx < e ? a.pk[gs + (idx - s)] : 0u; }
                 }
-            };
-            uint32_t rw = 0, wd[kSweep] = {0, 0, 0, 0};
-            if (nmine) fetch(0, rw, wd);
-            for (uint32_t t = 0; t < nmine; t++) {
-                const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)vi, (int)t), s = (uint32_t)__builtin_amdgcn_readlane((int)vs, (int)t);
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ve, (int)t), gs = (uint32_t)__builtin_amdgcn_readlane((int)vg, (int)t);
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)vc, (int)t);
-                uint32_t rwn = 0, wn[kSweep] = {0, 0, 0, 0};
-                if (t + 1 < nmine) fetch(t + 1, rwn, wn);
                 PS_PHASE(2);
                 PS_COUNT(8, 1);
                 unsigned long long nm[4];
@@ -791,24 +861,20 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     PS_PHASE(4);
                     if (res) {
                         auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pts)[4 * idx + 3] = (uint8_t)l; };
-                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
+                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, st);
                         else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, agg, st PS_PROF_ARGS) && uniform;
                     } else {
                         auto st = [&](uint32_t idx, uint32_t l) { reinterpret_cast<uint8_t *>(pkc)[4 * (size_t)(idx - s) + 3] = (uint8_t)l; };
-                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, tab, K, cbk, cwc, acc, moved, st);
+                        if (first) ps_sweep_first(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, st);
                         else uniform = ps_sweep(wd, base, e, s, lane, nm, ncand, cand4, tab, K, cbk, cwc, acc, moved, agg, st PS_PROF_ARGS) && uniform;
                     }
                     PS_PHASE(5);
 #pragma unroll
                     for (int u = 0; u < kSweep; u++) wd[u] = w2[u];
                 }
-                if (lane == 0) rec[1] = (r1 & 0xffff0000u) | (uniform && ncand == 1 ? cand4 & 255u : 0xffffu);
+                if (lane == 0) rec[1] = (r1 & ~kPsUlMask) | (uniform && ncand == 1 ? cand4 & 255u : kPsUlMask);
                 evals += (unsigned long long)(e - s) * (ncand + 1);
-                rw = rwn;
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) wd[u] = wn[u];
                 PS_PHASE(6);
-            }
             }
         }
         PS_PHASE(9);
@@ -921,8 +987,8 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
     }
     for (uint32_t i = wid; i < C; i += kPsWaves) {   // the labels of the block's points, a wave per cell
         const uint32_t s = cstart[i], n = cstart[i + 1] - s, gs = gstart[i];
-        if (i < Cres) { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(pts[s + t] >> 24); }
-        else { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(a.pk[gs + t] >> 24); }
+        if (i < Cres) { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(255u - (pts[s + t] >> 24)); }
+        else { for (uint32_t t = lane; t < n; t += 64) a.labels[gs + t] = (uint8_t)(255u - (a.pk[gs + t] >> 24)); }
     }
     if (blockIdx.x == 0) {
         __syncthreads();
@@ -1071,6 +1137,9 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
         std::vector<unsigned long long> b((size_t)G * 128 * 8);
         CNIIC_HIP_TRY(c, hipMemcpy(b.data(), bts.p, b.size() * 8, hipMemcpyDeviceToHost));
         if (FILE *f = fopen(bt_path, "w")) {
+            fprintf(f, "# block cells points lists:");
+            for (int g = 0; g < G; g++) fprintf(f, " %d %llu %llu %llu;", g, b[((size_t)g * 128 + 0) * 8 + 7], b[((size_t)g * 128 + 1) * 8 + 7], b[((size_t)g * 128 + 2) * 8 + 7]);
+            fprintf(f, "\n");
             fprintf(f, "block,iteration,assign_us,flush_us,barrier_us,update_us,lists_us,classify_us,sweeps_us,cells_swept\n");
             for (int g = 0; g < G; g++)
                 for (uint64_t i = 1; i < xh->iter && i < 128; i++) {

@@ -56,7 +56,7 @@ def test_any_grid_gives_the_oracles_run(ctx, monkeypatch, K, shape, blocks):
     run_both(ctx, synth_img(*shape, seed=11 + K), K)
 
 
-@pytest.mark.parametrize("lds_bytes", ["45000", "60000", "120000"])
+@pytest.mark.parametrize("lds_bytes", ["60000", "80000", "130000"])
 @pytest.mark.parametrize("no_skip", [False, True])
 def test_points_that_do_not_fit_lds_live_in_memory(ctx, monkeypatch, lds_bytes, no_skip):
     """a block's LDS budget shrunk until most of its cells keep their packed words in memory (45000: a thousand or two stay)"""
