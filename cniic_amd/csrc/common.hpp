@@ -579,6 +579,8 @@ uint64_t km_rgbw_points(KmRgbwState *s);
 int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
                  const cniic_kmeans_opts *opts, cniic_colorpos *centroids_h, uint32_t *labels_d_u32,
                  uint64_t *members_h, cniic_kmeans_stats *stats);
+int km_xyrgb_run_wide(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K, const cniic_kmeans_opts *opts, cniic_colorpos *centroids_h,
+                      uint32_t *labels_d_u32, uint64_t *members_h, cniic_kmeans_stats *stats);   // k_kmeans_wide.hip: any K, any sides
 int km_xyrgb_step(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K,
                   const cniic_colorpos *centroids_h, uint32_t *labels_d_u32, uint64_t *sums_h,
                   uint64_t *wsum_h, uint64_t *members_h, uint64_t *changed_h, const cniic_kmeans_opts *opts);

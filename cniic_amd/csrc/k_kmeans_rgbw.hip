@@ -2292,12 +2292,16 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (points_dev && !points_follow) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: a device-side point count needs points_follow");
     if (!points_dev && Ulist / K == 0) return c->fail(CNIIC_ERR_TOO_FEW_POINTS, "kmeans: %llu points for %u clusters (src/kmeans.rs:68)",
                                        (unsigned long long)Ulist, K);
-    if (K > 2048) return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 2048 not supported", K);
+    // K > 2048: the every-centroid kernel with its sums in memory (k_kmeans_wide.hip); u16 labels end at 65535
+    if (K > 65535) return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 65535 not supported", K);
+    if (K > 2048 && (nshards != 1 || (opts && (opts->flags & CNIIC_KM_BRUTE_FORCE))))
+        return c->fail(CNIIC_ERR_UNSUPPORTED, "kmeans_rgbw: K=%u > 2048 runs unsharded on the cell-major arrays only", K);
     if (U >= (1ull << 32)) return c->fail(CNIIC_ERR_BAD_ARG, "kmeans_rgbw: too many points");
     auto *s = new KmRgbwState();
     s->c = c; s->U = U; s->lo = lo; s->hi = hi; s->K = K; s->shard = shard; s->nshards = nshards;
     s->Kpad = (K + 3) & ~3u;
     s->wide = K > 256;
+    s->big = K > 2048;
     s->idbits = s->wide ? 12 : 8;
     s->seed = (opts && opts->seed) ? opts->seed : kDefaultSeed;
     s->max_iters = opts ? opts->max_iters : 0;
@@ -2382,7 +2386,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         KM_ALLOC(s->ne_count, 4);
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
-        KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
+        if (!s->big) KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
         s->no_block_build = !(test_env("CNIIC_KM_BLOCK_BUILD") && atoi(test_env("CNIIC_KM_BLOCK_BUILD")));
         // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
         // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
@@ -2451,7 +2455,9 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)G + 1, 256)), dim3(256), 0, c->stream, s->ne_cost.as<uint32_t>(),
                            s->ne_count.as<uint32_t>(), G, s->wfirst.as<uint32_t>());
         // the loop as one persistent launch (k_kmeans_persist.hip): its block ranges, barrier words and sums
-        if (s->fused && !s->sup && !s->packed && nshards == 1 && c->opt(CNIIC_OPT_KM_LOOP, "CNIIC_KM_LOOP", 0) == 0) {
+        // (not for the worker contexts of a batch encode: eight persistent launches side by side each hold an eighth of the CUs for a
+        // whole run while the other stages of their neighbours' encodes wait for a CU -- 2.6 ms a frame against 0.67 with launches)
+        if (s->fused && !s->sup && !s->packed && nshards == 1 && c->ps_div <= 1 && c->opt(CNIIC_OPT_KM_LOOP, "CNIIC_KM_LOOP", 0) == 0) {
             const int rc_ps = ps_prepare(s);
             if (rc_ps != CNIIC_OK) { delete s; return rc_ps; }
         }
@@ -2529,7 +2535,9 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
         CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
                      s->no_skip ? 0u : s->max_skip, s->dbg_timeline,
                      (s->no_block_build ? 1u : 0u) | ((fz.on && s->abl_launch == fz.launch_no + 1) ? s->abl_bits << 8 : 0u)};
-        if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
+        if (s->big) {   // K > 2048: every colour against every centroid, sums in memory (k_kmeans_wide.hip)
+            launch_rgbw_assign_big(c, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->U, s->K, s->cent.as<uint32_t>(), s->labels.as<uint16_t>(), part, st);
+        } else if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
             // wave's candidate strip in 150 KiB of LDS -- one wave per block (K = 512: five waves per CU, K = 2048: one) took 0.10
             // and 0.69 ms per iteration at 4096^2 against 0.03 at K = 256.  The ranges are per wave: any grouping that divides them.
             auto lds_for = [&](uint32_t wv) {

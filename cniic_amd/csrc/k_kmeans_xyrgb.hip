@@ -1062,6 +1062,8 @@ static uint32_t xy_grid(uint64_t n) { return (uint32_t)std::min<uint64_t>(std::m
 
 int km_xyrgb_run(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint32_t h, uint32_t K, const cniic_kmeans_opts *opts,
                  cniic_colorpos *centroids_h, uint32_t *labels_d_u32, uint64_t *members_h, cniic_kmeans_stats *stats) {
+    // beyond what the tiled kernel is laid out for (table and sums in LDS, 24-bit coordinate products): the exact, slow route
+    if (K > kXMaxK || w > 16384 || h > 16384) return km_xyrgb_run_wide(c, rgb_d, w, h, K, opts, centroids_h, labels_d_u32, members_h, stats);
     KmXyState s;
     CNIIC_TRY(xy_create(c, rgb_d, w, h, K, opts, s));
     hipLaunchKernelGGL(k_xy_init, dim3(xy_grid(std::max<uint64_t>(s.N, K))), dim3(256), 0, c->stream, rgb_d, w, s.N, K,

@@ -39,6 +39,7 @@ struct KmRgbwState {
     uint64_t U = 0, lo = 0, hi = 0, seed = 0, max_iters = 0;
     uint32_t K = 0, Kpad = 0, idbits = 8, nblocks = 1;
     bool wide = false;   // u16 labels
+    bool big = false;    // K > 2048: k_rgbw_assign_big (k_kmeans_wide.hip)
     bool cells = true;   // cell-pruned assign (default) vs brute force
     bool profile = false; // per-launch event timing of the assign kernel (CNIIC_KM_PROFILE)
     bool no_skip = false; // CNIIC_KM_NO_SKIP: always run the full schedule (A/B measurement)
@@ -97,6 +98,8 @@ struct alignas(128) PsLine { uint32_t v; uint32_t pad[31]; };
 struct PsBar { PsLine xcount[8], xgen[8], xblocks[8], top, topgen, count, gen, abort_; };   // every counter on a line of its own
 constexpr uint32_t kPsStatusDone = 1, kPsStatusAborted = 2, kPsStatusRanges = 3;
 struct PsExit { uint32_t status, pad; uint64_t iter, moved_last, reseeds, active, pair_evals; };   // pinned: how the launch ended
+void launch_rgbw_assign_big(Ctx *c, const uint32_t *ckeys, const uint32_t *cweight, uint64_t U, uint32_t K, const uint32_t *cent, uint16_t *labels,
+                            unsigned long long *partials, const KmDevState *st);
 int ps_prepare(KmRgbwState *s);
 int km_rgbw_run_persistent(KmRgbwState *s, bool *ran);
 constexpr uint32_t kAggMin = 16;  // points that must share the first mover's (old, new) pair for a round of aggregated booking to be worth it
