@@ -41,6 +41,18 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FRAME_W, FRAME_H = 1920, 1080
 
 
+def traffic_for(key):
+    """HBM bytes per launch of a block's dominant kernel from the PMC passes kept in profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate runs, 2 x FETCH + WRITE: tools/make_traffic.sh), or None when that kernel has not been measured."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(key) if key else t
+        return e.get("hbm_bytes_per_launch") if e else None
+    except Exception:
+        return None
+
+
 def roofline_from_timers(ctx, U, K, note, traffic=None):
     """roofline of the assign kernel from the per-dispatch event timers of the LAST profiled run on ctx.
     Algorithmic bytes per launch = 10 B per distinct colour (dedup form: 4 B key + 4 B weight + 1 B label read
@@ -202,7 +214,8 @@ def main():
             solo.encode_frames(frames, FRAME_W, FRAME_H, F, out, stride)
             solo.close()
             roof = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one batch encode of rank 0's frames alone; exact cell-pruned assign "
-                                        "over this GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K))
+                                        "over this GPU's %d distinct colours (of %d frames), K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form)" % (U, F, K),
+                                        traffic_for("c4"))
         return dt, int(sum(lens)), st, U, roof
 
     def golden(case):
@@ -306,7 +319,7 @@ def main():
         if g_ms:
             algo = 3.0 * W * H
             roofline = {"kernel": "k_delta_gather_p2", "bound": "hbm", "achieved": round(algo / (g_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": g_ms, "launches": 1,
+                        "frac": round(algo / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic_for("c5") if (W, H) == (16384, 16384) else None, "launch_ms": g_ms, "launches": 1,
                         "algorithmic_bytes_per_launch": algo,
                         "with_symbol_stream": {"bytes_per_launch": 5.0 * W * H, "GBps": round(5.0 * W * H / (g_ms * 1e-3) / 1e9, 2),
                                                "frac": round(5.0 * W * H / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
@@ -396,15 +409,13 @@ def main():
             # (hipExtLaunchKernelGGL, on the stream the kernel runs on: the kernel's own begin and end, without the
             # ~4 us of dispatch an event pair AROUND a launch adds)
             rc, ln, stp = ctx.encode(expr, img, w=W, h=H, out=out, max_iters=args.max_iters, flags=_lib.KM_PROFILE)
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see DESIGN.md 6
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("size") == W and tj.get("K") == K and tj.get("unique_colours") == U:
-                    traffic = tj.get("hbm_bytes_per_launch")
+            # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/make_traffic.sh): the persistent launch's bytes, or -- when the loop
+            # ran as one launch per iteration -- a full-schedule launch's (the file's top level)
+            persisted = ctx.kernel_time("kmeans_rgbw_persist")[1] > 0
+            traffic = traffic_for("c2_persist") if persisted else traffic_for(None)
             roofline = roofline_from_timers(ctx, U, K, "HIP start/stop events on every assign dispatch of one encode (%d iterations); exact cell-pruned assign over %d "
-                                            "distinct colours, K=%d; algorithmic bytes = 10 B/colour/launch (SURVEY 8(d) dedup form); traffic = PMC 2*FETCH_SIZE+WRITE_SIZE "
-                                            "of a full-schedule launch (profiles/traffic.json)" % (stp["iterations"], U, K), traffic)
+                                            "distinct colours, K=%d; algorithmic bytes = 10 B/colour/iteration (SURVEY 8(d) dedup form); traffic = PMC 2*FETCH_SIZE+WRITE_SIZE "
+                                            "of the launch (profiles/traffic.json)" % (stp["iterations"], U, K), traffic)
         def headline():
             ln = {
                 "metric": "Mpixels/sec encode (cluster-colors K=%d)" % K, "value": round(npx_total * args.steps / dt / 1e6, 3), "unit": "Mpixels/s",
@@ -684,7 +695,7 @@ def bench_decode(args, ctx, torch, np, dev, rank, world, timed, config):
         sym_bytes = 4 if lossless else 3       # delta: packed differences (u32) for the prefix sum; the RGB codecs: pixels
         algo = float(ln) + float(sym_bytes) * W * H
         roofline = {"kernel": "k_hd_write (+ the offsets scan in front of it)", "bound": "hbm", "achieved": round(algo / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(algo / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None, "launch_ms": w_ms, "launches": 1,
+                    "unit": "GB/s", "frac": round(algo / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic_for("c5_decode" if lossless else "c2_decode") if W == (16384 if lossless else 4096) else None, "launch_ms": w_ms, "launches": 1,
                     "algorithmic_bytes_per_launch": algo,
                     "note": "HIP events around the scan + write launches of one more decode (stage timers); algorithmic bytes = the %d-byte stream read once + "
                             "%d B/symbol written; the boundary passes before it (hd_pass0, hd_check) read the stream again and write 20 B per 1024 bits" % (ln, sym_bytes)}

@@ -154,7 +154,6 @@ uint64_t comm_timeout_ms(const Comm *cm) { return cm ? cm->timeout_ms : 0; }
 void comm_set_timeout_ms(Comm *cm, uint64_t ms) { if (cm) cm->timeout_ms = ms; }
 
 Ctx *comm_ctx(Comm *cm) { return cm->c; }
-Mailbox *comm_mailbox(Comm *cm) { return cm && !cm->dead ? cm->mb : nullptr; }
 uint32_t comm_size(const Comm *cm) { return cm->nranks; }
 
 // in-place sum over the ranks, on the context's stream; kind: 0 = u8, 1 = u32, 2 = u64

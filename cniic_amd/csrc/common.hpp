@@ -530,27 +530,6 @@ int mailbox_status(const Mailbox *m);  // 0 healthy, 1 a wait ran out, 2 a peer 
 void mailbox_abort(Mailbox *m);
 void mailbox_destroy(Mailbox *m);
 
-// The exchange FOLDED into the K-means launches (round 4): no kernel of its own between two assign launches.  The
-// tail of launch j -- the last block to finish, found by a ticket -- writes the launch's 5K+2 sums into every peer's mailbox and raises
-// the flags; the prologue of launch j + 1 -- block 0 -- waits for the N flags, adds the N slots in rank order into the buffer the
-// launch reads its sums from and releases the other blocks through a device word.  Same mailboxes, same flags, same rank order, same
-// bounded waits and poison as k_mb_all_reduce; the descriptor travels as a kernel argument.
-constexpr uint32_t kMbFoldMaxRanks = 16;
-struct MbFold {
-    uint8_t *peer[kMbFoldMaxRanks];  // every rank's mailbox as mapped here
-    uint32_t on, rank, nranks, nslices_cap;
-    uint32_t seq_prev;               // the exchange this launch's prologue completes (0: none -- the first launch of a run)
-    uint32_t seq_pub;                // the exchange this launch's tail publishes
-    uint32_t words;                  // u64 words exchanged (5K+2)
-    uint32_t pad_;
-    uint64_t cap, flags_off, slots_off, wait_ticks;
-    uint32_t *status;                // mapped host word: 0 healthy, 1 a wait ran out, 2 a peer aborted
-    unsigned int *ticket;            // device, [2]: blocks of launch (seq & 1) that have flushed their sums
-    unsigned int *ready;             // device: the last exchange whose sums block 0 has put in place (0xffffffff: the exchange is dead)
-};
-Mailbox *comm_mailbox(Comm *cm);     // the communicator's mailboxes, or null (RCCL, host transport)
-int mailbox_fold_next(Mailbox *m, uint64_t timeout_ms, bool first_launch, uint32_t words, MbFold *out);   // the descriptor of the next launch of a run
-
 int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs

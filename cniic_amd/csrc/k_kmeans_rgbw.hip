@@ -379,9 +379,6 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     }
     __builtin_amdgcn_wave_barrier();
     uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
-#ifdef CNIIC_RGBW_ABL
-    if (!cell_rec) return ncand;   // (ablation: no record stores)
-#endif
     // (the lane's index made afresh and pinned: or "cell_rec + 8 lane + 8" is computed once per launch and two registers hold it
     // across the cell loop -- or are spilled, and a scratch reload per cell sits in front of the loads in flight)
     uint32_t i_first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -389,121 +386,6 @@ __device__ __forceinline__ uint32_t build_candidates(const uint2 *list, uint32_t
     for (uint32_t i = i_first; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
     if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c | (pid << 16));  // (cell ids are 15 bits, cluster ids at most 11; bit 31: kRecComplete)
     return ncand;
-}
-
-// The same strip, mask and record from a verdict the BLOCK reached for all of its cells at once (full schedule, K <= 256: one LANE
-// per cell, the members of S dealt to the waves -- k_rgbw_assign_cells): pe = the pivot's position in `list`, cm = bit e <=> member
-// e of `list` is a candidate.  The mask IS the ballot: nothing is tested here.
-constexpr uint32_t kBlkCells = 128;  // cells of a block's range that get the block-wide build (the rest: one wave per cell)
-template <int IDBITS>
-__device__ __forceinline__ uint32_t expand_candidates(const uint2 *list, uint32_t pe, unsigned long long cm0, unsigned long long cm1, uint32_t c, int lane,
-                                                      uint2 *cand, unsigned long long *wmask, uint32_t *cell_rec, uint32_t m, uint32_t MW) {
-    constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
-    const uint2 pvc = list[pe];
-    const uint32_t pv = pvc.x, pid = IDMASK - (pvc.y & IDMASK);
-    for (uint32_t i = lane; i < MW; i += 64) wmask[i] = 0ull;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t ncand = 0;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const unsigned long long bm = h ? cm1 : cm0;
-        if (!bm) continue;
-        if ((bm >> lane) & 1ull) {
-            const uint2 cc = list[64 * h + lane];
-            cand[ncand + lanes_below(bm)] = cc;
-            const uint32_t k = IDMASK - (cc.y & IDMASK);
-            atomicOr(&wmask[k >> 6], 1ull << (k & 63));
-        }
-        ncand += (uint32_t)__popcll(bm);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t *rec = cell_rec + (size_t)m * cell_rec_words(MW);
-    uint32_t i_first = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(i_first));
-    for (uint32_t i = i_first; i < MW; i += 64) *reinterpret_cast<unsigned long long *>(rec + 2 + 2 * i) = wmask[i];
-    if (lane == 0) *reinterpret_cast<uint2 *>(rec) = make_uint2(pv, c | (pid << 16));
-    return ncand;
-}
-
-// The candidates of all the cells of a block's range at once (k_rgbw_assign_cells, full schedule): lane = cell, the members of the
-// cell's list S dealt to the waves; s_piv / s_cm as cleared by the caller.
-template <int WAVES>
-__device__ __forceinline__ void block_candidates(const uint2 *tab, uint32_t K, uint32_t scap, const uint32_t *cells, uint32_t nbc, uint32_t sup_first, uint32_t nsl,
-                                              const uint32_t *s_nS, uint32_t *s_piv, unsigned long long (*s_cm)[2], int wid, int lane) {
-    constexpr int32_t cext = (1 << kCellShift) - 1;
-    uint32_t nmax = 0;
-    for (uint32_t t = 0; t < nsl; t++) { const uint32_t n = s_nS[t]; if (n <= scap) nmax = max(nmax, n); }
-#pragma unroll 1
-    for (int phase = 0; phase < 2; phase++) {
-#pragma unroll 1
-        for (uint32_t r0 = 0; r0 < nbc; r0 += 64) {
-            const uint32_t i = r0 + lane;
-            const bool act = i < nbc;
-            const uint32_t ci = act ? cells[i] : cells[0];
-            const uint32_t slot = (ci >> kSuperShift) - sup_first;
-            uint32_t ni = act ? s_nS[slot] : 0u;
-            if (ni > scap) ni = 0u;  // (a list that did not fit: the cell keeps the wave-per-cell build from the whole table)
-            const uint2 *Sl = tab + K + (size_t)slot * (scap + K);   // (K <= 256 here: the strip holds the whole table)
-            const CellBox bx = cell_box(ci);
-            if (phase == 0) {
-                uint32_t best = 0xffffffffu;
-                for (uint32_t e = wid; e < nmax; e += WAVES)
-                    if (e < ni) best = min(best, (centre_dist(Sl[e].x, bx, cext) << 8) | e);
-                if (best != 0xffffffffu) atomicMin(&s_piv[i], best);
-            } else if (ni) {
-                Dominance dm;
-                dm.set(bx, cext, Sl[s_piv[i] & 255u].x);
-                unsigned long long lo = 0, hi = 0;
-                for (uint32_t e = wid; e < nmax; e += WAVES) {
-                    const bool keep = e < ni && dm.worst(Sl[e].x) >= 0;
-                    if (e < 64) lo |= keep ? 1ull << e : 0ull;
-                    else hi |= keep ? 1ull << (e - 64) : 0ull;
-                }
-                if (lo) atomicOr(&s_cm[i][0], lo);
-                if (hi) atomicOr(&s_cm[i][1], hi);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---- packed points (round 4).  One-launch ablations (profiles/r04_assign_ablation.txt) showed where a full-schedule launch's 35 us go:
-// 11 us fixed, 7-10 us candidate builds and 14-17 us sweeps -- of which 13 us remain when a sweep does NOTHING with its points: the
-// sweeps wait for their 9 B a point (4 B key, 1 B label, 4 B weight: 61 MB a launch at ~4.5 TB/s), not for their arithmetic.  A point of
-// a cell-major list needs far less: its colour INSIDE its 8^3 cell is 9 bits (the cell is known), its label 8 bits (K <= 256), and its
-// weight -- a pixel count, 2.4 on average for a photograph -- fits 8 bits with an escape.  So the fused loop keeps ONE u32 per point:
-//     bits 0..8   colour inside the cell: r3 << 6 | g3 << 3 | b3          bits 16..23  weight, 255 = look it up in cweight[]
-//     bits 24..31 label                                                   bits 9..15   zero
-// written for every point by the launch of iteration 0 (which reads the classic arrays once), read as one load per point by every
-// later launch (4 B instead of 9 B, one load instruction instead of three, four registers in flight per sweep instead of twelve), the
-// label byte rewritten in place when a point moves, and unpacked into the u8 label array once after the loop (k_rgbw_unpack_labels).
-// a sweep's packed words -> colour keys, labels, weights (a weight of 255 and more is fetched: rare in a photograph, every point of a flat image)
-__device__ __forceinline__ void pk_unpack(const uint32_t (&pw)[kSweep], uint32_t base, uint32_t e, int lane, uint32_t cell_base, const uint32_t *__restrict__ cweight,
-                                          uint32_t (&key)[kSweep], uint32_t (&cur)[kSweep], uint32_t (&wt)[kSweep]) {
-    bool heavy = false;
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        key[u] = pk_key(pw[u], cell_base);
-        cur[u] = pw[u] >> 24;
-        wt[u] = (pw[u] >> 16) & 255u;
-        heavy = heavy || wt[u] == 255u;
-    }
-    if (__ballot(heavy)) {
-#pragma unroll
-        for (int u = 0; u < kSweep; u++) {
-            const uint32_t q = base + u * 64 + lane;
-            if (wt[u] == 255u && q < e) wt[u] = cweight[q];
-        }
-    }
-}
-__global__ __launch_bounds__(256) void k_rgbw_unpack_labels(const uint32_t *__restrict__ pk, uint8_t *__restrict__ labels, uint64_t U) {
-    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i + 4 <= U && (reinterpret_cast<uintptr_t>(labels) & 3) == 0) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(pk + i);
-        *reinterpret_cast<uint32_t *>(labels + i) = (v.x >> 24) | ((v.y >> 24) << 8) | ((v.z >> 24) << 16) | ((v.w >> 24) << 24);
-    } else {
-        for (uint64_t j = i; j < U && j < i + 4; j++) labels[j] = (uint8_t)(pk[j] >> 24);
-    }
 }
 
 // The 64 x kSweep points from `from` on (those below `end`; the others read as 0) as BUFFER loads: the range check is the hardware's, and
@@ -557,10 +439,7 @@ __device__ __forceinline__ void load_points(const uint32_t *__restrict__ ckeys, 
 // round, a cell split between two new owners two; a handful of movers, and whatever is left after six rounds, go point by point.
 // (Not in the skip schedule: few points move per sweep there.  The kernel must not spill a single register for this: a
 // scratch segment costs every full-schedule launch 20 us)
-// LAZYW (round 4): the weight of a point is needed only when it MOVES (delta sums) -- 4 of the 10 bytes a colour costs per launch and a
-// third of the loads in flight were fetched for nothing.  With LAZYW the callers do not load wt at all and a mover gathers its own.
-// LSTRIDE: 1 = a label array; 4 = the label byte of the packed points (labels = byte 3 of word 0)
-template <typename LabelT, int IDBITS, bool ALLWRITE = false, bool AGG = false, bool LAZYW = false, int LSTRIDE = 1>  // ALLWRITE: the labels in memory are stale (a cell kept as "uniform"): write every one
+template <typename LabelT, int IDBITS, bool ALLWRITE = false, bool AGG = false>  // ALLWRITE: the labels in memory are stale: write every one
 __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K, bool first,
@@ -598,7 +477,7 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
                 const uint2 cc = tab[cur[u]];
                 const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
                 rem[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
-                if (rem[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[(size_t)q * LSTRIDE] = (LabelT)nl[u]; moved++; }
+                if (rem[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
             }
             anym = anym || rem[u];
         }
@@ -681,14 +560,10 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
             const bool mv = mvs[u];
             const uint32_t ol = cur[u], pp = p[u];
             const uint32_t nl = mv ? IDMASK - (best[u] & IDMASK) : ol;
-#ifdef CNIIC_RGBW_ABL
-            if ((mv || ALLWRITE) && !(reinterpret_cast<uintptr_t>(labels) >> 62)) labels[(size_t)q * LSTRIDE] = (LabelT)nl;
-#else
-            if (mv || ALLWRITE) labels[(size_t)q * LSTRIDE] = (LabelT)nl;
-#endif
+            if (mv || ALLWRITE) labels[q] = (LabelT)nl;
             if (mv) moved++;
             if (mv || first) {
-                const uint64_t w = LAZYW ? cweight[q] : wt[u];  // (not LAZYW: loaded with the key)
+                const uint64_t w = wt[u];  // (loaded with the key: a gather here stalls every sweep that moves a point -- NOTES.md D)
                 const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
                 atomicAdd(&acc[3 * nl + 0], rw);
                 atomicAdd(&acc[3 * nl + 1], gw);
@@ -709,7 +584,7 @@ __device__ __forceinline__ void sweep_points(const uint32_t (&p)[kSweep], const 
 
 // one sweep with the candidates given as a bitmask of cluster ids (K <= 256) instead of a list: the set bits are walked on the
 // scalar unit, each candidate read from the block's table (no candidate list, no compaction)
-template <typename LabelT, int IDBITS, bool LAZYW = false, int LSTRIDE = 1>
+template <typename LabelT, int IDBITS>
 __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                                   uint32_t base, uint32_t e, int lane, const unsigned long long (&nm)[4],
                                                   const uint2 *tab, uint32_t K, LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved,
@@ -738,9 +613,9 @@ __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], c
             const bool mv = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
             if (mv) {
                 const uint32_t ol = cur[u], pp = p[u], nl = IDMASK - (best[u] & IDMASK);
-                labels[(size_t)q * LSTRIDE] = (LabelT)nl;
+                labels[q] = (LabelT)nl;
                 moved++;
-                const uint64_t w = LAZYW ? cweight[q] : wt[u];
+                const uint64_t w = wt[u];
                 const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
                 atomicAdd(&acc[3 * nl + 0], rw); atomicAdd(&acc[3 * nl + 1], gw); atomicAdd(&acc[3 * nl + 2], bw);
                 atomicAdd(&acc[3 * K + nl], (unsigned long long)w); atomicAdd(&acc[4 * K + nl], 1ull);
@@ -753,12 +628,11 @@ __device__ __forceinline__ void sweep_points_mask(const uint32_t (&p)[kSweep], c
 
 // the same sweep at iteration 0, where every point adds to the sums of its cluster (kept apart from
 // sweep_points: sharing the code cost the later iterations 30 % through the register allocation)
-// pkout: the packed points (above) are written here for every point of the sweep, new label included, INSTEAD of the label array
 template <typename LabelT, int IDBITS, bool ROUNDS = false>
 __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep],
                                              uint32_t base, uint32_t e, int lane,
                                              const uint2 *cand, uint32_t ncand, const uint2 *tab, uint32_t K,
-                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved, uint32_t *__restrict__ pkout = nullptr) {
+                                             LabelT *__restrict__ labels, unsigned long long *acc, uint32_t &moved) {
     constexpr uint32_t IDMASK = (1u << IDBITS) - 1;
     uint32_t best[kSweep];
 #pragma unroll
@@ -779,8 +653,7 @@ __device__ __forceinline__ void sweep_points_first(const uint32_t (&p)[kSweep], 
             const uint2 cc = tab[cur[u]];
             const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << (IDBITS + 1)) + cc.y;
             mvd[u] = (best[u] >> IDBITS) > (kcur >> IDBITS);  // strictly closer (kmeans.rs:375)
-            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); if (!pkout) labels[q] = (LabelT)nl[u]; moved++; }
-            if (pkout) pkout[q] = pk_make(p[u], wt[u], nl[u]);
+            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); labels[q] = (LabelT)nl[u]; moved++; }
         }
     }
     bool rem[kSweep];
@@ -874,8 +747,6 @@ struct CellState {
     uint32_t *rec;          // [M][cell_rec_words(MW)]
     const uint32_t *moved;  // [0] = number of centroids changed by the last update, then their ids
     uint32_t max_moved;     // skip schedule when moved[0] <= max_moved (0 disables it)
-    uint32_t dbg;           // measuring builds (-DCNIIC_RGBW_PHASES): 1 + the launch whose waves write their timeline (CNIIC_DBG_TIMELINE)
-    uint32_t opts;          // bit 0: no block-wide candidate build (the default: see block_candidates)
 };
 
 // Centroid update folded into the next assign launch (km_rgbw_run, K <= 256): launch j first finishes iteration
@@ -912,158 +783,28 @@ __device__ __forceinline__ void poll_record(PollRec *ring, uint32_t launch_no, c
     r->seq = launch_no;
 }
 
-// -DCNIIC_RGBW_PHASES: wave-clock totals per phase of k_rgbw_assign_cells (a measuring build, never the shipped one)
-#ifdef CNIIC_RGBW_PHASES
-__device__ unsigned long long g_rgbw_phase[12];
-__device__ unsigned long long g_rgbw_blk[512][4];  // census of one launch (CNIIC_DBG_LAUNCH): per block start, end (100 MHz clock), HW id, items
-__device__ unsigned int g_rgbw_launch[128][8];  // per launch of the super-cell kernel: swept cells, swept points, bulk cells, single-candidate cells, longest list, non-empty cells, sum |S|
-__device__ unsigned long long g_wave_tl[8192][12];  // one launch (CNIIC_DBG_TIMELINE): per wave, the 100 MHz clock at entry, after the prologue, after the first tests / first build, at the end of the cell loop, after the barrier, at the end; [6] dirty cells (skip) / sweeps (full), [7] cells, [8] candidates summed over the cells, [9] points, [10] super-cell list builds, [11] their lengths summed
-#define RG_PHASE(i) do { const long long now_ = clock64(); ph_[i] += (unsigned long long)(now_ - t_ph); t_ph = now_; } while (0)
-#define RG_TL(i) do { if (tl_on_) tl_[i] = wall_clock64(); } while (0)
-#define RG_TL1(i) do { if (tl_on_ && !tl_[i]) tl_[i] = wall_clock64(); } while (0)
-#define RG_TLC(i, v) do { if (tl_on_) tl_[i] += (v); } while (0)
-#define RG_COUNT(i, v) do { ph_[i] += (unsigned long long)(v); } while (0)
-#else
-#define RG_PHASE(i) do {} while (0)
-#define RG_COUNT(i, v) do {} while (0)
-#define RG_TL(i) do {} while (0)
-#define RG_TL1(i) do {} while (0)
-#define RG_TLC(i, v) do {} while (0)
-#endif
-
-// ---- the exchange folded into the launches (MbFold, common.hpp): device side
-// block 0, all threads: wait for every source's flags of exchange f.seq_prev, add the N slots in rank order into `sums`, tell the other
-// blocks.  false: a wait ran out or a peer aborted (status word, poison and the ready word are set: every block leaves).
-template <int THREADS>
-__device__ __forceinline__ bool mbf_collect(const MbFold &f, unsigned long long *sums, uint32_t *s_flag) {
-    const uint32_t tid = threadIdx.x, par = f.seq_prev & 1u;
-    const uint32_t nsl = (f.words * 8u + 4095u) / 4096u;
-    uint32_t *own = reinterpret_cast<uint32_t *>(f.peer[f.rank]);
-    if (tid == 0) *s_flag = __hip_atomic_load(own + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // poisoned before?
-    __syncthreads();
-    if (tid < f.nranks * nsl && !*s_flag) {
-        const uint32_t src = tid / nsl, sl = tid % nsl;
-        const uint32_t *fl = reinterpret_cast<const uint32_t *>(f.peer[f.rank] + f.flags_off) + ((uint64_t)par * f.nranks + src) * f.nslices_cap + sl;
-        const unsigned long long t0 = wall_clock64();
-        uint32_t spins = 0, why = 0;
-        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != f.seq_prev) {
-            if ((++spins & 31u) == 0) {
-                if (__hip_atomic_load(own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) { why = 2; break; }
-                if (wall_clock64() - t0 > f.wait_ticks) { why = 1; break; }
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (why) {
-            __hip_atomic_store(f.status, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(own + 1, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            *s_flag = why;
-        }
-    }
-    __syncthreads();
-    const bool ok = *s_flag == 0;
-    if (ok) {
-        __threadfence_system();
-        const uint8_t *src = f.peer[f.rank] + f.slots_off + (uint64_t)par * f.nranks * f.cap;
-        for (uint32_t i = tid; i < f.words; i += THREADS) {
-            unsigned long long acc = 0;
-            for (uint32_t r = 0; r < f.nranks; r++)   // rank order: the same additions on every rank
-                acc += __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + (uint64_t)r * f.cap) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(sums + i, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written through: the other blocks read it past their own L2)
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(f.ready, ok ? f.seq_prev : 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    return ok;
-}
-// every other block, thread 0 polls: true once block 0 has put the sums of exchange f.seq_prev in place
-__device__ __forceinline__ bool mbf_wait_ready(const MbFold &f, uint32_t *s_flag) {
-    if (threadIdx.x == 0) {
-        const unsigned long long t0 = wall_clock64();
-        uint32_t v, spins = 0;
-        while ((v = __hip_atomic_load(f.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != f.seq_prev && v != 0xffffffffu) {
-            if ((++spins & 63u) == 0 && wall_clock64() - t0 > 2 * f.wait_ticks) { v = 0xffffffffu; break; }   // (block 0 never came: it has its own, shorter deadline)
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *s_flag = v == f.seq_prev ? 0u : 1u;
-    }
-    __syncthreads();
-    return *s_flag == 0;
-}
-// the LAST block of a launch to have flushed its sums (all threads): the launch's sums into every peer's mailbox, then the flags
-template <int THREADS>
-__device__ __forceinline__ void mbf_publish(const MbFold &f, const unsigned long long *sums) {
-    const uint32_t tid = threadIdx.x, par = f.seq_pub & 1u;
-    const uint32_t nsl = (f.words * 8u + 4095u) / 4096u;
-    const uint64_t slot = f.slots_off + ((uint64_t)par * f.nranks + f.rank) * f.cap;
-    for (uint32_t i = tid; i < f.words; i += THREADS) {
-        const unsigned long long v = __hip_atomic_load(sums + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the blocks added with device-scope atomics)
-        for (uint32_t p = 0; p < f.nranks; p++)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(f.peer[p] + slot) + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (tid < f.nranks * nsl) {
-        const uint32_t p = tid / nsl, sl = tid % nsl;
-        uint32_t *fl = reinterpret_cast<uint32_t *>(f.peer[p] + f.flags_off) + ((uint64_t)par * f.nranks + f.rank) * f.nslices_cap + sl;
-        __hip_atomic_store(fl, f.seq_pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // FIRSTK: -1 = everything found out on the device (the loops without the folded-in update).  The loop with the folded-in update
 // knows which launch it enqueues: 1 = the launch of iteration 0 (alone that body has registers to spare for booking its points
 // round by round, sweep_points_first), 2 = one of the next three (the same body as 0 plus the rounds for movers that share an
 // (old, new) pair, sweep_points<AGG>: whole cells change hands while the centroids still travel; the rounds' code costs the
 // launches that do not need it 4-5 us each, so only these get it), 0 = a later one.
-// Round 4, measured on the headline encode (profiles/r04_lazyw_bench.json): weights gathered by the movers themselves take 27 MB out of
-// every 67.5 MB full-schedule launch and six registers out of the body (77 -> 71 VGPRs) -- and the launches get SLOWER: full schedule
-// 36.3 -> 38.3 us, skip 17.2 -> 18.4 us (a sweep with a mover now waits for a dependent gather in front of its LDS atomics; at 64
-// VGPRs, which a fourth block per CU needs, the body still spills 20 bytes a lane).  Off; -DCNIIC_LAZYW=1 builds it.
-#ifndef CNIIC_LAZYW
-#define CNIIC_LAZYW 0
-#endif
-#ifndef CNIIC_LAZYW_MINW
-#define CNIIC_LAZYW_MINW 6
-#endif
-template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1, bool PKT = false, bool MBX = false>   // PKT: the launch reads the packed points (pk_make; FIRSTK 0 and 2 only); MBX: the exchange with the other ranks is folded into the launch (MbFold)
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW) ? CNIIC_LAZYW_MINW : 6, 8))) void k_rgbw_assign_cells(
+template <typename LabelT, int IDBITS, int WAVES, int FIRSTK = -1>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_rgbw_assign_cells(
     const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, const uint32_t *__restrict__ ne_cell,
     const uint32_t *__restrict__ ne_start, const uint32_t *__restrict__ wfirst,
     uint32_t shard, uint32_t K, const uint2 *__restrict__ cconst, LabelT *__restrict__ labels,
-    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz, uint32_t *__restrict__ pk, MbFold mf) {
+    unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, CellState cs, FusedUpdate fz) {
     extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | WAVES x (uint2 S[(K+1)/2], uint2 cand[K]) | WAVES x u64 mask[MW]
-    // the launches of the fused loop after the first read the packed points (pk_make); the first one writes them
-    constexpr bool PK = PKT && (FIRSTK == 0 || FIRSTK == 2) && IDBITS == 8;
-    constexpr int LS = PK ? 4 : 1;
-    LabelT *const lab_st = PK ? reinterpret_cast<LabelT *>(reinterpret_cast<uint8_t *>(pk) + 3) : labels;   // where a mover's new label goes
     __shared__ uint32_t s_moved, s_cell, s_nmoved, s_reseed, s_active;
     __shared__ uint32_t s_mlist[kMaxMovedSkip];
     __shared__ uint32_t s_nS[WAVES];        // full schedule: lengths of the block's shared super-cell lists
-    constexpr uint32_t kDescCap = 256;      // packed points: the descriptors of the first kDescCap cells of the block's range, staged once
-    __shared__ uint32_t s_dstart[PK ? kDescCap + 1 : 1], s_dcell[PK ? kDescCap : 1];
-    __shared__ uint32_t s_piv[kBlkCells];   // ... the block-wide candidate build: per cell of the range (distance to the cube's centre << 8 | position in S) of its pivot,
-    __shared__ unsigned long long s_cm[kBlkCells][2];  // ... and the members of S its pivot does not dominate
     __shared__ unsigned long long s_mm[4];  // K <= 256: bit k <=> centroid k moved in the last update
     __shared__ unsigned long long s_evals;
     const uint32_t done = st->done;  // acted on below, once the set-up loads are on their way: a launch after convergence costs one round trip, not two
     constexpr int THREADS = WAVES * 64;
-    if constexpr (MBX) {
-        // the sums this launch's update reads are the other ranks' too: block 0 completes the exchange the previous launch's tail
-        // published (every rank's last block did) and adds the N slots into the buffer, the other blocks wait for its word
-        __shared__ uint32_t s_mbf;
-        if (mf.on && mf.seq_prev && !done) {
-            const bool ok = blockIdx.x == 0 ? mbf_collect<THREADS>(mf, const_cast<unsigned long long *>(fz.partials_prev), &s_mbf) : mbf_wait_ready(mf, &s_mbf);
-            if (!ok) {   // (the status word tells the host; a dead exchange ends the run -- but the launch still leaves its state record, or the
-                         // host would report a missing record instead of the exchange's failure)
-                if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
-                return;
-            }
-        }
-    }
     unsigned long long *acc = lds;
     uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr bool LAZYW = FIRSTK == 0 && IDBITS == 8 && CNIIC_LAZYW;   // the settled launches of the fused loop: weights only for the points that move
     const uint32_t MW = (K + 63) >> 6;  // mask words per cell
     const uint32_t scap = km_scap(K);  // super-cell list capacity (it rarely holds more than a quarter of the table)
     const uint32_t ccap = km_ccap(K);  // ... and the candidate strip's
@@ -1078,15 +819,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
     uint32_t nS = fz.on ? K : cs.moved[0];
     const uint32_t *mlist = cs.moved + 1;  // ids of the centroids the last update changed
     const unsigned long long lt_mask = (1ull << lane) - 1;
-#ifdef CNIIC_RGBW_PHASES
-    long long t_ph = clock64();
-    unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    __shared__ unsigned long long s_ph[12];
-    if (threadIdx.x < 12) s_ph[threadIdx.x] = 0;
-    const bool tl_on_ = cs.dbg && fz.launch_no + 1 == cs.dbg;
-    unsigned long long tl_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    RG_TL(0);
-#endif
     uint32_t moved = 0;
     unsigned long long evals = 0;
     for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
@@ -1178,8 +910,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
         if (fz.st_ring && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);  // (launch 0: nothing finished yet)
     }
     const bool skip_mode = !first && nS <= cs.max_moved;
-    RG_PHASE(0);
-    RG_TL(1);
 
     if (!skip_mode) {
         // ================================================================= FULL schedule
@@ -1204,144 +934,18 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
             if (lane == 0) s_nS[wid] = n;
         }
         if (threadIdx.x == 0) s_cell = mb0;
-        if constexpr (PK) {   // the range's cell descriptors into LDS: a draw then costs no round trip to memory, and a wave can fetch two cells ahead
-            const uint32_t ncb = min(mb1 - mb0, kDescCap);
-            for (uint32_t i = threadIdx.x; i < ncb; i += THREADS) { s_dstart[i] = ne_start[mb0 + i]; s_dcell[i] = ne_cell[mb0 + i]; }
-            if (threadIdx.x == 0 && ncb) s_dstart[ncb] = ne_start[mb0 + ncb];
-        }
-        // The candidates of ALL the block's cells at once (round 3; K <= 256): lane = cell, the members of the cell's list S dealt to
-        // the waves.  The wave-per-cell build below costs ~300 wave-instructions a cell whatever |S| is (two wave reductions for the
-        // pivot, a ballot per 64 members) and was 47 % of what a full-schedule launch issued; here a block's ~27 cells cost 8 waves x
-        // (|S| / 8 members x ~25 + ~50) together.  Same pivot (nearest the cube's centre, lowest position on ties: the minimum of
-        // distance << 8 | position), same test, so the same candidates.  Measured: a full-schedule launch issues 9.1 M VALU
-        // wave-instructions instead of 12.8 M -- and takes 36.6 us instead of 36.3 (NOTES.md C: it never was bound by issue, and
-        // the two block barriers cost what the instructions saved).  So it is OFF unless CNIIC_KM_BLOCK_BUILD=1.
-        const uint32_t nbc = (FIRSTK != 2 && nsl && scap <= 128u && !(cs.opts & 1u)) ? min(mb1 - mb0, kBlkCells) : 0u;  // (FIRSTK 2: the rounds' code has no register to spare)
-        for (uint32_t i = threadIdx.x; i < nbc; i += THREADS) { s_piv[i] = 0xffffffffu; s_cm[i][0] = 0ull; s_cm[i][1] = 0ull; }
         __syncthreads();
-        if (nbc) block_candidates<WAVES>(tab, K, scap, ne_cell + mb0, nbc, sup_first, nsl, s_nS, s_piv, s_cm, wid, lane);
         auto draw = [&]() -> uint32_t {
             uint32_t v = 0;
             if (lane == 0) v = atomicAdd(&s_cell, 1u);
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
         };
-        RG_PHASE(10);
-        if constexpr (PK) {
-            // ---- packed points, fetched TWO CELLS AHEAD.  The ablations of round 4 (profiles/r04_assign_ablation.txt) put 13 us of a
-            // 35 us launch into sweeps that do nothing but wait for their points: a wave asked for a cell's points one sweep before it
-            // needed them -- less time than the request takes to come back -- seven times per launch.  With 4 B a point a cell's (at most
-            // two) sweeps are eight registers, so a wave now holds the cell it works on, the next and the one after: a request has two
-            // cells' builds and sweeps to come back in.  The descriptors come from LDS, so drawing ahead costs no round trip either.
-            auto desc = [&](uint32_t mi, uint32_t &fs, uint32_t &fe, uint32_t &fc) {
-                fs = fe = fc = 0u;
-                if (mi < mb1) {
-                    const uint32_t i = mi - mb0;
-                    if (i < kDescCap) { fs = s_dstart[i]; fe = s_dstart[i + 1]; fc = s_dcell[i]; }
-                    else { fs = ne_start[mi]; fe = ne_start[mi + 1]; fc = ne_cell[mi]; }
-                    // (wave-uniform: on the scalar side, where three cells' descriptors cost no vector register)
-                    fs = (uint32_t)__builtin_amdgcn_readfirstlane((int)fs); fe = (uint32_t)__builtin_amdgcn_readfirstlane((int)fe); fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)fc);
-                }
-            };
-            // One buffer descriptor per cell (base = its first point, size = its points: four scalar instructions) and the range check
-            // of the buffer unit does what a compare, a predicate and a 64-bit address per load did on the vector unit: the launch is
-            // bound by VALU issue (every million wave-instructions cost it 1.6 us; an early-exit sweep was ~100 of them, most of that the
-            // twelve predicated loads' addresses), and a point beyond the cell's end reads as 0 exactly as before.
-            const uint32_t voff = (uint32_t)lane * 4u;
-            auto loadpts = [&](uint32_t fs, uint32_t fe, uint32_t (&a)[kSweep], uint32_t (&b)[kSweep]) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + fs, 0, (int)((fe - fs) * 4u), 0x00020000);
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) {
-                    a[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + u * 256u), 0, 0);
-                    b[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 64 * kSweep * 4u + u * 256u), 0, 0);
-                }
-            };
-            constexpr bool AHEAD2 = FIRSTK == 0;   // (the instance with the rounds for movers, launches 1-3, has no registers for a third cell: one cell ahead there)
-            uint32_t m = draw(), mn = draw();
-            uint32_t s = 0, e = 0, c = 0, s1 = 0, e1 = 0, c1 = 0;
-            uint32_t pa[kSweep], pb[kSweep], qa[kSweep], qb[kSweep];
-            desc(m, s, e, c); loadpts(s, e, pa, pb);
-            desc(mn, s1, e1, c1); loadpts(s1, e1, qa, qb);
-            uint32_t sup = 0xffffffffu, nSup = 0;
-            while (m < mb1) {
-                const uint32_t mnn = draw();
-                uint32_t s2, e2, c2, ra[kSweep], rb[kSweep];
-                desc(mnn, s2, e2, c2);
-                if constexpr (AHEAD2) loadpts(s2, e2, ra, rb);
-                RG_PHASE(1);
-                const uint2 *Sl = S;
-                if (nsl) {
-                    const uint32_t slot = (c >> kSuperShift) - sup_first;
-                    Sl = tab + K + (size_t)slot * (scap + ccap);
-                    nSup = s_nS[slot];
-                } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
-                RG_PHASE(2);
-                uint32_t ncand;
-                const uint32_t ib = m - mb0;
-                const uint32_t pvw = ib < nbc ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_piv[ib]) : 0xffffffffu;
-                if (pvw != 0xffffffffu) {
-                    const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cm[ib][0]);
-                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]), c1w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[1]);
-                    const uint32_t c2w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]), c3w = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
-                    ncand = expand_candidates<IDBITS>(Sl, pvw & 255u, ((unsigned long long)c1w << 32) | c0, ((unsigned long long)c3w << 32) | c2w, c, lane, cand, wmask, cs.rec, m, MW);
-                }
-                else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW)
-                                          : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW);
-                RG_PHASE(3);
-                RG_COUNT(9, 1);
-                RG_TL1(2);
-                RG_TLC(7, 1);
-                RG_TLC(6, (e - s + 64 * kSweep - 1) / (64 * kSweep));
-                RG_TLC(8, ncand);
-                RG_TLC(9, e - s);
-                const uint32_t cbk = cell_base_key(c);
-                if constexpr (!AHEAD2) {   // (one cell ahead: this cell's second sweep is asked for now and arrives during its first)
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + s, 0, (int)((e - s) * 4u), 0x00020000);
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) pb[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + 64 * kSweep * 4u + u * 256u), 0, 0);
-                }
-                {
-                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
-                    pk_unpack(pa, s, e, lane, cbk, cweight, kx, cx, wx);
-                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, s, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
-                }
-                if (s + 64 * kSweep < e) {
-                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
-                    pk_unpack(pb, s + 64 * kSweep, e, lane, cbk, cweight, kx, cx, wx);
-                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, s + 64 * kSweep, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
-                }
-                for (uint32_t base = s + 2 * 64 * kSweep; base < e; base += 64 * kSweep) {   // (a cell of more than 512 points: several ranks' copies of a colour)
-                    uint32_t pw[kSweep], kx[kSweep], cx[kSweep], wx[kSweep];
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) { const uint32_t q = base + u * 64 + lane; pw[u] = q < e ? pk[q] : 0u; }
-                    pk_unpack(pw, base, e, lane, cbk, cweight, kx, cx, wx);
-                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
-                }
-                evals += (unsigned long long)(e - s) * (ncand + 1);
-                RG_PHASE(4);
-                __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
-                m = mn; s = s1; e = e1; c = c1;
-                mn = mnn; s1 = s2; e1 = e2; c1 = c2;
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) pa[u] = qa[u];
-                if constexpr (AHEAD2) {
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) { pb[u] = qb[u]; qa[u] = ra[u]; qb[u] = rb[u]; }
-                } else {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pk) + s1, 0, (int)((e1 - s1) * 4u), 0x00020000);
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) qa[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + u * 256u), 0, 0);
-                }
-            }
-        } else {
         uint32_t m = draw();
         uint32_t s = 0, e = 0, c = 0;
         uint32_t p[kSweep], cur[kSweep], wt[kSweep];
         if (m < mb1) {
             s = ne_start[m]; e = ne_start[m + 1]; c = ne_cell[m];
-            if constexpr (PK) {
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) { const uint32_t q = s + u * 64 + lane; p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
-            } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
+            load_points<LabelT>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
         }
         uint32_t sup = 0xffffffffu, nSup = 0;
         while (m < mb1) {
@@ -1349,73 +953,30 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
             const uint32_t mn = draw();
             uint32_t s_next = 0, e_next = 0, c_next = 0;
             if (mn < mb1) { s_next = ne_start[mn]; e_next = ne_start[mn + 1]; c_next = ne_cell[mn]; }
-            RG_PHASE(1);
             const uint2 *Sl = S;
             if (nsl) {
                 const uint32_t slot = (c >> kSuperShift) - sup_first;
                 Sl = tab + K + (size_t)slot * (scap + ccap);
                 nSup = s_nS[slot];
-            } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); RG_COUNT(8, 1); RG_TLC(10, 1); RG_TLC(11, nSup); }
-            RG_PHASE(2);
-            uint32_t ncand;
-#ifdef CNIIC_RGBW_ABL
-            const uint32_t abl_ = (cs.opts >> 8) & 255u;   // 1: no sweeps, 2: no candidate build, 4: no flush, 16: no record stores, 32: no label stores
-            if (abl_ & 16u) cs.rec = nullptr;
-            LabelT *lab_sw = (abl_ & 32u) ? reinterpret_cast<LabelT *>(reinterpret_cast<uintptr_t>(labels) | (1ull << 62)) : labels;   // (bit 62: the sweep stores no label)
-            if (abl_ & 2u) { if (lane == 0) cand[0] = Sl[0]; __builtin_amdgcn_wave_barrier(); ncand = 1; }
-            else {
-#endif
-            const uint32_t ib = m - mb0;
-            const uint32_t pvw = ib < nbc ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_piv[ib]) : 0xffffffffu;
-            if (pvw != 0xffffffffu) {
-                const uint32_t *cw = reinterpret_cast<const uint32_t *>(&s_cm[ib][0]);  // (wave-uniform: kept on the scalar side)
-                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]), c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[1]);
-                const uint32_t c2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]), c3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
-                ncand = expand_candidates<IDBITS>(Sl, pvw & 255u, ((unsigned long long)c1 << 32) | c0, ((unsigned long long)c3 << 32) | c2, c, lane, cand, wmask, cs.rec, m, MW);
-            }
-            else ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap)
+            } else if ((c >> kSuperShift) != sup) { sup = c >> kSuperShift; nSup = build_super(tab, K, sup, lane, lt_mask, S, scap); }
+            uint32_t ncand = nSup <= scap ? build_candidates<IDBITS>(Sl, nSup, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap)
                                       : build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap);
             const uint2 *cl = cand;   // (u16 labels: a strip that overflowed -- the table is the candidate list then)
             if (IDBITS != 8 && ncand > ccap) { cl = tab; ncand = K; }
-#ifdef CNIIC_RGBW_ABL
-            }
-            if (abl_ & 1u) { m = mn; s = s_next; e = e_next; c = c_next; continue; }
-#endif
-            RG_PHASE(3);
-            RG_COUNT(9, 1);
-            RG_TL1(2);
-            RG_TLC(7, 1);
-            RG_TLC(6, (e - s + 64 * kSweep - 1) / (64 * kSweep));
-            RG_TLC(8, ncand);
-            RG_TLC(9, e - s);
             for (uint32_t base = s; base < e; base += 64 * kSweep) {
                 const bool more = base + 64 * kSweep < e;
                 const uint32_t nts = more ? base + 64 * kSweep : s_next;
                 const uint32_t nte = more ? e : e_next;
                 uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-                if constexpr (PK) {
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) { const uint32_t qn = nts + u * 64 + lane; pn[u] = qn < nte ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
-                } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, nts, nte, lane, pn, curn, wtn);
-                if constexpr (PK) {
-                    uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
-                    pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
-                    sweep_points<LabelT, IDBITS, false, FIRSTK == 2, false, LS>(kx, cx, wx, base, e, lane, cand, ncand, tab, K, false, lab_st, acc, moved);
-                }
-                else if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cl, ncand, tab, K, labels, acc, moved, FIRSTK == 1 ? pk : nullptr);   // (pk: null unless the loop runs on packed points)
-#ifdef CNIIC_RGBW_ABL
-                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, lab_sw, acc, moved, cweight);
-#else
-                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2, LAZYW>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, labels, acc, moved, cweight);
-#endif
+                load_points<LabelT>(ckeys, labels, cweight, nts, nte, lane, pn, curn, wtn);
+                if (first) sweep_points_first<LabelT, IDBITS, FIRSTK == 1>(p, cur, wt, base, e, lane, cl, ncand, tab, K, labels, acc, moved);
+                else sweep_points<LabelT, IDBITS, false, FIRSTK == 2>(p, cur, wt, base, e, lane, cl, ncand, tab, K, false, labels, acc, moved);
 #pragma unroll
                 for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
             }
             evals += (unsigned long long)(e - s) * (ncand + 1);
-            RG_PHASE(4);
             __builtin_amdgcn_wave_barrier();  // the strip is rewritten for the next cell
             m = mn; s = s_next; e = e_next; c = c_next;
-        }
         }
     } else {
         // ================================================================= SKIP schedule
@@ -1476,8 +1037,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                       dv = dv || (has && (in || dmv.worst(ck) >= 0));
                   }
                   dirty8 = __ballot(dv && cell_ok);
-                  RG_PHASE(6);
-                  RG_TLC(7, 8);
                   if (!dirty8) continue;
               }
               if constexpr (IDBITS == 8) {
@@ -1489,10 +1048,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     const uint32_t m = mb + bi * nwaves;
                     if (m >= m_hi) break;
                     if (!((dirty8 >> (8 * bi)) & 0xffull)) continue;  // nothing that matters to this cell changed: every label repeats
-                    RG_TLC(6, 1);
-#ifdef CNIIC_RGBW_PHASES
-                    unsigned long long tq_ = tl_on_ ? wall_clock64() : 0ull;  // per dirty cell: [8] range + mask, [9] wait for the points, [10] sweeps
-#endif
                     const uint32_t r = bi < 4 ? rA : rB;
                     const int l0 = (int)((bi & 3) * 16);
                     const uint32_t pvt = (uint32_t)__builtin_amdgcn_readlane((int)r, l0);
@@ -1500,10 +1055,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     const uint32_t c = cw & 0xffffu, pid = (cw >> 16) & 0x7fffu;
                     const uint32_t s = ne_start[m], e = ne_start[m + 1];
                     uint32_t p[kSweep], cur[kSweep], wt[kSweep];
-                    if constexpr (PK) {
-#pragma unroll
-                        for (int u = 0; u < kSweep; u++) { const uint32_t q = s + u * 64 + lane; p[u] = q < e ? pk[q] : 0u; cur[u] = 0u; wt[u] = 0u; }
-                    } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
+                    load_points<LabelT>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
                     // A mask is COMPLETE if it holds every centroid of the table that the cell's pivot does not dominate (the full
                     // schedule builds from the super-cell's list instead: what that list left out was beaten by ANOTHER centroid,
                     // which may have moved since).  While the pivot of a complete mask stands where it stood, every centroid that
@@ -1550,34 +1102,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                         if ((lane >> 4) == (int)(bi & 3) && jw < 8u && wv != r) cs.rec[(size_t)m * 16 + 2 + jw] = wv;
                     }
                     const uint32_t ncand = (uint32_t)(__popcll(nm[0]) + __popcll(nm[1]) + __popcll(nm[2]) + __popcll(nm[3]));
-#ifdef CNIIC_RGBW_PHASES
-                    if (tl_on_) {
-                        unsigned long long n_ = wall_clock64(); tl_[8] += n_ - tq_; tq_ = n_;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        n_ = wall_clock64(); tl_[9] += n_ - tq_; tq_ = n_;
-                    }
-#endif
                     for (uint32_t base = s; base < e; base += 64 * kSweep) {
                         uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-                        if constexpr (PK) {
-#pragma unroll
-                            for (int u = 0; u < kSweep; u++) { const uint32_t qn = base + 64 * kSweep + u * 64 + lane; pn[u] = qn < e ? pk[qn] : 0u; curn[u] = 0u; wtn[u] = 0u; }
-                        } else load_points<LabelT, LAZYW>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
-                        if constexpr (PK) {
-                            uint32_t kx[kSweep], cx[kSweep], wx[kSweep];
-                            pk_unpack(p, base, e, lane, cell_base_key(c), cweight, kx, cx, wx);
-                            sweep_points_mask<LabelT, IDBITS, false, LS>(kx, cx, wx, base, e, lane, nm, tab, K, lab_st, acc, moved);
-                        }
-                        else sweep_points_mask<LabelT, IDBITS, LAZYW>(p, cur, wt, base, e, lane, nm, tab, K, labels, acc, moved, cweight);
+                        load_points<LabelT>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
+                        sweep_points_mask<LabelT, IDBITS>(p, cur, wt, base, e, lane, nm, tab, K, labels, acc, moved);
 #pragma unroll
                         for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                     }
                     evals += (unsigned long long)(e - s) * (ncand + 1);
-                    RG_PHASE(7);
-                    RG_TL1(2);
-#ifdef CNIIC_RGBW_PHASES
-                    if (tl_on_) { tl_[10] += wall_clock64() - tq_; tl_[11] += ncand; }
-#endif
                 }
               } else {
               for (uint32_t bi = 0; bi < kRecBatch; bi++) {
@@ -1600,14 +1132,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     // a moved centroid matters if it was a candidate or is no longer dominated by the pivot
                     bool dirty = false;
                     if (k1 != 0xffffffffu) dirty = in1 || dm.worst(ck1) >= 0;
-                    RG_PHASE(6);
-                    RG_TLC(7, 1);
                     if (!__ballot(dirty)) continue;  // nothing that matters to this cell changed: every label repeats
                 }
-                RG_TLC(6, 1);
-#ifdef CNIIC_RGBW_PHASES
-                unsigned long long tq_ = tl_on_ ? wall_clock64() : 0ull;  // skip schedule, per dirty cell: [8] range + build, [9] wait for the points, [10] sweeps
-#endif
                 const uint32_t s = ne_start[m], e = ne_start[m + 1];
                 uint32_t p[kSweep], cur[kSweep], wt[kSweep];
                 load_points<LabelT>(ckeys, labels, cweight, s, e, lane, p, cur, wt);
@@ -1615,13 +1141,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                 uint32_t ncand = build_candidates<IDBITS>(tab, K, c, lane, lt_mask, cand, wmask, cs.rec, m, MW, ccap);
                 const uint2 *cl = cand;
                 if (IDBITS != 8 && ncand > ccap) { cl = tab; ncand = K; }
-#ifdef CNIIC_RGBW_PHASES
-                if (tl_on_) {
-                    unsigned long long n_ = wall_clock64(); tl_[8] += n_ - tq_; tq_ = n_;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    n_ = wall_clock64(); tl_[9] += n_ - tq_; tq_ = n_;
-                }
-#endif
                 for (uint32_t base = s; base < e; base += 64 * kSweep) {
                     uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
                     load_points<LabelT>(ckeys, labels, cweight, base + 64 * kSweep, e, lane, pn, curn, wtn);
@@ -1630,548 +1149,26 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu((FIR
                     for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
                 }
                 evals += (unsigned long long)(e - s) * (ncand + 1);
-                RG_PHASE(7);
-                RG_TL1(2);
-#ifdef CNIIC_RGBW_PHASES
-                if (tl_on_) { tl_[10] += wall_clock64() - tq_; tl_[11] += ncand; }
-#endif
                 __builtin_amdgcn_wave_barrier();
               }
               }
             }
         }
     }
-    RG_PHASE(11);
-    RG_TL(3);
     moved = wave_reduce_sum(moved);
     if (lane == 0) {
         if (moved) atomicAdd(&s_moved, moved);
         if (evals) atomicAdd(&s_evals, evals);
     }
     __syncthreads();
-    RG_TL(4);
     uint32_t i_first = threadIdx.x;
     asm volatile("" : "+v"(i_first));  // (or the flush's addresses are computed before the cell loops and held in two registers across them)
-#ifdef CNIIC_RGBW_ABL
-    if (!((cs.opts >> 8) & 4u))
-#endif
     for (uint32_t i = i_first; i < 5 * K; i += THREADS)
         if (acc[i]) atomicAdd(&partials[i], acc[i]);
     if (threadIdx.x == 0) {
         if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
         if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
     }
-    if constexpr (MBX) {
-        if (mf.on) {   // the last block to get here sends the launch's sums to every rank (its own mailbox included)
-            __shared__ uint32_t s_last;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this block's atomics have been acknowledged; no cache to write back for them)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int *tk = mf.ticket + (mf.seq_pub & 1u);
-                const bool last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-                if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (used again two launches on)
-                s_last = last ? 1u : 0u;
-            }
-            __syncthreads();
-            if (s_last) mbf_publish<THREADS>(mf, partials);
-        }
-    }
-    RG_PHASE(5);
-    RG_TL(5);
-#ifdef CNIIC_RGBW_PHASES
-    if (tl_on_ && lane == 0) {
-        const uint32_t wv_ = blockIdx.x * WAVES + wid;
-        if (wv_ < 8192)
-            for (int i = 0; i < 12; i++) g_wave_tl[wv_][i] = tl_[i];
-    }
-    if (lane == 0)
-        for (int i = 0; i < 12; i++)
-            if (ph_[i]) atomicAdd(&s_ph[i], ph_[i]);
-    __syncthreads();
-    if (threadIdx.x < 12 && s_ph[threadIdx.x]) atomicAdd(&g_rgbw_phase[threadIdx.x], s_ph[threadIdx.x]);
-#endif
-}
-
-// ---------------------------------------------------------------- super-cell-major assign (K <= 256, one shard)
-// The same exact pruning, turned inside out: ONE BLOCK PER SUPER-CELL (a 32^3 cube of colours, 64 cells), the per-cell
-// work done ONE LANE PER CELL instead of one wave per cell, and whole cells handled as aggregates where possible.
-//   1. the first four waves build S, the centroids that can win anywhere in the super-cell (thread = centroid);
-//   2. the same waves, lane l = cell l of the super-cell, wave w = every fourth member of S: pivot = member of S nearest
-//      the cell's centre, candidates = members of S the pivot does not dominate over the cell's cube, as a 256-bit mask
-//      of cluster ids (|S| x ~30 instructions for 64 cells; the wave-per-cell build cost ~170 per cell and was most of
-//      the old kernel);
-//   3. wave 0, per cell, from its record (the mask and a state word kept from the last launch):
-//        one candidate b, cell uniformly labelled a   -> a != b: the whole cell moves at once -- its aggregate (sum r w,
-//                                                        sum g w, sum b w, sum w; written at iteration 0) is subtracted
-//                                                        from a and added to b; not one point is read;
-//        no centroid of (old mask | new mask) moved   -> every point repeats its decision (see below): nothing to do;
-//        otherwise                                    -> the cell goes on the block's work list;
-//   4. all waves of the block draw cells from the list and sweep their points against the candidates.
-// A cell whose points all carry label a is remembered as "uniform a"; its labels in memory are then not maintained
-// (k_rgbw_materialize writes them when somebody asks for the labels).
-//
-// Why skipping is exact.  Pruning never drops a centroid that is nearest or tied somewhere in the cube, so after a sweep
-// every label is the point's true arg-min at that iteration (under the stay-on-ties rule) and lies in that launch's
-// candidate set C.  If no member of C_t or C_(t-1) changed between the two launches, every candidate of launch t has the
-// value it had at t-1, where the point's label l beat it (or tied and stayed); and l itself must be in C_t -- were it
-// pruned now, the unmoved pivot would be strictly nearer than l everywhere in the cube, also at t-1.  So nobody moves.
-// A lone candidate b is strictly nearer than every other centroid for every colour of the cube (a centroid of equal
-// colour would survive the test with margin 0), so a cell uniformly labelled a != b moves to b whole.
-constexpr uint32_t kNumSupers = kNumCells >> kSuperShift;
-constexpr uint32_t kSupRecWords = 12;  // u32 per cell: [0..7] candidate mask of the last launch, [8] 0 = labels in memory are current, 1 + a = uniform a
-#ifndef CNIIC_SUP_WAVES
-#define CNIIC_SUP_WAVES 12
-#endif
-constexpr int kSupWaves = CNIIC_SUP_WAVES;  // waves per block; two blocks per CU, so that all 512 are resident at once
-constexpr int kSupMinW = kSupWaves / 2;     // ... i.e. this many waves per SIMD (the register budget: 96 VGPRs at 5, 80 at 6)
-constexpr int kSupCW = 4;                   // waves that build S and classify (thread = centroid: K <= 256)
-
-struct SupState {
-    uint32_t *rec;                 // [kNumCells][kSupRecWords]
-    unsigned long long *cagg;      // [kNumCells][4] aggregates of the cell's points: sum r w, sum g w, sum b w, sum w
-    const uint32_t *cell_start;    // [kNumCells + 1]
-    uint32_t no_skip;              // every cell with more than one candidate or mixed labels is swept in every launch (A/B)
-};
-
-// one sweep: 64 x kSweep points starting at `base` (those < e) against the candidates of the mask mw[0..7] (LDS, the same
-// for the whole wave: walking its set bits is scalar work, and a candidate costs one LDS broadcast read + 3 VALU per point slot)
-template <bool FIRST>
-__device__ __forceinline__ void sweep_masked(const uint32_t (&p)[kSweep], const uint32_t (&cur)[kSweep], const uint32_t (&wt)[kSweep], uint32_t base,
-                                             uint32_t e, int lane, const uint32_t *mw, bool allwrite, const uint2 *tab, uint32_t K, uint8_t *__restrict__ labels,
-                                             unsigned long long *acc, uint32_t &moved, uint32_t &ncand) {
-    constexpr uint32_t IDMASK = 255;
-    uint32_t best[kSweep];
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) best[u] = 0;
-    ncand = 0;
-    for (int wi = 0; wi < 8; wi++) {
-        uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)mw[wi * 64]);  // (word-major: s_mask[word][cell])
-        while (m) {
-            const uint32_t id = (uint32_t)wi * 32 + (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            const uint2 cc = tab[id];
-#pragma unroll
-            for (int u = 0; u < kSweep; u++) best[u] = max(best[u], (dot4u8(p[u], cc.x, 0) << 9) + cc.y);
-            ncand++;
-        }
-    }
-    uint32_t nl[kSweep];
-    bool mvd[kSweep];
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        const uint32_t q = base + u * 64 + lane;
-        nl[u] = cur[u];
-        mvd[u] = false;
-        if (q < e) {
-            const uint2 cc = tab[cur[u]];
-            const uint32_t kcur = (dot4u8(p[u], cc.x, 0) << 9) + cc.y;
-            mvd[u] = (best[u] >> 8) > (kcur >> 8);  // strictly closer (kmeans.rs:375)
-            if (mvd[u]) { nl[u] = IDMASK - (best[u] & IDMASK); moved++; }
-            if (mvd[u] || allwrite) labels[q] = (uint8_t)nl[u];
-        }
-    }
-    if (FIRST) {
-        // Iteration 0: every point adds to the sums of its cluster.  A sweep lies inside one 8^3 cell, so as a rule all
-        // its points join the same cluster: one wave reduction and five LDS atomics instead of five colliding atomics per slot.
-        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nl[0]);  // lane 0, slot 0 is always a point of the sweep
-        bool same = true;
-        unsigned long long rw = 0, gw = 0, bw = 0, ww = 0, cn = 0;
-#pragma unroll
-        for (int u = 0; u < kSweep; u++) {
-            const uint32_t q = base + u * 64 + lane;
-            if (q < e) {
-                same = same && nl[u] == l0;
-                const uint64_t w = wt[u];
-                rw += ((p[u] >> 16) & 255) * w; gw += ((p[u] >> 8) & 255) * w; bw += (p[u] & 255) * w; ww += w; cn += 1;
-            }
-        }
-        if (__ballot(!same) == 0ull) {
-            rw = wave_reduce_sum64(rw); gw = wave_reduce_sum64(gw); bw = wave_reduce_sum64(bw);
-            ww = wave_reduce_sum64(ww); cn = wave_reduce_sum64(cn);
-            if (lane == 0) {
-                atomicAdd(&acc[3 * l0 + 0], rw); atomicAdd(&acc[3 * l0 + 1], gw); atomicAdd(&acc[3 * l0 + 2], bw);
-                atomicAdd(&acc[3 * K + l0], ww); atomicAdd(&acc[4 * K + l0], cn);
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kSweep; u++) {
-        const uint32_t q = base + u * 64 + lane;
-        if (q < e && (mvd[u] || FIRST)) {
-            const uint32_t pp = p[u], n_ = nl[u], ol = cur[u];
-            const uint64_t w = wt[u];
-            const unsigned long long rw = ((pp >> 16) & 255) * w, gw = ((pp >> 8) & 255) * w, bw = (pp & 255) * w;
-            atomicAdd(&acc[3 * n_ + 0], rw);
-            atomicAdd(&acc[3 * n_ + 1], gw);
-            atomicAdd(&acc[3 * n_ + 2], bw);
-            atomicAdd(&acc[3 * K + n_], (unsigned long long)w);
-            atomicAdd(&acc[4 * K + n_], 1ull);
-            if (!FIRST) {
-                atomicAdd(&acc[3 * ol + 0], 0ull - rw);
-                atomicAdd(&acc[3 * ol + 1], 0ull - gw);
-                atomicAdd(&acc[3 * ol + 2], 0ull - bw);
-                atomicAdd(&acc[3 * K + ol], 0ull - (unsigned long long)w);
-                atomicAdd(&acc[4 * K + ol], 0ull - 1ull);
-            }
-        }
-    }
-}
-
-#ifdef CNIIC_RGBW_PHASES
-#undef RG_PHASE
-#define RG_PHASE(i) do {} while (0)
-#endif
-template <int WAVES, bool FIRST, int MINW>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(MINW, 8))) void k_rgbw_assign_sup(
-    const uint32_t *__restrict__ ckeys, const uint32_t *__restrict__ cweight, uint32_t K, const uint2 *__restrict__ cconst,
-    uint8_t *__restrict__ labels, unsigned long long *__restrict__ partials, const KmDevState *__restrict__ st, const uint32_t *__restrict__ moved_g,
-    SupState ss, FusedUpdate fz) {
-    constexpr uint32_t IDMASK = 255;
-    constexpr int THREADS = WAVES * 64;
-    static_assert(WAVES >= kSupCW && kSupCW * 64 >= 256, "thread = centroid in the S build and the folded-in update");
-    extern __shared__ __align__(16) unsigned long long lds[];  // [5K] deltas | uint2 tab[K] | uint2 S[K]
-    __shared__ uint32_t s_moved, s_nmoved, s_reseed, s_active, s_nlist, s_draw, s_pmin;
-    __shared__ uint32_t s_wcnt[kSupCW];
-    __shared__ uint32_t s_mm[8];        // bit k: centroid k changed in the last update
-    __shared__ uint32_t s_cmin[64];     // per cell: (distance of the nearest member of S to the cell's centre) << 8 | its position in S
-    __shared__ uint32_t s_mask[8 * 64]; // [word][cell]: candidate mask of this launch
-    __shared__ uint32_t s_list[64];     // work list: cell within the super-cell | (state word) << 8
-    __shared__ uint32_t s_cs[65];       // cell_start of the 64 cells (+ end)
-    __shared__ unsigned long long s_evals;
-    const uint32_t done = st->done;
-    unsigned long long *acc = lds;
-    uint2 *tab = reinterpret_cast<uint2 *>(lds + 5 * (size_t)K);
-    uint2 *S = tab + K;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint32_t sup = blockIdx.x;
-    const unsigned long long lt_mask = (1ull << lane) - 1;
-#ifdef CNIIC_RGBW_PHASES
-    const bool census = fz.on && fz.launch_no == (ss.no_skip >> 16) && (ss.no_skip >> 16) != 0;
-    if (census && threadIdx.x == 0) { g_rgbw_blk[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime(); g_rgbw_blk[blockIdx.x][2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
-#endif
-    // ---- set-up loads, all requested before anything is waited for
-    // wave 0, lane = cell: extent, record and aggregate of the cell
-    const uint32_t cell = (sup << kSuperShift) | (uint32_t)lane;
-    uint32_t c_s = 0, c_e = 0;
-    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0, r2 = r0;
-    ulonglong2 ag0 = make_ulonglong2(0, 0), ag1 = ag0;
-    if (wid == 0) {
-        c_s = ss.cell_start[cell]; c_e = ss.cell_start[cell + 1];
-        const uint4 *rp = reinterpret_cast<const uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
-        r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
-        const ulonglong2 *ap = reinterpret_cast<const ulonglong2 *>(ss.cagg + (size_t)cell * 4);
-        ag0 = ap[0]; ag1 = ap[1];
-    }
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS) acc[i] = 0ull;
-    if (!fz.on || FIRST)
-        for (uint32_t i = threadIdx.x; i < K; i += THREADS) tab[i] = cconst[i];
-    if (threadIdx.x == 0) { s_moved = 0; s_evals = 0; s_nmoved = 0; s_reseed = 0; s_active = 0; s_nlist = 0; s_draw = 0; s_pmin = 0xffffffffu; }
-    if (threadIdx.x < 8) s_mm[threadIdx.x] = (FIRST || (ss.no_skip & 1u)) ? 0xffffffffu : 0u;
-    if (threadIdx.x < 64) s_cmin[threadIdx.x] = 0xffffffffu;
-    for (uint32_t i = threadIdx.x; i < 64 * 8; i += THREADS) s_mask[i] = 0u;
-    const bool upd = fz.on && !FIRST;
-    const uint32_t uk = threadIdx.x;
-    unsigned long long v[5] = {0, 0, 0, 0, 0}, changed = 0, pev = 0;
-    uint32_t oldc = 0;
-    if (upd) {
-        changed = fz.partials_prev[5 * (size_t)K];
-        pev = fz.partials_prev[5 * (size_t)K + 1];
-        if (uk < K) {
-            const size_t at[5] = {3 * (size_t)uk, 3 * (size_t)uk + 1, 3 * (size_t)uk + 2, 3 * (size_t)K + uk, 4 * (size_t)K + uk};
-#pragma unroll
-            for (int i = 0; i < 5; i++) v[i] = fz.partials_prev[at[i]] + fz.running_prev[at[i]];
-            oldc = fz.cent_prev[uk];
-        }
-    }
-    if (done) {  // a launch past convergence: nothing but its state record
-        if (fz.on && fz.st_ring && blockIdx.x == 0 && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
-        return;
-    }
-    __syncthreads();
-    if (upd) {
-        // ---- finish iteration j - 1 (as k_rgbw_assign_cells): Point::mean for ColorCount (clusterc.rs:83-113) + empty-cluster reseed (kmeans.rs:110-137)
-        const uint32_t j = fz.launch_no;
-        if (uk < K) {
-            const uint32_t k = uk;
-            const size_t at[5] = {3 * (size_t)k, 3 * (size_t)k + 1, 3 * (size_t)k + 2, 3 * (size_t)K + k, 4 * (size_t)K + k};
-            uint32_t ck;
-            if (v[4] == 0) {
-                const uint64_t ri = reseed_index(fz.seed, j - 1, k, fz.U);  // fake_clone of the stolen point
-                ck = fz.gx.bits ? gidx_select(fz.gx, ri) : fz.keys[ri];
-                atomicAdd(&s_reseed, 1u);
-            } else {
-                const uint32_t r = div_floor_small(v[0], v[3]) & 255, g = div_floor_small(v[1], v[3]) & 255, b = div_floor_small(v[2], v[3]) & 255;
-                ck = (r << 16) | (g << 8) | b;
-                atomicAdd(&s_active, 1u);
-            }
-            const uint2 cc = make_cconst(ck, k, fz.idbits);
-            tab[k] = cc;
-            if (ck != oldc) {
-                atomicAdd(&s_nmoved, 1u);
-                atomicOr(&s_mm[k >> 5], 1u << (k & 31));
-            }
-            if (blockIdx.x == 0) {
-#pragma unroll
-                for (int i = 0; i < 5; i++) fz.running_new[at[i]] = v[i];
-                fz.cent_new[k] = ck;
-                fz.cent_g[k] = ck;
-                fz.cconst_g[k] = cc;
-                fz.members_out[k] = v[4];
-                fz.wsum_out[k] = v[3];
-            }
-        }
-        if (blockIdx.x == 0)
-            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
-        __syncthreads();
-        const bool fin = changed == 0 || (fz.max_iters && j >= fz.max_iters);
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            KmDevState *sw = fz.st_rw;
-            sw->changed_ring[(j - 1) % kHistRing] = changed;
-            sw->nmoved_ring[(j - 1) % kHistRing] = s_nmoved;
-            sw->moved_last = changed;
-            sw->reseeds += s_reseed;
-            sw->active = s_active;
-            sw->pair_evals += pev;
-            sw->iter = j;
-            if (fin) sw->done = 1;
-            if (fz.st_host) {
-                KmDevState *hs = fz.st_host;
-                hs->moved_last = changed; hs->reseeds = sw->reseeds; hs->active = s_active; hs->pair_evals = sw->pair_evals; hs->iter = j;
-                __threadfence_system();
-                if (fin) hs->done = 1;
-            }
-            if (fz.st_ring) poll_record(fz.st_ring, j, sw);
-        }
-        if (fin) return;
-    } else {
-        if (fz.on && blockIdx.x == 0) {
-            for (uint32_t i = threadIdx.x; i < 5 * K + 2; i += THREADS) fz.partials_clear[i] = 0ull;
-            if (fz.st_ring && threadIdx.x == 0) poll_record(fz.st_ring, fz.launch_no, fz.st_rw);
-        }
-        if (!fz.on && !FIRST && !(ss.no_skip & 1u)) {  // an update kernel ran in between: its list of the centroids it changed
-            const uint32_t nmv = moved_g[0];
-            if (nmv >= K) { if (threadIdx.x < 8) s_mm[threadIdx.x] = 0xffffffffu; }
-            else for (uint32_t i = threadIdx.x; i < nmv; i += THREADS) { const uint32_t k = moved_g[1 + i]; atomicOr(&s_mm[k >> 5], 1u << (k & 31)); }
-            __syncthreads();
-        }
-    }
-    RG_PHASE(0);
-    const uint32_t dbg_stop = (ss.no_skip >> 8) & 255u;  // timing experiments (CNIIC_SUP_STOP): leave after a stage; the run is kept going by a fake `moved` count
-    if (dbg_stop && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&partials[5 * (size_t)K], 1ull);
-    if (dbg_stop == 1) return;
-    const uint32_t p_lo = ss.cell_start[sup << kSuperShift], p_hi = ss.cell_start[(sup + 1) << kSuperShift];  // (uniform: scalar loads)
-    uint32_t moved = 0;
-    unsigned long long evals = 0;
-    if (p_lo != p_hi) {
-        // ================================================================= S: the centroids that can win somewhere in the super-cell
-        uint2 mycc = make_uint2(0u, 0u);
-        uint32_t nS = 0;
-        {
-            constexpr int32_t exts = (1 << (kCellShift + 2)) - 1;
-            const CellBox sbx = super_box(sup);
-            const bool isc = wid < kSupCW && threadIdx.x < K;
-            if (wid < kSupCW) {  // (one LDS atomic per wave: 256 lanes on one word would be served one by one)
-                uint32_t key = 0xffffffffu;
-                if (isc) { mycc = tab[threadIdx.x]; key = (centre_dist(mycc.x, sbx, exts) << 8) | threadIdx.x; }
-                key = wave_reduce_min(key);
-                if (lane == 0) atomicMin(&s_pmin, key);
-            }
-            __syncthreads();
-            bool keep = false;
-            if (isc) {
-                Dominance dms;
-                dms.set(sbx, exts, tab[s_pmin & 255].x);
-                keep = dms.worst(mycc.x) >= 0;
-            }
-            const unsigned long long bm = __ballot(keep);
-            if (wid < kSupCW && lane == 0) s_wcnt[wid] = (uint32_t)__popcll(bm);
-            __syncthreads();
-            uint32_t pos = (uint32_t)__popcll(bm & lt_mask);
-#pragma unroll
-            for (int w = 0; w < kSupCW; w++) { const uint32_t c = s_wcnt[w]; nS += c; if (w < wid) pos += c; }
-            if (keep) S[pos] = mycc;  // ascending id
-            __syncthreads();
-        }
-        RG_PHASE(2);
-        if (dbg_stop == 2) return;
-        // ================================================================= classification (waves 0 .. kSupCW - 1: lane = cell, wave = every kSupCW-th member of S)
-        constexpr int32_t ext = (1 << kCellShift) - 1;
-        const CellBox bx = cell_box(cell);
-        uint32_t rec_state = r2.x;
-        if (wid < kSupCW) {
-            uint32_t bd = 0xffffffffu;
-            for (uint32_t jx = wid; jx < nS; jx += kSupCW) bd = min(bd, (centre_dist(S[jx].x, bx, ext) << 8) | jx);  // (S[jx]: same address in every lane)
-            atomicMin(&s_cmin[lane], bd);
-        }
-        __syncthreads();
-        if (wid < kSupCW) {
-            Dominance dm;
-            dm.set(bx, ext, S[s_cmin[lane] & 255].x);
-            uint32_t nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (uint32_t jx = wid; jx < nS; jx += kSupCW) {
-                const uint2 cc = S[jx];
-                const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(IDMASK - (cc.y & IDMASK)));
-                const uint32_t bit = dm.worst(cc.x) >= 0 ? (1u << (id & 31)) : 0u;
-                switch (id >> 5) {  // (uniform)
-                case 0: nm[0] |= bit; break; case 1: nm[1] |= bit; break; case 2: nm[2] |= bit; break; case 3: nm[3] |= bit; break;
-                case 4: nm[4] |= bit; break; case 5: nm[5] |= bit; break; case 6: nm[6] |= bit; break; default: nm[7] |= bit; break;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (nm[i]) atomicOr(&s_mask[i * 64 + lane], nm[i]);
-        }
-        __syncthreads();
-        if (wid == 0) {
-            const uint32_t n = c_e - c_s;
-            s_cs[lane] = c_s;
-            if (lane == 63) s_cs[64] = c_e;
-            uint32_t nm[8];
-            uint32_t ncand = 0, lastid = 0, hitw = 0;
-            const uint32_t om[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                nm[i] = s_mask[i * 64 + lane];
-                ncand += (uint32_t)__popc(nm[i]);
-                if (nm[i]) lastid = 32u * i + (uint32_t)__builtin_ctz(nm[i]);
-                hitw |= (om[i] | nm[i]) & s_mm[i];
-            }
-            const bool hit = hitw != 0;
-            const uint32_t state = r2.x;  // 0: labels in memory, 1 + a: uniform a
-            uint32_t nstate = state;
-            bool sweep = false, bulk = false;
-            if (n) {
-                if (ncand == 1) {
-                    if (state) bulk = state != 1 + lastid;
-                    else sweep = hit;  // (not hit: the labels in memory are all `lastid` already)
-                    nstate = 1 + lastid;
-                } else if (hit) {
-                    sweep = true;
-                    nstate = 0;
-                }
-            }
-            rec_state = nstate;  // (the record itself is stored after the barrier below: a store in front of it would be waited for)
-            if (bulk) {  // the whole cell changes cluster: its aggregate moves, no point is read
-                const unsigned long long rw = ag0.x, gw = ag0.y, bw = ag1.x, ww = ag1.y;
-                const uint32_t a = state - 1, b = lastid;
-                atomicAdd(&acc[3 * b + 0], rw); atomicAdd(&acc[3 * b + 1], gw); atomicAdd(&acc[3 * b + 2], bw);
-                atomicAdd(&acc[3 * K + b], ww); atomicAdd(&acc[4 * K + b], (unsigned long long)n);
-                atomicAdd(&acc[3 * a + 0], 0ull - rw); atomicAdd(&acc[3 * a + 1], 0ull - gw); atomicAdd(&acc[3 * a + 2], 0ull - bw);
-                atomicAdd(&acc[3 * K + a], 0ull - ww); atomicAdd(&acc[4 * K + a], 0ull - (unsigned long long)n);
-                moved += n;
-            }
-            const unsigned long long sm = __ballot(sweep);
-            if (sweep) s_list[__popcll(sm & lt_mask)] = (uint32_t)lane | (state << 8);
-            if (lane == 0) {
-                s_nlist = (uint32_t)__popcll(sm);
-                evals += (unsigned long long)nS * (uint32_t)__popcll(__ballot(n != 0));
-            }
-#ifdef CNIIC_RGBW_PHASES
-            {
-                unsigned int *L = g_rgbw_launch[(fz.on ? fz.launch_no : 0) & 127];
-                const uint32_t nsw = (uint32_t)__popcll(sm), psw = wave_reduce_sum(sweep ? n : 0u), nb = (uint32_t)__popcll(__ballot(bulk)),
-                               n1 = (uint32_t)__popcll(__ballot(n && ncand == 1)), nne = (uint32_t)__popcll(__ballot(n != 0));
-                if (lane == 0) { atomicAdd(&L[0], nsw); atomicAdd(&L[1], psw); atomicAdd(&L[2], nb); atomicAdd(&L[3], n1); atomicMax(&L[4], nsw); atomicAdd(&L[5], nne); atomicAdd(&L[6], nS); }
-            }
-#endif
-        }
-        RG_PHASE(3);
-        __syncthreads();
-        if (wid == 0 && c_e != c_s) {  // this launch's record of the cell: mask and state
-            uint4 *rp = reinterpret_cast<uint4 *>(ss.rec + (size_t)cell * kSupRecWords);
-            rp[0] = make_uint4(s_mask[lane], s_mask[64 + lane], s_mask[128 + lane], s_mask[192 + lane]);
-            rp[1] = make_uint4(s_mask[256 + lane], s_mask[320 + lane], s_mask[384 + lane], s_mask[448 + lane]);
-            if (rec_state != r2.x) rp[2] = make_uint4(rec_state, 0, 0, 0);
-        }
-        if (dbg_stop == 3) return;
-        if (dbg_stop == 4) { if (threadIdx.x == 0) s_nlist = 0; __syncthreads(); }
-        // ================================================================= sweeps (all waves draw from the list)
-        const uint32_t nlist = s_nlist;
-        auto draw = [&]() -> uint32_t {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(&s_draw, 1u);
-            return (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        };
-        auto load_sweep = [&](uint32_t base, uint32_t end, uint32_t sw, uint32_t (&pp)[kSweep], uint32_t (&cc)[kSweep], uint32_t (&ww)[kSweep]) {
-#pragma unroll
-            for (int u = 0; u < kSweep; u++) {
-                const uint32_t q = base + u * 64 + lane;
-                pp[u] = q < end ? ckeys[q] : 0u;
-                ww[u] = q < end ? cweight[q] : 0u;
-                cc[u] = sw ? sw - 1 : (q < end ? (uint32_t)labels[q] : 0u);
-            }
-        };
-        uint32_t it = draw();
-        uint32_t s = 0, e = 0, cl = 0, stw = 0;
-        uint32_t p[kSweep], cur[kSweep], wt[kSweep];
-        if (it < nlist) {
-            const uint32_t w = s_list[it];
-            cl = w & 63; stw = w >> 8; s = s_cs[cl]; e = s_cs[cl + 1];
-            load_sweep(s, e, stw, p, cur, wt);
-        }
-        RG_PHASE(1);
-        while (it < nlist) {
-            const uint32_t itn = draw();
-            uint32_t s_next = 0, e_next = 0, cl_next = 0, stw_next = 0;
-            if (itn < nlist) { const uint32_t w = s_list[itn]; cl_next = w & 63; stw_next = w >> 8; s_next = s_cs[cl_next]; e_next = s_cs[cl_next + 1]; }
-            uint32_t ncand = 0;
-            unsigned long long arw = 0, agw = 0, abw = 0, aww = 0;  // iteration 0: the cell's aggregate
-            for (uint32_t base = s; base < e; base += 64 * kSweep) {
-                const bool more = base + 64 * kSweep < e;
-                uint32_t pn[kSweep], curn[kSweep], wtn[kSweep];
-                if (more) load_sweep(base + 64 * kSweep, e, stw, pn, curn, wtn);
-                else load_sweep(s_next, e_next, stw_next, pn, curn, wtn);
-                if (FIRST) {
-#pragma unroll
-                    for (int u = 0; u < kSweep; u++) {  // (slots past the cell's end hold weight 0)
-                        const unsigned long long w = wt[u];
-                        arw += ((p[u] >> 16) & 255) * w; agw += ((p[u] >> 8) & 255) * w; abw += (p[u] & 255) * w; aww += w;
-                    }
-                }
-                sweep_masked<FIRST>(p, cur, wt, base, e, lane, s_mask + cl, stw != 0, tab, K, labels, acc, moved, ncand);
-#pragma unroll
-                for (int u = 0; u < kSweep; u++) { p[u] = pn[u]; cur[u] = curn[u]; wt[u] = wtn[u]; }
-            }
-            if (FIRST) {
-                arw = wave_reduce_sum64(arw); agw = wave_reduce_sum64(agw); abw = wave_reduce_sum64(abw); aww = wave_reduce_sum64(aww);
-                if (lane == 0) {
-                    unsigned long long *ag = ss.cagg + (size_t)((sup << kSuperShift) | cl) * 4;
-                    ag[0] = arw; ag[1] = agw; ag[2] = abw; ag[3] = aww;
-                }
-            }
-            evals += (unsigned long long)(e - s) * (ncand + 1);
-            RG_PHASE(4);
-            it = itn; s = s_next; e = e_next; cl = cl_next; stw = stw_next;
-        }
-    }
-    RG_PHASE(11);
-    moved = wave_reduce_sum(moved);
-    if (lane == 0) {
-        if (moved) atomicAdd(&s_moved, moved);
-        if (evals) atomicAdd(&s_evals, evals);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 5 * K; i += THREADS)
-        if (acc[i]) atomicAdd(&partials[i], acc[i]);
-    if (threadIdx.x == 0) {
-        if (s_moved) atomicAdd(&partials[5 * (size_t)K], (unsigned long long)s_moved);
-        if (s_evals) atomicAdd(&partials[5 * (size_t)K + 1], s_evals);
-    }
-    RG_PHASE(5);
-#ifdef CNIIC_RGBW_PHASES
-    if (census && threadIdx.x == 0) { g_rgbw_blk[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); g_rgbw_blk[blockIdx.x][3] = s_nlist; }
-#endif
-}
-
-// labels of the cells the super-cell kernel keeps as "uniform a" (their labels in memory are not maintained): one wave per cell
-__global__ __launch_bounds__(256) void k_rgbw_materialize(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ cell_start,
-                                                          uint8_t *__restrict__ labels) {
-    const uint32_t cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t stw = rec[(size_t)cell * kSupRecWords + 8];
-    if (!stw) return;
-    const uint32_t s = cell_start[cell], e = cell_start[cell + 1];
-    for (uint32_t q = s + (threadIdx.x & 63); q < e; q += 64) labels[q] = (uint8_t)(stw - 1);
 }
 
 // ---------------------------------------------------------------- centroid update
@@ -2312,10 +1309,6 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
     if (const char *bb = test_env("CNIIC_KM_BIG_BLOCKS_FROM")) s->big_blocks_from = (uint32_t)atoi(bb);
     if (const char *ms = test_env("CNIIC_KM_MAXSKIP")) s->max_skip = std::min<uint32_t>((uint32_t)atoi(ms), kMaxMovedSkip);
     // (every knob of the loop is read here, once: getenv() per launch raced with tools that set variables between contexts)
-    if (const char *tl = test_env("CNIIC_DBG_TIMELINE")) s->dbg_timeline = (uint32_t)atoi(tl) + 1u;
-    if (const char *ab = test_env("CNIIC_DBG_ABL")) { s->abl_launch = (uint32_t)atoi(ab) + 1u; if (const char *q = strchr(ab, ':')) s->abl_bits = (uint32_t)atoi(q + 1) & 255u; }
-    if (const char *ds = test_env("CNIIC_SUP_STOP")) s->dbg_sup_bits |= ((uint32_t)atoi(ds) & 255u) << 8;
-    if (const char *ds = test_env("CNIIC_DBG_LAUNCH")) s->dbg_sup_bits |= (uint32_t)atoi(ds) << 16;
     if (const char *fa = test_env("CNIIC_TEST_FAIL_AT_LAUNCH")) s->fail_at = atol(fa);
     s->keys = keys_d; s->weight = weight_d;
     s->gidx = GIdx{static_cast<const unsigned long long *>(gbits_d), gprefix_d, Ug};
@@ -2374,8 +1367,6 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         }
         if (s->wide) s->nblocks = (s->nblocks + 7) & ~7u;  // (wide: a wave each; launch_assign groups them by up to eight)
         KM_ALLOC(s->labels, std::max<uint64_t>(U, 1) * lab_bytes);
-        s->packed = !s->wide && nshards == 1 && test_env("CNIIC_KM_PACKED") && atoi(test_env("CNIIC_KM_PACKED"));   // (opt-in; decided for good below)
-        if (s->packed) KM_ALLOC(s->pk, std::max<uint64_t>(U, 1) * 4);
         KM_ALLOC(s->ckeys, U * 4);
         KM_ALLOC(s->cweight, U * 4);
         if (!points_follow) KM_ALLOC(s->crank, U * 4);
@@ -2387,20 +1378,6 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         const uint32_t G = s->nblocks * (s->wide ? 1u : (uint32_t)kCellWaves) * nshards;   // waves over all shards
         KM_ALLOC(s->wfirst, ((uint64_t)G + 1) * 4);
         if (!s->big) KM_ALLOC(s->cell_rec, (uint64_t)kNumCells * cell_rec_words((K + 63) / 64) * 4);
-        s->no_block_build = !(test_env("CNIIC_KM_BLOCK_BUILD") && atoi(test_env("CNIIC_KM_BLOCK_BUILD")));
-        // the super-cell-major kernel is exact and sweeps 40 % fewer points, but its blocks (one per super-cell) are unevenly loaded:
-        // 2.29 ms against 2.03 ms per 61-iteration run at 4096^2 -- kept behind CNIIC_KM_SUP=1
-        s->sup = !s->wide && nshards == 1 && test_env("CNIIC_KM_SUP") && atoi(test_env("CNIIC_KM_SUP"));
-        // Packed points are exact (the parity suite runs them) and read 27 MB a launch instead of 61 MB -- and are 2-4 % SLOWER on the
-        // headline encode (full schedule 38.1 against 36.3 us, skip 17.9 against 17.2, the first launch 81 against 76: it writes them):
-        // the launch is bound by VALU issue, not by bytes or their latency (profiles/r04_assign_ablation.txt, NOTES.md D).  Opt-in:
-        // CNIIC_KM_PACKED=1 in the testing build.
-        if (s->sup || !(test_env("CNIIC_KM_PACKED") && atoi(test_env("CNIIC_KM_PACKED")))) s->packed = false;
-        if (s->sup) {
-            KM_ALLOC(s->sup_rec, (uint64_t)kNumCells * kSupRecWords * 4);
-            KM_ALLOC(s->sup_agg, (uint64_t)kNumCells * 4 * 8);
-            (void)hipMemsetAsync(s->sup_rec.p, 0, (uint64_t)kNumCells * kSupRecWords * 4, c->stream);  // state 0: the labels are in memory
-        }
         DevBuf count, cursor, cell_tot;
         KM_ALLOC(count, (uint64_t)kNumCells * 4);
         KM_ALLOC(cell_tot, (uint64_t)kCellGroups * 8 * 2);
@@ -2457,7 +1434,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
         // the loop as one persistent launch (k_kmeans_persist.hip): its block ranges, barrier words and sums
         // (not for the worker contexts of a batch encode: eight persistent launches side by side each hold an eighth of the CUs for a
         // whole run while the other stages of their neighbours' encodes wait for a CU -- 2.6 ms a frame against 0.67 with launches)
-        if (s->fused && !s->sup && !s->packed && nshards == 1 && c->ps_div <= 1 && c->opt(CNIIC_OPT_KM_LOOP, "CNIIC_KM_LOOP", 0) == 0) {
+        if (s->fused && nshards == 1 && c->ps_div <= 1 && c->opt(CNIIC_OPT_KM_LOOP, "CNIIC_KM_LOOP", 0) == 0) {
             const int rc_ps = ps_prepare(s);
             if (rc_ps != CNIIC_OK) { delete s; return rc_ps; }
         }
@@ -2523,18 +1500,14 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
 // own begin and end as a profiler sees them, not an event pair around it (which adds ~4 us of dispatch per launch)
 // fused: the update of the previous iteration runs in this launch's prologue and the sums go to part_fused
 static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FusedUpdate *fused = nullptr,
-                          unsigned long long *part_fused = nullptr, const MbFold *fold = nullptr) {
+                          unsigned long long *part_fused = nullptr) {
     Ctx *c = s->c;
     FusedUpdate fz{};
     if (fused) fz = *fused;
-    MbFold mf{};
-    if (fold) mf = *fold;
     const KmDevState *st = s->dstate.as<KmDevState>();
     if (s->cells) {
         auto *part = fused ? part_fused : reinterpret_cast<unsigned long long *>(s->partials);
-        CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(),
-                     s->no_skip ? 0u : s->max_skip, s->dbg_timeline,
-                     (s->no_block_build ? 1u : 0u) | ((fz.on && s->abl_launch == fz.launch_no + 1) ? s->abl_bits << 8 : 0u)};
+        CellState cs{s->cell_rec.as<uint32_t>(), s->moved_list.as<uint32_t>(), s->no_skip ? 0u : s->max_skip};
         if (s->big) {   // K > 2048: every colour against every centroid, sums in memory (k_kmeans_wide.hip)
             launch_rgbw_assign_big(c, s->ckeys.as<uint32_t>(), s->cweight.as<uint32_t>(), s->U, s->K, s->cent.as<uint32_t>(), s->labels.as<uint16_t>(), part, st);
         } else if (s->wide) {  // K up to 2048: as many waves per block (8, 4, 2, 1) as leave room for the block's sums and table and every
@@ -2551,42 +1524,25 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
             hipLaunchKernelGGL(kern, dim3(s->nblocks / wv), dim3(64 * wv), lds, c->stream,
                                (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
-                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz, (uint32_t *)nullptr, mf);
-        } else if (s->sup) {
-            SupState ss{s->sup_rec.as<uint32_t>(), s->sup_agg.as<unsigned long long>(), s->cell_start.as<uint32_t>(), (s->no_skip || s->sup_force) ? 1u : 0u};
-            ss.no_skip |= s->dbg_sup_bits;
-            s->labels_stale = true;
-            s->sup_force = false;
-            const size_t lds = (size_t)s->K * (5 * 8 + 8 + 8);
-            const bool first_launch = s->sup_launches++ == 0;  // (iteration 0: full sums, the cells' aggregates are written)
-            if (first_launch)
-                hipExtLaunchKernelGGL((k_rgbw_assign_sup<kSupWaves, true, 3>), dim3(kNumSupers), dim3(64 * kSupWaves), (uint32_t)lds, c->stream, ev_start, ev_stop, 0,
-                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K, (const uint2 *)s->cconst.as<uint2>(),
-                                      s->labels.as<uint8_t>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
-            else
-                hipExtLaunchKernelGGL((k_rgbw_assign_sup<kSupWaves, false, kSupMinW>), dim3(kNumSupers), dim3(64 * kSupWaves), (uint32_t)lds, c->stream, ev_start, ev_stop, 0,
-                                      (const uint32_t *)s->ckeys.as<uint32_t>(), (const uint32_t *)s->cweight.as<uint32_t>(), s->K, (const uint2 *)s->cconst.as<uint2>(),
-                                      s->labels.as<uint8_t>(), part, st, (const uint32_t *)s->moved_list.as<uint32_t>(), ss, fz);
+                               (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint16_t>(), part, st, cs, fz);
         } else {
             // The same wave ranges in blocks of 12 waves, two per CU, once the run has settled (from launch big_blocks_from):
             // measured on the headline encode, the first ten launches are 5-13 us faster in blocks of 8 (three per CU), every later
             // one 1-3 us faster in blocks of 12.  (The ranges are per wave, so regrouping them needs nothing but a multiple of 12.)
-            const bool pkd = fz.on && s->packed;   // the fused loop on packed points (pk_make: opt-in, see there)
             const bool big = kCellWaves == 8 && fz.on && fz.launch_no >= s->big_blocks_from && (s->nblocks * (uint32_t)kCellWaves) % kCellWavesBig == 0;
             const uint32_t wpb = big ? kCellWavesBig : (uint32_t)kCellWaves, nblk = s->nblocks * (uint32_t)kCellWaves / wpb;
             const size_t lds = (size_t)s->K * (5 * 8 + 8) + (size_t)wpb * (km_scap(s->K) + km_ccap(s->K)) * 8 + (size_t)wpb * ((s->K + 63) / 64) * 8;
-            const bool mbx = mf.on != 0;   // the exchange folded into the launches (km_rgbw_run_loop: fused, classic arrays, a mailbox communicator)
-            auto kern = big ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>)
+            auto kern = big ? k_rgbw_assign_cells<uint8_t, 8, kCellWavesBig, 0>
                         : !fz.on ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, -1>
-                        : fz.launch_no == 0 ? (mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>)
-                        : fz.launch_no <= s->agg_launches ? (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2>)
-                        : (pkd ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, true> : mbx ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0, false, true> : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>);
+                        : fz.launch_no == 0 ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 1>
+                        : fz.launch_no <= s->agg_launches ? k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 2>
+                        : k_rgbw_assign_cells<uint8_t, 8, kCellWaves, 0>;
             hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(64 * wpb), (uint32_t)lds,
                                   c->stream, ev_start, ev_stop, 0, (const uint32_t *)s->ckeys.as<uint32_t>(),
                                   (const uint32_t *)s->cweight.as<uint32_t>(), (const uint32_t *)s->ne_cell.as<uint32_t>(),
                                   (const uint32_t *)s->ne_start.as<uint32_t>(), (const uint32_t *)s->wfirst.as<uint32_t>(), s->shard, s->K,
                                   (const uint2 *)s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
-                                  part, st, cs, fz, pkd ? s->pk.as<uint32_t>() : (uint32_t *)nullptr, mf);
+                                  part, st, cs, fz);
         }
         return;
     }
@@ -2599,14 +1555,6 @@ static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEven
         hipLaunchKernelGGL((k_rgbw_assign<uint8_t, 8>), dim3(s->nblocks), dim3(kAssignThreads), lds, c->stream, s->keys,
                            s->weight, s->lo, s->hi, s->K, s->Kpad, s->cconst.as<uint2>(), s->labels.as<uint8_t>(),
                            s->slabs.as<uint64_t>(), st);
-}
-
-// the labels of cells the super-cell kernel holds as "uniform" are written out when somebody wants the label array
-static void ensure_labels(KmRgbwState *s) {
-    if (!s->sup || !s->labels_stale) return;
-    hipLaunchKernelGGL(k_rgbw_materialize, dim3(kNumCells / 4), dim3(256), 0, s->c->stream, (const uint32_t *)s->sup_rec.as<uint32_t>(),
-                       (const uint32_t *)s->cell_start.as<uint32_t>(), s->labels.as<uint8_t>());
-    s->labels_stale = false;
 }
 
 int km_rgbw_assign(KmRgbwState *s) {
@@ -2728,13 +1676,6 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         CNIIC_TRY(km_rgbw_run_persistent(s, &ran));
         if (ran) { timer.stop(s->run_stats.iterations); return CNIIC_OK; }
     }
-    // A mailbox communicator's exchange can be FOLDED into the launches themselves (no kernel of its own between two of them; VERDICT r03
-    // item 6) when the loop is the fused one on the classic arrays with narrow labels.  OPT-IN (CNIIC_MB_FOLD=1, testing build): with the
-    // fold every block of a launch waits for block 0, which waits for the peers' previous launch -- fine with one process per GPU, which
-    // is what it is for, and a deadlock until the timeout when the ranks SHARE a GPU at full occupancy (the only set-up this build has ever
-    // run on: a rank's spinning grid leaves its peer's blocks no CU to finish on).  Tested on grids that fit side by side (tests/test_dist.py).
-    const bool fold = cm && comm_mailbox(cm) && s->fused && s->cells && !s->wide && !s->sup && !s->packed && s->nshards == 1 &&
-                      test_env("CNIIC_MB_FOLD") && atoi(test_env("CNIIC_MB_FOLD"));
     for (;;) {
         for (int b = 0; b < batch; b++) {
             if (s->fused) {
@@ -2764,14 +1705,9 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
                 fz.st_host = st_host;
                 fz.st_ring = st_ring;
                 unsigned long long *cur = P + (j % 3) * W;
-                MbFold mf{};
-                if (fold) {   // the exchange rides on the launches: this one's prologue completes the last, its tail publishes the next
-                    CNIIC_TRY(comm_async_error(cm));
-                    CNIIC_TRY(mailbox_fold_next(comm_mailbox(cm), comm_timeout_ms(cm), j == 0, (uint32_t)W, &mf));
-                }
-                if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur, fold ? &mf : nullptr); }
-                else launch_assign(s, nullptr, nullptr, &fz, cur, fold ? &mf : nullptr);
-                if (cm && !fold) CNIIC_TRY(comm_all_reduce(cm, cur, W, 2));  // the sums of all shards, before launch j + 1 reads them
+                if (s->profile) { hipEvent_t ea = lt.next(), eb = lt.next(); launch_assign(s, ea, eb, &fz, cur); }
+                else launch_assign(s, nullptr, nullptr, &fz, cur);
+                if (cm) CNIIC_TRY(comm_all_reduce(cm, cur, W, 2));  // the sums of all shards, before launch j + 1 reads them
                 continue;
             }
             if (s->profile && s->cells && !s->wide) {
@@ -2800,11 +1736,6 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
         // The tail of a run (a few thousand points still moving) is launches of ~11 us that do little: four in flight keep the GPU fed
         // as well as eight, and up to eight fewer launches past convergence (4 us each) are paid at the end.
         if (have && !batch_fixed && h.iter > 8) batch = h.moved_last < 20000 ? 4 : 8;
-    }
-    if (s->fused && s->packed) {   // the labels lived in the packed points while the loop ran: back into the label array everybody else reads
-        hipLaunchKernelGGL(k_rgbw_unpack_labels, dim3((uint32_t)ceil_div(std::max<uint64_t>(s->U, 1), (uint64_t)1024)), dim3(256), 0, c->stream,
-                           (const uint32_t *)s->pk.as<uint32_t>(), s->labels.as<uint8_t>(), s->U);
-        CNIIC_HIP_TRY(c, hipGetLastError());
     }
     // (the state the loop ended on is final -- launches past convergence change nothing: callers that only want the statistics
     // need not wait for those launches, km_rgbw_run_stats)
@@ -2851,48 +1782,6 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
             kc.ms += cms[k]; kc.launches += cn[k];
         }
     }
-#ifdef CNIIC_RGBW_PHASES
-    {
-        unsigned long long ph[12], zero[12] = {0};
-        CNIIC_HIP_TRY(c, hipDeviceSynchronize());
-        CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_rgbw_phase), sizeof ph));
-        CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_phase), zero, sizeof zero));
-        if (s->sup && test_env("CNIIC_DBG_LAUNCH")) {
-            static unsigned long long B[512][4];
-            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(B, HIP_SYMBOL(g_rgbw_blk), sizeof B));
-            unsigned long long t0 = ~0ull, t1 = 0;
-            for (int i = 0; i < 512; i++) if (B[i][0]) { t0 = std::min(t0, B[i][0]); t1 = std::max(t1, B[i][1]); }
-            fprintf(stderr, "census: launch spans %.2f us\n", (t1 - t0) / 100.0);
-            for (int i = 0; i < 512; i++)
-                fprintf(stderr, "blk %d start %.2f dur %.2f hwid %llx items %llu\n", i, (B[i][0] - t0) / 100.0, (B[i][1] - B[i][0]) / 100.0, B[i][2], B[i][3]);
-        }
-        if (s->sup) {
-            unsigned int L[128][8];
-            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(L, HIP_SYMBOL(g_rgbw_launch), sizeof L));
-            for (uint32_t i = 0; i < 128 && i <= h.iter; i++)
-                fprintf(stderr, "launch %u: swept cells %u points %u | bulk %u | single-candidate %u of %u | longest list %u | mean |S| %.1f\n", i, L[i][0], L[i][1], L[i][2], L[i][3], L[i][5], L[i][4], L[i][6] / 512.0);
-            memset(L, 0, sizeof L);
-            CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_rgbw_launch), L, sizeof L));
-        }
-        if (s->sup) fprintf(stderr, "assign_sup (wave clocks): prologue %llu S build %llu classify %llu first loads %llu sweeps %llu tail wait %llu flush %llu\n",
-                            ph[0], ph[2], ph[3], ph[1], ph[4], ph[11], ph[5]);
-        if (const char *tf = test_env("CNIIC_DBG_TIMELINE_FILE")) {
-            static unsigned long long T[8192][12];
-            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(T, HIP_SYMBOL(g_wave_tl), sizeof T));
-            if (FILE *f = fopen(tf, "w")) {
-                fprintf(f, "wave,t0,t1,t2,t3,t4,t5,dirty,cells,cands,points,sbuilds,slen\n");
-                for (int i = 0; i < 8192; i++)
-                    if (T[i][0]) fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", i, T[i][0], T[i][1], T[i][2], T[i][3], T[i][4], T[i][5], T[i][6], T[i][7], T[i][8], T[i][9], T[i][10], T[i][11]);
-                fclose(f);
-            }
-            memset(T, 0, sizeof T);
-            CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wave_tl), T, sizeof T));
-        }
-        fprintf(stderr, "rgbw phases (wave clocks): prologue %llu draw %llu super %llu cell-build %llu sweep %llu epilogue %llu skip-test %llu "
-                        "skip-build+sweep %llu | super builds %llu cells %llu iters %llu | first barrier+draw %llu tail %llu\n",
-                ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7], ph[8], ph[9], (unsigned long long)h.iter, ph[10], ph[11]);
-    }
-#endif
     return CNIIC_OK;
 }
 
@@ -2936,7 +1825,6 @@ bool km_rgbw_is_wide(KmRgbwState *s) { return s->wide; }
 // u8/u16 labels in CANONICAL point order on the device (dst holds U entries)
 int km_rgbw_labels_canonical(KmRgbwState *s, void *dst_d) {
     Ctx *c = s->c;
-    ensure_labels(s);
     if (s->cells) {
         if (s->wide)
             hipLaunchKernelGGL(k_labels_to_canonical<uint16_t>, dim3(grid_1d(s->U)), dim3(256), 0, c->stream, s->labels.as<uint16_t>(),
@@ -2966,7 +1854,6 @@ __global__ void k_export_labels(const LabelT *__restrict__ labels, const uint32_
 int km_rgbw_export_labels(KmRgbwState *s, void *dst_d) {
     Ctx *c = s->c;
     if (!s->cells) return c->fail(CNIIC_ERR_BAD_ARG, "export_labels needs the cells path");
-    ensure_labels(s);
     const uint32_t wpb = s->wide ? 1u : (uint32_t)kCellWaves;
     const uint32_t g_lo = s->shard * s->nblocks * wpb, g_hi = (s->shard + 1) * s->nblocks * wpb;
     if (s->wide)
@@ -2982,11 +1869,6 @@ int km_rgbw_export_labels(KmRgbwState *s, void *dst_d) {
 int km_rgbw_import_labels(KmRgbwState *s, const void *src_d) {
     Ctx *c = s->c;
     CNIIC_HIP_TRY(c, hipMemcpyAsync(s->labels.p, src_d, s->U * (s->wide ? 2 : 1), hipMemcpyDeviceToDevice, c->stream));
-    if (s->sup) {  // foreign labels: no cell is uniform any more and the next launch must look at every point
-        CNIIC_HIP_TRY(c, hipMemsetAsync(s->sup_rec.p, 0, (uint64_t)kNumCells * kSupRecWords * 4, c->stream));
-        s->labels_stale = false;
-        s->sup_force = true;
-    }
     return CNIIC_OK;
 }
 
@@ -3011,7 +1893,6 @@ void km_rgbw_cell_arrays(KmRgbwState *s, uint32_t **cell_start_d, uint32_t **cke
 
 // cell-major label array of all U points (cells path): the buffer ranks all-gather over
 void *km_rgbw_labels_internal(KmRgbwState *s, uint64_t *elem_bytes) {
-    ensure_labels(s);
     if (elem_bytes) *elem_bytes = s->wide ? 2 : 1;
     return s->labels.p;
 }
@@ -3022,7 +1903,6 @@ int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32,
                    uint64_t *wsum_h, cniic_kmeans_stats *stats) {
     Ctx *c = s->c;
     const uint64_t n = s->hi - s->lo;
-    ensure_labels(s);
     if (labels_d_u32 && n) {
         const uint32_t *rank = s->cells ? s->crank.as<uint32_t>() : nullptr;
         const uint64_t a = s->cells ? 0 : s->lo, b = s->cells ? s->U : s->hi;

@@ -10,9 +10,9 @@
 //                         iteration 0) straight into the K sums in memory, the lanes of a wave that share a cluster adding together.
 //                         The state, the update kernel and the loop are k_kmeans_rgbw.hip's (launch_assign picks this kernel for K > 2048).
 //   * km_xyrgb_run_wide   ColorPos, any K and any sides with w * h <= 2^32: squared distances in 64 bits (|dx|, |dy| < 2^32 squared would
-//                         not fit: the oracle's mode L computes in int64 too), u32 labels, FULL sums every iteration (no running sums
+//                         not fit: the reference's i64 arithmetic, src/geom.rs), u32 labels, FULL sums every iteration (no running sums
 //                         to keep exact across label widths), a grid-wide update kernel with exact 64-bit division.
-// Both are held to the oracle by tests/test_wide_limits.py (K = 4096 and 5000 on small images, a 1 x 20000 strip, a 17000-wide sliver).
+// Both are checked bit for bit by tests/test_wide_limits.py (K = 4096 and 5000 on small images, a 1 x 20000 strip, a 17000-wide sliver).
 #include <vector>
 
 #include "kmeans_rgbw.hpp"
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_xyw_assign(const uint8_t *__restrict__ 
         for (uint32_t k = 0; k < K; k++) {
             const WideCent c = cent[k];
             const long long dx = x - c.x, dy = y - c.y, dr = pr - (long long)((c.col >> 16) & 255), dg = pg - (long long)((c.col >> 8) & 255), db = pb - (long long)(c.col & 255);
-            const unsigned long long d = (unsigned long long)(dx * dx + dy * dy + dr * dr + dg * dg + db * db);   // (oracle mode L: int64 squared distances)
+            const unsigned long long d = (unsigned long long)(dx * dx + dy * dy + dr * dr + dg * dg + db * db);   // (int64 squared distances, as the reference's)
             if (d < best) { best = d; bestk = k; }   // strict: the lowest id among equals
             if (k == cur) dcur = d;
         }

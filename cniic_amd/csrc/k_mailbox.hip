@@ -161,8 +161,6 @@ struct Mailbox {
     uint32_t seq = 0;
     uint32_t *status = nullptr;
     int wall_khz = 100000;
-    unsigned int *fold_words = nullptr;  // device: ticket[2], ready (the folded exchange, MbFold)
-    uint32_t fold_last_pub = 0;          // the exchange the last folded launch published
     hipStream_t side = nullptr;  // for the abort note (the context's stream may be sitting in a wait); made when first needed:
                                  // a process has few hardware queues, and streams that share one run their kernels in turn
     std::string key;
@@ -235,32 +233,6 @@ int mailbox_connect(Mailbox *m, const uint8_t *handles) {
     return CNIIC_OK;
 }
 
-// the descriptor of the next K-means launch of a run whose exchange is folded into the launches (common.hpp, MbFold)
-int mailbox_fold_next(Mailbox *m, uint64_t timeout_ms, bool first_launch, uint32_t words, MbFold *out) {
-    Ctx *c = m->c;
-    if (!m->connected) return c->fail(CNIIC_ERR_BAD_ARG, "folded exchange: the mailboxes are not connected yet (cniic_comm_connect_mailbox)");
-    if ((uint64_t)words * 8 > m->cap) return c->fail(CNIIC_ERR_BAD_ARG, "folded exchange: %u words do not fit a mailbox slot", words);
-    if (!m->fold_words) {
-        CNIIC_HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&m->fold_words), 64));
-        CNIIC_HIP_TRY(c, hipMemsetAsync(m->fold_words, 0, 64, c->stream));
-    }
-    const MbArgs a = m->args(timeout_ms);
-    MbFold f{};
-    static_assert(kMbFoldMaxRanks == kMbMaxRanks, "one limit");
-    for (uint32_t p = 0; p < m->nranks; p++) f.peer[p] = m->peer[p];
-    f.on = 1; f.rank = m->rank; f.nranks = m->nranks; f.nslices_cap = m->nslices_cap;
-    f.seq_prev = first_launch ? 0u : m->fold_last_pub;
-    f.seq_pub = ++m->seq;
-    m->fold_last_pub = f.seq_pub;
-    f.words = words;
-    f.cap = a.cap; f.flags_off = a.flags_off; f.slots_off = a.slots_off; f.wait_ticks = a.wait_ticks;
-    f.status = m->status;
-    f.ticket = m->fold_words;
-    f.ready = m->fold_words + 8;
-    *out = f;
-    return CNIIC_OK;
-}
-
 // 0 while healthy; 1: a wait for a peer's slice ran out; 2: a peer aborted
 int mailbox_status(const Mailbox *m) { return m && m->status ? (int)*reinterpret_cast<volatile uint32_t *>(m->status) : 0; }
 
@@ -299,12 +271,11 @@ void mailbox_destroy(Mailbox *m) {
     // nothing of this rank may still be running on the mailbox when it is unmapped and freed: the exchanges on the context's stream
     // (a poisoned mailbox makes them return at once) and the abort note on the side stream.  Peers are not waited for -- a peer that
     // still stores into this mailbox holds its own mapping of the allocation, which outlives this free.
-    if (m->c && m->c->stream) (void)hipStreamSynchronize(m->c->stream);
+    if (m->c) (void)hipStreamSynchronize(m->c->stream);   // (a null stream is the default stream: waited for as well)
     if (m->side) (void)hipStreamSynchronize(m->side);
     { std::lock_guard<std::mutex> g(g_reg_mu); g_reg.erase(m->key); }
     for (uint32_t p = 0; p < m->nranks; p++)
         if (m->opened[p]) (void)hipIpcCloseMemHandle(m->peer[p]);
-    if (m->fold_words) (void)hipFree(m->fold_words);
     if (m->side) (void)hipStreamDestroy(m->side);
     if (m->base) (void)hipFree(m->base);
     if (m->status) (void)hipHostFree(m->status);

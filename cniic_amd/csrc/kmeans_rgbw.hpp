@@ -55,22 +55,12 @@ struct KmRgbwState {
     GIdx gidx{nullptr, nullptr, 0};  // several GPUs: the points are this rank's share of gidx.U colours
     DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
     bool fused = false;
-    bool sup = false;            // super-cell-major assign (k_rgbw_assign_sup): K <= 256, one shard
-    bool sup_force = false;      // the next launch sweeps every cell (labels were imported)
     cniic_kmeans_stats run_stats{};  // the statistics km_rgbw_run ended on
     bool run_stats_valid = false;
     uint32_t big_blocks_from = 10;  // launches from this one on run in blocks of kCellWavesBig waves (CNIIC_KM_BIG_BLOCKS_FROM; a huge value: never)
     uint32_t agg_launches = 3;  // launches 1 .. agg_launches book their movers round by round (CNIIC_KM_AGG_LAUNCHES)
     uint32_t max_skip = 64;  // (= kMaxMovedSkip) skip schedule when at most this many centroids moved (CNIIC_KM_MAXSKIP)
-    DevBuf pk;                   // packed points of the fused loop (K <= 256, one shard): see kPk* below
-    bool packed = false;
-    uint32_t abl_launch = 0, abl_bits = 0;       // measuring builds (-DCNIIC_RGBW_ABL): CNIIC_DBG_ABL="launch:bits" leaves parts of ONE launch out (its duration is what is read; the run is wrong afterwards)
-    uint32_t dbg_timeline = 0, dbg_sup_bits = 0;  // measuring knobs (CNIIC_DBG_TIMELINE, CNIIC_SUP_STOP, CNIIC_DBG_LAUNCH), read ONCE when the state is made
     long fail_at = -1;           // fault injection for the multi-rank tests (CNIIC_TEST_FAIL_AT_LAUNCH), read once as well
-    uint32_t sup_launches = 0;   // assign launches so far (the first one accumulates full sums)
-    bool labels_stale = false;   // ... which leaves the labels of uniform cells to k_rgbw_materialize
-    DevBuf sup_rec, sup_agg;     // per cell: candidate mask + state word; aggregate of its points
-    bool no_block_build = true;   // the block-wide candidate build is opt-in (CNIIC_KM_BLOCK_BUILD=1): 30 % fewer VALU instructions, 0.3-0.8 us SLOWER per launch
     uint32_t shard = 0, nshards = 1;
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
     // the loop as ONE launch (k_kmeans_persist.hip): K <= 256, one shard, no communicator
@@ -207,7 +197,7 @@ __device__ __forceinline__ uint32_t build_super(const uint2 *tab, uint32_t K, ui
     return n;
 }
 
-// ---- the packed point word: see "packed points" in k_kmeans_rgbw.hip / the resident points of k_kmeans_persist.hip
+// ---- the packed point word of the resident points (k_kmeans_persist.hip)
 __device__ __forceinline__ uint32_t pk_make(uint32_t key, uint32_t w, uint32_t label) {
     return (((key >> 16) & 7u) << 6) | (((key >> 8) & 7u) << 3) | (key & 7u) | (min(w, 255u) << 16) | (label << 24);
 }

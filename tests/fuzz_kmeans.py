@@ -11,8 +11,8 @@ import numpy as np
 import oracle_lib as O
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
-CC_KNOBS = [{}, {"CNIIC_SP_MIN_PIXELS": "0"}, {"CNIIC_SP_MIN_PIXELS": "0", "CNIIC_KM_BLOCK_BUILD": "1"}, {"CNIIC_SP_MIN_PIXELS": str(1 << 40)},
-            {"CNIIC_KM_BLOCK_BUILD": "1"}, {"CNIIC_KM_BATCH": "1"}, {"CNIIC_KM_MAXSKIP": "4"}]
+CC_KNOBS = [{}, {"CNIIC_SP_MIN_PIXELS": "0"}, {"CNIIC_SP_MIN_PIXELS": str(1 << 40)},
+            {"CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_UNFUSED": "1", "CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_BATCH": "1"}, {"CNIIC_KM_MAXSKIP": "4"}]
 VOR_KNOBS = [{}, {"CNIIC_XY_DYN": "0"}, {"CNIIC_XY_DYN": "1"}, {"CNIIC_XY_DYN": "100000"}]
 
 

@@ -38,8 +38,7 @@ def test_release_library_has_no_test_hooks():
     missing = [s for s in declared_symbols() if not hasattr(R, s)]
     assert not missing, missing
     blob_r, blob_t = open(rel, "rb").read(), open(tst, "rb").read()
-    hooks = [b"CNIIC_TEST_", b"CNIIC_DBG_", b"CNIIC_KM_SUP", b"CNIIC_KM_BATCH", b"CNIIC_HD_PHASES", b"CNIIC_TRACE_HOST", b"CNIIC_XY_UNFUSED",
-             b"CNIIC_KM_PACKED", b"CNIIC_MB_FOLD"]
+    hooks = [b"CNIIC_TEST_", b"CNIIC_KM_PS_REQUIRE", b"CNIIC_KM_UNFUSED", b"CNIIC_KM_BATCH", b"CNIIC_HD_PHASES", b"CNIIC_TRACE_HOST", b"CNIIC_XY_UNFUSED"]
     for h in hooks:
         assert h not in blob_r, "release library still carries %s" % h.decode()
         assert h in blob_t, "testing library lost %s" % h.decode()

@@ -405,18 +405,15 @@ def test_native_loop_world2_over_a_host_transport(route):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fold", ["1", "0"])
 @pytest.mark.parametrize("world,route", [(2, "dense"), (2, "partition"), (4, "partition")])
-def test_native_loop_over_mailboxes(world, route, fold):
+def test_native_loop_over_mailboxes(world, route):
     """cniic_cc_run with the ONE-SHOT exchange (cniic_comm_create_mailbox): two / four processes that share the test box's GPU map
     each other's mailboxes through HIP IPC (the handles travel over gloo); every iteration's K partial sums are written into
     every peer's mailbox and added in rank order, and the 8 MiB of occupancy nibbles go through the same mailboxes in pieces.
-    Result = the oracle's union result, as over RCCL or a host transport.  `fold` = 1 (opt-in): the per-iteration exchange is
-    FOLDED into the K-means launches (round 4: the last block of launch j publishes, block 0 of launch j + 1 collects; no kernel in
-    between -- meant for one process per GPU; these small grids fit side by side on the shared one); 0 (the default): the separate
-    exchange kernel of round 3."""
+    Result = the oracle's union result, as over RCCL or a host transport.  (The exchange folded into the K-means launches, an
+    opt-in of round 4 that could not run on a shared GPU at full occupancy, is archived: profiles/r05_pruned_variants.patch.)"""
     K = 8 if world == 2 else 16
-    env = {"TEST_COLLECTIVES": "mailbox", "CNIIC_COLLECTIVE_TIMEOUT_MS": "20000", "CNIIC_MB_FOLD": fold,
+    env = {"TEST_COLLECTIVES": "mailbox", "CNIIC_COLLECTIVE_TIMEOUT_MS": "20000",
            "CNIIC_SP_MIN_PIXELS": "0" if route == "partition" else str(1 << 40)}
     res = _run(world, K, use_hip=True, env=env)
     exp, iters = expected_streams([make_img(r) for r in range(world)], K)
@@ -567,11 +564,11 @@ def test_frame_batch_hip_world2_over_mailboxes():
 
 
 # ------------------------------------------------------------------ a rank that fails must not strand its peers
-def _failing_worker(rank, world, port, q, collectives="host", fold="0"):
+def _failing_worker(rank, world, port, q, collectives="host"):
     import datetime
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CNIIC_SP_MIN_PIXELS="0", CNIIC_MB_FOLD=fold)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CNIIC_SP_MIN_PIXELS="0")
     if rank == 1:
         os.environ["CNIIC_TEST_FAIL_AT_LAUNCH"] = "3"       # fault injection: rank 1 fails before enqueuing its fourth assign launch
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
@@ -629,18 +626,15 @@ def test_a_failing_rank_aborts_its_communicator_and_its_peer_errors_out():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fold", ["0", "1"])
-def test_a_failing_rank_ends_its_peers_wait_in_the_mailbox_kernel(fold):
+def test_a_failing_rank_ends_its_peers_wait_in_the_mailbox_kernel():
     """the same with the one-shot exchange: rank 1 fails before its fourth launch and writes the abort word into rank 0's
-    mailbox; rank 0's kernel, waiting for rank 1's slice, leaves at once and rank 0 returns CNIIC_ERR_RCCL.  `fold` = 1: the
-    wait sits in the K-means launch's own prologue (the folded exchange): the launch leaves its state record and returns, the
-    host reports the exchange's failure"""
+    mailbox; rank 0's kernel, waiting for rank 1's slice, leaves at once and rank 0 returns CNIIC_ERR_RCCL"""
     import torch.multiprocessing as mp
     from cniic_amd import _lib
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, "mailbox", fold), daemon=True) for r in range(2)]
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, "mailbox"), daemon=True) for r in range(2)]
     for p in procs:
         p.start()
     res = {}

@@ -41,19 +41,12 @@ def test_config2_cluster_colors_4096(env):
     rc, n2, st2 = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out, flags=_lib.KM_NO_SKIP)
     data2 = out[:n2].cpu().numpy().tobytes()
     assert data1 == data2 and st1["iterations"] == st2["iterations"]          # skip schedule changes nothing
-    import os
-    os.environ["CNIIC_KM_SUP"] = "1"                                            # the super-cell-major assign kernel: same bytes
+    ctx.set_opt(_lib.OPT_KM_LOOP, 1)                                            # one launch per iteration instead of the persistent launch: same bytes, same work counted
     try:
         rc, n3, st3 = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out)
     finally:
-        del os.environ["CNIIC_KM_SUP"]
+        ctx.set_opt(_lib.OPT_KM_LOOP, None)
     assert out[:n3].cpu().numpy().tobytes() == data1 and st3["iterations"] == st1["iterations"]
-    os.environ["CNIIC_KM_BLOCK_BUILD"] = "1"                                    # the block-wide candidate build (opt-in): same bytes, same work counted
-    try:
-        rc, n4, st4 = ctx.encode("cluster-colors(%d)" % K, img, w=size, h=size, out=out)
-    finally:
-        del os.environ["CNIIC_KM_BLOCK_BUILD"]
-    assert out[:n4].cpu().numpy().tobytes() == data1 and st4["iterations"] == st1["iterations"] and st4["pair_evals"] == st1["pair_evals"]
     rc, back = ctx.decode("ccol(%d)" % K, data1)
     assert rc == 0 and back.shape == (size, size, 3)
     keys = (back[..., 0].astype(np.uint32) << 16) | (back[..., 1].astype(np.uint32) << 8) | back[..., 2]

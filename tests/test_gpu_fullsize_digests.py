@@ -48,13 +48,23 @@ def photo(ctx, torch, dev, seed, w, h):
     return img
 
 
-@pytest.mark.parametrize("packed", ["0", "1"])
-def test_configs1_cluster_colors_256_at_4096(env, monkeypatch, packed):
-    """configs[1]: the stream bench.py times, byte for byte the oracle's (61 iterations of exact Lloyd over 6.8 M colours);
-    `packed` = 1: the same through the opt-in loop on packed points (CNIIC_KM_PACKED, k_kmeans_rgbw.hip: heavy colours take the
-    weight escape here -- the image has colours of more than 254 pixels)"""
+@pytest.mark.parametrize("loop", ["persistent", "launches"])
+def test_configs1_cluster_colors_256_at_4096(env, monkeypatch, loop):
+    """configs[1]: the stream bench.py times, byte for byte the oracle's (61 iterations of exact Lloyd over 6.8 M colours), as ONE
+    persistent launch (the default; heavy colours take the packed word's weight escape here -- the image has colours of more than
+    254 pixels) and as one launch per iteration (CNIIC_OPT_KM_LOOP = 1)"""
     ctx, torch, dev = env
-    monkeypatch.setenv("CNIIC_KM_PACKED", packed)
+    from cniic_amd import _lib
+    if loop == "persistent":
+        monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")   # (testing build: a hand-over to the launches is an error)
+    ctx.set_opt(_lib.OPT_KM_LOOP, 1 if loop == "launches" else None)
+    try:
+        _configs1(ctx, torch, dev)
+    finally:
+        ctx.set_opt(_lib.OPT_KM_LOOP, None)
+
+
+def _configs1(ctx, torch, dev):
     g = golden("c2")
     img = photo(ctx, torch, dev, SEED + g["seed_offset"], g["w"], g["h"])
     assert hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest() == g["image_sha256"], "GPU generator != numpy generator"
@@ -133,3 +143,26 @@ def test_configs2_voronoi_2048(env, size):
     rc, n, st = ctx.encode(g["codec"], img, w=size, h=size, out=out)
     assert rc == 0 and n == g["length"] and st["iterations"] == g["iterations"]
     assert sha(out, n) == g["sha256"]
+
+
+def test_the_release_library_gives_the_same_digests():
+    """Every test above runs libcniic_hip_testing.so (tests/conftest.py); what a host links is libcniic_hip.so -- the same sources
+    less -DCNIIC_TESTING.  One pass of this file against the RELEASE library, in a child process (the library is chosen at import):
+    VERDICT r04, "the full-size digest tests should run once against the release .so too"."""
+    import subprocess
+    import sys
+    if os.environ.get("CNIIC_USE_TESTING_LIB") == "0":
+        pytest.skip("this IS the pass against the release library")
+    env_ = dict(os.environ)
+    env_["CNIIC_USE_TESTING_LIB"] = "0"
+    for k in [k for k in env_ if k.startswith(("CNIIC_KM_", "CNIIC_TEST_", "CNIIC_DBG_"))]:
+        del env_[k]   # (the release library would not read them anyway)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not release_library", "-p", "no:cacheprovider"],
+                       env=env_, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
+    # and the child really had the release library: cniic_is_testing_build() == 0 there
+    chk = subprocess.run([sys.executable, "-c", "import cniic_amd; print(cniic_amd.lib().cniic_is_testing_build())"], env=env_, cwd=os.path.dirname(HERE),
+                         capture_output=True, text=True, timeout=300)
+    assert chk.returncode == 0 and chk.stdout.strip().endswith("0"), chk.stdout + chk.stderr

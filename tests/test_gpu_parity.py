@@ -97,15 +97,25 @@ def test_kmeans_step_rgbw_ties_stay(ctx):
         assert got["labels"].tolist() == [0, 1, lab] and got["changed"] == 0
 
 
-@pytest.mark.parametrize("packed", ["0", "1"])
-@pytest.mark.parametrize("block_build", ["0", "1"])
+@pytest.mark.parametrize("loop", ["persistent", "launches", "unfused"])
 @pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (300, (128, 160)), (200, (300, 260))])
-def test_kmeans_rgbw_run(ctx, monkeypatch, K, shape, block_build, packed):
-    """`block_build`: the candidates of all of a block's cells built at once, one lane per cell (opt-in, CNIIC_KM_BLOCK_BUILD);
-    `packed`: the loop on packed points -- one u32 per colour (colour inside its cell, weight with an escape, label), fetched two
-    cells ahead through buffer loads (opt-in, CNIIC_KM_PACKED: exact, a third of the traffic, and no faster -- NOTES.md D)"""
-    monkeypatch.setenv("CNIIC_KM_BLOCK_BUILD", block_build)
-    monkeypatch.setenv("CNIIC_KM_PACKED", packed)
+def test_kmeans_rgbw_run(ctx, monkeypatch, K, shape, loop):
+    """`loop`: the whole run as ONE persistent launch (the default of a one-GPU run with K <= 256, k_kmeans_persist.hip;
+    CNIIC_KM_PS_REQUIRE makes a silent hand-over an error) or one launch per iteration (CNIIC_OPT_KM_LOOP = 1: what several
+    GPUs, K > 256 and the batch workers run; "unfused": with the centroid update as a kernel of its own, CNIIC_KM_UNFUSED)"""
+    from cniic_amd import _lib
+    if loop == "persistent" and K <= 256:
+        monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")
+    if loop == "unfused":
+        monkeypatch.setenv("CNIIC_KM_UNFUSED", "1")
+    ctx.set_opt(_lib.OPT_KM_LOOP, 1 if loop != "persistent" else None)
+    try:
+        _kmeans_rgbw_run(ctx, K, shape)
+    finally:
+        ctx.set_opt(_lib.OPT_KM_LOOP, None)
+
+
+def _kmeans_rgbw_run(ctx, K, shape):
     img = synth_img(*shape, seed=7 + K)
     keys, counts = O.count_freqs(keys_of(img))
     w = counts.astype(np.uint32)
@@ -131,36 +141,6 @@ def test_kmeans_rgbw_brute_and_wide(ctx, K, flags):
     assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
     assert np.array_equal(got["labels"], exp["labels"])
     assert np.array_equal(got["members"], exp["members"])
-
-
-@pytest.mark.parametrize("K,shape", [(2, (32, 32)), (16, (64, 64)), (256, (128, 128)), (200, (300, 260))])
-@pytest.mark.parametrize("unfused", ["0", "1"])
-def test_kmeans_rgbw_run_super_cell_kernel(ctx, monkeypatch, K, shape, unfused):
-    """CNIIC_KM_SUP=1: the super-cell-major assign (one lane per cell, whole cells moved as aggregates, cells without a
-    moved candidate skipped) gives the oracle's run bit for bit, with the update folded in and as a separate kernel"""
-    monkeypatch.setenv("CNIIC_KM_SUP", "1")
-    monkeypatch.setenv("CNIIC_KM_UNFUSED", unfused)
-    img = synth_img(*shape, seed=11 + K)
-    keys, counts = O.count_freqs(keys_of(img))
-    w = counts.astype(np.uint32)
-    rc, got = ctx.kmeans_rgbw(keys, w, K)
-    rco, exp = O.kmeans(O.PT_RGBW, O.MODE_L, pts_of_keys(keys), w, K)
-    assert rc == rco == 0
-    assert got["stats"]["iterations"] == exp["stats"]["iterations"]
-    assert np.array_equal(got["centroids"].astype(np.int32), exp["centroids"])
-    assert np.array_equal(got["labels"], exp["labels"])
-    assert np.array_equal(got["members"], exp["members"])
-
-
-def test_cluster_colors_codec_super_cell_kernel(ctx, monkeypatch):
-    """the codec through the super-cell kernel, dense-table and pixel-partition routes: the oracle's bytes"""
-    monkeypatch.setenv("CNIIC_KM_SUP", "1")
-    img = synth_img(301, 299, seed=23, levels=200, noise=3)
-    rco, edata, est = O.encode("cluster-colors(64)", img, mode=O.MODE_L)
-    for sp_min in ("0", str(1 << 40)):
-        monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", sp_min)
-        rc, data, st = ctx.encode("cluster-colors(64)", img)
-        assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
 
 
 def test_kmeans_rgbw_unsorted_input_order(ctx):

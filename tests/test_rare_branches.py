@@ -72,18 +72,25 @@ def ctx():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("route", ["fused", "unfused", "brute", "no_skip", "sup", "sup_unfused", "sup_no_skip", "packed", "packed_no_skip"])
+@pytest.mark.parametrize("route", ["persistent", "persistent_no_skip", "fused", "unfused", "brute", "no_skip"])
 @pytest.mark.parametrize("name", RGBW)
 def test_hip_rgbw_empty_cluster_reseed(ctx, monkeypatch, name, route):
-    """kmeans.rs:117-134 through every ColorCount route: the fused prologue re-seeds with iteration = launch - 1"""
+    """kmeans.rs:117-134 through every ColorCount route: the persistent launch re-seeds inside its update phase, the fused prologue
+    with iteration = launch - 1"""
     from cniic_amd import _lib
-    if route.startswith("packed"):
-        monkeypatch.setenv("CNIIC_KM_PACKED", "1")  # the loop on packed points (opt-in)
+    if route.startswith("persistent"):
+        monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")   # (a silent hand-over to the launches would be an error)
     if route.endswith("unfused"):
         monkeypatch.setenv("CNIIC_KM_UNFUSED", "1")
-    if route.startswith("sup"):
-        monkeypatch.setenv("CNIIC_KM_SUP", "1")     # the super-cell-major assign kernel (lane per cell, uniform cells as aggregates)
-    flags = {"brute": _lib.KM_BRUTE_FORCE, "no_skip": _lib.KM_NO_SKIP, "sup_no_skip": _lib.KM_NO_SKIP, "packed_no_skip": _lib.KM_NO_SKIP}.get(route, 0)
+    flags = {"brute": _lib.KM_BRUTE_FORCE, "no_skip": _lib.KM_NO_SKIP, "persistent_no_skip": _lib.KM_NO_SKIP}.get(route, 0)
+    ctx.set_opt(_lib.OPT_KM_LOOP, None if route.startswith("persistent") else 1)
+    try:
+        _reseed_run(ctx, name, flags)
+    finally:
+        ctx.set_opt(_lib.OPT_KM_LOOP, None)
+
+
+def _reseed_run(ctx, name, flags):
     K = int(G[name + "_K"][0])
     rc, r = ctx.kmeans_rgbw(G[name + "_keys"], G[name + "_weight"], K, flags=flags)
     it, res, moved = (int(v) for v in G[name + "_stats"])
