@@ -60,6 +60,8 @@ def lib_path():
     """libcniic_hip.so -- or, with CNIIC_USE_TESTING_LIB=1 (tests/conftest.py, tools/), libcniic_hip_testing.so: the same code built with
     -DCNIIC_TESTING, the only build in which the CNIIC_TEST_* / CNIIC_DBG_* / route-forcing environment knobs exist"""
     name = "libcniic_hip_testing.so" if os.environ.get("CNIIC_USE_TESTING_LIB") == "1" else "libcniic_hip.so"
+    if os.environ.get("CNIIC_LIB_FILE"):   # a measuring build made by a tool under tools/ (e.g. -DCNIIC_PS_PHASES), never a product path
+        name = os.environ["CNIIC_LIB_FILE"]
     return os.path.join(_HERE, name)
 
 

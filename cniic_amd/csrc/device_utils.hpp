@@ -154,7 +154,8 @@ __device__ __forceinline__ void atomic_count(uint32_t *table, uint32_t key) {
         const bool same = todo && key == k;
         const unsigned long long sm = __ballot(same);
         if (same) {
-            if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&table[k], (uint32_t)__popcll(sm));
+            // (the lane's number from the hardware, not from threadIdx: any block shape)
+            if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&table[k], (uint32_t)__popcll(sm));
             todo = false;
         }
     }

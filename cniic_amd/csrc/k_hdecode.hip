@@ -35,6 +35,9 @@ constexpr int kHdThreads = 256;
 constexpr int kHdMaxPasses = 48;
 constexpr int kHdBlindChecks = 2;
 constexpr uint32_t kHdDirect = 0x80000000u;   // second-table entry: x = symbol key, y = kHdDirect | length; else x = first leaf, y = leaves after it
+constexpr uint32_t kHdSub3 = 0x40000000u;     // ... or x = first entry of the prefix's own third table, y = kHdSub3 | e: the next e bits pick its entry (key, length)
+constexpr uint32_t kHd3MaxBits = 6;           // third tables of up to 2^6 entries (a prefix whose longest code runs further keeps the bisection)
+constexpr uint32_t kHd3MaxLeaves = 96;        // leaves under a prefix its builder is willing to walk
 constexpr uint32_t kHdTail = 4;               // words staged past the block's last subsequence (a symbol may run kLeafMaxLen bits over)
 constexpr uint32_t kHdStageWords = kHdThreads * (kHdSub / 32) + kHdWarm / 32 + kHdTail;
 // first table (LDS, 4 bytes an entry -- an 8-byte entry per lane is two LDS passes and twice the footprint): a code of up to
@@ -49,7 +52,17 @@ struct HdTables {
     const uint2 *lut2;      // [1 << bits2], or null when no code is longer than kHdLut bits
     uint32_t bits2;
     uint32_t n;
+    const uint2 *lut3;      // third tables (k_hd_build_lut3), or null
+    uint32_t use1;          // is the first table asked at all?  (the host's choice, see hd_use_first_table: without it the table is not
+                            // even staged and a block needs half the LDS)
 };
+// The first table answers codes of up to kHdLut bits.  The differences of a photograph have next to none (1.6 % of the symbols of `delta`
+// at 2048^2, 84 of 42 K leaves): every symbol paid an LDS look-up that said "ask the next table", and the table's 16 KiB held a CU to three
+// blocks where six fit -- for a walk that is a chain of dependent reads, twice the waves in flight.  A stream whose symbols average more
+// than 12.5 bits goes straight to the second table (which answers the short codes too).
+__host__ inline bool hd_use_first_table(uint64_t payload_bits, uint64_t nsyms, uint32_t bits2) {
+    return bits2 == 0 || payload_bits * 2 < nsyms * 25;
+}
 
 // the stream as the decoder sees it: 32-bit words from a 4-byte aligned address; the payload's first bit is bit `bit0`
 // of that word sequence and its last one bit `nbits` - 1 (positions below are in that frame)
@@ -77,6 +90,34 @@ __global__ void k_hd_build_lut(const uint64_t *__restrict__ code, const uint32_t
     const uint32_t hi = p + 1 == (1u << bits) ? n - 1 : (code[lo_next] == top + 1 ? lo_next - 1 : lo_next);
     if (lut1) lut1[p] = lo == hi ? (key[lo] << 5) | ((uint32_t)len[lo] << 1) | 1u : 0u;
     else lut2[p] = lo == hi ? make_uint2(key[lo], kHdDirect | len[lo]) : make_uint2(lo, hi - lo);
+}
+
+// The third tables (round 5).  A second-table entry that holds a RANGE of leaves sent its lane into a bisection of the code array
+// (two or three dependent reads) and then to the leaf's length and key (one more): 1.3 % of the symbols of a photograph's `delta` --
+// and so 57 % of the steps of a wave of 64 lanes, each waiting for its slowest lane.  A prefix whose longest code runs at most
+// kHd3MaxBits past the second table's bits gets a table of its own, 2^e entries (key, length), picked by the next e bits: ONE more read.
+// Entries are dealt out of a pool by an atomic cursor (a prefix that finds the pool empty keeps its range).
+__global__ __launch_bounds__(256) void k_hd_build_lut3(const uint64_t *__restrict__ code, const uint32_t *__restrict__ key, const uint8_t *__restrict__ len, uint32_t bits,
+                                                       uint2 *__restrict__ lut2, uint2 *__restrict__ lut3, uint32_t cap3, uint32_t *__restrict__ cursor) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= (1u << bits)) return;
+    const uint2 e = lut2[p];
+    if (e.y & kHdDirect) return;
+    const uint32_t lo = e.x, nl = e.y + 1;
+    if (nl > kHd3MaxLeaves) return;
+    uint32_t L = 0;
+    for (uint32_t i = 0; i < nl; i++) L = max(L, (uint32_t)len[lo + i]);
+    if (L <= bits || L - bits > kHd3MaxBits) return;
+    const uint32_t eb = L - bits, sz = 1u << eb;
+    const uint32_t at = atomicAdd(cursor, sz);
+    if (at + sz > cap3) return;
+    uint32_t a = lo;
+    for (uint32_t j = 0; j < sz; j++) {
+        const uint64_t win = ((uint64_t)p << (64 - bits)) | ((uint64_t)j << (64 - bits - eb));
+        while (a + 1 < lo + nl && code[a + 1] <= win) a++;   // the last leaf whose code is <= the window (windows ascend with j)
+        lut3[at + j] = make_uint2(key[a], (uint32_t)len[a]);
+    }
+    lut2[p] = make_uint2(at, kHdSub3 | eb);
 }
 
 // The same second table for a decoder of a million leaves, built from the LEAVES' side (round 3: 2^24 entries by binary search were
@@ -123,10 +164,16 @@ struct HdSym { uint32_t key, len; };
 // the leaf of the 64-bit window `win` (its top 33 bits are stream bits, or all of it when WIDE)
 template <bool KEY>
 __device__ __forceinline__ HdSym hd_lookup(const HdTables &T, const uint32_t *lut_s, uint64_t win) {
-    const uint32_t e1 = lut_s[win >> (64 - kHdLut)];
-    if (e1) return HdSym{e1 >> 5, (e1 >> 1) & 15u};
+    if (T.use1) {
+        const uint32_t e1 = lut_s[win >> (64 - kHdLut)];
+        if (e1) return HdSym{e1 >> 5, (e1 >> 1) & 15u};
+    }
     const uint2 e = T.lut2[win >> (64 - T.bits2)];   // (a code longer than kHdLut bits exists, so the second table does)
     if (e.y & kHdDirect) return HdSym{e.x, e.y & 0xffu};
+    if (e.y & kHdSub3) {
+        const uint2 f = T.lut3[e.x + (uint32_t)((win << T.bits2) >> (64 - (e.y & 63u)))];
+        return HdSym{f.x, f.y};
+    }
     uint32_t a = e.x, b = e.x + e.y + 1;  // code[a] <= win; the answer is in [a, b)
     while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (T.code[m] <= win) a = m; else b = m; }
     return HdSym{KEY ? T.key[a] : 0u, (uint32_t)T.len[a]};
@@ -135,7 +182,8 @@ __device__ __forceinline__ HdSym hd_lookup(const HdTables &T, const uint32_t *lu
 // Block prologue: the first table and the block's stretch of the stream into LDS (stage[i] = word i of the stretch, MSB-first).
 // Returns the bit position (stream frame) of stage word 0.
 __device__ __forceinline__ uint64_t hd_stage(const HdStream &S, const uint32_t *__restrict__ lut_g, uint32_t *lut_s, uint32_t *stage) {
-    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut_s[i] = lut_g[i];
+    if (lut_g)
+        for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut_s[i] = lut_g[i];
     const uint64_t blk_bit = (uint64_t)blockIdx.x * kHdThreads * kHdSub;
     const int64_t w0 = (int64_t)(blk_bit / 32) - (int64_t)(kHdWarm / 32);   // negative for block 0: those words read as zero
     for (uint32_t i = threadIdx.x; i < kHdStageWords; i += kHdThreads) {
@@ -181,16 +229,23 @@ struct HdBits {
 
 // decode from `at` until the first symbol boundary at or past `until`; cnt (COUNT) = the symbols met on the way.
 // A symbol that would end past the stream's last bit ends the walk there (at = nbits): DecStream yields None.
-template <bool WIDE, bool COUNT>
+// STORE (round 5): the symbols met are KEPT -- symbol number i of the walk goes to col[64 i] while i < kHdKeep, col = the
+// subsequence's column of the kept-symbol rows (hd_keep_col) -- so that the decode that used to follow the offsets scan (every
+// subsequence once more, each lane writing its own 150 bytes somewhere: 2.5 bytes moved per byte written, profiles/traffic.json
+// round 5) becomes a copy (k_hd_compact).
+constexpr uint32_t kHdKeep = 64;   // symbols kept per subsequence (a 512-bit subsequence of codes shorter than 8 bits has more: those are decoded again)
+__device__ __forceinline__ uint32_t *hd_keep_col(uint32_t *keep, uint64_t t) { return keep + (t >> 6) * (uint64_t)(kHdKeep * 64) + (t & 63); }
+template <bool WIDE, bool COUNT, bool STORE = false>
 __device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s, const uint32_t *stage, uint64_t base, uint64_t nbits,
-                                       uint64_t &at, uint64_t until, uint32_t &cnt) {
+                                       uint64_t &at, uint64_t until, uint32_t &cnt, uint32_t *col = nullptr) {
     if (at >= until) return;
     HdBits<WIDE> B;
     B.seek(stage, (uint32_t)(at - base));
     while (at < until) {
         if (at >= nbits) { at = nbits; return; }
-        const HdSym sy = hd_lookup<false>(T, lut_s, B.window());
+        const HdSym sy = hd_lookup<STORE>(T, lut_s, B.window());
         if (at + sy.len > nbits) { at = nbits; return; }
+        if (STORE && cnt < kHdKeep) __builtin_nontemporal_store(sy.key, &col[(size_t)cnt * 64]);   // (read once, by another kernel: past the tables in the caches)
         if (COUNT) cnt++;
         at += sy.len;
         B.skip(sy.len);
@@ -218,20 +273,22 @@ constexpr int kHdRoundsShort = 24;
 __host__ inline uint32_t hd_hopeless_pct(uint64_t nsub) { return nsub <= (1ull << 16) ? 35u : nsub <= (1ull << 19) ? 60u : 97u; }
 constexpr uint64_t kHdPhasesMaxSub = 1ull << 16;   // streams of up to this many subsequences (4 MiB) go to k_hd_phase_maps when the blind checks have not settled them
 template <bool WIDE>
-__global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ end_prev,
+__global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg, uint64_t nsub, const uint64_t *__restrict__ end_prev,
                                                         uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
-                                                        uint32_t *__restrict__ changed, int max_rounds, uint32_t hopeless_min, uint32_t hopeless_pct) {
+                                                        uint32_t *__restrict__ changed, int max_rounds, uint32_t hopeless_min, uint32_t hopeless_pct,
+                                                        uint32_t *__restrict__ keep /* the kept-symbol rows (hd_keep_col), or null */) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
     // (hopeless_min != 0: pass 0 counts in changed[5] the blocks whose threads do not fall into step -- see the settle loop -- and once
     // that many have said so, the checks and the write behind it return at once: the host takes k_hd_phase_maps after its one look)
     if (hopeless_min && end_prev && changed[5] >= hopeless_min) return;
+    const HdTables &T = Tg;
     __shared__ unsigned long long s_end[kHdThreads], s_nstart[kHdThreads], s_nend[kHdThreads];
     __shared__ uint32_t s_ncnt[kHdThreads];
     __shared__ uint16_t s_list[kHdThreads];
     __shared__ uint32_t s_n;
     __shared__ unsigned long long s_pred0;
     uint32_t *lut_s = hd_lds;
-    uint32_t *stage = hd_lds + (1u << kHdLut);
+    uint32_t *stage = hd_lds + (T.use1 ? (1u << kHdLut) : 0u);   // (without the first table the launch brought LDS for the stream alone)
     static_assert(kHdSub - kHdWarm >= 32, "a warm-up never starts before the stream's first bit");
     const uint32_t tid = threadIdx.x;
     const uint64_t t0 = (uint64_t)blockIdx.x * kHdThreads, t = t0 + tid;
@@ -241,7 +298,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
     uint32_t my_cnt = 0;
     uint64_t pred0 = 0;      // where the thread before the block's first one ended (pass 0: not known yet -- the first thread trusts its warm-up)
     if (!end_prev) {
-        base = hd_stage(S, T.lut1, lut_s, stage);
+        base = hd_stage(S, T.use1 ? T.lut1 : nullptr, lut_s, stage);
         if (live) {
             uint64_t at = S.bit0;
             if (t) {       // warm-up: from kHdWarm bits before the subsequence to the first boundary inside it
@@ -250,7 +307,8 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
                 hd_run<WIDE, false>(T, lut_s, stage, base, S.nbits, at, lo, dummy);
             }
             my_start = at;
-            hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, my_cnt);
+            if (keep) hd_run<WIDE, true, true>(T, lut_s, stage, base, S.nbits, at, hi, my_cnt, hd_keep_col(keep, t));
+            else hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hi, my_cnt);
             my_end = at;
         }
         pred0 = my_start;    // (read by thread 0 only)
@@ -269,7 +327,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
             if (tid == 0 && nredo) { atomicAdd(&changed[3], (uint32_t)nredo); atomicAdd(&changed[4], 1u); }
             if (!nredo) return;
         } else if (!__syncthreads_or(redo)) return;
-        base = hd_stage(S, T.lut1, lut_s, stage);
+        base = hd_stage(S, T.use1 ? T.lut1 : nullptr, lut_s, stage);
     }
     // ---- the block settles itself
     s_end[tid] = live ? my_end : ~0ull;
@@ -308,7 +366,8 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables T, 
             uint64_t at = j ? s_end[j - 1] : s_pred0;
             uint32_t cn = 0;
             s_nstart[j] = at;
-            hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hj, cn);
+            if (keep) hd_run<WIDE, true, true>(T, lut_s, stage, base, S.nbits, at, hj, cn, hd_keep_col(keep, tj));
+            else hd_run<WIDE, true>(T, lut_s, stage, base, S.nbits, at, hj, cn);
             s_nend[j] = at;
             s_ncnt[j] = cn;
         }
@@ -337,11 +396,13 @@ constexpr uint32_t kHpGroups = 512;   // groups of subsequences whose maps k_hd_
 // (a subsequence is entered at most max_len - 1 bits past its start -- the overshoot of the symbol that straddles its boundary -- so
 // only `phases` = max(16, longest code) of the 32 are walked: a block's 1024 threads take 1024 / phases subsequences)
 constexpr uint32_t kHpSubsMax = 64, kHpThreads = 1024, kHpStageWords = kHpSubsMax * (kHdSub / 32) + kHdTail + 2;
-__global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTables T, uint64_t nsub, uint8_t *__restrict__ maps /* [nsub][32] */,
+__global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTables Tg, uint64_t nsub, uint8_t *__restrict__ maps /* [nsub][32] */,
                                                               uint16_t *__restrict__ cnts /* [nsub][32] */, uint32_t phases, uint32_t subs_per_block) {
+    const HdTables &T = Tg;
     __shared__ uint32_t lut_s[1u << kHdLut];
     __shared__ uint32_t stage[kHpStageWords];
-    for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHpThreads) lut_s[i] = T.lut1[i];
+    if (T.use1)
+        for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHpThreads) lut_s[i] = T.lut1[i];
     const uint64_t t0 = (uint64_t)blockIdx.x * subs_per_block, base = t0 * kHdSub, w0 = base / 32;
     const uint32_t nstage = subs_per_block * (kHdSub / 32) + kHdTail + 2;
     for (uint32_t i = threadIdx.x; i < nstage; i += kHpThreads) stage[i] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
@@ -393,16 +454,20 @@ __global__ __launch_bounds__(kHpGroups) void k_hd_phase_chain(const uint8_t *__r
 // Four symbols leave together (16 / 12 bytes at an aligned address) where the symbol index allows: a store per symbol is one
 // L2 request per lane, 16.7 M of them at 4096^2.
 template <bool WIDE, int MODE>
-__global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables T, uint64_t nsub, const uint64_t *__restrict__ start,
+__global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables Tg, uint64_t nsub, const uint64_t *__restrict__ start,
                                                          const uint64_t *__restrict__ off, uint64_t nsyms, void *__restrict__ out,
-                                                         const uint32_t *__restrict__ hopeless /* null, or the count and its bound: see k_hd_pass */, uint32_t hopeless_min) {
+                                                         const uint32_t *__restrict__ hopeless /* null, or the count and its bound: see k_hd_pass */, uint32_t hopeless_min,
+                                                         const uint32_t *__restrict__ only_long = nullptr /* counts: only the subsequences of more than kHdKeep symbols (the others were copied) */) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
     if (hopeless && *hopeless >= hopeless_min) return;
+    const HdTables &T = Tg;
     uint32_t *lut_s = hd_lds;
-    uint32_t *stage = hd_lds + (1u << kHdLut);
-    const uint64_t base = hd_stage(S, T.lut1, lut_s, stage);
+    uint32_t *stage = hd_lds + (T.use1 ? (1u << kHdLut) : 0u);
     const uint64_t t = (uint64_t)blockIdx.x * kHdThreads + threadIdx.x;
+    if (only_long && !__syncthreads_or(t < nsub && only_long[t] > kHdKeep)) return;   // (the rule: nobody -- nothing is staged)
+    const uint64_t base = hd_stage(S, T.use1 ? T.lut1 : nullptr, lut_s, stage);
     if (t >= nsub) return;
+    if (only_long && only_long[t] <= kHdKeep) return;
     const uint64_t hi = min((t + 1) * kHdSub, S.nbits);
     uint64_t at = start[t], idx = off[t], widx = idx;   // idx: next symbol to be stored, widx: next to be decoded
     if (at >= hi) return;
@@ -443,6 +508,65 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables T,
             dst[0] = w0; dst[1] = w1; dst[2] = w2;
         }
         idx += 4;
+    }
+}
+
+// The kept symbols to their places (round 5): block b = the subsequences [256 b, 256 b + 256), whose symbols are the output positions
+// [off[256 b], off[256 b + 256)) -- a thread per GROUP of four consecutive positions (16 / 12 bytes at an aligned address), the owner of
+// a position found by bisection of the block's 257 offsets in LDS, its symbol read from the owner's column: the loads of a wave fall on
+// the few rows its neighbours' lanes read too (cache), the stores are whole lines.  Subsequences of more than kHdKeep symbols are left
+// to k_hd_write(only_long).
+template <int MODE>
+__global__ __launch_bounds__(kHdThreads) void k_hd_compact(const uint32_t *__restrict__ keep, const uint64_t *__restrict__ off, const uint32_t *__restrict__ count, uint64_t nsub,
+                                                           uint64_t nsyms, void *__restrict__ out, const uint32_t *__restrict__ hopeless, uint32_t hopeless_min) {
+    if (hopeless && *hopeless >= hopeless_min) return;
+    __shared__ unsigned long long s_off[kHdThreads + 1];
+    __shared__ uint32_t s_cnt[kHdThreads];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kHdThreads;
+    const uint32_t nt = (uint32_t)min<uint64_t>(kHdThreads, nsub - t0), tid = threadIdx.x;
+    if (tid < nt) { s_off[tid] = off[t0 + tid]; s_cnt[tid] = count[t0 + tid]; }
+    __syncthreads();
+    if (tid == 0) s_off[nt] = s_off[nt - 1] + s_cnt[nt - 1];
+    __syncthreads();
+    const uint64_t lo = s_off[0], hi = min(s_off[nt], nsyms);   // (the reference reads exactly nsyms symbols; what the padding decodes to is dropped)
+    if (lo >= hi) return;
+    uint32_t *keys = static_cast<uint32_t *>(out);
+    uint8_t *rgb = static_cast<uint8_t *>(out);
+    for (uint64_t g = (lo >> 2) + tid; g * 4 < hi; g += kHdThreads) {
+        const uint64_t p0 = g * 4;
+        uint32_t k[4] = {0, 0, 0, 0};
+        bool have[4] = {false, false, false, false};
+        // owner of the group's first position inside the block: the last subsequence whose offset is <= it (empty ones share an offset: the last wins)
+        uint32_t a = 0, b = nt;
+        const uint64_t pf = max(p0, lo);
+        while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (s_off[m] <= pf) a = m; else b = m; }
+        uint32_t own = a;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t p = p0 + u;
+            if (p < lo || p >= hi) continue;
+            while (p >= s_off[own + 1]) own++;          // (p < s_off[nt]: ends at a subsequence that holds it)
+            if (s_cnt[own] > kHdKeep) continue;         // decoded again by k_hd_write(only_long)
+            k[u] = hd_keep_col(const_cast<uint32_t *>(keep), t0 + own)[(size_t)(p - s_off[own]) * 64];
+            have[u] = true;
+        }
+        if (have[0] && have[1] && have[2] && have[3]) {
+            if (MODE == 0) *reinterpret_cast<uint4 *>(keys + p0) = make_uint4(k[0], k[1], k[2], k[3]);
+            else {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(rgb + 3 * p0);
+                dst[0] = ((k[0] >> 16) & 255) | (((k[0] >> 8) & 255) << 8) | ((k[0] & 255) << 16) | (((k[1] >> 16) & 255) << 24);
+                dst[1] = ((k[1] >> 8) & 255) | ((k[1] & 255) << 8) | (((k[2] >> 16) & 255) << 16) | (((k[2] >> 8) & 255) << 24);
+                dst[2] = (k[2] & 255) | (((k[3] >> 16) & 255) << 8) | (((k[3] >> 8) & 255) << 16) | ((k[3] & 255) << 24);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!have[u]) continue;
+                const uint64_t p = p0 + u;
+                if (MODE == 0) keys[p] = k[u];
+                else { rgb[3 * p] = (uint8_t)(k[u] >> 16); rgb[3 * p + 1] = (uint8_t)(k[u] >> 8); rgb[3 * p + 2] = (uint8_t)k[u]; }
+            }
+        }
     }
 }
 
@@ -507,11 +631,17 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     // `hufman` 4096^2 (6.8 M leaves) 7.0 / 5.3 / 4.6 / 4.6 ms with 20 / 22 / 24 / 26.  CNIIC_HD_LUT2_BITS: the cap, for measurements.
     const uint32_t cap2 = test_env("CNIIC_HD_LUT2_BITS") ? (uint32_t)atoi(test_env("CNIIC_HD_LUT2_BITS")) : (n >= (1u << 20) ? 24u : 18u);
     const uint32_t bits2 = max_len > (uint32_t)kHdLut ? std::min<uint32_t>(max_len, std::max(cap2, (uint32_t)kHdLut + 1)) : 0u;
-    DevBuf lut1_d, lut2_d;
+    DevBuf lut1_d, lut2_d, lut3_d, cnt_d;
     CNIIC_HIP_TRY(c, lut1_d.alloc((4ull << kHdLut)));
-    HdTables T{reinterpret_cast<const uint64_t *>(tab_d), reinterpret_cast<const uint32_t *>(tab_d + off_key), tab_d + off_len, lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n};
-    hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << kHdLut) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, (uint32_t)kHdLut, lut1_d.as<uint32_t>(),
-                       (uint2 *)nullptr);
+    CNIIC_HIP_TRY(c, cnt_d.alloc(4));   // the third tables' cursor
+    CNIIC_HIP_TRY(c, hipMemsetAsync(cnt_d.p, 0, 4, c->stream));
+    bool use1 = hd_use_first_table(payload_bytes * 8, nsyms, bits2);
+    if (const char *e = test_env("CNIIC_HD_LUT1")) use1 = bits2 == 0 || atoi(e) != 0;   // (tests: either way round)
+    HdTables T{reinterpret_cast<const uint64_t *>(tab_d), reinterpret_cast<const uint32_t *>(tab_d + off_key), tab_d + off_len, lut1_d.as<uint32_t>(), nullptr, bits2, (uint32_t)n,
+               nullptr, use1 ? 1u : 0u};
+    if (use1)
+        hipLaunchKernelGGL(k_hd_build_lut, dim3((1u << kHdLut) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, T.n, (uint32_t)kHdLut, lut1_d.as<uint32_t>(),
+                           (uint2 *)nullptr);
     DevBuf lo_d, big_d;
     if (bits2) {
         CNIIC_HIP_TRY(c, lut2_d.alloc(8ull << bits2));
@@ -531,6 +661,14 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
                                lut2_d.as<uint2>());
         }
         T.lut2 = lut2_d.as<uint2>();
+        if (!(test_env("CNIIC_HD_LUT3") && !atoi(test_env("CNIIC_HD_LUT3")))) {   // the third tables (k_hd_build_lut3) out of a pool of 4 n + 2^16 entries, 2^24 at most
+            const uint32_t cap3 = (uint32_t)std::min<uint64_t>(4 * n + 65536, 1ull << 24);
+            if (lut3_d.alloc((uint64_t)cap3 * 8) == hipSuccess) {
+                hipLaunchKernelGGL(k_hd_build_lut3, dim3((1u << bits2) / 256), dim3(256), 0, c->stream, T.code, T.key, T.len, bits2, lut2_d.as<uint2>(), lut3_d.as<uint2>(), cap3,
+                                   cnt_d.as<uint32_t>());
+                T.lut3 = lut3_d.as<uint2>();
+            } else (void)hipGetLastError();
+        }
     }
     CNIIC_HIP_TRY(c, hipGetLastError());
     const LeafMeta lt{max_len};
@@ -551,7 +689,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4096;   // (slots of this function's own) [0] total symbols, [1] did the last pass move an end?
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
-    const size_t lds = kHdLds;
+    const size_t lds = use1 ? kHdLds : (size_t)kHdStageWords * 4;
     const bool wide = lt.max_len > 32;
     const char *ph_env = test_env("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
     const bool phases_ok = !wide && !(ph_env && !atoi(ph_env)), phases_force = phases_ok && ph_env && atoi(ph_env);
@@ -563,14 +701,39 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     // to the phase maps -- instead of three passes that cure one subsequence a round first (1024^2 photograph, `hufman`: 3.2 -> 1.6 ms)
     const uint32_t hopeless_pct = test_env("CNIIC_HD_HOPELESS_PCT") ? (uint32_t)atoi(test_env("CNIIC_HD_HOPELESS_PCT")) : hd_hopeless_pct(nsub);   // (0: no such verdict)
     const uint32_t hopeless_min = phases_ok && !phases_force && hopeless_pct ? std::max(1u, grid / 4) : 0u;
+    // the symbols the passes meet are kept (hd_run<STORE>): kHdKeep words per subsequence, 4 x the payload; without the memory for it
+    // (or CNIIC_HD_KEEP=0, testing build) the write decodes everything once more, as until round 4.  Only streams whose subsequences
+    // hold 48 symbols on average at most: the 8-bit codes of 256 cluster colours put 65 into 512 bits, every other subsequence would be
+    // decoded again anyway and the kept rows were a loss (4096^2 cluster-colors: 0.30 -> 0.38 ms).  CNIIC_HD_KEEP=1: whatever the average.
+    DevBuf keep_d;
+    uint32_t *keep_p = nullptr;
+    const bool keep_forced = test_env("CNIIC_HD_KEEP") && atoi(test_env("CNIIC_HD_KEEP"));
+    if (!(test_env("CNIIC_HD_KEEP") && !atoi(test_env("CNIIC_HD_KEEP"))) && (keep_forced || nsyms * kHdSub <= payload_bytes * 8 * 48)) {
+        if (keep_d.alloc(ceil_div(nsub, 64) * (uint64_t)(kHdKeep * 64) * 4) == hipSuccess) keep_p = keep_d.as<uint32_t>();
+        else (void)hipGetLastError();
+    }
     auto pass = [&](const uint64_t *prev, uint64_t *cur) {
-        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds, 0u, 0u);
-        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), pass_rounds, hopeless_min, hopeless_pct);
+        if (wide) hipLaunchKernelGGL(k_hd_pass<true>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), kHdMaxRounds, 0u, 0u, keep_p);
+        else hipLaunchKernelGGL(k_hd_pass<false>, dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, prev, cur, start_d.as<uint64_t>(), count.as<uint32_t>(), changed.as<uint32_t>(), pass_rounds, hopeless_min, hopeless_pct, keep_p);
     };
-    auto write = [&](bool guarded) -> int {   // guarded: nothing to write if pass 0 has given the stream up
+    auto write = [&](bool guarded, bool kept) -> int {   // guarded: nothing to write if pass 0 has given the stream up; kept: the passes' symbols stand in keep_d
         CNIIC_TRY(pack_scan(c, count.as<uint32_t>(), (uint32_t)nsub, off.as<uint64_t>(), tot.as<uint64_t>()));
         const uint64_t *st = start_d.as<uint64_t>(), *of = off.as<uint64_t>();
         const uint32_t *hp = guarded && hopeless_min ? changed.as<uint32_t>() + 5 : nullptr;
+        if (kept && keep_p) {   // a copy, and one more decode of the few subsequences of more than kHdKeep symbols
+            const uint32_t *cn = count.as<uint32_t>();
+            if (mode == 0) hipLaunchKernelGGL(k_hd_compact<0>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min);
+            else hipLaunchKernelGGL(k_hd_compact<1>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min);
+            if (wide) {
+                if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn);
+                else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn);
+            } else {
+                if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn);
+                else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn);
+            }
+            CNIIC_HIP_TRY(c, hipGetLastError());
+            return CNIIC_OK;
+        }
         if (wide) {
             if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u);
             else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u);
@@ -614,14 +777,14 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         }
         t1.stop();
         ScopedKernelTimer t2(c, "hd_write");
-        CNIIC_TRY(write(true));
+        CNIIC_TRY(write(true, true));
         t2.stop();
     }
     CNIIC_TRY(look());
     auto phases = [&]() -> int {   // every phase of every subsequence (see k_hd_phase_maps) -> start_d, count
         DevBuf maps_d, cnts_d;
-        CNIIC_HIP_TRY(c, maps_d.alloc(nsub * 32));
-        CNIIC_HIP_TRY(c, cnts_d.alloc(nsub * 64));
+        // (96 bytes a subsequence: 400 MB for a 256 MiB payload.  Without the memory the caller decodes on the host -- slow, not an error)
+        if (maps_d.alloc(nsub * 32) != hipSuccess || cnts_d.alloc(nsub * 64) != hipSuccess) { (void)hipGetLastError(); *status = 2; return CNIIC_OK; }
         const uint32_t nph = std::min(32u, std::max(16u, lt.max_len)), spb = kHpThreads / nph;   // (the other entries of a map are never asked for)
         CNIIC_HIP_TRY(c, hipMemsetAsync(maps_d.p, 0, nsub * 32, c->stream));
         hipLaunchKernelGGL(k_hd_phase_maps, dim3((uint32_t)ceil_div(nsub, (uint64_t)spb)), dim3(kHpThreads), 0, c->stream, S, T, nsub, maps_d.as<uint8_t>(), cnts_d.as<uint16_t>(), nph, spb);
@@ -631,7 +794,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
                            (uint32_t)S.bit0, start_d.as<uint64_t>(), count.as<uint32_t>());
         CNIIC_HIP_TRY(c, hipGetLastError());
         if (hd_stats) fprintf(stderr, "[hd] not in step: every phase of every subsequence\n");
-        CNIIC_TRY(write(false));
+        CNIIC_TRY(write(false, false));   // (the maps count; they keep nothing)
         CNIIC_TRY(look());
         return CNIIC_OK;
     };
@@ -639,6 +802,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     if (hd_stats) fprintf(stderr, "[hd] blocks of pass 0 that did not fall into step: %u of %u%s\n", (uint32_t)pin[2], grid, hopeless ? " -- given up" : "");
     if (hopeless || (phases_first && ((uint32_t)pin[1] || phases_force))) {
         CNIIC_TRY(phases());   // not in step after the blind checks: no more checks one subsequence at a time
+        if (*status == 2) return CNIIC_OK;
     } else if ((uint32_t)pin[1]) {
         bool settled = false;
         for (int r = kHdBlindChecks; r < kHdMaxPasses; r++) {
@@ -650,8 +814,8 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
             if (!(uint32_t)pin[1]) { settled = true; break; }
         }
         if (!settled && !phases_ok) { *status = 2; return CNIIC_OK; }
-        if (!settled) CNIIC_TRY(phases());   // (a long stream that kHdMaxPasses checks have not settled)
-        else { CNIIC_TRY(write(false)); CNIIC_TRY(look()); }
+        if (!settled) { CNIIC_TRY(phases()); if (*status == 2) return CNIIC_OK; }   // (a long stream that kHdMaxPasses checks have not settled)
+        else { CNIIC_TRY(write(false, true)); CNIIC_TRY(look()); }
     }
     if (pin[0] < nsyms) { *status = 1; return CNIIC_OK; }
     return CNIIC_OK;

@@ -249,3 +249,57 @@ def test_rle_zero_count_records_behind_the_image_are_never_walked(env, shape, ze
     assert O.decode("hilbert(rle)", bytes(bad))[0] != 0
     rc, _ = ctx.decode("hilbert(rle)", bytes(bad), allow=(-6,))
     assert rc != 0
+
+
+@pytest.mark.parametrize("keep", ["0", "1"])
+@pytest.mark.parametrize("lut3", ["0", "1"])
+@pytest.mark.parametrize("lut1", ["0", "1"])
+@pytest.mark.parametrize("expr,shape", [("delta", (300, 420)), ("hufman", (256, 320)), ("cluster-colors(200)", (240, 320)), ("hilbert(rle)", (128, 200))])
+def test_decoder_routes_round_5(env, monkeypatch, expr, shape, keep, lut3, lut1):
+    """the parallel decoder with and without its kept symbols (CNIIC_HD_KEEP: the passes' symbols copied to their places by k_hd_compact,
+    subsequences of more than 64 symbols decoded again -- the 8-bit codes of `cluster-colors` are mostly those) and with and without the
+    third tables (CNIIC_HD_LUT3: codes beyond the second table's bits resolved by one more read), with the first table in LDS or
+    without it (CNIIC_HD_LUT1: long-coded streams go straight to the second table and the blocks take half the LDS): the oracle's
+    pixels on every route"""
+    ctx, torch, dev = env
+    from cniic_amd import _lib, synth
+    monkeypatch.setenv("CNIIC_HD_KEEP", keep)
+    monkeypatch.setenv("CNIIC_HD_LUT3", lut3)
+    monkeypatch.setenv("CNIIC_HD_LUT1", lut1)
+    h, w = shape
+    img = synth.photo(w, h, synth.SEED0 + 31 + h)
+    rc, data, _ = ctx.encode(expr, img)
+    rco, exp = O.decode(expr, data)
+    assert rc == 0 and rco == 0
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        out = torch.zeros(h * w * 3 + 16, dtype=torch.uint8, device=dev)
+        rc, dw, dh = ctx.decode_into(expr, buf, len(data), out)
+        assert rc == 0 and (dw, dh) == (w, h)
+        assert np.array_equal(out[:h * w * 3].cpu().numpy().reshape(h, w, 3), exp)
+        assert not out[h * w * 3:].any()
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
+
+
+def test_kept_symbols_with_long_and_short_subsequences(env, monkeypatch):
+    """a stream whose subsequences hold far more than 64 symbols in places (flat areas: 1- and 2-bit codes) and few elsewhere (noise):
+    the copy and the second decode of the long ones share the output"""
+    ctx, torch, dev = env
+    from cniic_amd import _lib
+    monkeypatch.setenv("CNIIC_HD_KEEP", "1")
+    rng = np.random.default_rng(11)
+    img = np.zeros((256, 384, 3), np.uint8)
+    img[:, :128] = 40                                              # flat
+    img[:, 128:256] = rng.integers(0, 256, (256, 128, 3))          # noise
+    img[:, 256:] = (np.arange(128)[None, :, None] // 8 * 8).astype(np.uint8)   # steps
+    ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, 0)
+    try:
+        for expr in ("delta", "hufman"):
+            rc, data, _ = ctx.encode(expr, img)
+            assert rc == 0
+            rc, back = ctx.decode(expr, data)
+            assert rc == 0 and np.array_equal(back, img), expr
+    finally:
+        ctx.set_opt(_lib.OPT_GPU_DECODE_MIN, None)
