@@ -1093,6 +1093,7 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         const bool dst_dev = is_device_ptr(rgb_out);
         int status = 2;
         DevBuf keys_d, lin_d, img_d, stream_up, tab_big;
+        UdSums ud_sums;   // (delta: FromDiff's chunk sums, when the decoder added them up on its way)
         uint8_t *dst = rgb_out;
         auto need_image = [&]() -> int {   // where the pixels are produced: the caller's image if it is in HBM and word-aligned
             if (!img_d.p && (!dst_dev || (reinterpret_cast<uintptr_t>(rgb_out) & 3))) { CNIIC_HIP_TRY(c, img_d.alloc(n * 3)); dst = img_d.as<uint8_t>(); }
@@ -1145,7 +1146,7 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
                         CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
                     }
                     CNIIC_TRY(huff_decode_tables_dev(c, tab_big.as<uint8_t>(), nl, off_key, off_len, max_len, key0, sd + ppos, true, nbytes - ppos, n,
-                                                     delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+                                                     delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status, delta ? &ud_sums : nullptr));
                     done_dev = status != 2;
                 }
             }
@@ -1167,10 +1168,11 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
                 // symbols on the GPU (parallel, self-synchronising), straight from the stream where it lies; small inputs and codes
                 // that do not settle go through the host walk (same answers)
                 if (n >= gpu_decode_min_symbols(c))
-                    CNIIC_TRY(huff_decode_dev(c, lt, bytes + tpos, bytes_dev, nbytes - tpos, n, delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status));
+                    CNIIC_TRY(huff_decode_dev(c, lt, bytes + tpos, bytes_dev, nbytes - tpos, n, delta ? 0 : 1, delta ? keys_d.p : (void *)dst, &status, delta ? &ud_sums : nullptr));
             }
         }
         if (status == 2) {  // the node walk on the host: needs the whole stream there
+            ud_sums.filled = false;
             if (bytes_dev) head.n = 0;  // (the pinned block the head was fetched into has served other purposes since: fetch again)
             CNIIC_TRY(stream_head(c, bytes, bytes_dev, nbytes, nbytes, &head));
             std::vector<TrieNode> trie;
@@ -1192,7 +1194,7 @@ int codec_decode(Ctx *c, const CodecDesc &d, const uint8_t *bytes, uint64_t nbyt
         if (delta) {
             uint32_t bad = 0;  // START (hilbertc.rs:445); FromDiff (hilbertc.rs:496-508); then follow the traversal (hilbertc.rs:426-428)
             ScopedKernelTimer tu(c, "undiff_scatter");
-            CNIIC_TRY(delta_undiff_scatter_dev(c, keys_d.as<uint32_t>(), *w, *h, dst, &bad));
+            CNIIC_TRY(delta_undiff_scatter_dev(c, keys_d.as<uint32_t>(), *w, *h, dst, &bad, &ud_sums));
             tu.stop();
             if (bad) return c->fail(CNIIC_ERR_DECODE, "delta: colour out of range (hilbertc.rs:505)");
         }

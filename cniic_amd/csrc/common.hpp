@@ -590,19 +590,20 @@ constexpr uint32_t kNumCells = kCellsPerDim * kCellsPerDim * kCellsPerDim;  // 3
 
 // ---- k_hdecode.hip: parallel Huffman decode (self-synchronising subsequences), keys -> pixels, FromDiff as a scan ----
 struct LeafTable;
+struct UdSums { DevBuf buf; bool filled = false; };   // FromDiff's channel sums per 4096 symbols, added up by the decoder while it writes them (k_hdecode.hip)
 // payload in host memory, or (payload_dev) anywhere in HBM; mode 0: out_d = nsyms packed keys (u32, 16-byte aligned), mode 1: nsyms RGB
 // triples (4-byte aligned).  status: 0 ok, 1 stream ends early, 2 did not settle (decode on the host)
 int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
-                    int mode, void *out_d, int *status);
+                    int mode, void *out_d, int *status, UdSums *sums = nullptr);
 // ... with the table of leaves already in HBM (code u64[n] | key u32[n] at off_key | len u8[n] at off_len)
 int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t off_key, uint64_t off_len, uint32_t max_len, uint32_t first_key,
-                           const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms, int mode, void *out_d, int *status);
+                           const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms, int mode, void *out_d, int *status, UdSums *sums = nullptr);
 // k_trieparse.hip: Dec::deserialize on the GPU (decoders of millions of leaves).  status: 0 ok, 1 malformed / truncated, 2 too deep
 int huff_parse_leaves_dev(Ctx *c, int sym_kind, const uint8_t *stream_d, uint64_t nbytes, uint64_t pos0, DevBuf *tab, uint64_t *n_leaves,
                           uint64_t *off_key, uint64_t *off_len, uint32_t *max_len, uint64_t *payload_pos, int *status);
 int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d);
 int delta_undiff_dev(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *lin_d, uint32_t *bad_h);
-int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h);  // + the walk along the scan
+int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h, UdSums *sums = nullptr);  // + the walk along the scan
 
 // ---- k_rle.hip: exact run-length coding of a linearised image (hilbertc.rs:100-196) ----
 struct RlePlan { uint64_t n = 0, nruns = 0; uint32_t nchunks = 0; DevBuf flags, run_off; };

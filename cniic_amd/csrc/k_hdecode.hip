@@ -4,7 +4,7 @@
 // The stream has no markers, so where a symbol starts is only known by decoding everything before it.  Huffman
 // codes resynchronise: a decoder started at a wrong bit position falls into step with the true symbol
 // boundaries after a few symbols.  The payload is cut into subsequences of kHdSub bits, one per thread:
-//   pass 0      every thread starts kHdWarm bits BEFORE its subsequence (a guess; exact for thread 0), decodes up to the
+//   pass 0      every thread starts `warm` bits BEFORE its subsequence (a guess; exact for thread 0), decodes up to the
 //               first symbol boundary inside it -- by then it has almost always fallen into step -- and notes that boundary
 //               (start[t]); then on to the first boundary at or past the subsequence's end (end[t]), counting the symbols
 //               that start in between
@@ -30,7 +30,7 @@ namespace cniic {
 
 constexpr int kHdLut = 12;
 constexpr uint32_t kHdSub = 512;        // bits per thread: short enough that a 4096^2 image fills the machine (2.6 x 10^5 threads for 16 MB)
-constexpr uint32_t kHdWarm = 128;       // bits of warm-up before the subsequence (a multiple of 32)
+constexpr uint32_t kHdWarm = 480;       // bits staged before a block's first subsequence (a multiple of 32): the longest warm-up a launch may ask for (HdStream::warm)
 constexpr int kHdThreads = 256;
 constexpr int kHdMaxPasses = 48;
 constexpr int kHdBlindChecks = 2;
@@ -40,9 +40,15 @@ constexpr uint32_t kHd3MaxBits = 6;           // third tables of up to 2^6 entri
 constexpr uint32_t kHd3MaxLeaves = 96;        // leaves under a prefix its builder is willing to walk
 constexpr uint32_t kHdTail = 4;               // words staged past the block's last subsequence (a symbol may run kLeafMaxLen bits over)
 constexpr uint32_t kHdStageWords = kHdThreads * (kHdSub / 32) + kHdWarm / 32 + kHdTail;
+// The staged stream is kept TRANSPOSED (round 5): word i of the stretch at (i mod 16) x kHdSwz + i / 16.  Thread t reads the words
+// 16 t + k of its own subsequence; word for word in stream order the 64 lanes of a wave -- each topping up its window from its own
+// subsequence -- hit two of the LDS's banks, a 32-way conflict on every read of every step (per block of pass 0: 47 us for 45 symbols, 24
+// waves a CU queueing for the one LDS).  Transposed, lanes t, t + 1, ... at the same k read neighbouring words.
+constexpr uint32_t kHdSwz = kHdStageWords / 16 + 1, kHdStageAlloc = 16 * kHdSwz;
+template <uint32_t SWS> __device__ __forceinline__ uint32_t hd_sw(uint32_t i) { return (i & 15u) * SWS + (i >> 4); }
 // first table (LDS, 4 bytes an entry -- an 8-byte entry per lane is two LDS passes and twice the footprint): a code of up to
 // kHdLut bits answers key << 5 | length << 1 | 1 (keys have at most 27 bits); anything longer answers 0 and goes to the second table
-constexpr size_t kHdLds = (4u << kHdLut) + kHdStageWords * 4;   // 16 KiB + 16.5 KiB: four blocks per CU
+constexpr size_t kHdLds = (4u << kHdLut) + kHdStageAlloc * 4;   // 16 KiB + 16.5 KiB
 
 struct HdTables {
     const uint64_t *code;   // [n] left-aligned codes, ascending
@@ -70,6 +76,7 @@ struct HdStream {
     const uint32_t *w;
     uint64_t nwords;   // words that may be read
     uint64_t bit0, nbits;
+    uint32_t warm;     // bits of warm-up before a subsequence in pass 0 (at most kHdWarm)
 };
 
 // table entries for the `bits` top bits p: all 64-bit windows that begin with p lie between base and top
@@ -186,9 +193,22 @@ __device__ __forceinline__ uint64_t hd_stage(const HdStream &S, const uint32_t *
         for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHdThreads) lut_s[i] = lut_g[i];
     const uint64_t blk_bit = (uint64_t)blockIdx.x * kHdThreads * kHdSub;
     const int64_t w0 = (int64_t)(blk_bit / 32) - (int64_t)(kHdWarm / 32);   // negative for block 0: those words read as zero
-    for (uint32_t i = threadIdx.x; i < kHdStageWords; i += kHdThreads) {
+    // (every word of the thread asked for before the first one is waited for: as a loop of load, swap, store the seventeen round trips
+    // to memory came one behind the other, 11 us of a block's 146)
+    constexpr uint32_t PER = (kHdStageWords + kHdThreads - 1) / kHdThreads;
+    uint32_t wv[PER];
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+        const uint32_t i = threadIdx.x + r * kHdThreads;
         const int64_t wi = w0 + i;
-        stage[i] = (wi >= 0 && (uint64_t)wi < S.nwords) ? __builtin_bswap32(S.w[wi]) : 0u;
+        const bool in = i < kHdStageWords && wi >= 0 && (uint64_t)wi < S.nwords;
+        wv[r] = S.w[in ? wi : 0];   // (word 0 exists: the payload is not empty; what must read as zero is zeroed below)
+        if (!in) wv[r] = 0u;
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < PER; r++) {
+        const uint32_t i = threadIdx.x + r * kHdThreads;
+        if (i < kHdStageWords) stage[hd_sw<kHdSwz>(i)] = __builtin_bswap32(wv[r]);
     }
     __syncthreads();
     return (uint64_t)(w0 * 32);  // (two's complement: position - base stays right for block 0)
@@ -197,27 +217,28 @@ __device__ __forceinline__ uint64_t hd_stage(const HdStream &S, const uint32_t *
 // A thread's view of the staged stream: the next bits left-aligned in a register, topped up a word at a time -- one LDS read per
 // 32 bits consumed instead of two or three per symbol.  WIDE (codes of more than 32 bits): the window is rebuilt from three
 // words for every symbol, all 64 bits valid.
-template <bool WIDE>
+template <bool WIDE, uint32_t SWS = kHdSwz>
 struct HdBits {
     const uint32_t *stage;
     uint64_t buf;      // !WIDE: bits from position `at`, the top nb of them valid
     uint32_t nb, wi;
     uint32_t rel;      // WIDE: at - base
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return stage[hd_sw<SWS>(i)]; }
     __device__ __forceinline__ void seek(const uint32_t *st, uint32_t r) {
         stage = st;
         if (WIDE) { rel = r; return; }
         const uint32_t i = r >> 5, s = r & 31;
-        buf = (((uint64_t)stage[i] << 32) | stage[i + 1]) << s;
+        buf = (((uint64_t)word(i) << 32) | word(i + 1)) << s;
         nb = 64 - s;
         wi = i + 2;
     }
     __device__ __forceinline__ uint64_t window() {
         if (WIDE) {
             const uint32_t i = rel >> 5, s = rel & 31;
-            const uint64_t hi = ((uint64_t)stage[i] << 32) | stage[i + 1];
-            return s ? (hi << s) | (stage[i + 2] >> (32 - s)) : hi;
+            const uint64_t hi = ((uint64_t)word(i) << 32) | word(i + 1);
+            return s ? (hi << s) | (word(i + 2) >> (32 - s)) : hi;
         }
-        if (nb < 33) { buf |= (uint64_t)stage[wi++] << (32 - nb); nb += 32; }
+        if (nb < 33) { buf |= (uint64_t)word(wi++) << (32 - nb); nb += 32; }
         return buf;
     }
     __device__ __forceinline__ void skip(uint32_t len) {
@@ -234,22 +255,33 @@ struct HdBits {
 // subsequence once more, each lane writing its own 150 bytes somewhere: 2.5 bytes moved per byte written, profiles/traffic.json
 // round 5) becomes a copy (k_hd_compact).
 constexpr uint32_t kHdKeep = 64;   // symbols kept per subsequence (a 512-bit subsequence of codes shorter than 8 bits has more: those are decoded again)
-__device__ __forceinline__ uint32_t *hd_keep_col(uint32_t *keep, uint64_t t) { return keep + (t >> 6) * (uint64_t)(kHdKeep * 64) + (t & 63); }
-template <bool WIDE, bool COUNT, bool STORE = false>
+// The rows of a wave's 64 subsequences: symbols 4 g .. 4 g + 3 of subsequence t as ONE 16-byte group at [t / 64][g][t % 64] -- a lane stores
+// a group every fourth symbol (a wave: 1 KiB in one piece).  A store per symbol cost more than its instruction: stores count in vmcnt
+// like loads on gfx9, so the wait for the NEXT symbol's table entry was also a wait for the previous symbol's store to be acknowledged.
+typedef uint32_t hd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t *hd_keep_col(uint32_t *keep, uint64_t t) { return keep + (t >> 6) * (uint64_t)(kHdKeep * 64) + (t & 63) * 4; }
+__device__ __forceinline__ uint32_t hd_keep_at(uint32_t j) { return (j >> 2) * 256u + (j & 3u); }   // symbol j of a subsequence, from its hd_keep_col
+template <bool WIDE, bool COUNT, bool STORE = false, uint32_t SWS = kHdSwz>
 __device__ __forceinline__ void hd_run(const HdTables &T, const uint32_t *lut_s, const uint32_t *stage, uint64_t base, uint64_t nbits,
                                        uint64_t &at, uint64_t until, uint32_t &cnt, uint32_t *col = nullptr) {
     if (at >= until) return;
-    HdBits<WIDE> B;
+    HdBits<WIDE, SWS> B;
     B.seek(stage, (uint32_t)(at - base));
+    uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     while (at < until) {
-        if (at >= nbits) { at = nbits; return; }
+        if (at >= nbits) { at = nbits; break; }
         const HdSym sy = hd_lookup<STORE>(T, lut_s, B.window());
-        if (at + sy.len > nbits) { at = nbits; return; }
-        if (STORE && cnt < kHdKeep) __builtin_nontemporal_store(sy.key, &col[(size_t)cnt * 64]);   // (read once, by another kernel: past the tables in the caches)
+        if (at + sy.len > nbits) { at = nbits; break; }
+        if (STORE) {
+            const uint32_t q = cnt & 3u;
+            k0 = q == 0 ? sy.key : k0; k1 = q == 1 ? sy.key : k1; k2 = q == 2 ? sy.key : k2; k3 = q == 3 ? sy.key : k3;
+            if (q == 3 && cnt < kHdKeep) __builtin_nontemporal_store(hd_u32x4{k0, k1, k2, k3}, reinterpret_cast<hd_u32x4 *>(col + (size_t)(cnt >> 2) * 256));
+        }
         if (COUNT) cnt++;
         at += sy.len;
         B.skip(sy.len);
     }
+    if (STORE && (cnt & 3u) && cnt < kHdKeep) __builtin_nontemporal_store(hd_u32x4{k0, k1, k2, k3}, reinterpret_cast<hd_u32x4 *>(col + (size_t)(cnt >> 2) * 256));   // the last, partial group
 }
 
 // pass 0 (end_prev == null) and the checking passes.
@@ -272,6 +304,16 @@ constexpr int kHdRoundsShort = 24;
 // different colours, 51 ms for a ramp.  A list that has kept 97 per cent of its length over three rounds is such a stream at any size.
 __host__ inline uint32_t hd_hopeless_pct(uint64_t nsub) { return nsub <= (1ull << 16) ? 35u : nsub <= (1ull << 19) ? 60u : 97u; }
 constexpr uint64_t kHdPhasesMaxSub = 1ull << 16;   // streams of up to this many subsequences (4 MiB) go to k_hd_phase_maps when the blind checks have not settled them
+// -DCNIIC_HD_PHASES (a measuring build, tools/build_variant.sh): per block of pass 0, thread 0's wall clock (100 MHz) spent staging, in the
+// first decode (until the whole block is through it), in the settle rounds, and the number of rounds; summed over the blocks
+#ifdef CNIIC_HD_PHASES
+__device__ unsigned long long g_hd_phase[8];
+#define HD_T(i) do { if (threadIdx.x == 0 && !end_prev) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_hd_phase[i], now_ - t_ph_); t_ph_ = now_; } } while (0)
+#define HD_C(i, v) do { if (threadIdx.x == 0 && !end_prev) atomicAdd(&g_hd_phase[i], (unsigned long long)(v)); } while (0)
+#else
+#define HD_T(i) do {} while (0)
+#define HD_C(i, v) do {} while (0)
+#endif
 template <bool WIDE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg, uint64_t nsub, const uint64_t *__restrict__ end_prev,
                                                         uint64_t *__restrict__ end_out, uint64_t *__restrict__ start, uint32_t *__restrict__ count,
@@ -297,12 +339,16 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg,
     uint64_t my_start = 0, my_end = 0, base = 0;
     uint32_t my_cnt = 0;
     uint64_t pred0 = 0;      // where the thread before the block's first one ended (pass 0: not known yet -- the first thread trusts its warm-up)
+#ifdef CNIIC_HD_PHASES
+    unsigned long long t_ph_ = wall_clock64();
+#endif
     if (!end_prev) {
         base = hd_stage(S, T.use1 ? T.lut1 : nullptr, lut_s, stage);
+        HD_T(0);
         if (live) {
             uint64_t at = S.bit0;
             if (t) {       // warm-up: from kHdWarm bits before the subsequence to the first boundary inside it
-                at = t * kHdSub - kHdWarm;
+                at = t * kHdSub - S.warm;
                 uint32_t dummy = 0;
                 hd_run<WIDE, false>(T, lut_s, stage, base, S.nbits, at, lo, dummy);
             }
@@ -341,12 +387,14 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg,
     for (int round = 0; round < max_rounds; round++) {
         if (tid == 0) s_n = 0;
         __syncthreads();                                   // s_end of the round before is in place
+        if (round == 0) HD_T(1); else HD_T(2);
         const uint64_t pred = tid ? s_end[tid - 1] : s_pred0;
         const bool redo = live && pred != my_start;
         if (redo) s_list[atomicAdd(&s_n, 1u)] = (uint16_t)tid;
         __syncthreads();
         const uint32_t nl = s_n;
-        if (nl == 0) { gave_up = false; break; }
+        HD_C(4, nl);
+        if (nl == 0) { gave_up = false; HD_C(3, round); HD_C(5, 1); break; }
         // Does this stream fall into step at all?  Every round re-decodes the listed subsequences from where their predecessors ended; on
         // an ordinary stream that cures four in five of them, on a near-fixed-length code next to none, and the loop becomes a chain of
         // one cure per round.  Curing a fraction p per round costs list / p decodes and ln(list) / p rounds per pass, the phase maps 32
@@ -374,6 +422,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg,
         __syncthreads();                                   // every s_end[j - 1] has been read
         if (redo) { my_start = s_nstart[tid]; my_end = s_nend[tid]; my_cnt = s_ncnt[tid]; s_end[tid] = my_end; }
     }
+    HD_T(2);
     if (!live) return;
     start[t] = my_start;
     end_out[t] = my_end;
@@ -395,17 +444,17 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_pass(HdStream S, HdTables Tg,
 constexpr uint32_t kHpGroups = 512;   // groups of subsequences whose maps k_hd_phase_chain composes (one thread each)
 // (a subsequence is entered at most max_len - 1 bits past its start -- the overshoot of the symbol that straddles its boundary -- so
 // only `phases` = max(16, longest code) of the 32 are walked: a block's 1024 threads take 1024 / phases subsequences)
-constexpr uint32_t kHpSubsMax = 64, kHpThreads = 1024, kHpStageWords = kHpSubsMax * (kHdSub / 32) + kHdTail + 2;
+constexpr uint32_t kHpSubsMax = 64, kHpThreads = 1024, kHpStageWords = kHpSubsMax * (kHdSub / 32) + kHdTail + 2, kHpSwz = kHpStageWords / 16 + 1;
 __global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTables Tg, uint64_t nsub, uint8_t *__restrict__ maps /* [nsub][32] */,
                                                               uint16_t *__restrict__ cnts /* [nsub][32] */, uint32_t phases, uint32_t subs_per_block) {
     const HdTables &T = Tg;
     __shared__ uint32_t lut_s[1u << kHdLut];
-    __shared__ uint32_t stage[kHpStageWords];
+    __shared__ uint32_t stage[16 * kHpSwz];   // (transposed like k_hd_pass's: one HdBits)
     if (T.use1)
         for (uint32_t i = threadIdx.x; i < (1u << kHdLut); i += kHpThreads) lut_s[i] = T.lut1[i];
     const uint64_t t0 = (uint64_t)blockIdx.x * subs_per_block, base = t0 * kHdSub, w0 = base / 32;
     const uint32_t nstage = subs_per_block * (kHdSub / 32) + kHdTail + 2;
-    for (uint32_t i = threadIdx.x; i < nstage; i += kHpThreads) stage[i] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
+    for (uint32_t i = threadIdx.x; i < nstage; i += kHpThreads) stage[hd_sw<kHpSwz>(i)] = w0 + i < S.nwords ? __builtin_bswap32(S.w[w0 + i]) : 0u;
     __syncthreads();
     const uint32_t sub = threadIdx.x / phases, o = threadIdx.x - sub * phases;
     const uint64_t t = t0 + sub;
@@ -413,7 +462,7 @@ __global__ __launch_bounds__(kHpThreads) void k_hd_phase_maps(HdStream S, HdTabl
     const uint64_t next = (t + 1) * kHdSub, hi = min(next, S.nbits);
     uint64_t at = t * kHdSub + o;
     uint32_t cn = 0;
-    if (at < hi) hd_run<false, true>(T, lut_s, stage, base, S.nbits, at, hi, cn);
+    if (at < hi) hd_run<false, true, false, kHpSwz>(T, lut_s, stage, base, S.nbits, at, hi, cn);
     maps[t * 32 + o] = (uint8_t)(at >= next ? min<uint64_t>(at - next, 31) : 0);   // (a walk that ends with the stream enters nothing)
     cnts[t * 32 + o] = (uint16_t)cn;
 }
@@ -450,6 +499,16 @@ __global__ __launch_bounds__(kHpGroups) void k_hd_phase_chain(const uint8_t *__r
     }
 }
 
+// FromDiff's chunks (below): the channel sums of the differences of every 4096 symbols are what its prefix scan starts from.  Where the
+// decoder writes packed differences (MODE 0) it can add them up on its way -- chunk_sum[3 chunk + channel], zero before the launch --
+// and save the undiff a pass over all the symbols (1.07 GB read at 16384^2).
+constexpr int kUdThreads = 256, kUdPer = 16;
+constexpr uint32_t kUdChunk = kUdThreads * kUdPer;
+static_assert(kUdChunk == 4096, "chunk of a position p: p >> 12");
+__device__ __forceinline__ void ud_unpack(uint32_t key, int32_t d[3]) {
+    d[0] = (int32_t)((key >> 18) & 511) - 255; d[1] = (int32_t)((key >> 9) & 511) - 255; d[2] = (int32_t)(key & 511) - 255;
+}
+
 // every thread decodes its symbols once more and writes them: MODE 0 = packed keys (u32 each), 1 = RGB bytes (3 each).
 // Four symbols leave together (16 / 12 bytes at an aligned address) where the symbol index allows: a store per symbol is one
 // L2 request per lane, 16.7 M of them at 4096^2.
@@ -457,7 +516,8 @@ template <bool WIDE, int MODE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables Tg, uint64_t nsub, const uint64_t *__restrict__ start,
                                                          const uint64_t *__restrict__ off, uint64_t nsyms, void *__restrict__ out,
                                                          const uint32_t *__restrict__ hopeless /* null, or the count and its bound: see k_hd_pass */, uint32_t hopeless_min,
-                                                         const uint32_t *__restrict__ only_long = nullptr /* counts: only the subsequences of more than kHdKeep symbols (the others were copied) */) {
+                                                         const uint32_t *__restrict__ only_long = nullptr /* counts: only the subsequences of more than kHdKeep symbols (the others were copied) */,
+                                                         int32_t *__restrict__ chunk_sum = nullptr /* MODE 0: see above */) {
     extern __shared__ __align__(16) uint32_t hd_lds[];
     if (hopeless && *hopeless >= hopeless_min) return;
     const HdTables &T = Tg;
@@ -475,12 +535,26 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables Tg
     uint8_t *rgb = static_cast<uint8_t *>(out);
     HdBits<WIDE> B;
     B.seek(stage, (uint32_t)(at - base));
+    int32_t cs[3] = {0, 0, 0};          // the thread's differences summed, of the chunk it is in (a subsequence spans two at most)
+    uint64_t cs_chunk = idx >> 12;
+    auto cs_flush = [&]() {
+        if (cs[0]) atomicAdd(&chunk_sum[3 * cs_chunk], cs[0]);
+        if (cs[1]) atomicAdd(&chunk_sum[3 * cs_chunk + 1], cs[1]);
+        if (cs[2]) atomicAdd(&chunk_sum[3 * cs_chunk + 2], cs[2]);
+        cs[0] = cs[1] = cs[2] = 0;
+    };
     auto next = [&](uint32_t &key) -> bool {   // the reference reads exactly nsyms symbols; what the padding decodes to is dropped
         if (at >= hi || widx >= nsyms) return false;
         const HdSym sy = hd_lookup<true>(T, lut_s, B.window());
         if (at + sy.len > S.nbits) { at = hi; return false; }
         at += sy.len;
         B.skip(sy.len);
+        if (MODE == 0 && chunk_sum) {
+            if ((widx >> 12) != cs_chunk) { cs_flush(); cs_chunk = widx >> 12; }
+            int32_t d[3];
+            ud_unpack(sy.key, d);
+            cs[0] += d[0]; cs[1] += d[1]; cs[2] += d[2];
+        }
         widx++;
         key = sy.key;
         return true;
@@ -509,6 +583,7 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables Tg
         }
         idx += 4;
     }
+    if (MODE == 0 && chunk_sum) cs_flush();
 }
 
 // The kept symbols to their places (round 5): block b = the subsequences [256 b, 256 b + 256), whose symbols are the output positions
@@ -518,7 +593,8 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_write(HdStream S, HdTables Tg
 // to k_hd_write(only_long).
 template <int MODE>
 __global__ __launch_bounds__(kHdThreads) void k_hd_compact(const uint32_t *__restrict__ keep, const uint64_t *__restrict__ off, const uint32_t *__restrict__ count, uint64_t nsub,
-                                                           uint64_t nsyms, void *__restrict__ out, const uint32_t *__restrict__ hopeless, uint32_t hopeless_min) {
+                                                           uint64_t nsyms, void *__restrict__ out, const uint32_t *__restrict__ hopeless, uint32_t hopeless_min,
+                                                           int32_t *__restrict__ chunk_sum /* MODE 0: FromDiff's chunk sums, or null */) {
     if (hopeless && *hopeless >= hopeless_min) return;
     __shared__ unsigned long long s_off[kHdThreads + 1];
     __shared__ uint32_t s_cnt[kHdThreads];
@@ -532,10 +608,11 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_compact(const uint32_t *__res
     if (lo >= hi) return;
     uint32_t *keys = static_cast<uint32_t *>(out);
     uint8_t *rgb = static_cast<uint8_t *>(out);
-    for (uint64_t g = (lo >> 2) + tid; g * 4 < hi; g += kHdThreads) {
-        const uint64_t p0 = g * 4;
+    for (uint64_t g0 = lo >> 2; g0 * 4 < hi; g0 += kHdThreads) {   // (every lane goes round as often as the block's first: the wave sums below want them all)
+        const uint64_t g = g0 + tid, p0 = g * 4;
         uint32_t k[4] = {0, 0, 0, 0};
         bool have[4] = {false, false, false, false};
+        if (p0 < hi) {
         // owner of the group's first position inside the block: the last subsequence whose offset is <= it (empty ones share an offset: the last wins)
         uint32_t a = 0, b = nt;
         const uint64_t pf = max(p0, lo);
@@ -547,8 +624,24 @@ __global__ __launch_bounds__(kHdThreads) void k_hd_compact(const uint32_t *__res
             if (p < lo || p >= hi) continue;
             while (p >= s_off[own + 1]) own++;          // (p < s_off[nt]: ends at a subsequence that holds it)
             if (s_cnt[own] > kHdKeep) continue;         // decoded again by k_hd_write(only_long)
-            k[u] = hd_keep_col(const_cast<uint32_t *>(keep), t0 + own)[(size_t)(p - s_off[own]) * 64];
+            k[u] = hd_keep_col(const_cast<uint32_t *>(keep), t0 + own)[hd_keep_at((uint32_t)(p - s_off[own]))];
             have[u] = true;
+        }
+        }
+        if (MODE == 0 && chunk_sum) {   // a wave's 256 positions lie in one chunk of 4096, or in two
+            int32_t d[3] = {0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (have[u]) { int32_t e[3]; ud_unpack(k[u], e); d[0] += e[0]; d[1] += e[1]; d[2] += e[2]; }
+            const uint32_t ch = (uint32_t)(p0 >> 12), ch0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch);
+            const bool first = ch == ch0;
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int32_t a = (int32_t)wave_reduce_sum((uint32_t)(first ? d[q] : 0)), b = (int32_t)wave_reduce_sum((uint32_t)(first ? 0 : d[q]));
+                if (lane == 0 && a) atomicAdd(&chunk_sum[3 * (size_t)ch0 + q], a);
+                if (lane == 0 && b) atomicAdd(&chunk_sum[3 * (size_t)(ch0 + 1) + q], b);
+            }
         }
         if (have[0] && have[1] && have[2] && have[3]) {
             if (MODE == 0) *reinterpret_cast<uint4 *>(keys + p0) = make_uint4(k[0], k[1], k[2], k[3]);
@@ -597,8 +690,9 @@ struct LeafMeta { uint32_t max_len; };
 // boundary below it).  mode 0: out_d receives nsyms packed keys (u32, 16-byte aligned); mode 1: nsyms RGB triples (u8, 4-byte aligned).
 // *status: 0 = decoded, 1 = the stream ends early (None), 2 = did not settle (caller decodes on the host)
 int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t off_key, uint64_t off_len, uint32_t max_len, uint32_t first_key,
-                           const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms, int mode, void *out_d, int *status) {
+                           const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms, int mode, void *out_d, int *status, UdSums *sums) {
     *status = 0;
+    if (sums) sums->filled = false;
     if (nsyms == 0) return CNIIC_OK;
     if (n == 0 || max_len > kLeafMaxLen) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
     if (n == 1) {  // one symbol, zero-length code, no payload (huf.rs:140-142)
@@ -624,6 +718,12 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     }
     S.nbits = S.bit0 + payload_bytes * 8;
     S.nwords = ceil_div(S.nbits, 32);
+    // The warm-up.  A thread that has not fallen into step by the time it enters its subsequence is decoded again in the block's settle
+    // loop, and a RUN of such threads one round per member: every round is a chain as long as the whole first decode with a handful of
+    // lanes at work.  Codes of 14 bits need ~300 bits to fall into step: 128 bits of warm-up left a third of the threads for the rounds.
+    S.warm = 128;
+    if (payload_bytes * 8 >= nsyms * 12) S.warm = 384;   // long codes (the differences of a photograph)
+    if (const char *e = test_env("CNIIC_HD_WARM")) S.warm = std::min<uint32_t>(kHdWarm, std::max(32, atoi(e)) & ~31u);
     // ---- the look-up tables
     // The second table, measured (round 3): 2^18 entries = 2 MiB, which stays in an XCD's L2 -- `delta` 16384^2 (54 K leaves, 14.5 bits a
     // symbol) decodes in 12.3 / 10.0 / 8.8 / 11.0 / 17.9 ms with 14 / 16 / 18 / 20 / 24 bits; for a decoder of a million leaves and more
@@ -689,7 +789,7 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
     CNIIC_HIP_TRY(c, ctx_pinned_u(c));
     volatile uint64_t *pin = reinterpret_cast<volatile uint64_t *>(c->pinned_u) + 4096;   // (slots of this function's own) [0] total symbols, [1] did the last pass move an end?
     const uint32_t grid = (uint32_t)ceil_div(nsub, kHdThreads);
-    const size_t lds = use1 ? kHdLds : (size_t)kHdStageWords * 4;
+    const size_t lds = use1 ? kHdLds : (size_t)kHdStageAlloc * 4;
     const bool wide = lt.max_len > 32;
     const char *ph_env = test_env("CNIIC_HD_PHASES");   // 1: the phase maps whatever the blind checks say (tests); 0: never
     const bool phases_ok = !wide && !(ph_env && !atoi(ph_env)), phases_force = phases_ok && ph_env && atoi(ph_env);
@@ -720,16 +820,25 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         CNIIC_TRY(pack_scan(c, count.as<uint32_t>(), (uint32_t)nsub, off.as<uint64_t>(), tot.as<uint64_t>()));
         const uint64_t *st = start_d.as<uint64_t>(), *of = off.as<uint64_t>();
         const uint32_t *hp = guarded && hopeless_min ? changed.as<uint32_t>() + 5 : nullptr;
+        if (sums) sums->filled = false;
         if (kept && keep_p) {   // a copy, and one more decode of the few subsequences of more than kHdKeep symbols
             const uint32_t *cn = count.as<uint32_t>();
-            if (mode == 0) hipLaunchKernelGGL(k_hd_compact<0>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min);
-            else hipLaunchKernelGGL(k_hd_compact<1>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min);
+            int32_t *cs = nullptr;   // packed differences: FromDiff's chunk sums on the way (a write that is repeated starts them again)
+            if (mode == 0 && sums) {
+                const uint64_t cs_bytes = ceil_div(nsyms, kUdChunk) * 12;
+                if (sums->buf.bytes < cs_bytes) CNIIC_HIP_TRY(c, sums->buf.alloc(cs_bytes));
+                CNIIC_HIP_TRY(c, hipMemsetAsync(sums->buf.p, 0, cs_bytes, c->stream));
+                cs = sums->buf.as<int32_t>();
+                sums->filled = true;
+            }
+            if (mode == 0) hipLaunchKernelGGL(k_hd_compact<0>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min, cs);
+            else hipLaunchKernelGGL(k_hd_compact<1>, dim3(grid), dim3(kHdThreads), 0, c->stream, (const uint32_t *)keep_p, of, cn, nsub, nsyms, out_d, hp, hopeless_min, (int32_t *)nullptr);
             if (wide) {
-                if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn);
-                else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn);
+                if (mode == 0) hipLaunchKernelGGL((k_hd_write<true, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn, cs);
+                else hipLaunchKernelGGL((k_hd_write<true, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, (const uint32_t *)nullptr, 0u, cn, (int32_t *)nullptr);
             } else {
-                if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn);
-                else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn);
+                if (mode == 0) hipLaunchKernelGGL((k_hd_write<false, 0>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn, cs);
+                else hipLaunchKernelGGL((k_hd_write<false, 1>), dim3(grid), dim3(kHdThreads), lds, c->stream, S, T, nsub, st, of, nsyms, out_d, hp, hopeless_min, cn, (int32_t *)nullptr);
             }
             CNIIC_HIP_TRY(c, hipGetLastError());
             return CNIIC_OK;
@@ -762,6 +871,17 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
         ScopedKernelTimer t0(c, "hd_pass0");   // (stage timers: CNIIC_OPT_STAGE_TIMERS; they synchronise)
         pass(nullptr, cur);
         t0.stop();
+#ifdef CNIIC_HD_PHASES
+        {
+            unsigned long long ph[8], zero[8] = {0};
+            CNIIC_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_hd_phase), sizeof ph));
+            CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_hd_phase), zero, sizeof zero));
+            const double nb = (double)grid;
+            fprintf(stderr, "[hd phases] pass 0, %u blocks, warm %u: per block (us) stage %.2f | first decode %.2f | settle rounds %.2f | rounds %.2f, list entries %.1f, blocks that settled %.0f %%\n",
+                    grid, S.warm, ph[0] / nb / 100.0, ph[1] / nb / 100.0, ph[2] / nb / 100.0, ph[3] / nb, ph[4] / nb, 100.0 * ph[5] / nb);
+        }
+#endif
         ScopedKernelTimer t1(c, "hd_check");
         for (int r = 0; r < kHdBlindChecks; r++) {
             CNIIC_HIP_TRY(c, hipMemsetAsync(changed.p, 0, 4, c->stream));
@@ -824,8 +944,9 @@ int huff_decode_tables_dev(Ctx *c, const uint8_t *tab_d, uint64_t n, uint64_t of
 // the same from the host's table of leaves (huff_parse_leaves; not too_deep): one pinned block, one copy up (three copies out of
 // pageable vectors were ~100 us of a 0.5 ms decode)
 int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool payload_dev, uint64_t payload_bytes, uint64_t nsyms,
-                    int mode, void *out_d, int *status) {
+                    int mode, void *out_d, int *status, UdSums *sums) {
     *status = 0;
+    if (sums) sums->filled = false;
     if (nsyms == 0) return CNIIC_OK;
     const uint64_t n = lt.n();
     if (n == 0 || lt.too_deep) return c->fail(CNIIC_ERR_BAD_ARG, "huff_decode_dev: no usable leaf table");
@@ -838,7 +959,7 @@ int huff_decode_dev(Ctx *c, const LeafTable &lt, const uint8_t *payload, bool pa
     memcpy(ph + off_key, lt.key.data(), n * 4);
     memcpy(ph + off_len, lt.len.data(), n);
     CNIIC_HIP_TRY(c, hipMemcpyAsync(tab_d.p, c->pinned_huf, tab_bytes, hipMemcpyHostToDevice, c->stream));
-    return huff_decode_tables_dev(c, tab_d.as<uint8_t>(), n, off_key, off_len, lt.max_len, lt.key[0], payload, payload_dev, payload_bytes, nsyms, mode, out_d, status);
+    return huff_decode_tables_dev(c, tab_d.as<uint8_t>(), n, off_key, off_len, lt.max_len, lt.key[0], payload, payload_dev, payload_bytes, nsyms, mode, out_d, status, sums);
 }
 
 int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d) {
@@ -851,12 +972,6 @@ int keys_to_rgb(Ctx *c, const uint32_t *keys_d, uint64_t n, uint8_t *rgb_d) {
 // ---------------------------------------------------------------- FromDiff (hilbertc.rs:482-509): c_i = c_{i-1} + s_i, c_{-1} = 0
 // per channel, as a prefix sum of the signed differences; a value outside 0..255 is the reference's
 // `try_into().unwrap()` failure (:505-506), reported through *bad.
-constexpr int kUdThreads = 256, kUdPer = 16;
-constexpr uint32_t kUdChunk = kUdThreads * kUdPer;
-
-__device__ __forceinline__ void ud_unpack(uint32_t key, int32_t d[3]) {
-    d[0] = (int32_t)((key >> 18) & 511) - 255; d[1] = (int32_t)((key >> 9) & 511) - 255; d[2] = (int32_t)(key & 511) - 255;
-}
 
 __global__ __launch_bounds__(kUdThreads) void k_ud_sums(const uint32_t *__restrict__ keys, uint64_t n, int32_t *__restrict__ chunk_sum) {
     __shared__ int32_t sh[3][kUdThreads / 64];
@@ -972,7 +1087,7 @@ int delta_undiff_prefix(Ctx *c, const uint32_t *keys_d, uint64_t n, DevBuf *sums
 // FromDiff (hilbertc.rs:482-509) and the walk along the scan (hilbertc.rs:426-428): keys_d = the w x h decoded symbols in scan
 // order -> rgb_out_d.  2^n squares: one fused pass by tiles (k_hilbert_move_p2<true, true>); other rectangles: the linearised
 // colours first, then the per-position scatter.  *bad_h != 0: a colour left 0..255 (the reference's unwrap, hilbertc.rs:505).
-int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h) {
+int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_t h, uint8_t *rgb_out_d, uint32_t *bad_h, UdSums *made) {
     *bad_h = 0;
     const uint64_t n = (uint64_t)w * h;
     if (!n) return CNIIC_OK;
@@ -980,7 +1095,11 @@ int delta_undiff_scatter_dev(Ctx *c, const uint32_t *keys_d, uint32_t w, uint32_
     DevBuf sums, bad, lin;
     CNIIC_HIP_TRY(c, bad.alloc(4));
     CNIIC_HIP_TRY(c, hipMemsetAsync(bad.p, 0, 4, c->stream));
-    CNIIC_TRY(delta_undiff_prefix(c, keys_d, n, &sums));
+    if (made && made->filled && ceil_div(n, kUdChunk) <= 0x7fffffffull) {   // the decoder added the chunks up while it wrote the symbols: only the scan is left
+        sums.view(made->buf.p, made->buf.bytes);
+        hipLaunchKernelGGL(k_ud_scan, dim3(1), dim3(1024), 0, c->stream, sums.as<int32_t>(), (uint32_t)ceil_div(n, kUdChunk));
+        CNIIC_HIP_TRY(c, hipGetLastError());
+    } else CNIIC_TRY(delta_undiff_prefix(c, keys_d, n, &sums));
     bool fused = false;
     CNIIC_TRY(hilbert_undiff_scatter(c, keys_d, sums.as<int32_t>(), w, h, rgb_out_d, bad.as<uint32_t>(), &fused));
     if (!fused) {
