@@ -429,12 +429,15 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
     // The result block starts towards the host; behind it goes everything that needs no code table - the
     // colour -> label table and the label of every pixel (the one random read per pixel) - so that the GPU
     // is busy while the host waits for the block and builds the tree.
-    CNIIC_TRY(km_rgbw_result_begin(km));
     const bool wide = km_rgbw_is_wide(km);
     DevBuf lab_d, key2label, pixlab;
     CNIIC_HIP_TRY(c, pixlab.alloc(n * (wide ? 2 : 1) + 16));
     DevBuf lw;
     bool lw_early = false;
+    // (twice only if a persistent K-means launch that nobody had waited for turns out to have given up: km_rgbw_result_end has run the
+    // launch-per-iteration loop by then and answers kKmRetry -- what was enqueued on the labels is enqueued again)
+    for (int attempt = 0;; attempt++) {
+    CNIIC_TRY(km_rgbw_result_begin(km));
     if (s->sp_mode) {  // every pixel's label from the partition: no table of 2^24 entries, no random read
         uint32_t *cell_start, *ckeys, *cweight;
         km_rgbw_cell_arrays(km, &cell_start, &ckeys, &cweight);
@@ -459,7 +462,11 @@ int cc_finish(CcSession *s, const uint8_t *rgb_d, uint32_t w, uint32_t h, const 
         CNIIC_TRY(pixel_labels(c, rgb_d, n, key2label.p, wide, pixlab.p));
     }
     host_trace().mark("labels + pixel labels enq");
-    CNIIC_TRY(km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st));
+    const int rc_res = km_rgbw_result_end(km, cent.data(), members.data(), wsum.data(), &st);
+    if (rc_res == kKmRetry && attempt == 0) continue;
+    CNIIC_TRY(rc_res);
+    break;
+    }
     host_trace().mark("km_result");
     if (stats) *stats = st;
     // check_enough_active_clusters (kmeans.rs:41-57)
@@ -749,7 +756,7 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
         CcSession *raw = nullptr;
         CNIIC_TRY(cc_prepare_image(c, rgb_d, n, K, opts, &raw));
         std::unique_ptr<CcSession> s(raw);
-        CNIIC_TRY(km_rgbw_run(s->km));
+        CNIIC_TRY(km_rgbw_run(s->km, nullptr, /*may_defer=*/true));   // (cc_finish looks at how a persistent launch ended where it fetches the result)
         host_trace().mark("km_run");
         const int rc_all = cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
         host_trace().dump();
@@ -767,7 +774,7 @@ static int encode_cluster_colors(Ctx *c, const uint8_t *rgb_d, uint32_t w, uint3
     CcSession *raw = nullptr;
     CNIIC_TRY(cc_prepare(c, table, K, opts, 0, 1, nullptr, &raw));
     std::unique_ptr<CcSession> s(raw);
-    CNIIC_TRY(km_rgbw_run(s->km));
+    CNIIC_TRY(km_rgbw_run(s->km, nullptr, /*may_defer=*/true));
     host_trace().mark("km_run");
     const int rc_all = cc_finish(s.get(), rgb_d, w, h, nullptr, out, cap, len, stats);
     host_trace().dump();

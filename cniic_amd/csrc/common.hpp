@@ -530,7 +530,10 @@ int mailbox_status(const Mailbox *m);  // 0 healthy, 1 a wait ran out, 2 a peer 
 void mailbox_abort(Mailbox *m);
 void mailbox_destroy(Mailbox *m);
 
-int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr);       // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration
+constexpr int kKmRetry = 1000;    // km_rgbw_result_end after a deferred run: the persistent launch had given up, the launch-per-iteration loop has run since -- what the
+                                  // caller enqueued on the labels must be enqueued again (never returned through the C ABI)
+int km_rgbw_run(KmRgbwState *s, Comm *cm = nullptr, bool may_defer = false);   // full loop to convergence; with cm the partial sums are all-reduced in-stream each iteration;
+                                                           // may_defer: the caller goes on to km_rgbw_result_begin / _end (which may answer kKmRetry, kmeans_rgbw.hpp) and wants no wait in between
 int km_rgbw_poll_changed(KmRgbwState *s, uint64_t *changed);  // syncs
 int km_rgbw_poll(KmRgbwState *s, cniic_kmeans_stats *st, uint32_t *done);  // syncs
 bool km_rgbw_run_stats(KmRgbwState *s, cniic_kmeans_stats *st);  // of the last km_rgbw_run; no stream work

@@ -90,11 +90,32 @@ __global__ __launch_bounds__(1024) void k_ps_ranges(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ cb, uint32_t *__restrict__ fail) {
     const uint32_t M = *ne_count, NC = G * kPsChunks;
     const uint64_t total = ne_cost[M];
-    for (uint32_t g = threadIdx.x; g <= NC; g += blockDim.x) {
-        const uint64_t c_lo = total * g / NC;
-        uint32_t a = 0, b = M;   // first cell whose cost prefix is >= c_lo
-        while (a < b) { const uint32_t mid = (a + b) >> 1; if (ne_cost[mid] < c_lo) a = mid + 1; else b = mid; }
-        cb[g] = g == NC ? M : a;
+    // (a thread's boundaries searched TOGETHER, eight at a time: one after the other the 4097 bisections of the headline image were 60
+    // dependent reads a thread, 21 us in front of the launch)
+    for (uint32_t g0 = threadIdx.x; g0 <= NC; g0 += 8 * blockDim.x) {
+        uint32_t a[8], b[8];
+        uint64_t c_lo[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t g = g0 + r * blockDim.x;
+            c_lo[r] = total * min(g, NC) / NC;
+            a[r] = 0; b[r] = g <= NC ? M : 0u;   // first cell whose cost prefix is >= c_lo
+        }
+        bool more = true;
+        while (more) {
+            more = false;
+            uint32_t mid[8], v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { mid[r] = (a[r] + b[r]) >> 1; v[r] = a[r] < b[r] ? ne_cost[mid[r]] : 0u; }
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (a[r] < b[r]) { if (v[r] < c_lo[r]) a[r] = mid[r] + 1; else b[r] = mid[r]; more = more || a[r] < b[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t g = g0 + r * blockDim.x;
+            if (g <= NC) cb[g] = g == NC ? M : a[r];
+        }
     }
     __syncthreads();   // (one block: its own stores are visible to it behind the barrier)
     for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) {
@@ -1054,14 +1075,14 @@ int ps_prepare(KmRgbwState *s) {
 // The whole loop as one launch.  *ran = false: not tried (the CUs are promised to another persistent launch of this process) or given
 // up without harm (the grid was not resident together in time; a block's range does not fit): the caller runs the classic loop, whose
 // inputs are untouched.
-int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
+int km_rgbw_run_persistent(KmRgbwState *s, bool *ran, bool may_defer) {
     Ctx *c = s->c;
     *ran = false;
     if (!s->ps || s->ps_tried) return CNIIC_OK;
     s->ps_tried = true;   // (a second km_rgbw_run on the same state continues classically: the persistent launch starts from the initial assignment)
     const int dev = c->device >= 0 && c->device < 16 ? c->device : 0, G = (int)s->ps_blocks;
     if (g_ps_cus_in_use[dev].fetch_add(G) + G > ps_cu_count(c->device)) { g_ps_cus_in_use[dev].fetch_sub(G); return CNIIC_OK; }
-    struct Release { int dev, G; ~Release() { g_ps_cus_in_use[dev].fetch_sub(G); } } release{dev, G};
+    std::shared_ptr<void> release(nullptr, [dev, G](void *) { g_ps_cus_in_use[dev].fetch_sub(G); });   // (given back when this goes -- or, deferred, when the state's copy does)
     if (!c->pinned_ps) CNIIC_HIP_TRY(c, hipHostMalloc(&c->pinned_ps, 1024, hipHostMallocDefault));
     static_assert(sizeof(PsCold) <= 1024, "the pinned block holds a PsCold");
     PsCold *cold = static_cast<PsCold *>(c->pinned_ps);
@@ -1095,6 +1116,15 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
     if (s->profile) { CNIIC_HIP_TRY(c, hipEventCreate(&e0)); CNIIC_HIP_TRY(c, hipEventCreate(&e1)); }
     hipExtLaunchKernelGGL(k_rgbw_persist, dim3((uint32_t)G), dim3(kPsThreads), kPsDynBytes, c->stream, e0, e1, 0, a);
     CNIIC_HIP_TRY(c, hipGetLastError());
+    // The caller of an encode goes straight on to the labels of the pixels and to fetching the result block (cc_finish): nothing of
+    // that needs the host to have seen how the launch ended, and the look cost the stream 40 us (a wait, a copy, the next launch's
+    // way to the GPU).  The verdict is read where the result block is (km_rgbw_result_end -> km_rgbw_persistent_verdict).
+    if (may_defer && !s->profile && !want_ts && !bt_path) {
+        s->ps_pending = true;
+        s->ps_hold = release;
+        *ran = true;
+        return CNIIC_OK;
+    }
     CNIIC_HIP_TRY(c, ctx_spin_sync(c));
     const uint32_t status = xh->status;
     if (status != kPsStatusDone) {
@@ -1152,7 +1182,7 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
         }
     }
 #ifdef CNIIC_PS_PHASES
-    {
+    {   // (a measuring build: run it with the per-iteration trace or KM_PROFILE, which wait for the launch)
         unsigned long long ph[16], zero[16] = {0};
         CNIIC_HIP_TRY(c, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ps_phase), sizeof ph));
         CNIIC_HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(g_ps_phase), zero, sizeof zero));
@@ -1163,6 +1193,26 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran) {
     }
 #endif
     *ran = true;
+    return CNIIC_OK;
+}
+
+// How the deferred launch ended (the stream has been waited for).  Done: its statistics.  Given up: the loop of launches, now, from the
+// inputs the persistent launch has not touched -- *retry tells the caller to fetch the result again.
+int km_rgbw_persistent_verdict(KmRgbwState *s, bool *retry) {
+    Ctx *c = s->c;
+    *retry = false;
+    s->ps_pending = false;
+    s->ps_hold.reset();
+    const PsExit *xh = &static_cast<const PsCold *>(c->pinned_ps)->exit;
+    if (xh->status == kPsStatusDone) {
+        s->run_stats.iterations = xh->iter; s->run_stats.moved_last = xh->moved_last; s->run_stats.empty_reseeds = xh->reseeds;
+        s->run_stats.active = xh->active; s->run_stats.pair_evals = xh->pair_evals;
+        s->run_stats_valid = true;
+        return CNIIC_OK;
+    }
+    if (test_env("CNIIC_KM_PS_REQUIRE")) return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw: the persistent launch ended with status %u (CNIIC_KM_PS_REQUIRE)", xh->status);
+    CNIIC_TRY(km_rgbw_run(s, nullptr, false));   // (ps_tried is set: the launches)
+    *retry = true;
     return CNIIC_OK;
 }
 

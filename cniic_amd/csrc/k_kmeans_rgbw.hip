@@ -1639,17 +1639,17 @@ struct LaunchTimer {
 // result is exactly that of the reference's `while changed_assignment` loop (kmeans.rs:26-32).
 // With CNIIC_KM_PROFILE every assign launch is bracketed by HIP events on the ctx stream and the
 // summed kernel time is reported as "kmeans_rgbw_assign" (launch count = iterations).
-static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm);
+static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm, bool may_defer);
 
 // With a communicator, a failure on this rank (a launch error, a collective that fails, a missing state record) must not
 // strand the peers in their next all-reduce: the communicator is aborted before the error is returned (comm.cpp).
-int km_rgbw_run(KmRgbwState *s, Comm *cm) {
-    const int rc = km_rgbw_run_loop(s, cm);
+int km_rgbw_run(KmRgbwState *s, Comm *cm, bool may_defer) {
+    const int rc = km_rgbw_run_loop(s, cm, may_defer);
     if (rc != CNIIC_OK && cm) comm_abort(cm);
     return rc;
 }
 
-static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
+static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm, bool may_defer) {
     Ctx *c = s->c;
     int batch = test_env("CNIIC_KM_BATCH") ? atoi(test_env("CNIIC_KM_BATCH")) : cm ? 2 : 8;  // iterations enqueued between two looks at the state; with collectives an iteration past convergence still
                                    // pays a full all-reduce, so fewer are in flight (and each is long enough for the host to keep up)
@@ -1673,7 +1673,7 @@ static int km_rgbw_run_loop(KmRgbwState *s, Comm *cm) {
     uint32_t launch_no = 0;
     if (!cm && s->ps && s->fused) {   // one GPU, K <= 256: the whole loop as ONE launch (k_kmeans_persist.hip)
         bool ran = false;
-        CNIIC_TRY(km_rgbw_run_persistent(s, &ran));
+        CNIIC_TRY(km_rgbw_run_persistent(s, &ran, may_defer));
         if (ran) { timer.stop(s->run_stats.iterations); return CNIIC_OK; }
     }
     for (;;) {
@@ -1913,7 +1913,12 @@ int km_rgbw_result(KmRgbwState *s, uint8_t *centroids_h, uint32_t *labels_d_u32,
         CNIIC_HIP_TRY(c, hipGetLastError());
     }
     CNIIC_TRY(km_rgbw_result_begin(s));
-    return km_rgbw_result_end(s, centroids_h, members_h, wsum_h, stats);
+    int rc = km_rgbw_result_end(s, centroids_h, members_h, wsum_h, stats);
+    if (rc == kKmRetry) {   // (only after a deferred run, which this file's callers of km_rgbw_result do not ask for)
+        CNIIC_TRY(km_rgbw_result_begin(s));
+        rc = km_rgbw_result_end(s, centroids_h, members_h, wsum_h, stats);
+    }
+    return rc;
 }
 
 // state, centroids, members, weight sums are one block: one copy into pinned memory, one event
@@ -1934,6 +1939,11 @@ int km_rgbw_result_begin(KmRgbwState *s) {
 int km_rgbw_result_end(KmRgbwState *s, uint8_t *centroids_h, uint64_t *members_h, uint64_t *wsum_h, cniic_kmeans_stats *stats) {
     Ctx *c = s->c;
     CNIIC_HIP_TRY(c, hipEventSynchronize(c->res_ev));
+    if (s->ps_pending) {   // the persistent launch nobody waited for: did it run to the end?  If not, the loop of launches has run by now (from the untouched inputs)
+        bool retry = false;
+        CNIIC_TRY(km_rgbw_persistent_verdict(s, &retry));
+        if (retry) return kKmRetry;
+    }
     const uint8_t *blk = static_cast<const uint8_t *>(c->pinned_res);
     KmDevState h;
     memcpy(&h, blk, sizeof h);

@@ -65,6 +65,8 @@ struct KmRgbwState {
     uint64_t *partials = nullptr;  // device: 5K+2 words (per-iteration sums or deltas)
     // the loop as ONE launch (k_kmeans_persist.hip): K <= 256, one shard, no communicator
     bool ps = false, ps_tried = false;
+    bool ps_pending = false;     // the persistent launch is in the stream and nobody has looked at how it ended yet (km_rgbw_run with may_defer): km_rgbw_result_end does
+    std::shared_ptr<void> ps_hold;   // the CUs promised to that launch, given back when the verdict is in (or the state goes)
     uint32_t ps_blocks = 0;
     DevBuf ps_arena;             // [PsBar | 3 x kPsPartWords sums | fail word | PsRange[ps_blocks]]
     DevBuf ps_pk;                // packed words of the points that do not fit their block's LDS
@@ -91,7 +93,8 @@ struct PsExit { uint32_t status, pad; uint64_t iter, moved_last, reseeds, active
 void launch_rgbw_assign_big(Ctx *c, const uint32_t *ckeys, const uint32_t *cweight, uint64_t U, uint32_t K, const uint32_t *cent, uint16_t *labels,
                             unsigned long long *partials, const KmDevState *st);
 int ps_prepare(KmRgbwState *s);
-int km_rgbw_run_persistent(KmRgbwState *s, bool *ran);
+int km_rgbw_run_persistent(KmRgbwState *s, bool *ran, bool may_defer);
+int km_rgbw_persistent_verdict(KmRgbwState *s, bool *retry);   // for km_rgbw_result_end: how a deferred launch ended
 constexpr uint32_t kAggMin = 16;  // points that must share the first mover's (old, new) pair for a round of aggregated booking to be worth it
 
 

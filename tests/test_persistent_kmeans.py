@@ -144,3 +144,24 @@ def test_two_states_of_one_context_back_to_back_and_a_second_run(ctx, monkeypatc
     monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")
     for seed in (1, 2, 3):
         run_both(ctx, synth_img(96, 160, seed=seed), 24)
+
+
+@pytest.mark.parametrize("sp_min", ["0", str(1 << 40)])
+def test_an_encode_whose_unwatched_launch_gave_up_runs_the_launches_and_enqueues_the_labels_again(ctx, monkeypatch, sp_min):
+    """Codec::encode does not wait for the persistent launch: it goes on to the pixels' labels and reads the verdict where it fetches
+    the result block (km_rgbw_result_end).  A launch that gave up (CNIIC_TEST_PS_ABORT_AT) is followed by the launch-per-iteration loop
+    and a second round of label kernels: the oracle's stream; with CNIIC_KM_PS_REQUIRE the same abort is an error"""
+    from cniic_amd import _lib
+    monkeypatch.setenv("CNIIC_SP_MIN_PIXELS", sp_min)
+    monkeypatch.delenv("CNIIC_KM_PS_REQUIRE", raising=False)
+    monkeypatch.setenv("CNIIC_TEST_PS_ABORT_AT", "2")
+    img = synth_img(200, 280, seed=17)
+    rc, data, st = ctx.encode("cluster-colors(48)", img)
+    rco, edata, est = O.encode("cluster-colors(48)", img, mode=O.MODE_L)
+    assert rc == rco == 0 and data == edata and st["iterations"] == est["iterations"]
+    monkeypatch.setenv("CNIIC_KM_PS_REQUIRE", "1")
+    rc, _, _ = ctx.encode("cluster-colors(48)", img, allow=(_lib.HIP,))
+    assert rc == _lib.HIP
+    monkeypatch.delenv("CNIIC_TEST_PS_ABORT_AT")
+    rc, data, st = ctx.encode("cluster-colors(48)", img)          # ... and the context is fine afterwards
+    assert rc == 0 and data == edata
