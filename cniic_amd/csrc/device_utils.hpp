@@ -146,6 +146,7 @@ template <int THREADS> __device__ __forceinline__ uint32_t block_reduce_sum(uint
 // dominant keys at ~8 instructions each; whoever is left adds alone.  Safe under divergence: the ballots see the calling lanes only.
 __device__ __forceinline__ void atomic_count(uint32_t *table, uint32_t key) {
     bool todo = true;
+    int small = 0;
 #pragma unroll 1
     for (int r = 0; r < 8; r++) {   // (a call with one or two lanes -- the ordinary case of a rare symbol -- leaves after as many rounds)
         const unsigned long long act = __ballot(todo);
@@ -158,6 +159,11 @@ __device__ __forceinline__ void atomic_count(uint32_t *table, uint32_t key) {
             if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(sm)) atomicAdd(&table[k], (uint32_t)__popcll(sm));
             todo = false;
         }
+        // (a photograph's wave holds some fifty different keys -- a leader that speaks for less than an eighth of the lanes still
+        // to do says the rounds will not pay: the others add alone, after two rounds instead of eight)
+#ifndef CNIIC_ATOMIC_COUNT_EIGHT   // (a measuring build keeps all eight rounds: profiles/r05_hist_atomic_count_gate.txt)
+        if ((uint32_t)__popcll(sm) * 8u < (uint32_t)__popcll(act) && ++small == 2) break;   // (twice: one odd lane in front of a flat wave must not send 63 lanes to one address)
+#endif
     }
     if (todo) atomicAdd(&table[key], 1u);
 }
