@@ -554,6 +554,7 @@ struct PsArgs {
     PsCold *cold;                         // pinned
     uint64_t max_iters;
     uint32_t K, max_skip, agg_iters, test_abort_at, lds_budget;
+    uint32_t clean_skip;                  // full schedule: cells none of whose old or new candidates moved are not swept (0: A/B measurements, CNIIC_KM_PS_CLEANSKIP)
     unsigned long long timeout_ticks;
     unsigned long long *iter_ts;          // block 0's clock (100 MHz) when iteration j's centroids stood, [0] at entry; kPsTsCap entries, or null
     unsigned long long *blk_ts;           // measuring runs (CNIIC_KM_PS_BLOCK_TRACE): [block][iteration < 128][4] clock at: assign done, flushed, through the barrier, centroids stand
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     const uint32_t c = ccell[i], slot = cslot[i];
                     const uint32_t nl = slot != 255u ? s_nS[slot] : 0xffffffffu;
                     uint32_t *rec = recs + (size_t)kPsRecWords * i;
+                    const uint32_t w_old = l16 < 8 ? rec[2 + l16] : 0u;   // the mask of the iteration before (whose sweep, or whose reasons for none, left every label inside it)
                     bool needs;
                     if (nl <= kPsScap) {
                         const uint32_t pid = ps_row_build_list(tab, Sent + slot * kPsScap, nl, c, l16, rec);
@@ -733,6 +735,14 @@ __global__ __launch_bounds__(kPsThreads) void k_rgbw_persist(PsArgs a) {
                     } else {
                         const uint32_t pid = ps_row_build_table(tab, K, c, l16, rec);
                         needs = ps_row_finish(rec, l16, pid, 0u, true);
+                    }
+                    // A cell none of whose candidates -- old or new -- moved repeats every decision: its points' labels are among the old
+                    // candidates, every centroid that can win now is among the new ones, and all of them stand where they stood when the
+                    // labels were given.  (Half of the swept cells of iterations 15 .. 25, where a quarter to a half of the centroids move.)
+                    if (!first && a.clean_skip) {
+                        const uint32_t mm32 = l16 < 8 ? (uint32_t)(s_mm[l16 >> 1] >> (32u * (l16 & 1u))) : 0u;
+                        const uint32_t w_new = l16 < 8 ? rec[2 + l16] : 0u;
+                        needs = needs && row_max(((w_old | w_new) & mm32) ? 1u : 0u) != 0u;
                     }
                     if (l16 == 0 && (needs || first)) queue[atomicAdd(&s_qn, 1u)] = (uint16_t)i;
                 }
@@ -1105,6 +1115,8 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran, bool may_defer) {
     a.K = s->K; a.max_skip = s->no_skip ? 0u : s->max_skip; a.agg_iters = s->agg_launches;
     a.test_abort_at = 0;
     if (const char *e = test_env("CNIIC_TEST_PS_ABORT_AT")) a.test_abort_at = (uint32_t)atoi(e);
+    a.clean_skip = 1;
+    if (const char *e = test_env("CNIIC_KM_PS_CLEANSKIP")) a.clean_skip = atoi(e) ? 1u : 0u;
     uint64_t tmo_ms = 2000;
     if (const char *e = test_env("CNIIC_KM_PS_TIMEOUT_MS")) tmo_ms = (uint64_t)atoll(e);
     a.timeout_ticks = tmo_ms * 100000ull;   // 100 MHz
