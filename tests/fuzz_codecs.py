@@ -19,6 +19,10 @@ KNOBS = [{}, {"CNIIC_DELTA_ROUTE": "32"}, {"CNIIC_DELTA_GATHER": "any", "CNIIC_H
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_TEST_TRIE_GPU": "1", "CNIIC_HD_LUT2_BITS": "21"},  # the second table built from the leaves' side
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT2_BITS": "13"},
          {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "1"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_HOPELESS_PCT": "0"},   # pass 0's verdict: eager / never
+         # round 5: the decoder with / without its kept symbols, third tables and first table, short and long warm-ups
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_KEEP": "1"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_KEEP": "0", "CNIIC_HD_LUT3": "0"},
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_KEEP": "1", "CNIIC_HD_LUT1": "0", "CNIIC_HD_WARM": "32"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_LUT1": "1", "CNIIC_HD_WARM": "480"},
+         {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_KEEP": "1", "CNIIC_HD_LUT2_BITS": "13", "CNIIC_HD_LUT1": "0"}, {"CNIIC_GPU_DECODE_MIN": "0", "CNIIC_HD_KEEP": "1", "CNIIC_HD_PHASES": "1"},
          {"CNIIC_SCAN_LEAVES_MIN": "0"}, {"CNIIC_SCAN_LEAVES_MIN": "0", "CNIIC_SCAN_LEAF_AREA": "7"},   # the scan of rectangles from leaves + class tables
          {"CNIIC_SCAN_LEAVES_MIN": "0", "CNIIC_SCAN_LEAF_AREA": "64", "CNIIC_GPU_DECODE_MIN": "0"}]
 

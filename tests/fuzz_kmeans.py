@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 # tests/fuzz_kmeans.py [seconds] -- the two lossy codecs against the oracle on random small images: `cluster-colors(K)` (dense
-# table and pixel partition, the block-wide candidate build on and off) and `voronoi(K)` (pivot pruning / brute force, static and
+# table and pixel partition, the persistent launch and the launches) and `voronoi(K)` (pivot pruning / brute force, static and
 # dynamic dealing of super-tiles): same return code, same bytes, same iteration count; the stream decodes to what the oracle
 # decodes it to.  Test infrastructure: the oracle is the checker.  FUZZ_SEED picks the sequence.
 import os, sys, time
@@ -12,7 +12,11 @@ import oracle_lib as O
 
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 CC_KNOBS = [{}, {"CNIIC_SP_MIN_PIXELS": "0"}, {"CNIIC_SP_MIN_PIXELS": str(1 << 40)},
-            {"CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_UNFUSED": "1", "CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_BATCH": "1"}, {"CNIIC_KM_MAXSKIP": "4"}]
+            {"CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_UNFUSED": "1", "CNIIC_KM_LOOP": "1"}, {"CNIIC_KM_BATCH": "1"}, {"CNIIC_KM_MAXSKIP": "4"},
+            # round 5, the persistent launch: odd grids, most points in memory, a launch that gives up under the encode that did not wait for it,
+            # the full schedule without its clean-cell skip
+            {"CNIIC_KM_PS_BLOCKS": "3", "CNIIC_SP_MIN_PIXELS": "0"}, {"CNIIC_KM_PS_BLOCKS": "37"}, {"CNIIC_KM_PS_BLOCKS": "8", "CNIIC_TEST_PS_LDS_BYTES": "60000"},
+            {"CNIIC_TEST_PS_ABORT_AT": "2"}, {"CNIIC_TEST_PS_ABORT_AT": "1", "CNIIC_SP_MIN_PIXELS": "0"}, {"CNIIC_KM_PS_CLEANSKIP": "0"}, {"CNIIC_KM_MAXSKIP": "4", "CNIIC_KM_PS_BLOCKS": "5"}]
 VOR_KNOBS = [{}, {"CNIIC_XY_DYN": "0"}, {"CNIIC_XY_DYN": "1"}, {"CNIIC_XY_DYN": "100000"}]
 
 

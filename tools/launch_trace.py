@@ -24,6 +24,7 @@ from cniic_amd import _lib, synth  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 ctx = cniic_amd.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx.set_opt(_lib.OPT_KM_LOOP, 1)   # (round 5: the loop as launches -- the default is ONE persistent launch, tools/ps_trace.py)
 img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev)
 ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
 out = torch.empty(size * size * 4 + (1 << 20), dtype=torch.uint8, device=dev)
