@@ -147,6 +147,8 @@ struct Ctx {
     void  *pinned = nullptr; // 4 KiB of pinned host memory: two KmDevState slots for lagged convergence polling
     void  *pinned_ps = nullptr;  // pinned: how the persistent K-means launch ended (PsExit, k_kmeans_persist.hip)
     uint32_t ps_div = 1;         // the persistent K-means launch takes 1 / ps_div of the CUs (worker contexts of a batch encode)
+    uint32_t ps_backoff = 0, ps_backoff_left = 0;   // after a persistent launch whose grid was not resident together in time (somebody else's kernels on the CUs: a 2 s
+                                                    // wait before the launches take over) the next 4, 8, ... 256 K-means runs of this context do not try one
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     void  *pinned_res = nullptr;  // pinned landing area of K-means result blocks (grown on demand)
     uint64_t pinned_res_bytes = 0;

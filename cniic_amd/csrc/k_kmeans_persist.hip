@@ -1054,8 +1054,17 @@ uint32_t ps_grid_for(Ctx *c, uint64_t Umax) {
 }
 
 // the set-up the persistent launch needs beyond the classic loop's (km_rgbw_create calls this once the cell list is enqueued)
+// a launch that ended: what the context learns from it (a grid that could not get the CUs in time costs seconds: do not try again at once)
+static void ps_learn(Ctx *c, uint32_t status, bool injected) {
+    if (status == kPsStatusDone) { c->ps_backoff = 0; c->ps_backoff_left = 0; return; }
+    if (status != kPsStatusAborted || injected) return;   // (a range that does not fit is found out before any block waits; the tests' aborts are no news)
+    c->ps_backoff = std::min<uint32_t>(256u, std::max<uint32_t>(4u, 2u * c->ps_backoff));
+    c->ps_backoff_left = c->ps_backoff;
+}
+
 int ps_prepare(KmRgbwState *s) {
     Ctx *c = s->c;
+    if (c->ps_backoff_left) { c->ps_backoff_left--; return CNIIC_OK; }   // (see ps_learn: the launches meanwhile)
     const uint32_t G = ps_grid_for(c, s->U);
     if (!G) return CNIIC_OK;   // (no device properties: the classic loop)
     static bool attr_set[16] = {};
@@ -1139,6 +1148,7 @@ int km_rgbw_run_persistent(KmRgbwState *s, bool *ran, bool may_defer) {
     }
     CNIIC_HIP_TRY(c, ctx_spin_sync(c));
     const uint32_t status = xh->status;
+    ps_learn(c, status, a.test_abort_at != 0);
     if (status != kPsStatusDone) {
         if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
         if (test_env("CNIIC_KM_PS_REQUIRE")) return c->fail(CNIIC_ERR_HIP, "kmeans_rgbw: the persistent launch ended with status %u (CNIIC_KM_PS_REQUIRE)", status);
@@ -1216,6 +1226,7 @@ int km_rgbw_persistent_verdict(KmRgbwState *s, bool *retry) {
     s->ps_pending = false;
     s->ps_hold.reset();
     const PsExit *xh = &static_cast<const PsCold *>(c->pinned_ps)->exit;
+    ps_learn(c, xh->status, test_env("CNIIC_TEST_PS_ABORT_AT") != nullptr);
     if (xh->status == kPsStatusDone) {
         s->run_stats.iterations = xh->iter; s->run_stats.moved_last = xh->moved_last; s->run_stats.empty_reseeds = xh->reseeds;
         s->run_stats.active = xh->active; s->run_stats.pair_evals = xh->pair_evals;

@@ -1429,8 +1429,7 @@ int km_rgbw_create(Ctx *c, const uint32_t *keys_d, const uint32_t *weight_d, uin
                 hipLaunchKernelGGL(k_rgbw_init_labels<uint8_t>, dim3(grid_1d(U)), dim3(256), 0, c->stream, s->crank.as<uint32_t>(), U,
                                    (uint64_t)0, U, K, s->labels.as<uint8_t>());
         }
-        hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)G + 1, 256)), dim3(256), 0, c->stream, s->ne_cost.as<uint32_t>(),
-                           s->ne_count.as<uint32_t>(), G, s->wfirst.as<uint32_t>());
+        s->wfirst_waves = G;   // (the waves' ranges are the launches' business: made when the first of them is enqueued -- ensure_wave_ranges -- not in front of a persistent launch)
         // the loop as one persistent launch (k_kmeans_persist.hip): its block ranges, barrier words and sums
         // (not for the worker contexts of a batch encode: eight persistent launches side by side each hold an eighth of the CUs for a
         // whole run while the other stages of their neighbours' encodes wait for a CU -- 2.6 ms a frame against 0.67 with launches)
@@ -1499,9 +1498,17 @@ int km_rgbw_set_state(KmRgbwState *s, const uint8_t *centroids_h, const uint32_t
 // ev_start / ev_stop (profiling): events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's
 // own begin and end as a profiler sees them, not an event pair around it (which adds ~4 us of dispatch per launch)
 // fused: the update of the previous iteration runs in this launch's prologue and the sums go to part_fused
+static void ensure_wave_ranges(KmRgbwState *s) {
+    if (!s->wfirst_waves) return;
+    hipLaunchKernelGGL(k_wave_ranges, dim3(ceil_div((uint64_t)s->wfirst_waves + 1, 256)), dim3(256), 0, s->c->stream, s->ne_cost.as<uint32_t>(),
+                       s->ne_count.as<uint32_t>(), s->wfirst_waves, s->wfirst.as<uint32_t>());
+    s->wfirst_waves = 0;
+}
+
 static void launch_assign(KmRgbwState *s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, const FusedUpdate *fused = nullptr,
                           unsigned long long *part_fused = nullptr) {
     Ctx *c = s->c;
+    if (s->cells) ensure_wave_ranges(s);
     FusedUpdate fz{};
     if (fused) fz = *fused;
     const KmDevState *st = s->dstate.as<KmDevState>();
@@ -1854,6 +1861,7 @@ __global__ void k_export_labels(const LabelT *__restrict__ labels, const uint32_
 int km_rgbw_export_labels(KmRgbwState *s, void *dst_d) {
     Ctx *c = s->c;
     if (!s->cells) return c->fail(CNIIC_ERR_BAD_ARG, "export_labels needs the cells path");
+    ensure_wave_ranges(s);
     const uint32_t wpb = s->wide ? 1u : (uint32_t)kCellWaves;
     const uint32_t g_lo = s->shard * s->nblocks * wpb, g_hi = (s->shard + 1) * s->nblocks * wpb;
     if (s->wide)

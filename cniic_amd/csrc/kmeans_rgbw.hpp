@@ -52,6 +52,7 @@ struct KmRgbwState {
     std::unique_ptr<LaggedPoll> lagged;  // cniic_cc_poll_lagged
     DevBuf ckeys, cweight, crank, cell_start, running, ne_cell, ne_start, ne_cost, ne_count, wfirst;
     DevBuf cell_rec, moved_list;  // skip schedule state
+    uint32_t wfirst_waves = 0;    // != 0: wfirst has not been computed yet for this many waves (ensure_wave_ranges)
     GIdx gidx{nullptr, nullptr, 0};  // several GPUs: the points are this rank's share of gidx.U colours
     DevBuf fused_partials, fused_running, fused_cent;  // km_rgbw_run with the update folded into the assign launches (3 / 2 / 2 buffers)
     bool fused = false;

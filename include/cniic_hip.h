@@ -96,7 +96,8 @@ int32_t     cniic_ctx_unset_opt(cniic_ctx *ctx, int32_t opt);
 int32_t     cniic_ctx_get_opt(cniic_ctx *ctx, int32_t opt, uint64_t *value);
 /* dominant-kernel timing of the most recent call on this ctx, measured with HIP events on the
  * ctx stream: *ms = summed duration, *launches = number of launches of that kernel.
- * Names: "kmeans_rgbw_assign", "kmeans_xyrgb_iter", "hist_rgb", "remap_rgb", "huff_pack", "hilbert_delta", "undiff_scatter", "hd_pass0" /
+ * Names: "kmeans_rgbw_persist" (the colour K-means as one persistent launch; "kmeans_rgbw_persist_iters": the same duration, launches =
+ * its iterations), "kmeans_rgbw_assign" (... as one launch per iteration), "kmeans_xyrgb_iter", "hist_rgb", "remap_rgb", "huff_pack", "hilbert_delta", "undiff_scatter", "hd_pass0" /
  * "hd_check" / "hd_write", and the five consecutive stages of a `delta` encode, which together are the whole call: "delta_gather",
  * "delta_hist", "delta_tree" (compaction, the leaves' sort, the host's merge, the codes), "huff_pack", "delta_finish". */
 int32_t     cniic_last_kernel_time(cniic_ctx *ctx, const char *which, double *ms, uint64_t *launches);
