@@ -76,8 +76,16 @@ struct KmRgbwState {
 };
 
 // ---- k_kmeans_persist.hip: the LDS of a block and what the launch shares with its set-up
-constexpr uint32_t kPsChunks = 16;                      // chunks of the cell list a block owns (interleaved with the other blocks')
-constexpr uint32_t kPsSlotsMax = 32;                    // shared super-cell lists of a block (cells of further super-cells build from the table)
+#ifndef CNIIC_PS_CHUNKS
+#define CNIIC_PS_CHUNKS 24
+#endif
+constexpr uint32_t kPsChunks = CNIIC_PS_CHUNKS;         // chunks of the cell list a block owns (interleaved with the other blocks').  24 by measurement (16 / 20 / 24 / 28 / 32 / 48 on
+                                                        // six images, profiles/r05_persist_chunks_probe.txt: finer chunks spread a moved centroid's dirty cells over more blocks; beyond ~28 a block's
+                                                        // cells lie in more super-cells than it has shared lists)
+#ifndef CNIIC_PS_SLOTS
+#define CNIIC_PS_SLOTS 32
+#endif
+constexpr uint32_t kPsSlotsMax = CNIIC_PS_SLOTS;                    // shared super-cell lists of a block (cells of further super-cells build from the table)
 constexpr uint32_t kPsScap = 96;                        // members a shared list holds (a longer list: its cells build from the table)
 constexpr uint32_t kPsRecWords = 11;                    // a cell's record: pivot colour, common label | pivot id << 16 | candidates << 24 | kRecComplete, 8 mask words, four candidate ids
 constexpr uint32_t kPsMaxCells = 2048;                  // cells a block may own (two per thread of its set-up)

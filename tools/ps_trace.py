@@ -26,7 +26,7 @@ from cniic_amd import _lib, synth
 dev = torch.device("cuda:0")
 with cniic_amd.Context(0) as ctx:
     img = torch.empty((size, size, 3), dtype=torch.uint8, device=dev)
-    ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + 2, size, size, out=img)
+    ctx.synth_image(_lib.SYNTH_PHOTO, synth.SEED0 + int(os.environ.get('PS_SEED', '2')), size, size, out=img)
     out = torch.empty(size * size * 2, dtype=torch.uint8, device=dev)
     expr = "cluster-colors(%d)" % K
     for _ in range(3):
