@@ -63,20 +63,20 @@ __device__ __forceinline__ bool ps_barrier_flat(PsBar *b, uint32_t nblocks, unsi
     }
     return ps_spin(&b->gen.v, g, b, ticks);
 }
-// two levels: the last block of an XCD to arrive reports to the top counter, the last XCD releases the others, each releases its own blocks
+// two levels: the last block of an XCD to arrive reports to the top counter, the last XCD bumps the top generation -- which EVERY block
+// watches (round 5, late: until then the XCDs' last blocks watched it and each released its own XCD through a word of its own: one more
+// store-to-poll hop, ~0.5 us, on the path behind the slowest block of every iteration; 256 pollers of one line are no load worth the hop)
 __device__ __forceinline__ bool ps_barrier_xcd(PsBar *b, uint32_t x, uint32_t nx_blocks, uint32_t nxcd, unsigned long long ticks) {
-    bool ok = true;
-    const uint32_t g = ps_ld(&b->xgen[x].v);
+    const uint32_t tg = ps_ld(&b->topgen.v);   // (before the arrival: nobody can bump it until this block has arrived)
     if (__hip_atomic_fetch_add(&b->xcount[x].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nx_blocks - 1) {
-        ps_st(&b->xcount[x].v, 0u);
-        const uint32_t tg = ps_ld(&b->topgen.v);
+        ps_st(&b->xcount[x].v, 0u);   // (its XCD's blocks come back only after the top generation has moved, which this block's report precedes)
         if (__hip_atomic_fetch_add(&b->top.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nxcd - 1) {
             ps_st(&b->top.v, 0u);
             ps_st(&b->topgen.v, tg + 1);
-        } else ok = ps_spin(&b->topgen.v, tg, b, ticks);
-        ps_st(&b->xgen[x].v, g + 1);   // (also after a failed wait: the abort word is set and the block's own XCD must not wait out its clock)
-    } else ok = ps_spin(&b->xgen[x].v, g, b, ticks);
-    return ok;
+            return true;
+        }
+    }
+    return ps_spin(&b->topgen.v, tg, b, ticks);
 }
 
 // ---------------------------------------------------------------- who owns what
