@@ -694,11 +694,14 @@ def bench_decode(args, ctx, torch, np, dev, rank, world, timed, config):
     if w_ms:
         sym_bytes = 4 if lossless else 3       # delta: packed differences (u32) for the prefix sum; the RGB codecs: pixels
         algo = float(ln) + float(sym_bytes) * W * H
-        roofline = {"kernel": "k_hd_write (+ the offsets scan in front of it)", "bound": "hbm", "achieved": round(algo / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+        roofline = {"kernel": "k_hd_compact (+ the offsets scan in front of it; k_hd_write for the subsequences of more than 64 symbols)" if lossless
+                              else "k_hd_write (+ the offsets scan in front of it)", "bound": "hbm", "achieved": round(algo / (w_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(algo / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": traffic_for("c5_decode" if lossless else "c2_decode") if W == (16384 if lossless else 4096) else None, "launch_ms": w_ms, "launches": 1,
                     "algorithmic_bytes_per_launch": algo,
                     "note": "HIP events around the scan + write launches of one more decode (stage timers); algorithmic bytes = the %d-byte stream read once + "
-                            "%d B/symbol written; the boundary passes before it (hd_pass0, hd_check) read the stream again and write 20 B per 1024 bits" % (ln, sym_bytes)}
+                            "%d B/symbol written; the boundary passes before it (hd_pass0, hd_check) read the stream again and write 20 B per 1024 bits%s"
+                            % (ln, sym_bytes, " -- and, for this long-coded stream, keep the symbols they meet: the write is a copy of those (k_hd_compact reads 4 B/symbol "
+                                              "of kept rows instead of the stream; `traffic` is that kernel's)" if lossless else "")}
     cpu = None
     if args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

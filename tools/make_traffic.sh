@@ -4,7 +4,7 @@
 #   c2_persist  k_rgbw_persist        the headline encode's one K-means launch
 #   c4          k_rgbw_persist        configs[3]'s one-GPU share (128 frames, one palette)
 #   c5          k_delta_gather_p2     configs[4]
-#   c2_decode   k_hd_write            decode of the headline stream        c5_decode   k_hd_write   decode of configs[4]'s stream
+#   c2_decode   k_hd_write            decode of the headline stream        c5_decode   k_hd_compact decode of configs[4]'s stream (kept symbols copied to their places)
 # usage (on the GPU box): bash tools/make_traffic.sh [outdir]   -- then copy outdir/traffic.json over profiles/traffic.json
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -42,6 +42,6 @@ run c2_persist k_rgbw_persist python3 $R/bench.py --no-extras --cpu-sample 0 --s
 run c4 k_rgbw_persist python3 $R/bench.py --config c4 --cpu-sample 0 --steps 1 --warmup 1
 run c5 k_delta_gather_p2 python3 $R/bench.py --config c5 --cpu-sample 0 --steps 2 --warmup 1
 run c2_decode k_hd_write python3 $R/bench.py --decode --cpu-sample 0 --steps 2 --warmup 1
-run c5_decode k_hd_write python3 $R/bench.py --decode --config c5 --cpu-sample 0 --steps 2 --warmup 1
+run c5_decode k_hd_compact python3 $R/bench.py --decode --config c5 --cpu-sample 0 --steps 2 --warmup 1
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 cat $O/traffic.json
