@@ -17,7 +17,7 @@ with cniic_amd.Context(0) as ctx:
     stride = W * H
     out = torch.empty(stride * F, dtype=torch.uint8, device=dev)
     ref = None
-    for mode, pct in (("launches", 0), ("persistent", 75), ("persistent", 100)):   # (persistent: with profiles/r05_batch_persistent_budget.patch applied)
+    for mode, pct in (("launches", 0),) + ((("persistent", 75), ("persistent", 100)) if os.environ.get("BATCH_PERSIST") else ()):   # (persistent: with profiles/r05_batch_persistent_budget.patch applied)
         os.environ["CNIIC_KM_PS_BATCH"] = "0" if mode == "launches" else "1"
         os.environ["CNIIC_KM_PS_BATCH_PCT"] = str(pct)
         for streams in (4, 6, 8, 12, 16):
