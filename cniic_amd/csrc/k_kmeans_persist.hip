@@ -1064,7 +1064,7 @@ static void ps_learn(Ctx *c, uint32_t status, bool injected) {
 
 int ps_prepare(KmRgbwState *s) {
     Ctx *c = s->c;
-    if (c->ps_backoff_left) { c->ps_backoff_left--; return CNIIC_OK; }   // (see ps_learn: the launches meanwhile)
+    if (c->ps_backoff_left && !test_env("CNIIC_KM_PS_REQUIRE")) { c->ps_backoff_left--; return CNIIC_OK; }   // (see ps_learn: the launches meanwhile; the tests' REQUIRE always tries)
     const uint32_t G = ps_grid_for(c, s->U);
     if (!G) return CNIIC_OK;   // (no device properties: the classic loop)
     static bool attr_set[16] = {};
